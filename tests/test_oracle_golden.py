@@ -52,6 +52,8 @@ def test_pdist_and_grad(key, dname, init):
         if f'{tag}/x' not in G:
             continue
         tol = TOL[dname]
+        if dname == 'f32' and init == 'rand' and key.startswith('grassmann'):
+            tol *= 50  # acos(sigma ~ 1) in fp32: LAPACK-rounding-level changes in sigma show
         x, g = T(G[f'{tag}/x']), T(G[f'{tag}/g'])
         xr = x.clone().requires_grad_()
         d2 = man.pdist(xr, squared=True)

@@ -1,0 +1,117 @@
+/* mm_manifolds.h — C ABI of libmm_manifolds.so (MI355X / gfx950).
+ *
+ * Drop-in boundary for graphembed's pairwise manifold-distance training path.
+ * The reference has no FFI of its own: the interface these entry points
+ * replace is the Python plugin class `Manifold`
+ * (graphembed/graphembed/manifolds/base.py:7-81) and its callers
+ * (optim/rsgd.py:40-82, modules.py:84-88).  Each entry point below cites the
+ * reference method whose arithmetic it performs; INTEGRATION.md shows the
+ * ctypes binding that plugs them back into that class.
+ *
+ * Rules of the ABI
+ *   - plain C: pointers, sizes, scalars.  No torch / C++ types.
+ *   - every `const void*` / `void*` data pointer is DEVICE memory (HBM),
+ *     contiguous, row-major, batch-first; element type given by `dtype`.
+ *   - the caller owns all buffers, including the workspace `ws`
+ *     (size from the matching *_ws_bytes()); nothing is allocated inside.
+ *   - kernels are enqueued on `stream` (a hipStream_t) and never synchronise;
+ *     no call blocks the host.
+ *   - return value: MM_OK, a negative MM_ERR_* for argument errors, or a
+ *     positive hipError_t from the launch.  No exceptions cross the ABI.
+ *   - pair order everywhere: k <-> (i,j), i<j, row-major upper triangle
+ *     (torch.triu_indices(n,n,1); base.py:62, spd.py:179).
+ *   - a row range [row_begin,row_end) selects the pairs (i,j) with
+ *     row_begin <= i < row_end: a contiguous slice of the pair list starting at
+ *     mm_pair_offset(n,row_begin).  This is the multi-GPU sharding unit.
+ */
+#ifndef MM_MANIFOLDS_H
+#define MM_MANIFOLDS_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* mm_stream_t; /* hipStream_t */
+
+enum { MM_F32 = 0, MM_F64 = 1 };
+enum { MM_OK = 0, MM_ERR_ARG = -1, MM_ERR_UNSUPPORTED = -2 };
+
+/* vector-manifold kinds for mm_vec_* */
+enum { MM_EUCLIDEAN = 0, MM_LORENTZ = 1, MM_SPHERE = 2 };
+
+/* ---- library info -------------------------------------------------------- */
+int mm_abi_version(void);
+const char* mm_target_arch(void); /* "gfx950" */
+
+/* ---- pair-list geometry (host-side helpers, no GPU work) ----------------- */
+/* number of pairs in rows < row:  row*(2n-row-1)/2 */
+int64_t mm_pair_offset(int64_t n, int64_t row);
+/* contiguous row range of shard `rank` of `world`, balanced by pair count */
+int mm_shard_rows(int64_t n, int world, int rank, int64_t* row_begin, int64_t* row_end);
+
+/* ---- SPD(d), affine-invariant metric ------------------------------------- */
+/* Largest d the pairwise / per-node SPD kernels are instantiated for. */
+int mm_spd_max_dim(void);
+
+/* Workspace bytes for mm_spd_pdist_fwd/bwd on n points. */
+size_t mm_spd_pdist_ws_bytes(int dtype, int64_t n, int d);
+
+/* flags for the pdist calls */
+enum { MM_WS_PREPARED = 1 /* ws already holds the per-node factors of this x */ };
+
+/* SymmetricPositiveDefinite.pdist — manifolds/spd.py:175-181 (+ _norm_log
+ * 163-169, _lult 108-111).  out[k] = sum_m log^2 lambda_m(L_i^-1 X_j L_i^-T)
+ * (sqrt of it if !squared), eigenvalues value-clamped to [wmin,wmax], result
+ * value-clamped >= wmin.
+ *   x    [n,d,d]   out  [mm_pair_offset(n,row_end)-mm_pair_offset(n,row_begin)]
+ * A non-positive-definite x[i] sets the status word (mm_spd_status). */
+int mm_spd_pdist_fwd(int dtype, const void* x, int64_t n, int d, int64_t row_begin,
+                     int64_t row_end, int squared, double wmin, double wmax, void* out,
+                     void* ws, int flags, mm_stream_t stream);
+
+/* Backward of the above (what autograd computes in the reference; symmetric
+ * part — SURVEY.md §8 a5).  g has the layout of `out`.  grad_x [n,d,d] is
+ * OVERWRITTEN with this shard's partial gradient (full shape; sum the shards). */
+int mm_spd_pdist_bwd(int dtype, const void* x, const void* g, int64_t n, int d,
+                     int64_t row_begin, int64_t row_end, int squared, double wmin,
+                     double wmax, void* grad_x, void* ws, int flags, mm_stream_t stream);
+
+/* Copies the workspace status word to *host_status (0 = all factorizations
+ * succeeded).  Synchronises `stream` — the only blocking call of the ABI. */
+int mm_spd_status(const void* ws, int* host_status, mm_stream_t stream);
+
+/* SymmetricPositiveDefinite.dist — spd.py:171-173, element-wise over m pairs
+ * (x[k], y[k]).  x,y [m,d,d]; out [m]. */
+int mm_spd_dist_fwd(int dtype, const void* x, const void* y, int64_t m, int d, int squared,
+                    double wmin, double wmax, void* out, mm_stream_t stream);
+int mm_spd_dist_bwd(int dtype, const void* x, const void* y, const void* g, int64_t m, int d,
+                    int squared, double wmin, double wmax, void* grad_x, void* grad_y,
+                    mm_stream_t stream);
+
+/* Per-point maps used by RiemannianSGD (optim/rsgd.py:56-82); all [m,d,d]. */
+enum {
+  MM_SPD_EGRAD2RGRAD = 0, /* X sym(U) X                         spd.py:134-135 */
+  MM_SPD_EXP = 1,         /* L expm(L^-1 U L^-T) L^T            spd.py:137-144 */
+  MM_SPD_RETR = 2,        /* sym(X + U + 1/2 U X^-1 U)          spd.py:146-154 */
+  MM_SPD_LOG = 3,         /* L logm(L^-1 Y L^-T) L^T  (U = Y)   spd.py:156-161 */
+  MM_SPD_PROJX = 4,       /* V clamp(w) V^T of sym(X) (U unused) spd.py:126-132 */
+  MM_SPD_PROJU = 5        /* sym(U)                             spd.py:119-124 */
+};
+int mm_spd_map(int dtype, int op, const void* x, const void* u, int64_t m, int d, double wmin,
+               double wmax, void* out, mm_stream_t stream);
+/* SymmetricPositiveDefinite.norm — spd.py:113-117: ||L^-1 U L^-T||_F  -> out [m] */
+int mm_spd_norm(int dtype, const void* x, const void* u, int64_t m, int d, int squared, void* out,
+                mm_stream_t stream);
+/* One fused RiemannianSGD update without momentum (rsgd.py:63-68, 82):
+ *   r = X sym(G) X; r *= min(max_grad_norm/||r||_X, 1) (skipped if
+ *   max_grad_norm <= 0); x_new = (exact ? exp : retr)(X, -lr r). */
+int mm_spd_rsgd_step(int dtype, const void* x, const void* egrad, int64_t m, int d, double lr,
+                     double max_grad_norm, int exact, void* x_new, mm_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MM_MANIFOLDS_H */

@@ -1,0 +1,607 @@
+// SPD(d) affine-invariant pairwise distance + gradient, and the per-point maps
+// RiemannianSGD needs, as hand-written gfx950 kernels.
+//
+// Reference arithmetic: graphembed/graphembed/manifolds/spd.py:108-181 and
+// linalg/{fast,torch_batch}.py (see include/mm_manifolds.h for the per-entry
+// citations).  Design notes: DESIGN.md §3.
+//
+// Pair kernels: one workgroup = 256 lanes = 256 consecutive columns j of the
+// upper triangle; it walks TI rows i.  Each lane keeps its X_j (packed
+// symmetric) in VGPRs for the whole tile; the row operand L_i^-1 is
+// wave-uniform, so it is fetched with scalar loads into SGPRs (no LDS, no VGPRs)
+// and every `L_i^-1 X_j L_i^-T` FMA takes one scalar and one vector operand.
+// The eigensolve is a cyclic Jacobi entirely in registers (smallmat.hpp).
+// Forward stores d^2 with lanes on consecutive j -> 256-B coalesced segments of
+// the row-major pair vector.  Backward recomputes the decomposition (cheaper
+// than a 28-48 B/pair round trip through HBM), accumulates the column-side
+// gradient per lane in registers, reduces the row-side gradient across the
+// wavefront, and flushes both once per tile with coalesced float atomics into
+// structure-of-arrays accumulators.
+#include <hip/hip_runtime.h>
+
+#include "../../include/mm_manifolds.h"
+#include "smallmat.hpp"
+
+namespace mm {
+
+constexpr int kBlock = 256;  // 4 wavefronts
+constexpr int kSpdMaxD = 5;
+
+__host__ __device__ inline int64_t pair_off(int64_t n, int64_t row) { return row * (2 * n - row - 1) / 2; }
+
+// Workspace layout (T = element type, NP = d(d+1)/2):
+//   [0,64)            status words (int32[16]); word 0 = #non-PD points seen
+//   nodeL  T[n][NP]   packed lower L_i^-1
+//   nodeX  T[n][NP]   packed sym(X_i)
+//   accM   T[NP][n]   row-side accumulators   (sum_j V diag(2 g log w) V^T)
+//   accN   T[NP][n]   column-side accumulators (sum_i L_i^-T N_ij L_i^-1)
+template <typename T> struct Ws {
+  int* status;
+  T* nodeL;
+  T* nodeX;
+  T* accM;
+  T* accN;
+  static size_t bytes(int64_t n, int np) { return 64 + sizeof(T) * size_t(n) * np * 4; }
+  Ws(void* base, int64_t n, int np) {
+    char* p = static_cast<char*>(base);
+    status = reinterpret_cast<int*>(p);
+    nodeL = reinterpret_cast<T*>(p + 64);
+    nodeX = nodeL + n * np;
+    accM = nodeX + n * np;
+    accN = accM + n * np;
+  }
+};
+
+// ------------------------------------------------------------------ prep
+template <typename T, int D>
+__global__ void spd_prep_kernel(const T* __restrict__ x, int n, T* __restrict__ nodeL, T* __restrict__ nodeX,
+                                int* __restrict__ status) {
+  constexpr int NP = Packed<D>::NP;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  T xs[NP], l[NP], li[NP];
+  load_sym_packed<T, D>(x + size_t(i) * D * D, xs);
+  const bool ok = cholesky<T, D>(xs, l);
+  invert_lower<T, D>(l, li);
+#pragma unroll
+  for (int k = 0; k < NP; ++k) {
+    nodeL[size_t(i) * NP + k] = li[k];
+    nodeX[size_t(i) * NP + k] = xs[k];
+  }
+  if (!ok) atomicAdd(status, 1);
+}
+
+// A = Li X Li^T, eigen-decompose, return s = sum log^2 clamp(w).
+template <typename T, int D, bool WITH_V, typename TL>
+__device__ __forceinline__ T pair_core(const TL (&li)[Packed<D>::NP], const T (&xj)[Packed<D>::NP], T wmin, T wmax,
+                                       T (&w)[D], T (&lw)[D], T (&v)[D][D]) {
+  T a[Packed<D>::NP];
+  congr_lower<T, D>(li, xj, a);
+  jacobi_eig<T, D, WITH_V>(a, v);
+  T s = T(0);
+#pragma unroll
+  for (int k = 0; k < D; ++k) {
+    w[k] = Num<T>::min(Num<T>::max(a[pidx(k, k)], wmin), wmax);
+    lw[k] = Num<T>::log(w[k]);
+    s = Num<T>::fma(lw[k], lw[k], s);
+  }
+  return s;
+}
+
+// ------------------------------------------------------------------ forward
+template <typename T, int D, int TI>
+__global__ __launch_bounds__(kBlock) void spd_pdist_fwd_kernel(const T* __restrict__ nodeL,
+                                                               const T* __restrict__ nodeX, int n, int row_begin,
+                                                               int row_end, int squared, T wmin, T wmax,
+                                                               T* __restrict__ out) {
+  constexpr int NP = Packed<D>::NP;
+  const int i0 = row_begin + blockIdx.y * TI;
+  const int i1 = min(i0 + TI, row_end);
+  const int jblk = (i0 + 1) / kBlock + blockIdx.x;
+  const int jbase = jblk * kBlock;
+  if (jbase >= n) return;
+  const int wave_j0 = jbase + (threadIdx.x & ~63);
+  if (wave_j0 + 63 <= i0) return;  // whole wavefront below the diagonal
+  const int j = jbase + threadIdx.x;
+  const bool jin = j < n;
+
+  T xj[NP];
+#pragma unroll
+  for (int k = 0; k < NP; ++k) xj[k] = T(0);
+#pragma unroll
+  for (int k = 0; k < D; ++k) xj[pidx(k, k)] = T(1);
+  if (jin) {
+#pragma unroll
+    for (int k = 0; k < NP; ++k) xj[k] = nodeX[size_t(j) * NP + k];
+  }
+  const int64_t base = pair_off(n, row_begin);
+  for (int i = i0; i < i1; ++i) {
+    T li[NP];
+#pragma unroll
+    for (int k = 0; k < NP; ++k) li[k] = nodeL[size_t(i) * NP + k];  // wave-uniform -> s_load
+    T w[D], lw[D], v[D][D];
+    T s = pair_core<T, D, false>(li, xj, wmin, wmax, w, lw, v);
+    s = Num<T>::max(s, wmin);
+    if (!squared) s = Num<T>::sqrt(s);
+    if (jin && j > i) out[pair_off(n, i) - base + (j - i - 1)] = s;
+  }
+}
+
+// ------------------------------------------------------------------ backward
+template <typename T, int D, int TI>
+__global__ __launch_bounds__(kBlock) void spd_pdist_bwd_kernel(const T* __restrict__ nodeL,
+                                                               const T* __restrict__ nodeX,
+                                                               const T* __restrict__ g, int n, int row_begin,
+                                                               int row_end, int squared, T wmin, T wmax,
+                                                               T* __restrict__ accM, T* __restrict__ accN) {
+  constexpr int NP = Packed<D>::NP;
+  __shared__ T redM[kBlock / 64][TI][NP];
+  const int i0 = row_begin + blockIdx.y * TI;
+  const int i1 = min(i0 + TI, row_end);
+  const int jblk = (i0 + 1) / kBlock + blockIdx.x;
+  const int jbase = jblk * kBlock;
+  if (jbase >= n) return;  // block-uniform
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wave_j0 = jbase + wave * 64;
+  const bool wave_live = wave_j0 + 63 > i0;  // else no pair of this wave is above the diagonal
+  const int j = jbase + threadIdx.x;
+  const bool jin = j < n;
+
+  T xj[NP], accJ[NP];
+#pragma unroll
+  for (int k = 0; k < NP; ++k) { xj[k] = T(0); accJ[k] = T(0); }
+#pragma unroll
+  for (int k = 0; k < D; ++k) xj[pidx(k, k)] = T(1);
+  if (jin) {
+#pragma unroll
+    for (int k = 0; k < NP; ++k) xj[k] = nodeX[size_t(j) * NP + k];
+  }
+  const int64_t base = pair_off(n, row_begin);
+  if (wave_live) {
+    for (int i = i0; i < i1; ++i) {
+      T li[NP];
+#pragma unroll
+      for (int k = 0; k < NP; ++k) li[k] = nodeL[size_t(i) * NP + k];
+      const bool valid = jin && j > i;
+      T gs = valid ? g[pair_off(n, i) - base + (j - i - 1)] : T(0);
+      T w[D], lw[D], v[D][D];
+      const T s = pair_core<T, D, true>(li, xj, wmin, wmax, w, lw, v);
+      if (!squared) gs *= T(0.5) * Num<T>::rsqrt(Num<T>::max(s, wmin));
+      T cm[D], cn[D];
+#pragma unroll
+      for (int k = 0; k < D; ++k) {
+        cm[k] = (gs + gs) * lw[k];
+        cn[k] = cm[k] / w[k];
+      }
+      T m[NP], nn[NP], cj[NP];
+      vdvt<T, D>(v, cm, m);
+      vdvt<T, D>(v, cn, nn);
+      congr_lower_t<T, D>(li, nn, cj);
+#pragma unroll
+      for (int k = 0; k < NP; ++k) {
+        accJ[k] += cj[k];
+        const T r = wave_sum(m[k]);
+        if (lane == 0) redM[wave][i - i0][k] = r;
+      }
+    }
+  }
+  __syncthreads();
+  // row side: sum the live wavefronts' partials, one coalesced atomic per (k, row)
+  for (int t = threadIdx.x; t < TI * NP; t += kBlock) {
+    const int k = t / TI, il = t % TI;
+    if (i0 + il < i1) {
+      T sum = T(0);
+#pragma unroll
+      for (int wv = 0; wv < kBlock / 64; ++wv)
+        if (jbase + wv * 64 + 63 > i0) sum += redM[wv][il][k];
+      atomic_add(&accM[size_t(k) * n + i0 + il], sum);
+    }
+  }
+  // column side: lanes hold consecutive j -> 256-B contiguous atomics per k
+  if (jin && wave_live) {
+#pragma unroll
+    for (int k = 0; k < NP; ++k) atomic_add(&accN[size_t(k) * n + j], accJ[k]);
+  }
+}
+
+// grad_x[i] = -L_i^-T accM_i L_i^-1 + accN_i   (symmetric, full DxD)
+template <typename T, int D>
+__global__ void spd_pdist_finalize_kernel(const T* __restrict__ nodeL, const T* __restrict__ accM,
+                                          const T* __restrict__ accN, int n, T* __restrict__ grad) {
+  constexpr int NP = Packed<D>::NP;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  T li[NP], m[NP], gi[NP];
+#pragma unroll
+  for (int k = 0; k < NP; ++k) {
+    li[k] = nodeL[size_t(i) * NP + k];
+    m[k] = accM[size_t(k) * n + i];
+  }
+  congr_lower_t<T, D>(li, m, gi);
+#pragma unroll
+  for (int k = 0; k < NP; ++k) gi[k] = accN[size_t(k) * n + i] - gi[k];
+  store_sym_full<T, D>(grad + size_t(i) * D * D, gi);
+}
+
+// ------------------------------------------------------- element-wise dist
+template <typename T, int D>
+__global__ void spd_dist_fwd_kernel(const T* __restrict__ x, const T* __restrict__ y, int64_t m, int squared, T wmin,
+                                    T wmax, T* __restrict__ out) {
+  constexpr int NP = Packed<D>::NP;
+  const int64_t k0 = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  const bool in = k0 < m;
+  const int64_t k = in ? k0 : 0;
+  T xs[NP], ys[NP], l[NP], li[NP];
+  load_sym_packed<T, D>(x + k * D * D, xs);
+  load_sym_packed<T, D>(y + k * D * D, ys);
+  cholesky<T, D>(xs, l);
+  invert_lower<T, D>(l, li);
+  T w[D], lw[D], v[D][D];
+  T s = pair_core<T, D, false>(li, ys, wmin, wmax, w, lw, v);
+  s = Num<T>::max(s, wmin);
+  if (!squared) s = Num<T>::sqrt(s);
+  if (in) out[k] = s;
+}
+
+template <typename T, int D>
+__global__ void spd_dist_bwd_kernel(const T* __restrict__ x, const T* __restrict__ y, const T* __restrict__ g,
+                                    int64_t m, int squared, T wmin, T wmax, T* __restrict__ gx,
+                                    T* __restrict__ gy) {
+  constexpr int NP = Packed<D>::NP;
+  const int64_t k0 = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  const bool in = k0 < m;
+  const int64_t k = in ? k0 : 0;
+  T xs[NP], ys[NP], l[NP], li[NP];
+  load_sym_packed<T, D>(x + k * D * D, xs);
+  load_sym_packed<T, D>(y + k * D * D, ys);
+  cholesky<T, D>(xs, l);
+  invert_lower<T, D>(l, li);
+  T w[D], lw[D], v[D][D];
+  const T s = pair_core<T, D, true>(li, ys, wmin, wmax, w, lw, v);
+  T gs = g[k];
+  if (!squared) gs *= T(0.5) * Num<T>::rsqrt(Num<T>::max(s, wmin));
+  T cm[D], cn[D];
+#pragma unroll
+  for (int q = 0; q < D; ++q) {
+    cm[q] = -(gs + gs) * lw[q];
+    cn[q] = -cm[q] / w[q];
+  }
+  T mm_[NP], nn[NP], o[NP];
+  vdvt<T, D>(v, cm, mm_);
+  vdvt<T, D>(v, cn, nn);
+  if (in) {
+    congr_lower_t<T, D>(li, mm_, o);
+    store_sym_full<T, D>(gx + k * D * D, o);
+    congr_lower_t<T, D>(li, nn, o);
+    store_sym_full<T, D>(gy + k * D * D, o);
+  }
+}
+
+// ------------------------------------------------------ per-point maps
+template <typename T, int D> __device__ __forceinline__ void load_full(const T* __restrict__ p, T (&f)[D * D]) {
+#pragma unroll
+  for (int k = 0; k < D * D; ++k) f[k] = p[k];
+}
+
+// expand packed lower-triangular to a full row-major matrix
+template <typename T, int D> __device__ __forceinline__ void lower_to_full(const T (&l)[Packed<D>::NP], T (&f)[D * D]) {
+#pragma unroll
+  for (int r = 0; r < D; ++r)
+#pragma unroll
+    for (int c = 0; c < D; ++c) f[r * D + c] = (c <= r) ? l[pidx(r, c)] : T(0);
+}
+
+// sym(X + U + 1/2 (L^-1 U)^T (L^-1 U)) with U symmetric packed (spd.py:146-154)
+template <typename T, int D>
+__device__ __forceinline__ void spd_retr(const T (&xs)[Packed<D>::NP], const T (&li)[Packed<D>::NP],
+                                         const T (&us)[Packed<D>::NP], T (&out)[Packed<D>::NP]) {
+  T b[D][D];  // B = L^-1 U
+#pragma unroll
+  for (int r = 0; r < D; ++r)
+#pragma unroll
+    for (int c = 0; c < D; ++c) {
+      T acc = T(0);
+#pragma unroll
+      for (int k = 0; k <= r; ++k) acc = Num<T>::fma(li[pidx(r, k)], us[pidx(k, c)], acc);
+      b[r][c] = acc;
+    }
+#pragma unroll
+  for (int r = 0; r < D; ++r)
+#pragma unroll
+    for (int c = 0; c <= r; ++c) {
+      T acc = T(0);
+#pragma unroll
+      for (int k = 0; k < D; ++k) acc = Num<T>::fma(b[k][r], b[k][c], acc);
+      out[pidx(r, c)] = xs[pidx(r, c)] + us[pidx(r, c)] + T(0.5) * acc;
+    }
+}
+
+// L f(L^-1 U L^-T) L^T with f = exp or log applied to the eigenvalues
+template <typename T, int D, bool IS_LOG>
+__device__ __forceinline__ void spd_explog(const T (&l)[Packed<D>::NP], const T (&li)[Packed<D>::NP],
+                                           const T (&us)[Packed<D>::NP], T (&out)[Packed<D>::NP]) {
+  T a[Packed<D>::NP], v[D][D], f[D], fa[Packed<D>::NP];
+  congr_lower<T, D>(li, us, a);
+  jacobi_eig<T, D, true>(a, v);
+#pragma unroll
+  for (int k = 0; k < D; ++k) f[k] = IS_LOG ? Num<T>::log(a[pidx(k, k)]) : Num<T>::exp(a[pidx(k, k)]);
+  vdvt<T, D>(v, f, fa);
+  congr_lower<T, D>(l, fa, out);
+}
+
+template <typename T, int D>
+__global__ void spd_map_kernel(int op, const T* __restrict__ x, const T* __restrict__ u, int64_t m, T wmin, T wmax,
+                               T* __restrict__ out) {
+  constexpr int NP = Packed<D>::NP;
+  const int64_t k0 = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  const bool in = k0 < m;
+  const int64_t k = in ? k0 : 0;
+  T xs[NP], us[NP], o[NP];
+  load_sym_packed<T, D>(x + k * D * D, xs);
+  if (op != MM_SPD_PROJX) load_sym_packed<T, D>(u + k * D * D, us);
+  if (op == MM_SPD_EGRAD2RGRAD) {
+    T xf[D * D];
+#pragma unroll
+    for (int r = 0; r < D; ++r)
+#pragma unroll
+      for (int c = 0; c < D; ++c) xf[r * D + c] = xs[pidx(r, c)];
+    congr_full<T, D>(xf, us, o);
+  } else if (op == MM_SPD_PROJU) {
+#pragma unroll
+    for (int q = 0; q < NP; ++q) o[q] = us[q];
+  } else if (op == MM_SPD_PROJX) {
+    T v[D][D], f[D];
+    jacobi_eig<T, D, true>(xs, v);
+#pragma unroll
+    for (int q = 0; q < D; ++q) f[q] = Num<T>::min(Num<T>::max(xs[pidx(q, q)], wmin), wmax);
+    vdvt<T, D>(v, f, o);
+  } else {
+    T l[NP], li[NP];
+    cholesky<T, D>(xs, l);
+    invert_lower<T, D>(l, li);
+    if (op == MM_SPD_RETR) spd_retr<T, D>(xs, li, us, o);
+    else if (op == MM_SPD_EXP) spd_explog<T, D, false>(l, li, us, o);
+    else spd_explog<T, D, true>(l, li, us, o);
+  }
+  if (in) store_sym_full<T, D>(out + k * D * D, o);
+}
+
+template <typename T, int D>
+__global__ void spd_norm_kernel(const T* __restrict__ x, const T* __restrict__ u, int64_t m, int squared,
+                                T* __restrict__ out) {
+  constexpr int NP = Packed<D>::NP;
+  const int64_t k0 = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  const bool in = k0 < m;
+  const int64_t k = in ? k0 : 0;
+  T xs[NP], us[NP], l[NP], li[NP], a[NP];
+  load_sym_packed<T, D>(x + k * D * D, xs);
+  load_sym_packed<T, D>(u + k * D * D, us);
+  cholesky<T, D>(xs, l);
+  invert_lower<T, D>(l, li);
+  congr_lower<T, D>(li, us, a);
+  T s = T(0);
+#pragma unroll
+  for (int r = 0; r < D; ++r)
+#pragma unroll
+    for (int c = 0; c <= r; ++c) s += (r == c ? T(1) : T(2)) * a[pidx(r, c)] * a[pidx(r, c)];
+  if (in) out[k] = squared ? s : Num<T>::sqrt(s);
+}
+
+template <typename T, int D>
+__global__ void spd_rsgd_step_kernel(const T* __restrict__ x, const T* __restrict__ eg, int64_t m, T lr,
+                                     T max_grad_norm, int exact, T* __restrict__ xnew) {
+  constexpr int NP = Packed<D>::NP;
+  const int64_t k0 = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  const bool in = k0 < m;
+  const int64_t k = in ? k0 : 0;
+  T xs[NP], gs[NP], r[NP], l[NP], li[NP], o[NP];
+  load_sym_packed<T, D>(x + k * D * D, xs);
+  load_sym_packed<T, D>(eg + k * D * D, gs);
+  T xf[D * D];
+#pragma unroll
+  for (int a = 0; a < D; ++a)
+#pragma unroll
+    for (int c = 0; c < D; ++c) xf[a * D + c] = xs[pidx(a, c)];
+  congr_full<T, D>(xf, gs, r);  // Riemannian gradient X sym(G) X
+  cholesky<T, D>(xs, l);
+  invert_lower<T, D>(l, li);
+  T scale = -lr;
+  if (max_grad_norm > T(0)) {
+    T a[NP];
+    congr_lower<T, D>(li, r, a);
+    T s = T(0);
+#pragma unroll
+    for (int p = 0; p < D; ++p)
+#pragma unroll
+      for (int c = 0; c <= p; ++c) s += (p == c ? T(1) : T(2)) * a[pidx(p, c)] * a[pidx(p, c)];
+    scale *= Num<T>::min(max_grad_norm / Num<T>::sqrt(s), T(1));
+  }
+#pragma unroll
+  for (int q = 0; q < NP; ++q) r[q] *= scale;
+  if (exact) spd_explog<T, D, false>(l, li, r, o);
+  else spd_retr<T, D>(xs, li, r, o);
+  if (in) store_sym_full<T, D>(xnew + k * D * D, o);
+}
+
+// ------------------------------------------------------------------ launchers
+#define MM_CHECK_LAUNCH()                         \
+  do {                                            \
+    hipError_t e_ = hipGetLastError();            \
+    if (e_ != hipSuccess) return static_cast<int>(e_); \
+  } while (0)
+
+template <typename T, int D>
+int spd_pdist_prepare(const T* x, int64_t n, Ws<T>& ws, int flags, hipStream_t st) {
+  if (!(flags & MM_WS_PREPARED)) {
+    hipError_t e = hipMemsetAsync(ws.status, 0, 64, st);
+    if (e != hipSuccess) return int(e);
+    spd_prep_kernel<T, D><<<dim3((n + 127) / 128), dim3(128), 0, st>>>(x, int(n), ws.nodeL, ws.nodeX, ws.status);
+    MM_CHECK_LAUNCH();
+  }
+  return MM_OK;
+}
+
+template <int D> struct Tile { static constexpr int TI = 16; };
+
+template <typename T, int D>
+int spd_pdist_fwd_t(const T* x, int64_t n, int64_t rb, int64_t re, int squared, double wmin, double wmax, T* out,
+                    void* wsp, int flags, hipStream_t st) {
+  constexpr int TI = Tile<D>::TI;
+  Ws<T> ws(wsp, n, Packed<D>::NP);
+  int rc = spd_pdist_prepare<T, D>(x, n, ws, flags, st);
+  if (rc) return rc;
+  if (re <= rb) return MM_OK;
+  const int nJB = int((n + kBlock - 1) / kBlock);
+  const int gx = nJB - int((rb + 1) / kBlock);
+  const int gy = int((re - rb + TI - 1) / TI);
+  if (gx <= 0) return MM_OK;
+  spd_pdist_fwd_kernel<T, D, TI><<<dim3(gx, gy), dim3(kBlock), 0, st>>>(ws.nodeL, ws.nodeX, int(n), int(rb), int(re),
+                                                                       squared, T(wmin), T(wmax), out);
+  MM_CHECK_LAUNCH();
+  return MM_OK;
+}
+
+template <typename T, int D>
+int spd_pdist_bwd_t(const T* x, const T* g, int64_t n, int64_t rb, int64_t re, int squared, double wmin, double wmax,
+                    T* grad, void* wsp, int flags, hipStream_t st) {
+  constexpr int TI = Tile<D>::TI;
+  constexpr int NP = Packed<D>::NP;
+  Ws<T> ws(wsp, n, NP);
+  int rc = spd_pdist_prepare<T, D>(x, n, ws, flags, st);
+  if (rc) return rc;
+  hipError_t e = hipMemsetAsync(ws.accM, 0, sizeof(T) * size_t(n) * NP * 2, st);
+  if (e != hipSuccess) return int(e);
+  const int nJB = int((n + kBlock - 1) / kBlock);
+  const int gx = nJB - int((rb + 1) / kBlock);
+  const int gy = int((re - rb + TI - 1) / TI);
+  if (re > rb && gx > 0) {
+    spd_pdist_bwd_kernel<T, D, TI><<<dim3(gx, gy), dim3(kBlock), 0, st>>>(
+        ws.nodeL, ws.nodeX, g, int(n), int(rb), int(re), squared, T(wmin), T(wmax), ws.accM, ws.accN);
+    MM_CHECK_LAUNCH();
+  }
+  spd_pdist_finalize_kernel<T, D><<<dim3((n + 127) / 128), dim3(128), 0, st>>>(ws.nodeL, ws.accM, ws.accN, int(n),
+                                                                               grad);
+  MM_CHECK_LAUNCH();
+  return MM_OK;
+}
+
+// dtype x D dispatch ---------------------------------------------------------
+#define MM_DISPATCH_D(T, d, CALL)                \
+  switch (d) {                                   \
+    case 2: { constexpr int D = 2; return CALL; } \
+    case 3: { constexpr int D = 3; return CALL; } \
+    case 4: { constexpr int D = 4; return CALL; } \
+    case 5: { constexpr int D = 5; return CALL; } \
+    default: return MM_ERR_UNSUPPORTED;          \
+  }
+
+#define MM_DISPATCH(dtype, d, CALL_T)                                 \
+  do {                                                                \
+    if ((dtype) == MM_F32) { using T = float; MM_DISPATCH_D(T, d, CALL_T) } \
+    if ((dtype) == MM_F64) { using T = double; MM_DISPATCH_D(T, d, CALL_T) } \
+    return MM_ERR_ARG;                                                \
+  } while (0)
+
+template <typename T, int D, typename K, typename... A>
+int launch_pointwise(K kernel, int64_t m, hipStream_t st, A... args) {
+  if (m <= 0) return MM_OK;
+  const int bs = 128;
+  kernel<<<dim3((unsigned)((m + bs - 1) / bs)), dim3(bs), 0, st>>>(args...);
+  MM_CHECK_LAUNCH();
+  return MM_OK;
+}
+
+}  // namespace mm
+
+using namespace mm;
+
+extern "C" {
+
+int mm_spd_max_dim(void) { return kSpdMaxD; }
+
+size_t mm_spd_pdist_ws_bytes(int dtype, int64_t n, int d) {
+  const int np = d * (d + 1) / 2;
+  return dtype == MM_F64 ? Ws<double>::bytes(n, np) : Ws<float>::bytes(n, np);
+}
+
+int mm_spd_pdist_fwd(int dtype, const void* x, int64_t n, int d, int64_t row_begin, int64_t row_end, int squared,
+                     double wmin, double wmax, void* out, void* ws, int flags, mm_stream_t stream) {
+  if (!x || !ws || n < 0 || row_begin < 0 || row_end > n || row_begin > row_end || n > (1 << 30)) return MM_ERR_ARG;
+  if (n == 0) return MM_OK;
+  if (!out && mm_pair_offset(n, row_end) > mm_pair_offset(n, row_begin)) return MM_ERR_ARG;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  MM_DISPATCH(dtype, d,
+              (spd_pdist_fwd_t<T, D>(static_cast<const T*>(x), n, row_begin, row_end, squared, wmin, wmax,
+                                     static_cast<T*>(out), ws, flags, st)));
+}
+
+int mm_spd_pdist_bwd(int dtype, const void* x, const void* g, int64_t n, int d, int64_t row_begin, int64_t row_end,
+                     int squared, double wmin, double wmax, void* grad_x, void* ws, int flags, mm_stream_t stream) {
+  if (!x || !ws || !grad_x || n < 0 || row_begin < 0 || row_end > n || row_begin > row_end || n > (1 << 30))
+    return MM_ERR_ARG;
+  if (n == 0) return MM_OK;
+  if (!g && mm_pair_offset(n, row_end) > mm_pair_offset(n, row_begin)) return MM_ERR_ARG;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  MM_DISPATCH(dtype, d,
+              (spd_pdist_bwd_t<T, D>(static_cast<const T*>(x), static_cast<const T*>(g), n, row_begin, row_end,
+                                     squared, wmin, wmax, static_cast<T*>(grad_x), ws, flags, st)));
+}
+
+int mm_spd_status(const void* ws, int* host_status, mm_stream_t stream) {
+  if (!ws || !host_status) return MM_ERR_ARG;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  hipError_t e = hipMemcpyAsync(host_status, ws, sizeof(int), hipMemcpyDeviceToHost, st);
+  if (e != hipSuccess) return int(e);
+  e = hipStreamSynchronize(st);
+  return e == hipSuccess ? MM_OK : int(e);
+}
+
+int mm_spd_dist_fwd(int dtype, const void* x, const void* y, int64_t m, int d, int squared, double wmin, double wmax,
+                    void* out, mm_stream_t stream) {
+  if (m < 0 || (m > 0 && (!x || !y || !out))) return MM_ERR_ARG;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  MM_DISPATCH(dtype, d,
+              (launch_pointwise<T, D>(spd_dist_fwd_kernel<T, D>, m, st, static_cast<const T*>(x),
+                                      static_cast<const T*>(y), m, squared, T(wmin), T(wmax), static_cast<T*>(out))));
+}
+
+int mm_spd_dist_bwd(int dtype, const void* x, const void* y, const void* g, int64_t m, int d, int squared,
+                    double wmin, double wmax, void* grad_x, void* grad_y, mm_stream_t stream) {
+  if (m < 0 || (m > 0 && (!x || !y || !g || !grad_x || !grad_y))) return MM_ERR_ARG;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  MM_DISPATCH(dtype, d,
+              (launch_pointwise<T, D>(spd_dist_bwd_kernel<T, D>, m, st, static_cast<const T*>(x),
+                                      static_cast<const T*>(y), static_cast<const T*>(g), m, squared, T(wmin),
+                                      T(wmax), static_cast<T*>(grad_x), static_cast<T*>(grad_y))));
+}
+
+int mm_spd_map(int dtype, int op, const void* x, const void* u, int64_t m, int d, double wmin, double wmax, void* out,
+               mm_stream_t stream) {
+  if (m < 0 || op < 0 || op > MM_SPD_PROJU || (m > 0 && (!x || !out))) return MM_ERR_ARG;
+  if (m > 0 && op != MM_SPD_PROJX && !u) return MM_ERR_ARG;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  MM_DISPATCH(dtype, d,
+              (launch_pointwise<T, D>(spd_map_kernel<T, D>, m, st, op, static_cast<const T*>(x),
+                                      static_cast<const T*>(u), m, T(wmin), T(wmax), static_cast<T*>(out))));
+}
+
+int mm_spd_norm(int dtype, const void* x, const void* u, int64_t m, int d, int squared, void* out,
+                mm_stream_t stream) {
+  if (m < 0 || (m > 0 && (!x || !u || !out))) return MM_ERR_ARG;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  MM_DISPATCH(dtype, d,
+              (launch_pointwise<T, D>(spd_norm_kernel<T, D>, m, st, static_cast<const T*>(x),
+                                      static_cast<const T*>(u), m, squared, static_cast<T*>(out))));
+}
+
+int mm_spd_rsgd_step(int dtype, const void* x, const void* egrad, int64_t m, int d, double lr, double max_grad_norm,
+                     int exact, void* x_new, mm_stream_t stream) {
+  if (m < 0 || (m > 0 && (!x || !egrad || !x_new))) return MM_ERR_ARG;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  MM_DISPATCH(dtype, d,
+              (launch_pointwise<T, D>(spd_rsgd_step_kernel<T, D>, m, st, static_cast<const T*>(x),
+                                      static_cast<const T*>(egrad), m, T(lr), T(max_grad_norm), exact,
+                                      static_cast<T*>(x_new))));
+}
+
+}  // extern "C"

@@ -1,0 +1,11 @@
+"""graphembed — MI355X-native implementation of the pairwise manifold-distance
+training path of dalab/matrix-manifolds, behind the reference's own dotted names
+(`graphembed.manifolds.*`, `graphembed.modules.*`, `graphembed.optim.*`,
+`graphembed.objectives.*`).  Arithmetic runs in libmm_manifolds.so (gfx950)."""
+from . import utils
+from . import manifolds
+from . import modules
+from . import objectives
+from . import optim
+
+__version__ = '0.1.0'

@@ -1,0 +1,132 @@
+"""ctypes binding of libmm_manifolds.so (the C ABI in include/mm_manifolds.h).
+
+There is exactly one compute backend: the hand-written gfx950 library.  If it is
+missing or a tensor is not on the GPU, calls fail loudly — there is no CPU
+fallback (use the reference itself for CPU work).
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), 'lib', 'libmm_manifolds.so')
+
+MM_F32, MM_F64 = 0, 1
+MM_WS_PREPARED = 1
+EUCLIDEAN, LORENTZ, SPHERE = 0, 1, 2
+SPD_EGRAD2RGRAD, SPD_EXP, SPD_RETR, SPD_LOG, SPD_PROJX, SPD_PROJU = range(6)
+
+_c = ctypes
+_vp, _i, _i64, _dbl, _sz = _c.c_void_p, _c.c_int, _c.c_int64, _c.c_double, _c.c_size_t
+
+# name -> (restype, argtypes); mirrors include/mm_manifolds.h one to one
+SIGNATURES = {
+    'mm_abi_version': (_i, []),
+    'mm_target_arch': (_c.c_char_p, []),
+    'mm_pair_offset': (_i64, [_i64, _i64]),
+    'mm_shard_rows': (_i, [_i64, _i, _i, _c.POINTER(_i64), _c.POINTER(_i64)]),
+    'mm_spd_max_dim': (_i, []),
+    'mm_spd_pdist_ws_bytes': (_sz, [_i, _i64, _i]),
+    'mm_spd_pdist_fwd': (_i, [_i, _vp, _i64, _i, _i64, _i64, _i, _dbl, _dbl, _vp, _vp, _i, _vp]),
+    'mm_spd_pdist_bwd': (_i, [_i, _vp, _vp, _i64, _i, _i64, _i64, _i, _dbl, _dbl, _vp, _vp, _i, _vp]),
+    'mm_spd_status': (_i, [_vp, _c.POINTER(_i), _vp]),
+    'mm_spd_dist_fwd': (_i, [_i, _vp, _vp, _i64, _i, _i, _dbl, _dbl, _vp, _vp]),
+    'mm_spd_dist_bwd': (_i, [_i, _vp, _vp, _vp, _i64, _i, _i, _dbl, _dbl, _vp, _vp, _vp]),
+    'mm_spd_map': (_i, [_i, _i, _vp, _vp, _i64, _i, _dbl, _dbl, _vp, _vp]),
+    'mm_spd_norm': (_i, [_i, _vp, _vp, _i64, _i, _i, _vp, _vp]),
+    'mm_spd_rsgd_step': (_i, [_i, _vp, _vp, _i64, _i, _dbl, _dbl, _i, _vp, _vp]),
+}
+
+
+class BackendError(RuntimeError):
+    pass
+
+
+def dtype_code(t):
+    if t.dtype == torch.float32:
+        return MM_F32
+    if t.dtype == torch.float64:
+        return MM_F64
+    raise TypeError(f'matrix-manifolds_amd kernels exist for float32/float64, got {t.dtype}')
+
+
+class HipLibrary:
+    """Thin, typed view of the shared library. Every call checks the return code."""
+
+    def __init__(self, path=LIB_PATH):
+        if not os.path.isfile(path):
+            raise BackendError(
+                f'{path} not found: build it with `python __graft_entry__.py` (hipcc, gfx950). '
+                'There is no CPU fallback.')
+        self.path = path
+        self._lib = ctypes.CDLL(path)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(self._lib, name)  # AttributeError if the .so lacks a declared symbol
+            fn.restype, fn.argtypes = res, args
+        arch = self._lib.mm_target_arch().decode()
+        if arch != 'gfx950':
+            raise BackendError(f'library built for {arch}, expected gfx950')
+
+    def call(self, name, *args):
+        rc = getattr(self._lib, name)(*args)
+        if rc != 0:
+            kind = {-1: 'invalid argument', -2: 'unsupported size/dtype'}.get(rc, f'hipError_t {rc}')
+            raise BackendError(f'{name} failed: {kind}')
+
+    def raw(self, name):
+        return getattr(self._lib, name)
+
+
+_instance = None
+
+
+def lib():
+    """The process-wide library handle (loaded on first use; raises if absent)."""
+    global _instance
+    if _instance is None:
+        _instance = HipLibrary()
+    return _instance
+
+
+def require_gpu(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise BackendError(
+                'matrix-manifolds_amd runs on MI355X only: got a CPU tensor. Move the embedding to '
+                "'cuda' (torch-ROCm device); CPU execution is the reference's job.")
+
+
+def ptr(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def stream_of(t):
+    return ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+
+
+# ---- pair-list geometry (pure host arithmetic; usable without a GPU) ----------
+def pair_offset(n, row):
+    return row * (2 * n - row - 1) // 2
+
+
+def shard_rows(n, world, rank):
+    """Row range of shard ``rank``: contiguous, balanced by pair count.
+
+    Same rule as ``mm_shard_rows`` (csrc/common.hip), restated in Python so that
+    host logic can be tested without the library."""
+    P = n * (n - 1) // 2
+
+    def first_row_at_or_after(target):
+        lo, hi = 0, n
+        while lo < hi:
+            mid = (lo + hi) // 2
+            if pair_offset(n, mid) >= target:
+                hi = mid
+            else:
+                lo = mid + 1
+        return lo
+
+    rb = 0 if rank == 0 else first_row_at_or_after(P * rank // world)
+    re = n if rank == world - 1 else first_row_at_or_after(P * (rank + 1) // world)
+    return rb, re

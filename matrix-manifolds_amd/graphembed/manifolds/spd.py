@@ -1,0 +1,238 @@
+"""SPD(n) with the affine-invariant metric, on the gfx950 kernels.
+
+Mirror of graphembed/graphembed/manifolds/spd.py:21-243 (same constructor,
+methods, shapes and clamps).  Differences, all documented in DESIGN.md §6:
+
+* one eigensolver for every n (cyclic Jacobi in registers) instead of the
+  eps-fudged closed forms for n=2,3 and a CPU LAPACK offload for n>=4 —
+  `fast_symeig` / `fast_chol` are accepted and ignored;
+* the gradient of `pdist`/`dist` is the symmetric part of what the reference's
+  autograd returns (the reference reads only one triangle and yields a
+  non-symmetric matrix; everything downstream symmetrises it, spd.py:119-135);
+* the Stein-divergence path (`use_stein_div=True`) is not on this hot path.
+"""
+import math
+
+import torch
+
+from graphembed import _backend as B
+from graphembed.manifolds.base import Manifold, _like
+from graphembed.utils import squareform0
+
+
+def _flat(t, n):
+    """(…, n, n) -> contiguous (m, n, n)."""
+    return t.reshape(-1, n, n).contiguous()
+
+
+class _SpdPdist(torch.autograd.Function):
+    """pdist over rows [row_begin,row_end) of the pair list; backward gives the
+    full-shape partial gradient of this shard."""
+
+    @staticmethod
+    def forward(ctx, x, n_mat, squared, wmin, wmax, row_begin, row_end, check_pd):
+        B.require_gpu(x)
+        lib = B.lib()
+        xc = x.detach().contiguous()
+        n = xc.shape[0]
+        dt = B.dtype_code(xc)
+        npairs = B.pair_offset(n, row_end) - B.pair_offset(n, row_begin)
+        with torch.cuda.device(xc.device):
+            ws = torch.empty(lib.raw('mm_spd_pdist_ws_bytes')(dt, n, n_mat), dtype=torch.uint8,
+                             device=xc.device)
+            out = torch.empty(npairs, dtype=xc.dtype, device=xc.device)
+            lib.call('mm_spd_pdist_fwd', dt, B.ptr(xc), n, n_mat, row_begin, row_end, int(squared),
+                     wmin, wmax, B.ptr(out), B.ptr(ws), 0, B.stream_of(xc))
+            if check_pd:
+                import ctypes
+                st = ctypes.c_int(0)
+                lib.call('mm_spd_status', B.ptr(ws), ctypes.byref(st), B.stream_of(xc))
+                if st.value:
+                    raise torch.linalg.LinAlgError(
+                        f'pdist: {st.value} input matrices are not positive-definite')
+        ctx.save_for_backward(xc)
+        ctx.ws = ws
+        ctx.args = (n_mat, squared, wmin, wmax, row_begin, row_end)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        xc, = ctx.saved_tensors
+        n_mat, squared, wmin, wmax, row_begin, row_end = ctx.args
+        lib = B.lib()
+        g = g.contiguous()
+        n = xc.shape[0]
+        with torch.cuda.device(xc.device):
+            grad = torch.empty_like(xc)
+            lib.call('mm_spd_pdist_bwd', B.dtype_code(xc), B.ptr(xc), B.ptr(g), n, n_mat, row_begin,
+                     row_end, int(squared), wmin, wmax, B.ptr(grad), B.ptr(ctx.ws),
+                     B.MM_WS_PREPARED, B.stream_of(xc))
+        return grad, None, None, None, None, None, None, None
+
+
+class _SpdDist(torch.autograd.Function):
+
+    @staticmethod
+    def forward(ctx, x, y, n_mat, squared, wmin, wmax):
+        B.require_gpu(x, y)
+        xc, yc = _flat(x.detach(), n_mat), _flat(y.detach(), n_mat)
+        m = xc.shape[0]
+        with torch.cuda.device(xc.device):
+            out = torch.empty(m, dtype=xc.dtype, device=xc.device)
+            B.lib().call('mm_spd_dist_fwd', B.dtype_code(xc), B.ptr(xc), B.ptr(yc), m, n_mat,
+                         int(squared), wmin, wmax, B.ptr(out), B.stream_of(xc))
+        ctx.save_for_backward(xc, yc)
+        ctx.args = (n_mat, squared, wmin, wmax, x.shape, y.shape)
+        return out.reshape(x.shape[:-2])
+
+    @staticmethod
+    def backward(ctx, g):
+        xc, yc = ctx.saved_tensors
+        n_mat, squared, wmin, wmax, xs, ys = ctx.args
+        g = g.reshape(-1).contiguous()
+        with torch.cuda.device(xc.device):
+            gx, gy = torch.empty_like(xc), torch.empty_like(yc)
+            B.lib().call('mm_spd_dist_bwd', B.dtype_code(xc), B.ptr(xc), B.ptr(yc), B.ptr(g),
+                         xc.shape[0], n_mat, int(squared), wmin, wmax, B.ptr(gx), B.ptr(gy),
+                         B.stream_of(xc))
+        return gx.reshape(xs), gy.reshape(ys), None, None, None, None
+
+
+class SymmetricPositiveDefinite(Manifold):
+
+    def __init__(self, n, *, fast_symeig=True, fast_chol=True, use_stein_div=False, wmin=1e-8,
+                 wmax=1e8, check_pd=False):
+        if use_stein_div:
+            raise NotImplementedError(
+                'the Stein-divergence path (spd.py:183-194) is outside the accelerated hot path')
+        self.n = n
+        self.wmin = wmin
+        self.wmax = wmax
+        self.check_pd = check_pd
+
+    # -- Vec(.) of Pennec et al. (spd.py:66-81)
+    @staticmethod
+    def to_vec(x):
+        n = x.shape[-1]
+        fact = x.new_full((n, n), math.sqrt(2)).fill_diagonal_(1.0)
+        return squareform0(fact * x)
+
+    @staticmethod
+    def from_vec(x_vec):
+        x = squareform0(x_vec / math.sqrt(2))
+        x.diagonal(dim1=-2, dim2=-1).mul_(math.sqrt(2))
+        return x
+
+    @property
+    def ndim(self):
+        return 2
+
+    @property
+    def dim(self):
+        return self.n * (self.n + 1) // 2
+
+    def zero(self, *shape, out=None):
+        return torch.eye(self.n, **_like(out)).repeat(*shape, 1, 1)
+
+    def zero_vec(self, *shape, out=None):
+        return torch.zeros(*shape, self.n, self.n, **_like(out))
+
+    # -- per-point maps ------------------------------------------------------
+    def _map(self, op, x, u=None):
+        B.require_gpu(x, u)
+        if torch.is_grad_enabled() and (x.requires_grad or (u is not None and u.requires_grad)):
+            raise NotImplementedError(
+                'SPD exp/log/retr/projx are optimizer-side maps (torch.no_grad); '
+                'only dist/pdist are differentiable on the HIP path')
+        shape = torch.broadcast_shapes(x.shape, u.shape) if u is not None else x.shape
+        xc = _flat(x.expand(shape), self.n)
+        uc = _flat(u.expand(shape), self.n) if u is not None else None
+        with torch.cuda.device(xc.device):
+            out = torch.empty_like(xc)
+            B.lib().call('mm_spd_map', B.dtype_code(xc), op, B.ptr(xc), B.ptr(uc), xc.shape[0],
+                         self.n, self.wmin, self.wmax, B.ptr(out), B.stream_of(xc))
+        return out.reshape(shape)
+
+    def symeig(self, x):
+        """Eigenvalues (ascending) — used by the reference's monitor (monitor.py:39-45)."""
+        return torch.linalg.eigvalsh(x)
+
+    def inner(self, x, u, v, keepdim=False):  # spd.py:96-106: tr(X^-1 U X^-1 V)
+        assert not x.requires_grad and not u.requires_grad and not v.requires_grad
+        p = self.norm(x, u + v, squared=True, keepdim=keepdim)
+        q = self.norm(x, u - v, squared=True, keepdim=keepdim)
+        return 0.25 * (p - q)
+
+    def norm(self, x, u, squared=False, keepdim=False):  # spd.py:113-117
+        B.require_gpu(x, u)
+        shape = torch.broadcast_shapes(x.shape, u.shape)
+        xc, uc = _flat(x.detach().expand(shape), self.n), _flat(u.detach().expand(shape), self.n)
+        with torch.cuda.device(xc.device):
+            out = torch.empty(xc.shape[0], dtype=xc.dtype, device=xc.device)
+            B.lib().call('mm_spd_norm', B.dtype_code(xc), B.ptr(xc), B.ptr(uc), xc.shape[0], self.n,
+                         int(squared), B.ptr(out), B.stream_of(xc))
+        out = out.reshape(shape[:-2])
+        return out.reshape(*out.shape, 1, 1) if keepdim else out
+
+    def proju(self, x, u, inplace=False):  # spd.py:119-124
+        u_new = 0.5 * (u + u.transpose(-2, -1))
+        if not inplace:
+            return u_new
+        u.set_(u_new)
+        return u
+
+    def projx(self, x, inplace=False):  # spd.py:126-132
+        x_new = self._map(B.SPD_PROJX, x.detach() if inplace else x)
+        if not inplace:
+            return x_new
+        x.set_(x_new)
+        return x
+
+    def egrad2rgrad(self, x, u):  # spd.py:134-135
+        return self._map(B.SPD_EGRAD2RGRAD, x, u)
+
+    def exp(self, x, u):  # spd.py:137-144
+        return self._map(B.SPD_EXP, x, u)
+
+    def retr(self, x, u):  # spd.py:146-154
+        return self._map(B.SPD_RETR, x, u)
+
+    def log(self, x, y):  # spd.py:156-161
+        return self._map(B.SPD_LOG, x, y)
+
+    # -- distances -------------------------------------------------------------
+    def dist(self, x, y, squared=False, keepdim=False):  # spd.py:171-173
+        shape = torch.broadcast_shapes(x.shape, y.shape)
+        d = _SpdDist.apply(x.expand(shape), y.expand(shape), self.n, squared, self.wmin, self.wmax)
+        return d.reshape(*d.shape, 1, 1) if keepdim else d
+
+    def pdist(self, x, squared=False, rows=None):  # spd.py:175-181
+        """All-pairs distances in row-major upper-triangle order.
+
+        `rows=(row_begin,row_end)` restricts the result to the contiguous slice of the
+        pair list owned by one shard (see graphembed.parallel)."""
+        assert x.ndim == 3
+        rb, re = (0, x.shape[0]) if rows is None else rows
+        return _SpdPdist.apply(x, self.n, squared, self.wmin, self.wmax, rb, re, self.check_pd)
+
+    def transp(self, x, y, u):  # spd.py:196-199
+        return u
+
+    def rand(self, *shape, out=None, ir=1e-1):  # spd.py:201-208
+        eyes = self.zero(*shape, out=out)
+        u = torch.randn(*shape, self.dim, dtype=eyes.dtype, device=eyes.device)
+        u.div_(u.norm(dim=-1, keepdim=True)).mul_(ir)
+        with torch.no_grad():
+            return self.exp(eyes, self.from_vec(u))
+
+    def randvec(self, x, norm=1):  # spd.py:210-221: X^1/2 U X^1/2
+        shape = x.shape[:-2] + (self.dim, )
+        u = torch.randn(shape, dtype=x.dtype, device=x.device)
+        u.div_(u.norm(dim=-1, keepdim=True)).mul_(norm)
+        u = self.from_vec(u)
+        w, v = torch.linalg.eigh(x)
+        xs = (v * w.clamp(self.wmin, self.wmax).sqrt().unsqueeze(-2)) @ v.transpose(-2, -1)
+        return xs @ u @ xs.transpose(-2, -1)
+
+    def __str__(self):
+        return 'Manifold of {n}x{n} positive definite matrices'.format(n=self.n)

@@ -1,0 +1,92 @@
+"""Embedding containers that call the Manifold API — counterparts of
+graphembed/graphembed/modules.py:9-105 (state_dict keys `xs.k` / `scales.k` kept so
+checkpoints interchange with the reference)."""
+import torch
+from torch.nn.functional import softplus
+
+
+class ManifoldParameter(torch.nn.Parameter):
+    """A Parameter that knows the manifold it lives on (modules.py:9-23)."""
+
+    def __new__(cls, data=None, manifold=None, requires_grad=True):
+        if data is None:
+            data = torch.empty(0)
+        instance = torch.Tensor._make_subclass(cls, data, requires_grad)
+        instance.manifold = manifold
+        return instance
+
+    def proj_(self):
+        self.manifold.projx(self, inplace=True)
+
+    def __repr__(self):
+        return 'Parameter on {} containing:\n'.format(self.manifold) + torch.Tensor.__repr__(self)
+
+
+class ManifoldEmbedding(torch.nn.Module):
+    """n points on a product of manifolds with learnable per-factor scales
+    (modules.py:42-91).  Parameters are created with `manifold.rand(n)` on the
+    default device, as in the reference; move with `.to(device)`."""
+
+    def __init__(self, n, manifolds):
+        super().__init__()
+        self.n = n
+        self.n_components = len(manifolds)
+        self.manifolds = manifolds
+        self.xs = torch.nn.ParameterList(
+            [ManifoldParameter(data=man.rand(n), manifold=man) for man in manifolds])
+        # softplus(0.5) ~ 1 (modules.py:57-59)
+        self.scales = torch.nn.ParameterList(
+            [torch.nn.Parameter(torch.tensor(0.5)) for _ in manifolds])
+
+    def _apply(self, fn, *a, **k):
+        # Module.to()/cuda() rebuild Parameters; keep the manifold tag on them
+        mans = [p.manifold for p in self.xs]
+        out = super()._apply(fn, *a, **k)
+        for p, m in zip(self.xs, mans):
+            p.manifold = m
+        return out
+
+    @property
+    def device(self):
+        return self.xs[0].device
+
+    @property
+    def curvature_params(self):
+        return self.scales
+
+    def burnin(self, value=True):  # modules.py:36-39
+        for p in self.curvature_params:
+            p.requires_grad_(not value)
+
+    @torch.no_grad()
+    def perturb(self, norm):
+        for x, man in zip(self.xs, self.manifolds):
+            x.set_(man.retr(x, man.randvec(x, norm)))
+
+    @torch.no_grad()
+    def stabilize(self):
+        for x in self.xs:
+            x.proj_()
+
+    def compute_dists(self, i=None):
+        """sum_k softplus(s_k) * pdist_k(x_k[i], squared=True) — modules.py:84-88."""
+        return sum(
+            softplus(s) * man.pdist(x if i is None else x[i], squared=True)
+            for x, s, man in zip(self.xs, self.scales, self.manifolds))
+
+    def __len__(self):
+        return self.n
+
+
+class BatchedObjective(torch.nn.Module):
+    """loss(dataset[idx], embedding.compute_dists(idx)) — modules.py:94-105."""
+
+    def __init__(self, objective_fn, dataset, embedding):
+        super().__init__()
+        self.objective_fn = objective_fn
+        self.dataset = dataset
+        self.embedding = embedding
+
+    def forward(self, indices, *args, **kwargs):
+        return self.objective_fn(self.dataset[indices].to(self.embedding.device),
+                                 self.embedding.compute_dists(indices), *args, **kwargs)

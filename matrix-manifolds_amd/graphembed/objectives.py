@@ -1,0 +1,57 @@
+"""Losses on vectors of *squared* distances used by the path's configs —
+counterparts of graphembed/graphembed/objectives.py:16-45 (Stress, Quotient).
+The KL / curvature losses are outside the accelerated path."""
+import abc
+
+import torch
+
+
+class ObjectiveFunction:
+
+    @abc.abstractmethod
+    def __call__(self, gdists, mdists, *, epoch, alpha):
+        pass
+
+
+class QuotientLoss(ObjectiveFunction):
+    """|m/(a g) - 1| (+ |a g/(m + 1/(epoch+1)) - 1|), summed (objectives.py:16-36)."""
+
+    def __init__(self, inc_l1=True, inc_l2=True):
+        if not inc_l1 and not inc_l2:
+            raise ValueError('At least one of the terms must be included.')
+        self.inc_l1 = inc_l1
+        self.inc_l2 = inc_l2
+
+    def __call__(self, gdists, mdists, *, epoch, alpha):
+        gdists = gdists * alpha
+        loss = 0
+        if self.inc_l1:
+            loss = loss + (mdists / gdists - 1.0).abs().sum()
+        if self.inc_l2:
+            loss = loss + (gdists / (mdists + 1.0 / (epoch + 1)) - 1.0).abs().sum()
+        return loss
+
+    def __str__(self):
+        return 'quotient_loss'
+
+
+class StressLoss(ObjectiveFunction):
+    """sum (m - g)^2 (objectives.py:39-45)."""
+
+    def __call__(self, gdists, mdists, *, epoch=None, alpha=None):
+        return torch.pow(mdists - gdists, 2).sum()
+
+    def __str__(self):
+        return 'stress_loss'
+
+
+class Sum(ObjectiveFunction):
+
+    def __init__(self, *fns):
+        self.fns = fns
+
+    def __call__(self, *args, **kwargs):
+        return sum(fn(*args, **kwargs) for fn in self.fns)
+
+    def __str__(self):
+        return '__'.join(str(f) for f in self.fns)

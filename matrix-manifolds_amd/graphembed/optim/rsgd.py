@@ -1,0 +1,85 @@
+"""Riemannian SGD over the Manifold API — counterpart of
+graphembed/graphembed/optim/rsgd.py:10-82 (same param-group keys and update order:
+egrad2rgrad -> per-point norm clip -> momentum/transport or plain exp|retr step)."""
+import torch
+from torch.optim.optimizer import required
+
+from graphembed.modules import ManifoldParameter
+
+
+class _Flat:
+    """Flat parameters (scales, curvatures): the reference falls back to Euclidean(1)
+    (rsgd.py:7,56-59); the arithmetic is trivial and stays in torch."""
+
+    def egrad2rgrad(self, x, u):
+        return u
+
+    def norm(self, x, u, keepdim=False):
+        return (u * u).sum(-1, keepdim=keepdim).clamp(min=1e-8).sqrt()
+
+    def exp(self, x, u):
+        return x + u
+
+    retr = exp
+
+    def transp(self, x, y, u):
+        return u
+
+
+_default_manifold = _Flat()
+
+
+class RiemannianSGD(torch.optim.Optimizer):
+
+    def __init__(self, params, lr=required, momentum=0, dampening=0, max_grad_norm=None,
+                 exact=False):
+        if momentum < 0.0:
+            raise ValueError('Invalid momentum value: {}'.format(momentum))
+        defaults = dict(lr=lr, momentum=momentum, dampening=dampening,
+                        max_grad_norm=max_grad_norm, exact=exact)
+        super().__init__(params, defaults)
+
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            loss = closure()
+        with torch.no_grad():
+            for group in self.param_groups:
+                self._step(group)
+        return loss
+
+    def _step(self, group):
+        lr, momentum, dampening = group['lr'], group['momentum'], group['dampening']
+        max_grad_norm = group['max_grad_norm']
+        for x in group['params']:
+            grad = x.grad
+            if grad is None:
+                continue
+            state = self.state[x]
+            if len(state) == 0 and momentum > 0:
+                state['momentum_buffer'] = grad.clone()
+            if isinstance(x, ManifoldParameter) and x.manifold is not None:
+                manifold = x.manifold
+            else:
+                manifold = _default_manifold
+
+            # one fused kernel per parameter when the manifold offers it
+            fused = getattr(manifold, 'rsgd_step', None)
+            if momentum == 0 and fused is not None:
+                x.set_(fused(x, grad, lr=lr, max_grad_norm=max_grad_norm, exact=group['exact']))
+                continue
+
+            retr = manifold.exp if group['exact'] else manifold.retr
+            grad = manifold.egrad2rgrad(x, grad)
+            if max_grad_norm is not None:
+                grad_norm = manifold.norm(x, grad, keepdim=True)
+                grad = grad * torch.clamp(max_grad_norm / grad_norm, max=1.0)
+            if momentum > 0:
+                buf = state['momentum_buffer']
+                buf.mul_(momentum).add_(grad, alpha=1 - dampening)
+                new_x = retr(x, -lr * buf)
+                new_buf = manifold.transp(x, new_x, buf)
+                x.set_(new_x)
+                buf.set_(new_buf)
+            else:
+                x.set_(retr(x, -lr * grad))

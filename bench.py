@@ -1,0 +1,186 @@
+#!/usr/bin/env python3
+"""Headline benchmark: pairwise manifold-dist/sec (fwd+bwd), SPD(3), 5k-node graph.
+
+One step = one pass of the hot path over all pairs of the synthetic embedding:
+    d2 = SPD(3).pdist(x, squared=True);  d2.backward(g)
+(`g` a fixed random upstream gradient, so no loss is fused in — SURVEY.md §8d),
+with the pair list sharded by rows across the ranks and, for N > 1, ONE RCCL
+all-reduce(sum) of the embedding gradient inside the timed region.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+N > 1 is launched by torch.distributed.run (one rank per GPU).  Rank 0 prints one
+JSON line.  Inputs are resident in HBM before the timed region starts.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, 'matrix-manifolds_amd')):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import torch  # noqa: E402
+
+N_NODES = 5000
+DIM = 3
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+FP32_VALU_PEAK_TFLOPS = 157.3
+
+
+def synthetic_spd(n, d, seed, device):
+    """SPD.rand (spd.py:201-208): X = expm(U), ||vec U|| = 0.1 — the reference's init."""
+    gen = torch.Generator().manual_seed(seed)
+    m = d * (d + 1) // 2
+    u = torch.randn(n, m, generator=gen, dtype=torch.float64)
+    u = u / u.norm(dim=-1, keepdim=True) * 0.1
+    iu = torch.triu_indices(d, d)
+    U = torch.zeros(n, d, d, dtype=torch.float64)
+    U[:, iu[0], iu[1]] = u / 2 ** 0.5
+    U[:, iu[1], iu[0]] = u / 2 ** 0.5
+    k = torch.arange(d)
+    U[:, k, k] *= 2 ** 0.5
+    X = torch.linalg.matrix_exp(U)
+    P = n * (n - 1) // 2
+    g = torch.randn(P, generator=gen, dtype=torch.float32)
+    return X.float().to(device), g.to(device)
+
+
+def cpu_baseline(seed):
+    """The oracle port (reference-faithful op sequence) on this host's cores, on a
+    bounded sample: n=2500 nodes (3.1 M pairs) of the same workload, best of 3."""
+    from oracle import ref_port
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    n = 2500
+    x, g = synthetic_spd(n, DIM, seed, 'cpu')
+    man = ref_port.SPD(DIM)
+    best = float('inf')
+    for it in range(4):
+        xr = x.clone().requires_grad_()
+        t0 = time.perf_counter()
+        d2 = man.pdist(xr, squared=True)
+        d2.backward(g)
+        dt = time.perf_counter() - t0
+        if it:
+            best = min(best, dt)
+    P = n * (n - 1) // 2
+    return {'value': P / best, 'unit': 'pairs/s', 'cores': torch.get_num_threads(), 'kind': 'port',
+            'sample': f'SPD(3) fp32 reference-init, n={n} ({P} pairs), fwd+bwd, best of 3; '
+                      f'oracle/ref_port.py (torch CPU, reference op sequence)'}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=50)
+    ap.add_argument('--warmup', type=int, default=10)
+    ap.add_argument('--n', type=int, default=N_NODES)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-prof', action='store_true', help='no HIP-event bracketing of the kernels')
+    args = ap.parse_args()
+
+    rank = int(os.environ.get('RANK', 0))
+    local_rank = int(os.environ.get('LOCAL_RANK', 0))
+    world = int(os.environ.get('WORLD_SIZE', 1))
+    if world != args.gpus:
+        raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run')
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group('nccl', device_id=dev)
+
+    from graphembed import _backend as B
+    from graphembed.manifolds import SymmetricPositiveDefinite
+    lib = B.lib()
+
+    n = args.n
+    x, g = synthetic_spd(n, DIM, 42, dev)           # replicated embedding, same on every rank
+    rb, re = B.shard_rows(n, world, rank)
+    lo, hi = B.pair_offset(n, rb), B.pair_offset(n, re)
+    g_local = g[lo:hi].contiguous()
+    del g
+    man = SymmetricPositiveDefinite(DIM)
+    x.requires_grad_()
+
+    def step():
+        x.grad = None
+        d2 = man.pdist(x, squared=True, rows=(rb, re))
+        d2.backward(g_local)
+        if world > 1:
+            dist.all_reduce(x.grad)               # the single collective of a step
+        return d2
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    prof = not args.no_prof
+    lib.call('mm_prof_enable', int(prof))
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    lib.call('mm_prof_enable', 0)
+
+    kern = {}
+    for name, kid in (('fwd', 0), ('bwd', 1)):
+        cnt, ms = ctypes.c_int64(0), ctypes.c_double(0.0)
+        lib.call('mm_prof_collect', kid, ctypes.byref(cnt), ctypes.byref(ms))
+        kern[name] = (ms.value / cnt.value * 1e-3) if cnt.value else None
+
+    t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = t.item()
+
+    if rank == 0:
+        P = n * (n - 1) // 2
+        pairs_local = hi - lo
+        esz = 4
+        out = {
+            'metric': 'pairwise manifold-dist/sec (fwd+bwd), SPD(3) 5k-node',
+            'value': P * args.steps / elapsed, 'unit': 'pairs/s',
+            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': elapsed / args.steps * 1e3,
+            'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None,
+            'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': f'grqc-class graph, n={n} nodes -> SPD(3) affine-invariant, all '
+                                   f'{P} pairs, squared distance + backward, reference init (||log X||=0.1)',
+                       'pairs_per_step': P, 'parallelism': f'pair-rows sharded x{world}, 1 all-reduce'},
+        }
+        if kern['bwd']:
+            # dominant kernel: spd_pdist_bwd.  Algorithmic HBM bytes per launch: read g (4 B per
+            # pair) + node factors in (2*6 floats) + accumulators out (2*6 floats) per node.
+            by = pairs_local * esz + n * 24 * esz
+            flops = pairs_local * 850.0  # ~850 fp32 flop per pair in bwd
+            out['roofline'] = {'bound': 'hbm', 'kernel': 'spd_pdist_bwd_kernel<float,3>',
+                               'achieved': by / kern['bwd'] / 1e9, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                               'frac': by / kern['bwd'] / 1e9 / HBM_PEAK_GBS, 'traffic': None,
+                               'avg_launch_us': kern['bwd'] * 1e6,
+                               'valu_tflops': flops / kern['bwd'] / 1e12,
+                               'valu_frac': flops / kern['bwd'] / 1e12 / FP32_VALU_PEAK_TFLOPS}
+            if kern['fwd']:
+                byf = pairs_local * esz + n * 12 * esz
+                out['roofline_fwd'] = {'bound': 'hbm', 'kernel': 'spd_pdist_fwd_kernel<float,3>',
+                                       'achieved': byf / kern['fwd'] / 1e9, 'peak': HBM_PEAK_GBS,
+                                       'unit': 'GB/s', 'frac': byf / kern['fwd'] / 1e9 / HBM_PEAK_GBS,
+                                       'avg_launch_us': kern['fwd'] * 1e6}
+        if world == 1 and not args.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline(42)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -46,6 +46,14 @@ enum { MM_EUCLIDEAN = 0, MM_LORENTZ = 1, MM_SPHERE = 2 };
 int mm_abi_version(void);
 const char* mm_target_arch(void); /* "gfx950" */
 
+/* ---- optional live kernel timing (HIP events on the launch stream) ---------- */
+enum { MM_PROF_SPD_FWD = 0, MM_PROF_SPD_BWD = 1, MM_PROF_VEC_FWD = 2, MM_PROF_VEC_BWD = 3 };
+/* When on, each pair-kernel launch is bracketed by hipEventRecord on its stream. */
+int mm_prof_enable(int on);
+/* Waits for the recorded events of kernel `id`; returns their count and summed
+ * duration since the previous collect. */
+int mm_prof_collect(int id, int64_t* launches, double* total_ms);
+
 /* ---- pair-list geometry (host-side helpers, no GPU work) ----------------- */
 /* number of pairs in rows < row:  row*(2n-row-1)/2 */
 int64_t mm_pair_offset(int64_t n, int64_t row);

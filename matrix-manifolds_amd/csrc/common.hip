@@ -1,7 +1,29 @@
 // Library info and pair-list geometry helpers (host side; no GPU work).
 #include <hip/hip_runtime.h>
 
+#include <vector>
+
 #include "../../include/mm_manifolds.h"
+#include "prof.hpp"
+
+namespace mm {
+namespace {
+struct Span { hipEvent_t a, b; };
+bool g_on = false;
+std::vector<Span> g_spans[PROF_COUNT];
+std::vector<Span> g_pool;
+hipEvent_t g_open[PROF_COUNT];
+}  // namespace
+bool prof_on() { return g_on; }
+void prof_begin(int id, hipStream_t st) {
+  Span s;
+  if (!g_pool.empty()) { s = g_pool.back(); g_pool.pop_back(); }
+  else { (void)hipEventCreate(&s.a); (void)hipEventCreate(&s.b); }
+  (void)hipEventRecord(s.a, st);
+  g_spans[id].push_back(s);
+}
+void prof_end(int id, hipStream_t st) { (void)hipEventRecord(g_spans[id].back().b, st); }
+}  // namespace mm
 
 extern "C" {
 
@@ -28,6 +50,26 @@ int mm_shard_rows(int64_t n, int world, int rank, int64_t* row_begin, int64_t* r
   const __int128 p = P;
   *row_begin = rank == 0 ? 0 : first_row_at_or_after(n, (int64_t)(p * rank / world));
   *row_end = rank == world - 1 ? n : first_row_at_or_after(n, (int64_t)(p * (rank + 1) / world));
+  return MM_OK;
+}
+
+int mm_prof_enable(int on) { mm::g_on = on != 0; return MM_OK; }
+
+// Synchronises the recorded events; returns launches and total milliseconds of
+// kernel `id` since the last collect, then clears them.
+int mm_prof_collect(int id, int64_t* launches, double* total_ms) {
+  if (id < 0 || id >= mm::PROF_COUNT || !launches || !total_ms) return MM_ERR_ARG;
+  *launches = 0; *total_ms = 0.0;
+  for (auto& s : mm::g_spans[id]) {
+    hipError_t e = hipEventSynchronize(s.b);
+    if (e != hipSuccess) return int(e);
+    float ms = 0.f;
+    e = hipEventElapsedTime(&ms, s.a, s.b);
+    if (e != hipSuccess) return int(e);
+    *total_ms += ms; ++*launches;
+    mm::g_pool.push_back(s);
+  }
+  mm::g_spans[id].clear();
   return MM_OK;
 }
 

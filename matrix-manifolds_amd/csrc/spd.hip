@@ -20,6 +20,7 @@
 #include <hip/hip_runtime.h>
 
 #include "../../include/mm_manifolds.h"
+#include "prof.hpp"
 #include "smallmat.hpp"
 
 namespace mm {
@@ -455,8 +456,11 @@ int spd_pdist_fwd_t(const T* x, int64_t n, int64_t rb, int64_t re, int squared, 
   const int gx = nJB - int((rb + 1) / kBlock);
   const int gy = int((re - rb + TI - 1) / TI);
   if (gx <= 0) return MM_OK;
-  spd_pdist_fwd_kernel<T, D, TI><<<dim3(gx, gy), dim3(kBlock), 0, st>>>(ws.nodeL, ws.nodeX, int(n), int(rb), int(re),
-                                                                       squared, T(wmin), T(wmax), out);
+  {
+    ProfScope prof(PROF_SPD_FWD, st);
+    spd_pdist_fwd_kernel<T, D, TI><<<dim3(gx, gy), dim3(kBlock), 0, st>>>(ws.nodeL, ws.nodeX, int(n), int(rb),
+                                                                         int(re), squared, T(wmin), T(wmax), out);
+  }
   MM_CHECK_LAUNCH();
   return MM_OK;
 }
@@ -475,8 +479,11 @@ int spd_pdist_bwd_t(const T* x, const T* g, int64_t n, int64_t rb, int64_t re, i
   const int gx = nJB - int((rb + 1) / kBlock);
   const int gy = int((re - rb + TI - 1) / TI);
   if (re > rb && gx > 0) {
-    spd_pdist_bwd_kernel<T, D, TI><<<dim3(gx, gy), dim3(kBlock), 0, st>>>(
-        ws.nodeL, ws.nodeX, g, int(n), int(rb), int(re), squared, T(wmin), T(wmax), ws.accM, ws.accN);
+    {
+      ProfScope prof(PROF_SPD_BWD, st);
+      spd_pdist_bwd_kernel<T, D, TI><<<dim3(gx, gy), dim3(kBlock), 0, st>>>(
+          ws.nodeL, ws.nodeX, g, int(n), int(rb), int(re), squared, T(wmin), T(wmax), ws.accM, ws.accN);
+    }
     MM_CHECK_LAUNCH();
   }
   spd_pdist_finalize_kernel<T, D><<<dim3((n + 127) / 128), dim3(128), 0, st>>>(ws.nodeL, ws.accM, ws.accN, int(n),

@@ -24,6 +24,8 @@ _vp, _i, _i64, _dbl, _sz = _c.c_void_p, _c.c_int, _c.c_int64, _c.c_double, _c.c_
 SIGNATURES = {
     'mm_abi_version': (_i, []),
     'mm_target_arch': (_c.c_char_p, []),
+    'mm_prof_enable': (_i, [_i]),
+    'mm_prof_collect': (_i, [_i, _c.POINTER(_i64), _c.POINTER(_dbl)]),
     'mm_pair_offset': (_i64, [_i64, _i64]),
     'mm_shard_rows': (_i, [_i64, _i, _i, _c.POINTER(_i64), _c.POINTER(_i64)]),
     'mm_spd_max_dim': (_i, []),

@@ -37,6 +37,10 @@ class _SpdPdist(torch.autograd.Function):
         n = xc.shape[0]
         dt = B.dtype_code(xc)
         npairs = B.pair_offset(n, row_end) - B.pair_offset(n, row_begin)
+        ctx.empty = npairs == 0
+        if ctx.empty:
+            ctx.save_for_backward(xc)
+            return xc.new_empty(0)
         with torch.cuda.device(xc.device):
             ws = torch.empty(lib.raw('mm_spd_pdist_ws_bytes')(dt, n, n_mat), dtype=torch.uint8,
                              device=xc.device)
@@ -58,6 +62,8 @@ class _SpdPdist(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         xc, = ctx.saved_tensors
+        if ctx.empty:
+            return (torch.zeros_like(xc), ) + (None, ) * 7
         n_mat, squared, wmin, wmax, row_begin, row_end = ctx.args
         lib = B.lib()
         g = g.contiguous()
@@ -217,6 +223,18 @@ class SymmetricPositiveDefinite(Manifold):
 
     def transp(self, x, y, u):  # spd.py:196-199
         return u
+
+    def rsgd_step(self, x, egrad, *, lr, max_grad_norm=None, exact=False):
+        """Fused momentum-free RiemannianSGD update (optim/rsgd.py:63-68,82):
+        egrad2rgrad -> norm clip -> exp|retr in one kernel. Returns the new points."""
+        B.require_gpu(x, egrad)
+        xc, gc = _flat(x.detach(), self.n), _flat(egrad.detach(), self.n)
+        with torch.cuda.device(xc.device):
+            out = torch.empty_like(xc)
+            B.lib().call('mm_spd_rsgd_step', B.dtype_code(xc), B.ptr(xc), B.ptr(gc), xc.shape[0],
+                         self.n, float(lr), -1.0 if max_grad_norm is None else float(max_grad_norm),
+                         int(bool(exact)), B.ptr(out), B.stream_of(xc))
+        return out.reshape(x.shape)
 
     def rand(self, *shape, out=None, ir=1e-1):  # spd.py:201-208
         eyes = self.zero(*shape, out=out)

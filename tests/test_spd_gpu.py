@@ -1,0 +1,228 @@
+"""GPU parity: SPD kernels (through the C ABI / Manifold API) vs the golden vectors
+of the real reference and vs the oracle port on seeded inputs."""
+import itertools
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, sym
+
+pytestmark = pytest.mark.gpu
+
+DT = {'f32': torch.float32, 'f64': torch.float64}
+# Stated tolerances.  d2: |err| <= A + R*|d2|;  gradients: relative to
+# max|grad| of the call.  fp64 is bounded by the REFERENCE's own eps-fudge bias
+# (~1e-6 relative), not by the kernels.
+D2_TOL = {'f32': (1e-6, 2e-5), 'f64': (1e-9, 2e-6)}
+GRAD_TOL = {'f32': 2e-5, 'f64': 5e-6}
+MAP_TOL = {'f32': 2e-5, 'f64': 1e-9}
+
+
+def dev(a, dt=None):
+    t = torch.from_numpy(np.array(a)).cuda()
+    return t if dt is None else t.to(dt)
+
+
+def check_d2(got, ref, dname, what):
+    got, ref = got.detach().double().cpu().numpy(), np.asarray(ref, dtype=np.float64)
+    a, r = D2_TOL[dname]
+    bad = np.abs(got - ref) - (a + r * np.abs(ref))
+    assert bad.max() <= 0, f'{what}: worst excess {bad.max():.3e} (|ref| up to {np.abs(ref).max():.3e})'
+
+
+def check_rel(got, ref, tol, what):
+    got = got.detach().double().cpu().numpy() if torch.is_tensor(got) else np.asarray(got, np.float64)
+    ref = np.asarray(ref, dtype=np.float64)
+    assert got.shape == ref.shape, (what, got.shape, ref.shape)
+    err = np.abs(got - ref).max() / max(np.abs(ref).max(), 1e-30)
+    assert err <= tol, f'{what}: {err:.3e} > {tol:.1e}'
+
+
+@pytest.mark.parametrize('d', [2, 3, 4, 5])
+@pytest.mark.parametrize('dname,init', list(itertools.product(DT, ['rand', 'wide'])))
+def test_pdist_vs_reference_golden(d, dname, init):
+    from graphembed.manifolds import SymmetricPositiveDefinite as SPD
+    G = load_golden(f'spd{d}')
+    man = SPD(d)
+    for n in (33, 96):
+        tag = f'{dname}/{init}/n{n}'
+        if f'{tag}/x' not in G:
+            continue
+        x = dev(G[f'{tag}/x']).requires_grad_()
+        g = dev(G[f'{tag}/g'])
+        d2 = man.pdist(x, squared=True)
+        check_d2(d2, G[f'{tag}/d2'], dname, f'd2 {tag}')
+        gr, = torch.autograd.grad((d2 * g).sum(), x)
+        assert torch.equal(gr, gr.transpose(-2, -1))
+        check_rel(gr, sym(G[f'{tag}/grad_d2']), GRAD_TOL[dname], f'grad_d2 {tag}')
+        d1 = man.pdist(x, squared=False)
+        check_rel(d1, G[f'{tag}/d1'], 2e-5 if dname == 'f32' else 2e-6, f'd1 {tag}')
+        gr, = torch.autograd.grad((d1 * g).sum(), x)
+        check_rel(gr, sym(G[f'{tag}/grad_d1']), GRAD_TOL[dname] * 5, f'grad_d1 {tag}')
+        dxy = man.dist(x.detach(), x.detach().flip(0), squared=True)
+        check_d2(dxy, G[f'{tag}/dist_xy'], dname, f'dist_xy {tag}')
+
+
+@pytest.mark.parametrize('d', [2, 3, 4, 5])
+@pytest.mark.parametrize('dname,init', list(itertools.product(DT, ['rand', 'wide'])))
+def test_maps_vs_reference_golden(d, dname, init):
+    from graphembed.manifolds import SymmetricPositiveDefinite as SPD
+    G = load_golden(f'spd{d}')
+    man = SPD(d)
+    tag = f'{dname}/{init}/n33'
+    tol = MAP_TOL[dname]
+    x = dev(G[f'{tag}/x'])
+    with torch.no_grad():
+        rg = man.egrad2rgrad(x, dev(G[f'{tag}/grad_d2']))
+        check_rel(rg, G[f'{tag}/rgrad'], tol * 10, 'egrad2rgrad')
+        check_rel(man.norm(x, dev(G[f'{tag}/rgrad']), keepdim=True), G[f'{tag}/rgrad_norm'], tol * 10, 'norm')
+        u = dev(G[f'{tag}/u'])
+        pu = man.proju(x, u)
+        check_rel(pu, G[f'{tag}/proju'], tol, 'proju')
+        # the reference's d=2 Cholesky adds +1e-8 under the sqrt (fast.py:103): allow for it
+        etol = max(tol, 1e-7) if d == 2 else tol
+        check_rel(man.exp(x, pu), G[f'{tag}/exp'], etol, 'exp')
+        check_rel(man.retr(x, pu), G[f'{tag}/retr'], etol, 'retr')
+        check_rel(man.log(x, x.flip(0)), G[f'{tag}/log'], max(etol, tol) * 10, 'log')
+        check_rel(man.projx(dev(G[f'{tag}/projx_in'])), G[f'{tag}/projx'], tol, 'projx')
+        check_rel(man.transp(x, man.retr(x, pu), pu), G[f'{tag}/transp'], tol, 'transp')
+
+
+@pytest.mark.parametrize('d', [2, 3, 4, 5])
+@pytest.mark.parametrize('dname', list(DT))
+def test_rsgd_vs_reference_golden(d, dname):
+    from graphembed.manifolds import SymmetricPositiveDefinite as SPD
+    from graphembed.modules import ManifoldParameter
+    from graphembed.optim import RiemannianSGD
+    G = load_golden(f'spd{d}')
+    man = SPD(d)
+    base = f'{dname}/rsgd'
+    tol = MAP_TOL[dname] * 10 if dname == 'f32' else 1e-7
+    for exact, clip, mom in itertools.product([0, 1], [0, 1], [0, 1]):
+        tag = f'{base}/exact{exact}_clip{clip}_mom{mom}'
+        p = ManifoldParameter(dev(G[f'{base}/x0']), manifold=man)
+        opt = RiemannianSGD([p], lr=0.05, momentum=0.9 if mom else 0, dampening=0.1 if mom else 0,
+                            max_grad_norm=2.0 if clip else None, exact=bool(exact))
+        p.grad = dev(G[f'{base}/g1'])
+        opt.step()
+        check_rel(p.data, G[f'{tag}/x1'], tol, tag + '/x1')
+        p.grad = dev(G[f'{base}/g2'])
+        opt.step()
+        check_rel(p.data, G[f'{tag}/x2'], tol, tag + '/x2')
+        if mom:
+            check_rel(opt.state[p]['momentum_buffer'], G[f'{tag}/buf2'], tol, tag + '/buf2')
+
+
+@pytest.mark.parametrize('d,n', [(2, 257), (3, 300), (3, 1000), (4, 130), (5, 70)])
+@pytest.mark.parametrize('dname', list(DT))
+def test_pdist_vs_oracle_seeded(d, n, dname):
+    """Sizes that exercise several tiles, the diagonal blocks and ragged edges."""
+    from graphembed.manifolds import SymmetricPositiveDefinite as SPD
+    from oracle import ref_port as rp
+    gen = torch.Generator().manual_seed(100 * d + n)
+    port = rp.SPD(d)
+    for init in ('rand', 'wide'):
+        if init == 'rand':
+            x64 = port.rand(n, dtype=torch.float64, generator=gen)
+        else:
+            a = torch.rand(n, d, d, dtype=torch.float64, generator=gen)
+            x64 = a @ a.transpose(1, 2) + torch.eye(d, dtype=torch.float64)
+        g64 = torch.randn(n * (n - 1) // 2, dtype=torch.float64, generator=gen)
+        xr = x64.clone().requires_grad_()
+        ref = port.pdist(xr, squared=True)
+        ref_g, = torch.autograd.grad((ref * g64).sum(), xr)
+        x = x64.to(DT[dname]).cuda().requires_grad_()
+        d2 = SPD(d).pdist(x, squared=True)
+        check_d2(d2, ref.detach().numpy(), dname, f'd2 d={d} n={n} {init}')
+        gr, = torch.autograd.grad((d2 * g64.to(DT[dname]).cuda()).sum(), x)
+        check_rel(gr, sym(ref_g.numpy()), GRAD_TOL[dname], f'grad d={d} n={n} {init}')
+
+
+@pytest.mark.parametrize('dname', list(DT))
+def test_row_sharding_is_exact(dname):
+    """Shards of the pair list reproduce the unsharded result bit for bit (forward) and
+    sum to it (backward)."""
+    from graphembed.manifolds import SymmetricPositiveDefinite as SPD
+    from graphembed import _backend as B
+    man = SPD(3)
+    torch.manual_seed(3)
+    n = 777
+    x = man.rand(n, out=torch.empty(0, dtype=DT[dname], device='cuda'))
+    g = torch.randn(n * (n - 1) // 2, dtype=DT[dname], device='cuda')
+    xr = x.clone().requires_grad_()
+    full = man.pdist(xr, squared=True)
+    gfull, = torch.autograd.grad((full * g).sum(), xr)
+    for world in (2, 3, 8):
+        parts, gsum = [], torch.zeros_like(x)
+        for r in range(world):
+            rb, re = B.shard_rows(n, world, r)
+            xr = x.clone().requires_grad_()
+            part = man.pdist(xr, squared=True, rows=(rb, re))
+            lo, hi = B.pair_offset(n, rb), B.pair_offset(n, re)
+            assert part.numel() == hi - lo
+            gp, = torch.autograd.grad((part * g[lo:hi]).sum(), xr)
+            parts.append(part.detach())
+            gsum += gp
+        assert torch.equal(torch.cat(parts), full.detach())
+        check_rel(gsum, gfull.cpu().numpy(), 1e-5 if dname == 'f32' else 1e-13, 'sum of shard grads')
+
+
+def test_properties_at_full_size():
+    """n = 5000 (the BASELINE metric size): symmetry-free invariants that need no oracle.
+    d(X,Y) is invariant under congruence X -> C X C^T; scaling all points by c leaves
+    distances unchanged; sum_i grad_i-contracted-with-X_i = 0 (scale invariance)."""
+    from graphembed.manifolds import SymmetricPositiveDefinite as SPD
+    man = SPD(3)
+    torch.manual_seed(0)
+    n = 5000
+    x = man.rand(n, out=torch.empty(0, device='cuda')).requires_grad_()
+    g = torch.randn(n * (n - 1) // 2, device='cuda')
+    d2 = man.pdist(x, squared=True)
+    assert d2.shape == (n * (n - 1) // 2, ) and bool(torch.isfinite(d2).all())
+    gr, = torch.autograd.grad((d2 * g).sum(), x)
+    assert bool(torch.isfinite(gr).all())
+    # Euler identity for a degree-0 homogeneous function: sum_i <grad_i, X_i> = 0
+    euler = (gr.double() * x.detach().double()).sum().abs().item()
+    assert euler <= 1e-4 * gr.double().abs().sum().item()
+    c = torch.tensor([[1.3, 0.2, -0.1], [0.0, 0.7, 0.4], [0.3, -0.2, 1.1]], device='cuda')
+    y = c @ x.detach() @ c.T
+    d2c = man.pdist(y, squared=True)
+    assert (d2c - d2.detach()).abs().max().item() <= 1e-6 + 1e-4 * d2.max().item()
+    # a few random pairs against the element-wise kernel
+    idx = torch.randint(0, n, (2, 1000), device='cuda')
+    i, j = idx.min(0).values, idx.max(0).values
+    keep = i < j
+    i, j = i[keep], j[keep]
+    k = i * (2 * n - i - 1) // 2 + (j - i - 1)
+    assert torch.equal(d2.detach()[k], man.dist(x.detach()[i], x.detach()[j], squared=True))
+
+
+def test_no_nan_dists():
+    """tests/test_spd.py:36-44 of the reference, GPU sizes."""
+    from graphembed.manifolds import SymmetricPositiveDefinite as SPD
+    for d, n in [(2, 10000), (3, 10000), (4, 2000)]:
+        torch.manual_seed(d)
+        a = torch.rand(n, d, d, device='cuda')
+        x = a @ a.transpose(1, 2) + torch.eye(d, device='cuda')
+        assert not torch.isnan(SPD(d).pdist(x)).any()
+
+
+def test_edge_cases():
+    from graphembed.manifolds import SymmetricPositiveDefinite as SPD
+    man = SPD(3)
+    eye = torch.eye(3, device='cuda')
+    assert man.pdist(eye[None]).numel() == 0                      # n = 1: no pairs
+    assert man.pdist(torch.empty(0, 3, 3, device='cuda')).numel() == 0
+    two = torch.stack([eye, 2 * eye])
+    np.testing.assert_allclose(man.pdist(two, squared=True).item(), 3 * np.log(2.0)**2, rtol=1e-6)
+    same = torch.stack([eye, eye]).requires_grad_()             # coincident points: clamp to wmin
+    d2 = man.pdist(same, squared=True)
+    assert d2.item() == pytest.approx(1e-8)
+    gr, = torch.autograd.grad(d2.sum(), same)
+    assert bool(torch.isfinite(gr).all())
+    with pytest.raises(Exception):
+        man.pdist(torch.eye(3)[None].repeat(4, 1, 1))            # CPU tensor: fail loudly
+    bad = torch.stack([eye, -eye])
+    with pytest.raises(torch.linalg.LinAlgError):
+        SPD(3, check_pd=True).pdist(bad)

@@ -53,24 +53,29 @@ def cpu_baseline(seed):
     """The oracle port (reference-faithful op sequence) on this host's cores, on a
     bounded sample: n=2500 nodes (3.1 M pairs) of the same workload, best of 3."""
     from oracle import ref_port
-    cores = os.cpu_count() or 1
-    torch.set_num_threads(cores)
+    ncpu = os.cpu_count() or 1
     n = 2500
     x, g = synthetic_spd(n, DIM, seed, 'cpu')
     man = ref_port.SPD(DIM)
-    best = float('inf')
-    for it in range(4):
-        xr = x.clone().requires_grad_()
-        t0 = time.perf_counter()
-        d2 = man.pdist(xr, squared=True)
-        d2.backward(g)
-        dt = time.perf_counter() - t0
-        if it:
-            best = min(best, dt)
     P = n * (n - 1) // 2
-    return {'value': P / best, 'unit': 'pairs/s', 'cores': torch.get_num_threads(), 'kind': 'port',
-            'sample': f'SPD(3) fp32 reference-init, n={n} ({P} pairs), fwd+bwd, best of 3; '
-                      f'oracle/ref_port.py (torch CPU, reference op sequence)'}
+    best, best_threads = float('inf'), 1
+    # torch's intra-op pool does not scale to hundreds of threads on these element-wise ops:
+    # time a few pool sizes and report the fastest (the fairest baseline for this host)
+    for threads in sorted({min(8, ncpu), min(32, ncpu), min(64, ncpu), ncpu}):
+        torch.set_num_threads(threads)
+        for it in range(3):
+            xr = x.clone().requires_grad_()
+            t0 = time.perf_counter()
+            d2 = man.pdist(xr, squared=True)
+            d2.backward(g)
+            dt = time.perf_counter() - t0
+            if it and dt < best:
+                best, best_threads = dt, threads
+    return {'value': P / best, 'unit': 'pairs/s', 'cores': best_threads, 'kind': 'port',
+            'host_cpus': ncpu,
+            'sample': f'SPD(3) fp32 reference-init, n={n} ({P} pairs), fwd+bwd, best of 2 per pool size '
+                      f'(8/32/64/all threads), fastest pool reported; oracle/ref_port.py '
+                      f'(torch CPU, reference op sequence)'}
 
 
 def main():

@@ -119,6 +119,53 @@ int mm_spd_norm(int dtype, const void* x, const void* u, int64_t m, int d, int s
 int mm_spd_rsgd_step(int dtype, const void* x, const void* egrad, int64_t m, int d, double lr,
                      double max_grad_norm, int exact, void* x_new, mm_stream_t stream);
 
+/* ---- vector manifolds: Euclidean R^m, Lorentz H^{m-1}, sphere S^{m-1} -------- */
+/* `kind` is MM_EUCLIDEAN / MM_LORENTZ / MM_SPHERE; points are rows of x [n,m]. */
+int mm_vec_max_dim(void);
+size_t mm_vec_pdist_ws_bytes(int dtype, int64_t n, int m);
+
+/* Manifold.pdist default = gather + dist — manifolds/base.py:59-63 with
+ *   Euclidean: max(sum (y-x)^2, 1e-8) [sqrt]                 base.py:29-33,56-57; euclidean.py:35-48
+ *   Lorentz  : max(acosh(max(-<x,y>_L,1)),1e-8)^2            lorentz.py:72-77,101-138
+ *   Sphere   : max(acos(clamp <x,y>),1e-8)^2                 sphere.py:68-74
+ * out has the row-range layout described at the top. */
+int mm_vec_pdist_fwd(int dtype, int kind, const void* x, int64_t n, int m, int64_t row_begin,
+                     int64_t row_end, int squared, void* out, mm_stream_t stream);
+/* Same, forward only, with the Gram matrix X J X^T formed on the matrix cores
+ * (v_mfma_f32_32x32x2_f32 / v_mfma_f64_16x16x4_f64) and the distance map fused
+ * into the accumulator epilogue.  Lorentz and sphere (the reference evaluates
+ * both from inner products); Euclidean uses the difference form above. */
+int mm_vec_pdist_fwd_gram(int dtype, int kind, const void* x, int64_t n, int m, int64_t row_begin,
+                          int64_t row_end, int squared, void* out, mm_stream_t stream);
+/* Backward: grad_x [n,m] OVERWRITTEN with this shard's partial gradient.
+ * (Sphere: the reference's 1/sqrt(1-c^2) is floored at 1e-8 instead of inf.) */
+int mm_vec_pdist_bwd(int dtype, int kind, const void* x, const void* g, int64_t n, int m,
+                     int64_t row_begin, int64_t row_end, int squared, void* grad_x, void* ws,
+                     mm_stream_t stream);
+/* Element-wise dist over cnt pairs (x[k],y[k]).  out may be NULL (backward only);
+ * grad_x/grad_y may both be NULL (forward only), else g [cnt] is required. */
+int mm_vec_dist(int dtype, int kind, const void* x, const void* y, const void* g, int64_t cnt, int m,
+                int squared, void* out, void* grad_x, void* grad_y, mm_stream_t stream);
+
+/* Per-point maps (optim/rsgd.py:56-82 call sites); x,u,y,out are [cnt,m]. */
+enum {
+  MM_VEC_EGRAD2RGRAD = 0, /* lorentz.py:52-57, sphere.py:41-44, identity for Euclidean      */
+  MM_VEC_PROJU = 1,       /* lorentz.py:39-42, sphere.py:41-44                              */
+  MM_VEC_EXP = 2,         /* lorentz.py:59-62, sphere.py:51-56, x+u                         */
+  MM_VEC_RETR = 3,        /* = exp for Lorentz/Euclidean (base.py:49-50); sphere.py:58-59   */
+  MM_VEC_PROJX = 4,       /* lorentz.py:44-50, sphere.py:46-49 (u unused)                   */
+  MM_VEC_TRANSP = 5,      /* u from x to y: lorentz.py:79-82; proju(y,u) (base.py:65-66)    */
+  MM_VEC_LOG = 6          /* log_x(u): lorentz.py:64-70, sphere.py:61-66, u-x               */
+};
+int mm_vec_map(int dtype, int kind, int op, const void* x, const void* u, const void* y, int64_t cnt,
+               int m, void* out, mm_stream_t stream);
+/* Manifold.norm — base.py:29-33: sqrt(max(<u,u>, 1e-8)) with the manifold's inner product */
+int mm_vec_norm(int dtype, int kind, const void* u, int64_t cnt, int m, int squared, void* out,
+                mm_stream_t stream);
+/* Fused momentum-free RiemannianSGD update (rsgd.py:63-68,82). */
+int mm_vec_rsgd_step(int dtype, int kind, const void* x, const void* egrad, int64_t cnt, int m,
+                     double lr, double max_grad_norm, int exact, void* x_new, mm_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

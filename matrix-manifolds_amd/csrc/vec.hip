@@ -1,0 +1,512 @@
+// Vector manifolds — Euclidean R^m, Lorentz (hyperboloid) H^{m-1}, sphere S^{m-1}:
+// pairwise distances, their gradients, and the per-point maps RiemannianSGD calls.
+//
+// Reference arithmetic: graphembed/graphembed/manifolds/{base,euclidean,lorentz,
+// sphere}.py (entry-by-entry citations in include/mm_manifolds.h).
+//
+// Pair kernels (this file, VALU form): lanes own consecutive columns j and keep
+// x_j in VGPRs; the row operand x_i is wave-uniform and arrives through scalar
+// loads (SGPR broadcast — no LDS).  Forward writes the row-major pair vector with
+// lanes on consecutive j (256-B segments).  Backward visits every ORDERED pair
+// (i,j), so each lane only ever accumulates into its own column's gradient in
+// registers: no cross-lane reduction at all, one coalesced atomic flush per tile
+// into structure-of-arrays accumulators, then a per-point finalize.
+// The MFMA Gram form of the forward lives in vec_gram.hip.
+#include <hip/hip_runtime.h>
+
+#include "../../include/mm_manifolds.h"
+#include "prof.hpp"
+#include "smallmat.hpp"
+
+namespace mm {
+
+constexpr int kVBlock = 256;
+constexpr int kVecMaxDim = 32;
+constexpr double kEps = 1e-8;  // utils.py:13 (both precisions)
+
+__host__ __device__ inline int64_t vpair_off(int64_t n, int64_t row) { return row * (2 * n - row - 1) / 2; }
+
+template <typename T> __device__ __forceinline__ T acos_t(T c);
+template <> __device__ __forceinline__ float acos_t<float>(float c) { return ::acosf(c); }
+template <> __device__ __forceinline__ double acos_t<double>(double c) { return ::acos(c); }
+
+// Forward value and d(out)/d(inner quantity) for one pair.
+//   Euclidean: q = sum (x_i - x_j)^2          out = max(q,eps) [sqrt]      base.py:29-33,56-57
+//   Lorentz  : q = -<x_i,x_j>_L               out = max(acosh(max(q,1)),eps)^2   lorentz.py:72-77
+//   Sphere   : q = <x_i,x_j>                  out = max(acos(clamp q),eps)^2     sphere.py:68-74
+template <typename T, int KIND> struct PairFn {
+  static __device__ __forceinline__ T value(T q, int squared) {
+    using N = Num<T>;
+    if (KIND == MM_EUCLIDEAN) {
+      const T s = N::max(q, T(kEps));
+      return squared ? s : N::sqrt(s);
+    } else if (KIND == MM_LORENTZ) {
+      const T t = N::max(q, T(1));
+      const T z = N::sqrt(N::fma(t, t, T(-1)));
+      const T d = N::max(N::log(t + z), T(kEps));
+      return squared ? d * d : d;
+    } else {
+      const T c = N::min(N::max(q, T(-1 + 1e-16)), T(1 - 1e-16));
+      const T th = N::max(acos_t<T>(c), T(kEps));
+      return squared ? th * th : th;
+    }
+  }
+  // d(out)/dq  (value clamps are gradient-transparent, as in the reference)
+  static __device__ __forceinline__ T dq(T q, int squared) {
+    using N = Num<T>;
+    if (KIND == MM_EUCLIDEAN) {
+      return squared ? T(1) : T(0.5) * N::rsqrt(N::max(q, T(kEps)));
+    } else if (KIND == MM_LORENTZ) {
+      const T t = N::max(q, T(1));
+      const T z = N::sqrt(N::fma(t, t, T(-1)));
+      const T d = N::max(N::log(t + z), T(kEps));
+      const T dz = T(1) / N::max(z, T(kEps));  // lorentz.py:134-138 (this clamp IS in the backward)
+      return squared ? (d + d) * dz : dz;
+    } else {
+      const T c = N::min(N::max(q, T(-1 + 1e-16)), T(1 - 1e-16));
+      const T th = N::max(acos_t<T>(c), T(kEps));
+      // the reference divides by sqrt(1-c^2) unguarded (inf at c = +-1); we floor it at eps
+      const T ds = T(-1) / N::max(N::sqrt(N::fma(-c, c, T(1))), T(kEps));
+      return squared ? (th + th) * ds : ds;
+    }
+  }
+};
+
+// q for one pair from register/scalar operands
+template <typename T, int KIND, int MP, typename TI>
+__device__ __forceinline__ T pair_q(const TI (&xi)[MP], const T (&xj)[MP]) {
+  using N = Num<T>;
+  T q = T(0);
+  if (KIND == MM_EUCLIDEAN) {
+#pragma unroll
+    for (int k = 0; k < MP; ++k) { const T df = xj[k] - xi[k]; q = N::fma(df, df, q); }
+  } else if (KIND == MM_LORENTZ) {
+#pragma unroll
+    for (int k = 1; k < MP; ++k) q = N::fma(xi[k], xj[k], q);
+    q = N::fma(xi[0], xj[0], -q);  // -( -x0 y0 + sum x_k y_k )
+  } else {
+#pragma unroll
+    for (int k = 0; k < MP; ++k) q = N::fma(xi[k], xj[k], q);
+  }
+  return q;
+}
+
+template <typename T, int MP>
+__device__ __forceinline__ void load_point(const T* __restrict__ x, int64_t idx, int m, T (&r)[MP]) {
+#pragma unroll
+  for (int k = 0; k < MP; ++k) r[k] = (k < m) ? x[idx * m + k] : T(0);
+}
+
+// ------------------------------------------------------------------ forward
+template <typename T, int KIND, int MP, int TI>
+__global__ __launch_bounds__(kVBlock) void vec_pdist_fwd_kernel(const T* __restrict__ x, int n, int m, int row_begin,
+                                                                int row_end, int squared, T* __restrict__ out) {
+  const int i0 = row_begin + blockIdx.y * TI;
+  const int i1 = min(i0 + TI, row_end);
+  const int jbase = ((i0 + 1) / kVBlock + blockIdx.x) * kVBlock;
+  if (jbase >= n) return;
+  if (jbase + (int(threadIdx.x) & ~63) + 63 <= i0) return;
+  const int j = jbase + threadIdx.x;
+  const bool jin = j < n;
+  T xj[MP];
+  load_point<T, MP>(x, jin ? j : 0, m, xj);
+  const int64_t base = vpair_off(n, row_begin);
+  for (int i = i0; i < i1; ++i) {
+    T xi[MP];
+    load_point<T, MP>(x, i, m, xi);  // wave-uniform -> scalar loads
+    const T v = PairFn<T, KIND>::value(pair_q<T, KIND, MP>(xi, xj), squared);
+    if (jin && j > i) out[vpair_off(n, i) - base + (j - i - 1)] = v;
+  }
+}
+
+// ------------------------------------------------------------------ backward
+// acc[k][j] += sum_i g_ij * dq_ij * (coefficient vector of x_i); finalize applies
+// the manifold-specific linear map (2(x_j - .) / -J / identity).
+template <typename T, int KIND, int MP, int TI>
+__global__ __launch_bounds__(kVBlock) void vec_pdist_bwd_kernel(const T* __restrict__ x, const T* __restrict__ g, int n,
+                                                                int m, int row_begin, int row_end, int squared,
+                                                                T* __restrict__ acc /* [MP+1][n] */) {
+  const int j = blockIdx.x * kVBlock + threadIdx.x;
+  const int i0 = blockIdx.y * TI, i1 = min(i0 + TI, n);
+  const bool jin = j < n;
+  const bool jown = jin && j >= row_begin && j < row_end;  // pairs (j, i>j) belong to this shard
+  T xj[MP], a[MP];
+  load_point<T, MP>(x, jin ? j : 0, m, xj);
+#pragma unroll
+  for (int k = 0; k < MP; ++k) a[k] = T(0);
+  T wsum = T(0);
+  const int64_t base = vpair_off(n, row_begin);
+  for (int i = i0; i < i1; ++i) {
+    T xi[MP];
+    load_point<T, MP>(x, i, m, xi);
+    const bool up = i < j;  // pair (i,j) stored under row i, else under row j
+    const bool valid = jin && (up ? (i >= row_begin && i < row_end) : (jown && i > j));
+    const int lo = up ? i : j, hi = up ? j : i;
+    T w = T(0);
+    if (valid) w = g[vpair_off(n, lo) - base + (hi - lo - 1)];
+    const T q = pair_q<T, KIND, MP>(xi, xj);
+    w *= PairFn<T, KIND>::dq(q, squared);
+    w = valid ? w : T(0);
+    wsum += w;
+#pragma unroll
+    for (int k = 0; k < MP; ++k) a[k] = Num<T>::fma(w, xi[k], a[k]);
+  }
+  if (jin) {
+#pragma unroll
+    for (int k = 0; k < MP; ++k)
+      if (k < m) atomic_add(&acc[size_t(k) * n + j], a[k]);
+    if (KIND == MM_EUCLIDEAN) atomic_add(&acc[size_t(MP) * n + j], wsum);
+  }
+}
+
+template <typename T, int KIND, int MP>
+__global__ void vec_pdist_finalize_kernel(const T* __restrict__ x, const T* __restrict__ acc, int n, int m,
+                                          T* __restrict__ grad) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n) return;
+  for (int k = 0; k < m; ++k) {
+    const T s = acc[size_t(k) * n + j];
+    T r;
+    if (KIND == MM_EUCLIDEAN) r = T(2) * (acc[size_t(MP) * n + j] * x[size_t(j) * m + k] - s);  // sum w 2(x_j - x_i)
+    else if (KIND == MM_LORENTZ) r = (k == 0) ? s : -s;                                           // dq/dx_j = -J x_i
+    else r = s;
+    grad[size_t(j) * m + k] = r;
+  }
+}
+
+// ------------------------------------------------------- element-wise dist
+template <typename T, int KIND>
+__global__ void vec_dist_kernel(const T* __restrict__ x, const T* __restrict__ y, const T* __restrict__ g, int64_t cnt,
+                                int m, int squared, T* __restrict__ out, T* __restrict__ gx, T* __restrict__ gy) {
+  using N = Num<T>;
+  const int64_t p = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (p >= cnt) return;
+  const T* xp = x + p * m;
+  const T* yp = y + p * m;
+  T q = T(0);
+  if (KIND == MM_EUCLIDEAN) {
+    for (int k = 0; k < m; ++k) { const T df = yp[k] - xp[k]; q = N::fma(df, df, q); }
+  } else if (KIND == MM_LORENTZ) {
+    for (int k = 1; k < m; ++k) q = N::fma(xp[k], yp[k], q);
+    q = N::fma(xp[0], yp[0], -q);
+  } else {
+    for (int k = 0; k < m; ++k) q = N::fma(xp[k], yp[k], q);
+  }
+  if (out) out[p] = PairFn<T, KIND>::value(q, squared);
+  if (gx) {
+    const T w = g[p] * PairFn<T, KIND>::dq(q, squared);
+    for (int k = 0; k < m; ++k) {
+      T ax, ay;
+      if (KIND == MM_EUCLIDEAN) { ax = T(2) * (xp[k] - yp[k]); ay = -ax; }
+      else if (KIND == MM_LORENTZ) { ax = (k == 0) ? yp[k] : -yp[k]; ay = (k == 0) ? xp[k] : -xp[k]; }
+      else { ax = yp[k]; ay = xp[k]; }
+      gx[p * m + k] = w * ax;
+      gy[p * m + k] = w * ay;
+    }
+  }
+}
+
+// ------------------------------------------------------ per-point maps
+template <typename T> __device__ __forceinline__ T ldot(const T* u, const T* v, int m) {
+  T s = T(0);
+  for (int k = 1; k < m; ++k) s = Num<T>::fma(u[k], v[k], s);
+  return Num<T>::fma(-u[0], v[0], s);
+}
+template <typename T> __device__ __forceinline__ T edot(const T* u, const T* v, int m) {
+  T s = T(0);
+  for (int k = 0; k < m; ++k) s = Num<T>::fma(u[k], v[k], s);
+  return s;
+}
+
+// One thread per point; `loc` = local scratch of the point's tangent (<= kVecMaxDim).
+template <typename T, int KIND>
+__device__ __forceinline__ void vec_exp_or_retr(const T* xp, const T* u, int m, int exact, T* o) {
+  using N = Num<T>;
+  if (KIND == MM_EUCLIDEAN) {
+    for (int k = 0; k < m; ++k) o[k] = xp[k] + u[k];
+  } else if (KIND == MM_LORENTZ) {  // lorentz.py:59-62 (retr == exp, base.py:49-50)
+    const T un = N::max(N::sqrt(N::max(ldot(u, u, m), T(0))), T(kEps));
+    const T ch = ::cosh(un), sh = ::sinh(un) / un;
+    for (int k = 0; k < m; ++k) o[k] = N::fma(xp[k], ch, sh * u[k]);
+  } else {  // sphere.py:51-59
+    const T nu = N::sqrt(N::max(edot(u, u, m), T(kEps)));
+    if (exact && nu > T(kEps)) {
+      const T c = ::cos(nu), s = ::sin(nu) / nu;
+      for (int k = 0; k < m; ++k) o[k] = N::fma(xp[k], c, s * u[k]);
+    } else {
+      T nn = T(0);
+      for (int k = 0; k < m; ++k) { o[k] = xp[k] + u[k]; nn = N::fma(o[k], o[k], nn); }
+      const T inv = T(1) / N::sqrt(N::max(nn, T(kEps)));
+      for (int k = 0; k < m; ++k) o[k] *= inv;
+    }
+  }
+}
+
+template <typename T, int KIND>
+__device__ __forceinline__ void vec_egrad2rgrad(const T* xp, const T* gp, int m, T* o) {
+  using N = Num<T>;
+  if (KIND == MM_EUCLIDEAN) {
+    for (int k = 0; k < m; ++k) o[k] = gp[k];
+  } else if (KIND == MM_LORENTZ) {  // lorentz.py:52-57: flip time coordinate, then u + <x,u>_L x
+    for (int k = 0; k < m; ++k) o[k] = (k == 0) ? -gp[k] : gp[k];
+    const T d = ldot(xp, o, m);
+    for (int k = 0; k < m; ++k) o[k] = N::fma(d, xp[k], o[k]);
+  } else {  // sphere.py:41-44
+    const T d = edot(xp, gp, m);
+    for (int k = 0; k < m; ++k) o[k] = N::fma(-d, xp[k], gp[k]);
+  }
+}
+
+template <typename T, int KIND> __device__ __forceinline__ T vec_norm(const T* u, int m) {
+  const T s = (KIND == MM_LORENTZ) ? ldot(u, u, m) : edot(u, u, m);
+  return Num<T>::sqrt(Num<T>::max(s, T(kEps)));  // base.py:29-33
+}
+
+template <typename T, int KIND>
+__global__ void vec_map_kernel(int op, const T* __restrict__ x, const T* __restrict__ u, const T* __restrict__ y,
+                               int64_t cnt, int m, T* __restrict__ out) {
+  using N = Num<T>;
+  const int64_t p = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (p >= cnt) return;
+  const T* xp = x + p * m;
+  const T* up = u ? u + p * m : nullptr;
+  const T* yp = y ? y + p * m : nullptr;
+  T* o = out + p * m;
+  T tmp[kVecMaxDim];
+  switch (op) {
+    case MM_VEC_EGRAD2RGRAD: vec_egrad2rgrad<T, KIND>(xp, up, m, tmp); for (int k = 0; k < m; ++k) o[k] = tmp[k]; break;
+    case MM_VEC_PROJU:
+      if (KIND == MM_EUCLIDEAN) { for (int k = 0; k < m; ++k) o[k] = up[k]; }
+      else if (KIND == MM_LORENTZ) { const T d = ldot(xp, up, m); for (int k = 0; k < m; ++k) o[k] = N::fma(d, xp[k], up[k]); }
+      else { const T d = edot(xp, up, m); for (int k = 0; k < m; ++k) o[k] = N::fma(-d, xp[k], up[k]); }
+      break;
+    case MM_VEC_EXP: vec_exp_or_retr<T, KIND>(xp, up, m, 1, tmp); for (int k = 0; k < m; ++k) o[k] = tmp[k]; break;
+    case MM_VEC_RETR: vec_exp_or_retr<T, KIND>(xp, up, m, 0, tmp); for (int k = 0; k < m; ++k) o[k] = tmp[k]; break;
+    case MM_VEC_PROJX:
+      if (KIND == MM_EUCLIDEAN) { for (int k = 0; k < m; ++k) o[k] = xp[k]; }
+      else if (KIND == MM_LORENTZ) {  // lorentz.py:44-50
+        T s = T(1);
+        for (int k = 1; k < m; ++k) s = N::fma(xp[k], xp[k], s);
+        o[0] = N::sqrt(s);
+        for (int k = 1; k < m; ++k) o[k] = xp[k];
+      } else {
+        const T inv = T(1) / vec_norm<T, KIND>(xp, m);
+        for (int k = 0; k < m; ++k) o[k] = xp[k] * inv;
+      }
+      break;
+    case MM_VEC_TRANSP:  // transport u from x to y
+      if (KIND == MM_EUCLIDEAN) { for (int k = 0; k < m; ++k) o[k] = up[k]; }
+      else if (KIND == MM_LORENTZ) {  // lorentz.py:79-82
+        const T xy = ldot(xp, yp, m), uy = ldot(up, yp, m);
+        const T f = uy / (T(1) - xy);
+        for (int k = 0; k < m; ++k) o[k] = N::fma(f, xp[k] + yp[k], up[k]);
+      } else {  // base.py:65-66: proju(y, u)
+        const T d = edot(yp, up, m);
+        for (int k = 0; k < m; ++k) o[k] = N::fma(-d, yp[k], up[k]);
+      }
+      break;
+    case MM_VEC_LOG:  // log_x(y), y passed in `u`
+      if (KIND == MM_EUCLIDEAN) { for (int k = 0; k < m; ++k) o[k] = up[k] - xp[k]; }
+      else if (KIND == MM_LORENTZ) {  // lorentz.py:64-70
+        const T xy = N::min(ldot(xp, up, m), T(-1));
+        const T den = N::max(N::sqrt(N::fma(xy, xy, T(-1))), T(kEps));
+        const T num = N::max(N::log(-xy + N::sqrt(N::fma(xy, xy, T(-1)))), T(kEps));
+        const T f = num / den;
+        for (int k = 0; k < m; ++k) tmp[k] = f * N::fma(xy, xp[k], up[k]);
+        const T d = ldot(xp, tmp, m);
+        for (int k = 0; k < m; ++k) o[k] = N::fma(d, xp[k], tmp[k]);
+      } else {  // sphere.py:61-66
+        T dmx[kVecMaxDim];
+        for (int k = 0; k < m; ++k) dmx[k] = up[k] - xp[k];
+        const T d0 = edot(xp, dmx, m);
+        for (int k = 0; k < m; ++k) tmp[k] = N::fma(-d0, xp[k], dmx[k]);
+        const T c = N::min(N::max(edot(xp, up, m), T(-1 + 1e-16)), T(1 - 1e-16));
+        const T th = N::max(acos_t<T>(c), T(kEps));
+        const T nu = vec_norm<T, KIND>(tmp, m);
+        const T f = (th > T(kEps)) ? th / nu : T(1);
+        for (int k = 0; k < m; ++k) o[k] = tmp[k] * f;
+      }
+      break;
+  }
+}
+
+template <typename T, int KIND>
+__global__ void vec_norm_kernel(const T* __restrict__ u, int64_t cnt, int m, int squared, T* __restrict__ out) {
+  const int64_t p = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (p >= cnt) return;
+  const T nv = vec_norm<T, KIND>(u + p * m, m);
+  out[p] = squared ? nv * nv : nv;
+}
+
+// fused momentum-free RSGD update (rsgd.py:63-68,82)
+template <typename T, int KIND>
+__global__ void vec_rsgd_step_kernel(const T* __restrict__ x, const T* __restrict__ eg, int64_t cnt, int m, T lr,
+                                     T max_grad_norm, int exact, T* __restrict__ xnew) {
+  const int64_t p = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (p >= cnt) return;
+  T r[kVecMaxDim], o[kVecMaxDim];
+  vec_egrad2rgrad<T, KIND>(x + p * m, eg + p * m, m, r);
+  T scale = -lr;
+  if (max_grad_norm > T(0)) scale *= Num<T>::min(max_grad_norm / vec_norm<T, KIND>(r, m), T(1));
+  for (int k = 0; k < m; ++k) r[k] *= scale;
+  vec_exp_or_retr<T, KIND>(x + p * m, r, m, exact, o);
+  for (int k = 0; k < m; ++k) xnew[p * m + k] = o[k];
+}
+
+// ------------------------------------------------------------------ launchers
+#define MMV_CHECK()                                    \
+  do {                                                 \
+    hipError_t e_ = hipGetLastError();                 \
+    if (e_ != hipSuccess) return static_cast<int>(e_); \
+  } while (0)
+
+template <typename T, int KIND, int MP>
+int vec_fwd_t(const T* x, int64_t n, int m, int64_t rb, int64_t re, int squared, T* out, hipStream_t st) {
+  constexpr int TI = 32;
+  if (re <= rb) return MM_OK;
+  const int nJB = int((n + kVBlock - 1) / kVBlock);
+  const int gx = nJB - int((rb + 1) / kVBlock);
+  const int gy = int((re - rb + TI - 1) / TI);
+  if (gx <= 0) return MM_OK;
+  {
+    ProfScope prof(PROF_VEC_FWD, st);
+    vec_pdist_fwd_kernel<T, KIND, MP, TI><<<dim3(gx, gy), dim3(kVBlock), 0, st>>>(x, int(n), m, int(rb), int(re),
+                                                                                 squared, out);
+  }
+  MMV_CHECK();
+  return MM_OK;
+}
+
+template <typename T, int KIND, int MP>
+int vec_bwd_t(const T* x, const T* g, int64_t n, int m, int64_t rb, int64_t re, int squared, T* grad, void* ws,
+              hipStream_t st) {
+  constexpr int TI = 64;
+  T* acc = static_cast<T*>(ws);
+  hipError_t e = hipMemsetAsync(acc, 0, sizeof(T) * size_t(n) * (MP + 1), st);
+  if (e != hipSuccess) return int(e);
+  if (re > rb) {
+    ProfScope prof(PROF_VEC_BWD, st);
+    vec_pdist_bwd_kernel<T, KIND, MP, TI>
+        <<<dim3(int((n + kVBlock - 1) / kVBlock), int((n + TI - 1) / TI)), dim3(kVBlock), 0, st>>>(
+            x, g, int(n), m, int(rb), int(re), squared, acc);
+  }
+  MMV_CHECK();
+  vec_pdist_finalize_kernel<T, KIND, MP><<<dim3(int((n + 127) / 128)), dim3(128), 0, st>>>(x, acc, int(n), m, grad);
+  MMV_CHECK();
+  return MM_OK;
+}
+
+constexpr int pad_dim(int m) { return m <= 4 ? 4 : m <= 8 ? 8 : m <= 12 ? 12 : m <= 16 ? 16 : m <= 24 ? 24 : 32; }
+
+#define MMV_DISPATCH_MP(m, ...)                             \
+  switch (pad_dim(m)) {                                     \
+    case 4: { constexpr int MP = 4; return __VA_ARGS__; }   \
+    case 8: { constexpr int MP = 8; return __VA_ARGS__; }   \
+    case 12: { constexpr int MP = 12; return __VA_ARGS__; } \
+    case 16: { constexpr int MP = 16; return __VA_ARGS__; } \
+    case 24: { constexpr int MP = 24; return __VA_ARGS__; } \
+    default: { constexpr int MP = 32; return __VA_ARGS__; } \
+  }
+
+#define MMV_DISPATCH_KIND(kind, ...)                                         \
+  switch (kind) {                                                            \
+    case MM_EUCLIDEAN: { constexpr int KIND = MM_EUCLIDEAN; __VA_ARGS__ }    \
+    case MM_LORENTZ: { constexpr int KIND = MM_LORENTZ; __VA_ARGS__ }        \
+    case MM_SPHERE: { constexpr int KIND = MM_SPHERE; __VA_ARGS__ }          \
+    default: return MM_ERR_ARG;                                              \
+  }
+
+#define MMV_DISPATCH_T(dtype, ...)                               \
+  if ((dtype) == MM_F32) { using T = float; __VA_ARGS__ }        \
+  else if ((dtype) == MM_F64) { using T = double; __VA_ARGS__ }  \
+  else return MM_ERR_ARG;
+
+}  // namespace mm
+
+using namespace mm;
+
+extern "C" {
+
+int mm_vec_max_dim(void) { return kVecMaxDim; }
+
+size_t mm_vec_pdist_ws_bytes(int dtype, int64_t n, int m) {
+  return (dtype == MM_F64 ? 8 : 4) * size_t(n) * (pad_dim(m) + 1);
+}
+
+int mm_vec_pdist_fwd(int dtype, int kind, const void* x, int64_t n, int m, int64_t row_begin, int64_t row_end,
+                     int squared, void* out, mm_stream_t stream) {
+  if (!x || n < 0 || m < 1 || row_begin < 0 || row_end > n || row_begin > row_end || n > (1 << 30)) return MM_ERR_ARG;
+  if (m > kVecMaxDim) return MM_ERR_UNSUPPORTED;
+  if (!out && mm_pair_offset(n, row_end) > mm_pair_offset(n, row_begin)) return MM_ERR_ARG;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  MMV_DISPATCH_T(dtype, MMV_DISPATCH_KIND(kind, MMV_DISPATCH_MP(m, (vec_fwd_t<T, KIND, MP>(
+      static_cast<const T*>(x), n, m, row_begin, row_end, squared, static_cast<T*>(out), st)))))
+}
+
+int mm_vec_pdist_bwd(int dtype, int kind, const void* x, const void* g, int64_t n, int m, int64_t row_begin,
+                     int64_t row_end, int squared, void* grad_x, void* ws, mm_stream_t stream) {
+  if (!x || !grad_x || !ws || n < 1 || m < 1 || row_begin < 0 || row_end > n || row_begin > row_end || n > (1 << 30))
+    return MM_ERR_ARG;
+  if (m > kVecMaxDim) return MM_ERR_UNSUPPORTED;
+  if (!g && mm_pair_offset(n, row_end) > mm_pair_offset(n, row_begin)) return MM_ERR_ARG;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  MMV_DISPATCH_T(dtype, MMV_DISPATCH_KIND(kind, MMV_DISPATCH_MP(m, (vec_bwd_t<T, KIND, MP>(
+      static_cast<const T*>(x), static_cast<const T*>(g), n, m, row_begin, row_end, squared,
+      static_cast<T*>(grad_x), ws, st)))))
+}
+
+int mm_vec_dist(int dtype, int kind, const void* x, const void* y, const void* g, int64_t cnt, int m, int squared,
+                void* out, void* grad_x, void* grad_y, mm_stream_t stream) {
+  if (cnt < 0 || m < 1 || (cnt > 0 && (!x || !y)) || ((grad_x != nullptr) != (grad_y != nullptr)) ||
+      (grad_x && !g))
+    return MM_ERR_ARG;
+  if (cnt == 0) return MM_OK;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const unsigned nb = unsigned((cnt + 127) / 128);
+  MMV_DISPATCH_T(dtype, MMV_DISPATCH_KIND(kind, {
+    vec_dist_kernel<T, KIND><<<dim3(nb), dim3(128), 0, st>>>(static_cast<const T*>(x), static_cast<const T*>(y),
+        static_cast<const T*>(g), cnt, m, squared, static_cast<T*>(out), static_cast<T*>(grad_x),
+        static_cast<T*>(grad_y));
+    MMV_CHECK(); return MM_OK; }))
+}
+
+int mm_vec_map(int dtype, int kind, int op, const void* x, const void* u, const void* y, int64_t cnt, int m, void* out,
+               mm_stream_t stream) {
+  if (cnt < 0 || m < 1 || op < 0 || op > MM_VEC_LOG || (cnt > 0 && (!x || !out))) return MM_ERR_ARG;
+  if (cnt > 0 && op != MM_VEC_PROJX && !u) return MM_ERR_ARG;
+  if (cnt > 0 && op == MM_VEC_TRANSP && !y) return MM_ERR_ARG;
+  if (m > kVecMaxDim) return MM_ERR_UNSUPPORTED;
+  if (cnt == 0) return MM_OK;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const unsigned nb = unsigned((cnt + 127) / 128);
+  MMV_DISPATCH_T(dtype, MMV_DISPATCH_KIND(kind, {
+    vec_map_kernel<T, KIND><<<dim3(nb), dim3(128), 0, st>>>(op, static_cast<const T*>(x), static_cast<const T*>(u),
+        static_cast<const T*>(y), cnt, m, static_cast<T*>(out));
+    MMV_CHECK(); return MM_OK; }))
+}
+
+int mm_vec_norm(int dtype, int kind, const void* u, int64_t cnt, int m, int squared, void* out, mm_stream_t stream) {
+  if (cnt < 0 || m < 1 || (cnt > 0 && (!u || !out))) return MM_ERR_ARG;
+  if (cnt == 0) return MM_OK;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const unsigned nb = unsigned((cnt + 127) / 128);
+  MMV_DISPATCH_T(dtype, MMV_DISPATCH_KIND(kind, {
+    vec_norm_kernel<T, KIND><<<dim3(nb), dim3(128), 0, st>>>(static_cast<const T*>(u), cnt, m, squared,
+        static_cast<T*>(out));
+    MMV_CHECK(); return MM_OK; }))
+}
+
+int mm_vec_rsgd_step(int dtype, int kind, const void* x, const void* egrad, int64_t cnt, int m, double lr,
+                     double max_grad_norm, int exact, void* x_new, mm_stream_t stream) {
+  if (cnt < 0 || m < 1 || (cnt > 0 && (!x || !egrad || !x_new))) return MM_ERR_ARG;
+  if (m > kVecMaxDim) return MM_ERR_UNSUPPORTED;
+  if (cnt == 0) return MM_OK;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const unsigned nb = unsigned((cnt + 127) / 128);
+  MMV_DISPATCH_T(dtype, MMV_DISPATCH_KIND(kind, {
+    vec_rsgd_step_kernel<T, KIND><<<dim3(nb), dim3(128), 0, st>>>(static_cast<const T*>(x),
+        static_cast<const T*>(egrad), cnt, m, T(lr), T(max_grad_norm), exact, static_cast<T*>(x_new));
+    MMV_CHECK(); return MM_OK; }))
+}
+
+}  // extern "C"

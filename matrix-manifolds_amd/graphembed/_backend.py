@@ -38,7 +38,17 @@ SIGNATURES = {
     'mm_spd_map': (_i, [_i, _i, _vp, _vp, _i64, _i, _dbl, _dbl, _vp, _vp]),
     'mm_spd_norm': (_i, [_i, _vp, _vp, _i64, _i, _i, _vp, _vp]),
     'mm_spd_rsgd_step': (_i, [_i, _vp, _vp, _i64, _i, _dbl, _dbl, _i, _vp, _vp]),
+    'mm_vec_max_dim': (_i, []),
+    'mm_vec_pdist_ws_bytes': (_sz, [_i, _i64, _i]),
+    'mm_vec_pdist_fwd': (_i, [_i, _i, _vp, _i64, _i, _i64, _i64, _i, _vp, _vp]),
+    'mm_vec_pdist_fwd_gram': (_i, [_i, _i, _vp, _i64, _i, _i64, _i64, _i, _vp, _vp]),
+    'mm_vec_pdist_bwd': (_i, [_i, _i, _vp, _vp, _i64, _i, _i64, _i64, _i, _vp, _vp, _vp]),
+    'mm_vec_dist': (_i, [_i, _i, _vp, _vp, _vp, _i64, _i, _i, _vp, _vp, _vp, _vp]),
+    'mm_vec_map': (_i, [_i, _i, _i, _vp, _vp, _vp, _i64, _i, _vp, _vp]),
+    'mm_vec_norm': (_i, [_i, _i, _vp, _i64, _i, _i, _vp, _vp]),
+    'mm_vec_rsgd_step': (_i, [_i, _i, _vp, _vp, _i64, _i, _dbl, _dbl, _i, _vp, _vp]),
 }
+VEC_EGRAD2RGRAD, VEC_PROJU, VEC_EXP, VEC_RETR, VEC_PROJX, VEC_TRANSP, VEC_LOG = range(7)
 
 
 class BackendError(RuntimeError):

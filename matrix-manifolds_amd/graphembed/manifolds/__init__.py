@@ -1,2 +1,5 @@
 from .base import Manifold
+from .euclidean import Euclidean
+from .lorentz import Lorentz
 from .spd import SymmetricPositiveDefinite
+from .sphere import Sphere

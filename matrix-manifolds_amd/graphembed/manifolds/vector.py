@@ -1,0 +1,180 @@
+"""Shared machinery of the vector manifolds (Euclidean, Lorentz, Sphere): every
+method of the Manifold API routed to the gfx950 kernels of csrc/vec.hip and
+csrc/vec_gram.hip.  A point is the flattened trailing `ndim` dimensions."""
+import numpy as np
+import torch
+
+from graphembed import _backend as B
+from graphembed.manifolds.base import Manifold
+
+
+class _VecPdist(torch.autograd.Function):
+
+    @staticmethod
+    def forward(ctx, x, kind, m, squared, row_begin, row_end, use_gram):
+        B.require_gpu(x)
+        lib = B.lib()
+        n = x.shape[0]
+        xc = x.detach().reshape(n, m).contiguous()
+        npairs = B.pair_offset(n, row_end) - B.pair_offset(n, row_begin)
+        ctx.save_for_backward(xc)
+        ctx.args = (kind, m, squared, row_begin, row_end, x.shape)
+        ctx.empty = npairs == 0
+        if ctx.empty:
+            return xc.new_empty(0)
+        with torch.cuda.device(xc.device):
+            out = torch.empty(npairs, dtype=xc.dtype, device=xc.device)
+            name = 'mm_vec_pdist_fwd_gram' if use_gram else 'mm_vec_pdist_fwd'
+            lib.call(name, B.dtype_code(xc), kind, B.ptr(xc), n, m, row_begin, row_end, int(squared),
+                     B.ptr(out), B.stream_of(xc))
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        xc, = ctx.saved_tensors
+        kind, m, squared, row_begin, row_end, shape = ctx.args
+        if ctx.empty:
+            return (torch.zeros(shape, dtype=xc.dtype, device=xc.device), ) + (None, ) * 6
+        lib = B.lib()
+        g = g.contiguous()
+        n = xc.shape[0]
+        dt = B.dtype_code(xc)
+        with torch.cuda.device(xc.device):
+            ws = torch.empty(lib.raw('mm_vec_pdist_ws_bytes')(dt, n, m), dtype=torch.uint8,
+                             device=xc.device)
+            grad = torch.empty_like(xc)
+            lib.call('mm_vec_pdist_bwd', dt, kind, B.ptr(xc), B.ptr(g), n, m, row_begin, row_end,
+                     int(squared), B.ptr(grad), B.ptr(ws), B.stream_of(xc))
+        return grad.reshape(shape), None, None, None, None, None, None
+
+
+class _VecDist(torch.autograd.Function):
+
+    @staticmethod
+    def forward(ctx, x, y, kind, m, squared):
+        B.require_gpu(x, y)
+        xc = x.detach().reshape(-1, m).contiguous()
+        yc = y.detach().reshape(-1, m).contiguous()
+        cnt = xc.shape[0]
+        with torch.cuda.device(xc.device):
+            out = torch.empty(cnt, dtype=xc.dtype, device=xc.device)
+            B.lib().call('mm_vec_dist', B.dtype_code(xc), kind, B.ptr(xc), B.ptr(yc), None, cnt, m,
+                         int(squared), B.ptr(out), None, None, B.stream_of(xc))
+        ctx.save_for_backward(xc, yc)
+        ctx.args = (kind, m, squared, x.shape, y.shape)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        xc, yc = ctx.saved_tensors
+        kind, m, squared, xs, ys = ctx.args
+        g = g.reshape(-1).contiguous()
+        with torch.cuda.device(xc.device):
+            gx, gy = torch.empty_like(xc), torch.empty_like(yc)
+            B.lib().call('mm_vec_dist', B.dtype_code(xc), kind, B.ptr(xc), B.ptr(yc), B.ptr(g),
+                         xc.shape[0], m, int(squared), None, B.ptr(gx), B.ptr(gy), B.stream_of(xc))
+        return gx.reshape(xs), gy.reshape(ys), None, None, None
+
+
+class VectorManifold(Manifold):
+    """Base of Euclidean / Lorentz / Sphere.  Subclasses set `_kind` and `shape`."""
+
+    _kind = None
+    use_gram = False  # forward pdist through the MFMA Gram kernel (inner-product manifolds)
+
+    @property
+    def _m(self):
+        return int(np.prod(self.shape))
+
+    @property
+    def ndim(self):
+        return len(self.shape)
+
+    def _batch(self, t):
+        return t.shape[:t.ndim - self.ndim]
+
+    # -- per-point maps ------------------------------------------------------
+    def _map(self, op, x, u=None, y=None):
+        B.require_gpu(x, u, y)
+        ts = [t for t in (x, u, y) if t is not None]
+        if torch.is_grad_enabled() and any(t.requires_grad for t in ts):
+            raise NotImplementedError(
+                'exp/log/retr/proj*/transp are optimizer-side maps (torch.no_grad) on the HIP path; '
+                'only dist/pdist are differentiable')
+        shape = torch.broadcast_shapes(*[t.shape for t in ts])
+        m = self._m
+        flat = [None if t is None else t.expand(shape).reshape(-1, m).contiguous() for t in (x, u, y)]
+        xc = flat[0]
+        with torch.cuda.device(xc.device):
+            out = torch.empty_like(xc)
+            B.lib().call('mm_vec_map', B.dtype_code(xc), self._kind, op, B.ptr(flat[0]), B.ptr(flat[1]),
+                         B.ptr(flat[2]), xc.shape[0], m, B.ptr(out), B.stream_of(xc))
+        return out.reshape(shape)
+
+    def _set_or_return(self, t, new, inplace):
+        if not inplace:
+            return new
+        t.set_(new)
+        return t
+
+    def norm(self, x, u, squared=False, keepdim=False):  # base.py:29-33
+        if torch.is_grad_enabled() and u.requires_grad:
+            return super().norm(x, u, squared, keepdim)
+        B.require_gpu(u)
+        m = self._m
+        uc = u.detach().reshape(-1, m).contiguous()
+        with torch.cuda.device(uc.device):
+            out = torch.empty(uc.shape[0], dtype=uc.dtype, device=uc.device)
+            B.lib().call('mm_vec_norm', B.dtype_code(uc), self._kind, B.ptr(uc), uc.shape[0], m,
+                         int(squared), B.ptr(out), B.stream_of(uc))
+        out = out.reshape(self._batch(u))
+        return out.reshape(*out.shape, *((1, ) * self.ndim)) if keepdim else out
+
+    def proju(self, x, u, inplace=False):
+        return self._set_or_return(u, self._map(B.VEC_PROJU, x, u), inplace)
+
+    def projx(self, x, inplace=False):
+        return self._set_or_return(x, self._map(B.VEC_PROJX, x.detach() if inplace else x), inplace)
+
+    def egrad2rgrad(self, x, u, inplace=False):
+        return self._set_or_return(u, self._map(B.VEC_EGRAD2RGRAD, x, u), inplace)
+
+    def exp(self, x, u):
+        return self._map(B.VEC_EXP, x, u)
+
+    def retr(self, x, u):
+        return self._map(B.VEC_RETR, x, u)
+
+    def log(self, x, y):
+        return self._map(B.VEC_LOG, x, y)
+
+    def transp(self, x, y, u):
+        return self._map(B.VEC_TRANSP, x, u, y)
+
+    def rsgd_step(self, x, egrad, *, lr, max_grad_norm=None, exact=False):
+        """Fused momentum-free RiemannianSGD update (optim/rsgd.py:63-68,82)."""
+        B.require_gpu(x, egrad)
+        m = self._m
+        xc = x.detach().reshape(-1, m).contiguous()
+        gc = egrad.detach().reshape(-1, m).contiguous()
+        with torch.cuda.device(xc.device):
+            out = torch.empty_like(xc)
+            B.lib().call('mm_vec_rsgd_step', B.dtype_code(xc), self._kind, B.ptr(xc), B.ptr(gc),
+                         xc.shape[0], m, float(lr),
+                         -1.0 if max_grad_norm is None else float(max_grad_norm), int(bool(exact)),
+                         B.ptr(out), B.stream_of(xc))
+        return out.reshape(x.shape)
+
+    # -- distances -------------------------------------------------------------
+    def dist(self, x, y, squared=False, keepdim=False):
+        shape = torch.broadcast_shapes(x.shape, y.shape)
+        d = _VecDist.apply(x.expand(shape), y.expand(shape), self._kind, self._m, squared)
+        d = d.reshape(shape[:len(shape) - self.ndim])
+        return d.reshape(*d.shape, *((1, ) * self.ndim)) if keepdim else d
+
+    def pdist(self, x, squared=False, rows=None):
+        """All-pairs distances, row-major upper triangle (base.py:59-63).  `rows` selects the
+        pair-list slice of one shard (graphembed.parallel)."""
+        assert x.ndim == self.ndim + 1
+        rb, re = (0, x.shape[0]) if rows is None else rows
+        return _VecPdist.apply(x, self._kind, self._m, squared, rb, re, self.use_gram)

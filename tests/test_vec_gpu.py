@@ -1,0 +1,295 @@
+"""GPU parity of the vector manifolds (Euclidean / Lorentz / Sphere), the product
+embedding, the losses and the RSGD training loop against the golden vectors recorded
+from the real reference."""
+import itertools
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, sym
+
+pytestmark = pytest.mark.gpu
+
+DT = {'f32': torch.float32, 'f64': torch.float64}
+KEYS = {'lorentz11': ('Lorentz', 11), 'lorentz6': ('Lorentz', 6), 'lorentz3': ('Lorentz', 3),
+        'sphere6': ('Sphere', 6), 'euclidean10': ('Euclidean', 10)}
+# Stated tolerances.  The distance maps are evaluated next to their singular points at the
+# reference's own init (acosh at 1, acos at 1), where an fp32 ulp of the inner product moves
+# d^2 by ~2e-7 absolute: hence absolute terms for fp32.  fp64 agrees to rounding.
+ABS = {'f32': 1e-6, 'f64': 1e-12}
+REL = {'f32': 2e-5, 'f64': 1e-10}
+GREL = {'f32': 5e-4, 'f64': 1e-9}   # gradients, relative to max|grad| of the call
+
+
+def make(key):
+    from graphembed import manifolds as M
+    name, n = KEYS[key]
+    return getattr(M, name)(n)
+
+
+def dev(a):
+    return torch.from_numpy(np.array(a)).cuda()
+
+
+def check_abs_rel(got, ref, dname, what, scale=1.0):
+    got, ref = got.detach().double().cpu().numpy(), np.asarray(ref, dtype=np.float64)
+    assert got.shape == ref.shape, (what, got.shape, ref.shape)
+    ok = np.isfinite(ref)
+    bad = np.abs(got - ref)[ok] - scale * (ABS[dname] + REL[dname] * np.abs(ref[ok]))
+    assert bad.max() <= 0, f'{what}: worst excess {bad.max():.3e}'
+
+
+def check_rel(got, ref, tol, what):
+    got = got.detach().double().cpu().numpy() if torch.is_tensor(got) else np.asarray(got, np.float64)
+    ref = np.asarray(ref, dtype=np.float64)
+    assert got.shape == ref.shape, (what, got.shape, ref.shape)
+    ok = np.isfinite(ref)
+    err = np.abs(got - ref)[ok].max() / max(np.abs(ref[ok]).max(), 1e-30)
+    assert err <= tol, f'{what}: {err:.3e} > {tol:.1e}'
+
+
+@pytest.mark.parametrize('key', list(KEYS))
+@pytest.mark.parametrize('dname,init', list(itertools.product(DT, ['rand', 'wide'])))
+def test_pdist_vs_reference_golden(key, dname, init):
+    G = load_golden(key)
+    man = make(key)
+    for n in (33, 96):
+        tag = f'{dname}/{init}/n{n}'
+        if f'{tag}/x' not in G:
+            continue
+        g = dev(G[f'{tag}/g'])
+        for gram in ([False, True] if man.use_gram else [False]):
+            man.use_gram = gram
+            x = dev(G[f'{tag}/x']).requires_grad_()
+            d2 = man.pdist(x, squared=True)
+            check_abs_rel(d2, G[f'{tag}/d2'], dname, f'd2 {tag} gram={gram}')
+            gr, = torch.autograd.grad((d2 * g).sum(), x)
+            check_rel(gr, G[f'{tag}/grad_d2'], GREL[dname], f'grad_d2 {tag}')
+            d1 = man.pdist(x, squared=False)
+            check_abs_rel(d1 * d1, np.asarray(G[f'{tag}/d1'], np.float64)**2, dname, f'd1^2 {tag} gram={gram}')
+            gr, = torch.autograd.grad((d1 * g).sum(), x)
+            check_rel(gr, G[f'{tag}/grad_d1'], GREL[dname] * 20, f'grad_d1 {tag}')
+        dxy = man.dist(x.detach(), x.detach().flip(0), squared=True)
+        check_abs_rel(dxy, G[f'{tag}/dist_xy'], dname, f'dist_xy {tag}')
+
+
+@pytest.mark.parametrize('key', list(KEYS))
+@pytest.mark.parametrize('dname,init', list(itertools.product(DT, ['rand', 'wide'])))
+def test_maps_vs_reference_golden(key, dname, init):
+    G = load_golden(key)
+    man = make(key)
+    tag = f'{dname}/{init}/n33'
+    tol = 2e-5 if dname == 'f32' else 1e-11
+    x = dev(G[f'{tag}/x'])
+    with torch.no_grad():
+        check_rel(man.egrad2rgrad(x, dev(G[f'{tag}/grad_d2'])), G[f'{tag}/rgrad'], tol, 'egrad2rgrad')
+        check_rel(man.norm(x, dev(G[f'{tag}/rgrad']), keepdim=True), G[f'{tag}/rgrad_norm'], tol, 'norm')
+        u = dev(G[f'{tag}/u'])
+        pu = man.proju(x, u)
+        check_rel(pu, G[f'{tag}/proju'], tol, 'proju')
+        check_rel(man.exp(x, pu), G[f'{tag}/exp'], tol, 'exp')
+        check_rel(man.retr(x, pu), G[f'{tag}/retr'], tol, 'retr')
+        # log at the reference init divides two O(1e-2) quantities that carry fp32 rounding
+        check_rel(man.log(x, x.flip(0)), G[f'{tag}/log'], 5e-3 if dname == 'f32' else 1e-7, 'log')
+        check_rel(man.projx(dev(G[f'{tag}/projx_in'])), G[f'{tag}/projx'], tol, 'projx')
+        check_rel(man.transp(x, man.retr(x, pu), pu), G[f'{tag}/transp'], tol * 5, 'transp')
+
+
+@pytest.mark.parametrize('key', list(KEYS))
+@pytest.mark.parametrize('dname', list(DT))
+def test_rsgd_vs_reference_golden(key, dname):
+    from graphembed.modules import ManifoldParameter
+    from graphembed.optim import RiemannianSGD
+    G = load_golden(key)
+    man = make(key)
+    base = f'{dname}/rsgd'
+    tol = 5e-5 if dname == 'f32' else 1e-10
+    for exact, clip, mom in itertools.product([0, 1], [0, 1], [0, 1]):
+        tag = f'{base}/exact{exact}_clip{clip}_mom{mom}'
+        p = ManifoldParameter(dev(G[f'{base}/x0']), manifold=man)
+        opt = RiemannianSGD([p], lr=0.05, momentum=0.9 if mom else 0, dampening=0.1 if mom else 0,
+                            max_grad_norm=2.0 if clip else None, exact=bool(exact))
+        p.grad = dev(G[f'{base}/g1'])
+        opt.step()
+        check_rel(p.data, G[f'{tag}/x1'], tol, tag + '/x1')
+        p.grad = dev(G[f'{base}/g2'])
+        opt.step()
+        check_rel(p.data, G[f'{tag}/x2'], tol, tag + '/x2')
+        if mom:
+            check_rel(opt.state[p]['momentum_buffer'], G[f'{tag}/buf2'], tol, tag + '/buf2')
+
+
+@pytest.mark.parametrize('key,n', [('lorentz11', 1000), ('sphere6', 700), ('euclidean10', 515), ('lorentz3', 300)])
+@pytest.mark.parametrize('dname', list(DT))
+def test_pdist_vs_oracle_seeded(key, n, dname):
+    from oracle import ref_port as rp
+    name, m = KEYS[key]
+    port = rp.make(name.lower(), m)
+    man = make(key)
+    gen = torch.Generator().manual_seed(n)
+    x64 = port.rand(n, ir=0.3 if name != 'Sphere' else 0.5, dtype=torch.float64, generator=gen)
+    g64 = torch.randn(n * (n - 1) // 2, dtype=torch.float64, generator=gen)
+    xr = x64.clone().requires_grad_()
+    ref = port.pdist(xr, squared=True)
+    ref_g, = torch.autograd.grad((ref * g64).sum(), xr)
+    for gram in ([False, True] if man.use_gram else [False]):
+        man.use_gram = gram
+        x = x64.to(DT[dname]).cuda().requires_grad_()
+        d2 = man.pdist(x, squared=True)
+        check_abs_rel(d2, ref.detach().numpy(), dname, f'd2 {key} gram={gram}')
+        gr, = torch.autograd.grad((d2 * g64.to(DT[dname]).cuda()).sum(), x)
+        check_rel(gr, ref_g.numpy(), GREL[dname], f'grad {key}')
+
+
+@pytest.mark.parametrize('key', ['lorentz11', 'sphere6', 'euclidean10'])
+def test_row_sharding(key):
+    from graphembed import _backend as B
+    man = make(key)
+    torch.manual_seed(5)
+    n = 611
+    x = man.rand(n, out=torch.empty(0, device='cuda'), ir=0.3)
+    g = torch.randn(n * (n - 1) // 2, device='cuda')
+    xr = x.clone().requires_grad_()
+    full = man.pdist(xr, squared=True)
+    gfull, = torch.autograd.grad((full * g).sum(), xr)
+    for world in (2, 5):
+        parts, gsum = [], torch.zeros_like(x)
+        for r in range(world):
+            rb, re = B.shard_rows(n, world, r)
+            xr = x.clone().requires_grad_()
+            part = man.pdist(xr, squared=True, rows=(rb, re))
+            lo, hi = B.pair_offset(n, rb), B.pair_offset(n, re)
+            gp, = torch.autograd.grad((part * g[lo:hi]).sum(), xr)
+            parts.append(part.detach())
+            gsum += gp
+        assert torch.equal(torch.cat(parts), full.detach())
+        check_rel(gsum, gfull.cpu().numpy(), 1e-5, 'sum of shard grads')
+
+
+@pytest.mark.parametrize('dname', list(DT))
+def test_product_embedding_and_losses(dname):
+    """ManifoldEmbedding.compute_dists over H^5 x S^5 x SPD(2) (config 4's product) incl. the
+    gradients of the learnable scales, full batch and node mini-batch (modules.py:84-88)."""
+    from graphembed import manifolds as M
+    from graphembed.modules import ManifoldEmbedding
+    from graphembed.objectives import QuotientLoss, StressLoss
+    G = load_golden('callers')
+    torch.set_default_dtype(DT[dname])
+    try:
+        with torch.device('cuda'):
+            emb = ManifoldEmbedding(33, [M.Lorentz(6), M.Sphere(6), M.SymmetricPositiveDefinite(2)])
+    finally:
+        torch.set_default_dtype(torch.float32)
+    idx = dev(G[f'{dname}/product/idx'])
+    for tag, ii in [('full', None), ('batch', idx)]:
+        base = f'{dname}/product/{tag}'
+        with torch.no_grad():
+            for k in range(3):
+                emb.xs[k].copy_(dev(G[f'{base}/x_{k}']))
+                emb.scales[k].fill_(float(G[f'{base}/scales'][k]))
+        md = emb.compute_dists(ii)
+        check_abs_rel(md, G[f'{base}/d2'], dname, f'product d2 {tag}', scale=3)
+        grads = torch.autograd.grad((md * dev(G[f'{base}/g'])).sum(), list(emb.xs) + list(emb.scales))
+        for k in range(3):
+            ref = G[f'{base}/grad_x_{k}']
+            check_rel(grads[k], sym(ref) if k == 2 else ref, GREL[dname], f'product grad_x_{k} {tag}')
+            check_rel(grads[3 + k], G[f'{base}/grad_s_{k}'], GREL[dname], f'product grad_s_{k} {tag}')
+    gd, md = dev(G[f'{dname}/loss/gd']), dev(G[f'{dname}/loss/md'])
+    check_rel(StressLoss()(gd, md), G[f'{dname}/loss/stress'], 1e-5, 'stress')
+    check_rel(QuotientLoss()(gd, md, epoch=3, alpha=1.7), G[f'{dname}/loss/quotient'], 1e-5, 'quotient')
+
+
+@pytest.mark.parametrize('case', ['euclidean10', 'lorentz11', 'spd3', 'product'])
+@pytest.mark.parametrize('loss_name', ['stress', 'quotient'])
+def test_tree40_training_trace(case, loss_name):
+    """config[0]-style plumbing: 20 full-batch epochs on tree40 in fp64 with the reference's
+    production optimizer settings (experiments/run_grid.py:24-36), through this package's
+    ManifoldEmbedding + RiemannianSGD + losses, against the reference's loss trace."""
+    from graphembed import manifolds as M
+    from graphembed.modules import ManifoldEmbedding
+    from graphembed.objectives import QuotientLoss, StressLoss
+    from graphembed.optim import RiemannianSGD
+    G = load_golden('callers')
+    mk = {'euclidean10': lambda: [M.Euclidean(10)], 'lorentz11': lambda: [M.Lorentz(11)],
+          'spd3': lambda: [M.SymmetricPositiveDefinite(3)],
+          'product': lambda: [M.Lorentz(6), M.Sphere(6), M.SymmetricPositiveDefinite(2)]}[case]
+    base = f'tree40/{case}/{loss_name}'
+    torch.set_default_dtype(torch.float64)
+    try:
+        with torch.device('cuda'):
+            emb = ManifoldEmbedding(40, mk())
+        with torch.no_grad():
+            for k, x in enumerate(emb.xs):
+                x.copy_(dev(G[f'{base}/x0_{k}']))
+        target = dev(G['tree40/target'])
+        opt = RiemannianSGD(list(emb.xs), lr=0.01, exact=True, max_grad_norm=20)
+        opt_s = RiemannianSGD(list(emb.scales), lr=1e-4, max_grad_norm=500)
+        fn = StressLoss() if loss_name == 'stress' else QuotientLoss()
+        losses = []
+        for epoch in range(20):
+            loss = fn(target, emb.compute_dists(None), epoch=epoch, alpha=1.0)
+            opt.zero_grad()
+            opt_s.zero_grad()
+            loss.backward()
+            opt.step()
+            opt_s.step()
+            losses.append(loss.item())
+    finally:
+        torch.set_default_dtype(torch.float32)
+    # SPD factors differ from the reference by its eps-fudged closed forms (~1e-7)
+    tol = 1e-9 if case in ('euclidean10', 'lorentz11') else 2e-5
+    check_rel(np.array(losses), G[f'{base}/losses'], tol, 'loss trace')
+    for k, x in enumerate(emb.xs):
+        check_rel(x.data, G[f'{base}/x20_{k}'], max(tol, 1e-8) * 10, f'x20_{k}')
+    check_rel(np.array([s.item() for s in emb.scales]), G[f'{base}/scales20'], 1e-6, 'scales')
+
+
+def test_isometry_spd2_lorentz3():
+    """tests/test_isometry.py:51-63 of the reference: SPD(2)/det=1 is isometric to H^2 with
+    curvature -1/2: spd.pdist(x) == sqrt(2) * lorentz.pdist(phi(x))."""
+    from graphembed import manifolds as M
+    torch.manual_seed(1)
+    n = 200
+    h = M.Lorentz(3).rand(n, out=torch.empty(0, dtype=torch.float64, device='cuda'), ir=1.0)
+    t, a, b = h[:, 0], h[:, 1], h[:, 2]
+    x = torch.stack([torch.stack([t + a, b], -1), torch.stack([b, t - a], -1)], -2)  # det = t^2-a^2-b^2 = 1
+    ds = M.SymmetricPositiveDefinite(2).pdist(x)
+    dl = M.Lorentz(3).pdist(h)
+    np.testing.assert_allclose(ds.cpu().numpy(), (2 ** 0.5) * dl.cpu().numpy(), rtol=1e-7, atol=1e-9)
+
+
+def test_sphere_antipodal_and_euclid_scipy():
+    """tests/test_sphere.py:9-15 and tests/test_euclidean.py:27-33 of the reference."""
+    from scipy.spatial.distance import pdist as sp_pdist
+    from graphembed import manifolds as M
+    x = torch.randn(10, 6, dtype=torch.float64, device='cuda')
+    x = x / x.norm(dim=-1, keepdim=True)
+    d = M.Sphere(6).dist(x, -x)
+    np.testing.assert_allclose(d.cpu().numpy(), np.pi, atol=1e-4)
+    for n, d_ in [(10, 10), (100, 19)]:
+        x = torch.randn(n, d_, dtype=torch.float64, device='cuda')
+        np.testing.assert_allclose(M.Euclidean(d_).pdist(x).cpu().numpy(), sp_pdist(x.cpu().numpy()), atol=1e-10)
+
+
+def test_optim_sphere_dominant_eigenvector():
+    """tests/test_optim.py:13-41 of the reference: RSGD on the sphere finds the dominant
+    eigenvector; the iterate stays on the manifold."""
+    from graphembed import manifolds as M
+    from graphembed.modules import ManifoldParameter
+    from graphembed.optim import RiemannianSGD
+    torch.manual_seed(0)
+    n = 8
+    a = torch.randn(n, n, dtype=torch.float64, device='cuda')
+    a = a @ a.T
+    man = M.Sphere(n)
+    x = ManifoldParameter(man.rand_uniform(1, out=a)[0], manifold=man)
+    opt = RiemannianSGD([x], lr=1e-2)
+    for _ in range(2000):
+        opt.zero_grad()
+        loss = -(x @ a @ x)
+        loss.backward()
+        opt.step()
+        assert abs(x.detach().norm().item() - 1) < 1e-6
+    w, v = torch.linalg.eigh(a)
+    assert abs(abs((v[:, -1] @ x.detach()).item()) - 1) < 1e-3

@@ -7,5 +7,7 @@ from . import manifolds
 from . import modules
 from . import objectives
 from . import optim
+from . import data
+from . import parallel
 
 __version__ = '0.1.0'

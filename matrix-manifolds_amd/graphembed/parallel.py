@@ -1,0 +1,94 @@
+"""Pair-range sharding across GPUs: one process per GPU, the embedding replicated,
+the pair list [0,P) split into contiguous row ranges, ONE all-reduce(sum) per step.
+
+This replaces the reference's only parallelism, `torch.nn.DataParallel` over
+`BatchedObjective` (graphembed/graphembed/train.py:107-109), which per step does a
+parameter broadcast, a scalar gather and a gradient reduce-add — and, because it
+scatters *node* indices, silently drops every cross-chunk pair (train.py:203-213).
+Here every pair is evaluated exactly once, each rank consumes only its slice of the
+targets, and since all ranks apply the same deterministic optimizer step to the same
+all-reduced gradient the replicas stay identical without any broadcast.
+
+With backend "nccl" the collective is RCCL over xGMI; with "gloo" the same code runs
+on CPUs (tests).  The message is n*point_size(+scales) elements (<= 1 MiB at the
+reference's sizes): latency-bound, so it is issued once, on the compute stream.
+"""
+import torch
+import torch.distributed as dist
+
+from graphembed import _backend as B
+
+
+def world_info(group=None):
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_world_size(group), dist.get_rank(group)
+    return 1, 0
+
+
+class PairShard:
+    """The slice of the pair list owned by this rank for an n-point embedding."""
+
+    def __init__(self, n, group=None, world=None, rank=None):
+        if world is None:
+            world, rank = world_info(group)
+        self.n, self.world, self.rank, self.group = n, world, rank, group
+        self.rows = B.shard_rows(n, world, rank)
+        self.lo = B.pair_offset(n, self.rows[0])
+        self.hi = B.pair_offset(n, self.rows[1])
+
+    @property
+    def num_pairs(self):
+        return self.hi - self.lo
+
+    def slice(self, pair_vector):
+        """This rank's part of a full-length (P,) vector (targets, upstream gradients)."""
+        return pair_vector[self.lo:self.hi]
+
+
+class _SyncGrads(torch.autograd.Function):
+    """Identity in the forward; in the backward all incoming gradients are packed into
+    one flat buffer, summed over the ranks with a single all-reduce, and unpacked."""
+
+    @staticmethod
+    def forward(ctx, group, *tensors):
+        ctx.group = group
+        return tuple(t.view_as(t) for t in tensors)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        present = [g for g in grads if g is not None]
+        if present and dist.is_available() and dist.is_initialized() and dist.get_world_size(ctx.group) > 1:
+            dtype = present[0].dtype
+            for g in present[1:]:
+                dtype = torch.promote_types(dtype, g.dtype)
+            flat = torch.cat([g.reshape(-1).to(dtype) for g in present])
+            dist.all_reduce(flat, group=ctx.group)  # the single collective of a step
+            out, off = [], 0
+            for g in grads:
+                if g is None:
+                    out.append(None)
+                    continue
+                k = g.numel()
+                out.append(flat[off:off + k].view_as(g).to(g.dtype))
+                off += k
+            grads = tuple(out)
+        return (None, ) + tuple(grads)
+
+
+def sync_grads(*tensors, group=None):
+    """Return views of `tensors` whose gradients are all-reduced (sum) over `group` in one
+    collective when backward reaches them."""
+    return _SyncGrads.apply(group, *tensors)
+
+
+def sharded_compute_dists(embedding, shard):
+    """ManifoldEmbedding.compute_dists (modules.py:84-88) restricted to this rank's pair
+    slice: sum_k softplus(s_k) * pdist_k(x_k, squared=True)[lo:hi].  Backward leaves the
+    all-reduced (i.e. full) gradients in `x.grad` / `scale.grad` on every rank."""
+    from torch.nn.functional import softplus
+    params = list(embedding.xs) + list(embedding.scales)
+    synced = sync_grads(*params, group=shard.group)
+    k = len(embedding.xs)
+    return sum(
+        softplus(s) * man.pdist(x, squared=True, rows=shard.rows)
+        for x, s, man in zip(synced[:k], synced[k:], embedding.manifolds))

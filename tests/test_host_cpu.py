@@ -1,0 +1,251 @@
+"""CPU-only tests: the C ABI loads and exports what include/mm_manifolds.h declares, the
+pair-list geometry, loud failure without a GPU, and the host logic (RSGD control flow,
+embedding containers, losses, pair-range sharding with its single all-reduce over gloo)."""
+import ctypes
+import itertools
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT, load_golden, sym
+
+from graphembed import _backend as B
+
+
+def header_symbols():
+    src = open(os.path.join(ROOT, 'include', 'mm_manifolds.h')).read()
+    src = re.sub(r'/\*.*?\*/', '', src, flags=re.S)
+    return set(re.findall(r'\b(mm_[a-z0-9_]+)\s*\(', src))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = B.lib()                       # raises if the .so is missing
+    declared = header_symbols()
+    assert len(declared) >= 25
+    raw = ctypes.CDLL(lib.path)
+    for name in declared:
+        assert hasattr(raw, name), f'{name} declared in mm_manifolds.h but not exported'
+    assert declared == set(B.SIGNATURES), declared ^ set(B.SIGNATURES)
+    assert lib.raw('mm_target_arch')() == b'gfx950'
+    assert lib.raw('mm_abi_version')() >= 1
+    assert lib.raw('mm_spd_max_dim')() >= 4 and lib.raw('mm_vec_max_dim')() >= 16
+
+
+def test_argument_errors_need_no_gpu():
+    lib = B.lib()
+    f = lib.raw('mm_spd_pdist_fwd')
+    assert f(B.MM_F32, None, 10, 3, 0, 10, 1, 1e-8, 1e8, None, None, 0, None) == -1      # null x
+    g = lib.raw('mm_vec_pdist_fwd')
+    assert g(B.MM_F32, B.LORENTZ, None, 10, 11, 0, 10, 1, None, None) == -1
+    buf = (ctypes.c_float * 4)()
+    p = ctypes.cast(buf, ctypes.c_void_p)
+    assert f(B.MM_F32, p, 10, 3, 5, 4, 1, 1e-8, 1e8, p, p, 0, None) == -1                # row_begin > row_end
+    assert g(B.MM_F32, B.LORENTZ, p, 10, 1000, 0, 10, 1, p, None) == -2                   # m too large
+    with pytest.raises(B.BackendError):
+        lib.call('mm_spd_pdist_fwd', B.MM_F32, None, 10, 3, 0, 10, 1, 1e-8, 1e8, None, None, 0, None)
+    assert lib.raw('mm_spd_pdist_ws_bytes')(B.MM_F32, 5000, 3) == 64 + 4 * 5000 * 6 * 4
+    assert lib.raw('mm_spd_pdist_ws_bytes')(B.MM_F64, 7, 4) == 64 + 8 * 7 * 10 * 4
+
+
+@pytest.mark.parametrize('n,world', [(1, 1), (2, 2), (5, 8), (40, 3), (5000, 8), (16384, 8), (4039, 7)])
+def test_shard_rows_cover_and_balance(n, world):
+    lib = B.lib()
+    P = n * (n - 1) // 2
+    prev_end, sizes = 0, []
+    for r in range(world):
+        a, b = ctypes.c_int64(), ctypes.c_int64()
+        lib.call('mm_shard_rows', n, world, r, ctypes.byref(a), ctypes.byref(b))
+        assert (a.value, b.value) == B.shard_rows(n, world, r)
+        assert a.value == prev_end and b.value >= a.value
+        prev_end = b.value
+        lo, hi = lib.raw('mm_pair_offset')(n, a.value), lib.raw('mm_pair_offset')(n, b.value)
+        assert (lo, hi) == (B.pair_offset(n, a.value), B.pair_offset(n, b.value))
+        sizes.append(hi - lo)
+    assert prev_end == n and sum(sizes) == P
+    if n >= 64 * world:
+        assert max(sizes) - min(sizes) <= 2 * n          # balanced to within a row or two
+
+
+def test_pair_offset_matches_triu_indices():
+    n = 37
+    m = torch.triu_indices(n, n, 1)
+    for k in [0, 1, 35, 36, 300, n * (n - 1) // 2 - 1]:
+        i, j = int(m[0, k]), int(m[1, k])
+        assert B.pair_offset(n, i) + (j - i - 1) == k
+
+
+def test_fails_loudly_without_gpu_or_library(tmp_path):
+    from graphembed.manifolds import Lorentz, SymmetricPositiveDefinite
+    with pytest.raises(B.BackendError, match='CPU tensor'):
+        SymmetricPositiveDefinite(3).pdist(torch.eye(3).repeat(4, 1, 1))
+    with pytest.raises(B.BackendError, match='CPU tensor'):
+        Lorentz(4).pdist(torch.randn(5, 4))
+    with pytest.raises(B.BackendError, match='CPU tensor'):
+        with torch.no_grad():
+            Lorentz(4).exp(torch.randn(5, 4), torch.randn(5, 4))
+    with pytest.raises(B.BackendError, match='not found'):
+        B.HipLibrary(str(tmp_path / 'libmm_manifolds.so'))
+    with pytest.raises(TypeError):
+        B.dtype_code(torch.zeros(1, dtype=torch.float16))
+
+
+def test_utils_and_vec_maps():
+    from graphembed import utils
+    from graphembed.manifolds import SymmetricPositiveDefinite as SPD
+    assert utils.nnm1d2_to_n(780) == 40 and utils.nnp1d2_to_n(6) == 3
+    with pytest.raises(AssertionError):
+        utils.nnm1d2_to_n(781)
+    v = torch.arange(10.)
+    sq = utils.squareform1(v)
+    assert sq.shape == (5, 5) and torch.equal(sq, sq.T) and torch.equal(utils.squareform1(sq), v)
+    assert torch.equal(sq[0, 1:], v[:4])                 # row-major upper triangle
+    u = torch.randn(7, 6)
+    U = SPD.from_vec(u)
+    assert torch.allclose(U, U.transpose(-1, -2)) and torch.allclose(SPD.to_vec(U), u, atol=1e-6)
+    assert torch.allclose((U * U).sum((-1, -2)), (u * u).sum(-1), atol=1e-5)   # Vec is an isometry
+    m = utils.triu_mask(4, d=1)
+    assert m.sum() == 6 and not m[2, 2] and m[0, 3]
+
+
+@pytest.mark.parametrize('key,args', [('spd3', ('spd', 3)), ('lorentz6', ('lorentz', 6)), ('sphere6', ('sphere', 6))])
+def test_rsgd_control_flow_matches_reference(key, args):
+    """graphembed.optim.RiemannianSGD (clip, momentum + transport, exact/retr, set_) driven
+    through CPU stand-in manifolds reproduces the reference optimizer's two-step traces."""
+    import cpu_double
+    from graphembed.modules import ManifoldParameter
+    from graphembed.optim import RiemannianSGD
+    G = load_golden(key)
+    man = cpu_double.make(*args)
+    base = 'f64/rsgd'
+    for exact, clip, mom in itertools.product([0, 1], [0, 1], [0, 1]):
+        tag = f'{base}/exact{exact}_clip{clip}_mom{mom}'
+        p = ManifoldParameter(torch.from_numpy(G[f'{base}/x0']).clone(), manifold=man)
+        opt = RiemannianSGD([p], lr=0.05, momentum=0.9 if mom else 0, dampening=0.1 if mom else 0,
+                            max_grad_norm=2.0 if clip else None, exact=bool(exact))
+        for step, gk in ((1, 'g1'), (2, 'g2')):
+            p.grad = torch.from_numpy(G[f'{base}/{gk}']).clone()
+            opt.step()
+            np.testing.assert_allclose(p.data.numpy(), G[f'{tag}/x{step}'], rtol=1e-9, atol=1e-11)
+        if mom:
+            np.testing.assert_allclose(opt.state[p]['momentum_buffer'].numpy(), G[f'{tag}/buf2'], rtol=1e-9, atol=1e-11)
+
+
+def test_flat_parameters_use_euclidean_fallback():
+    """rsgd.py:7,56-59: plain Parameters (scales) are stepped as Euclidean(1) points."""
+    from graphembed.optim import RiemannianSGD
+    s = torch.nn.Parameter(torch.tensor(0.5, dtype=torch.float64))
+    opt = RiemannianSGD([s], lr=0.1, max_grad_norm=2.0)
+    s.grad = torch.tensor(10.0, dtype=torch.float64)
+    opt.step()
+    assert s.item() == pytest.approx(0.5 - 0.1 * 2.0)
+    with pytest.raises(ValueError):
+        RiemannianSGD([s], lr=0.1, momentum=-1)
+
+
+def test_embedding_container_and_losses():
+    import cpu_double
+    from graphembed.modules import BatchedObjective, ManifoldEmbedding, ManifoldParameter
+    from graphembed.objectives import QuotientLoss, StressLoss, Sum
+    from graphembed.data import GraphDataset
+    G = load_golden('callers')
+    mans = [cpu_double.make('lorentz', 6), cpu_double.make('sphere', 6), cpu_double.make('spd', 2)]
+    emb = ManifoldEmbedding(33, mans)
+    assert list(emb.state_dict()) == ['xs.0', 'xs.1', 'xs.2', 'scales.0', 'scales.1', 'scales.2']
+    assert all(isinstance(p, ManifoldParameter) and p.manifold is m for p, m in zip(emb.xs, mans))
+    emb = emb.double()
+    assert all(p.manifold is m for p, m in zip(emb.xs, mans))      # tag survives Module._apply
+    base = 'f64/product/batch'
+    idx = torch.from_numpy(G['f64/product/idx'])
+    with torch.no_grad():
+        for k in range(3):
+            emb.xs[k].copy_(torch.from_numpy(G[f'{base}/x_{k}']))
+            emb.scales[k].fill_(float(G[f'{base}/scales'][k]))
+    md = emb.compute_dists(idx)
+    np.testing.assert_allclose(md.detach().numpy(), G[f'{base}/d2'], rtol=1e-9)
+    gd, mdl = torch.from_numpy(G['f64/loss/gd']), torch.from_numpy(G['f64/loss/md'])
+    assert StressLoss()(gd, mdl).item() == pytest.approx(float(G['f64/loss/stress']), rel=1e-12)
+    assert QuotientLoss()(gd, mdl, epoch=3, alpha=1.7).item() == pytest.approx(float(G['f64/loss/quotient']), rel=1e-12)
+    assert str(Sum(StressLoss(), QuotientLoss())) == 'stress_loss__quotient_loss'
+    with pytest.raises(ValueError):
+        QuotientLoss(inc_l1=False, inc_l2=False)
+    # GraphDataset: squared, max-normalised targets; subset indexing follows pdist order
+    gp = torch.from_numpy(G['tree40/gpdists'])
+    ds = GraphDataset(gp.clone())
+    np.testing.assert_allclose(ds[None].numpy(), G['tree40/target'], rtol=1e-12)
+    sub = torch.tensor([7, 3, 20, 11])
+    dense = torch.zeros(40, 40, dtype=gp.dtype)
+    iu = torch.triu_indices(40, 40, 1)
+    dense[iu[0], iu[1]] = ds[None]
+    dense = dense + dense.T
+    expect = torch.stack([dense[sub[a], sub[b]] for a in range(4) for b in range(a + 1, 4)])
+    assert torch.equal(ds[sub], expect) and len(ds) == 40
+    obj = BatchedObjective(StressLoss(), GraphDataset(torch.rand(33 * 32 // 2, dtype=torch.float64) + 0.1), emb)
+    assert obj(idx).ndim == 0
+
+
+def _sharded_worker(rank, world, port, tmp, key):
+    import sys
+    sys.path.insert(0, os.path.dirname(__file__))
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    import torch.distributed as dist
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        import cpu_double
+        from graphembed.modules import ManifoldEmbedding
+        from graphembed.objectives import StressLoss
+        from graphembed.optim import RiemannianSGD
+        from graphembed.parallel import PairShard, sharded_compute_dists
+        torch.manual_seed(0)                               # identical replicas
+        mans = [cpu_double.make('lorentz', 6), cpu_double.make('spd', 3)]
+        emb = ManifoldEmbedding(41, mans).double()
+        target = torch.rand(41 * 40 // 2, dtype=torch.float64)
+        shard = PairShard(41)
+        assert (shard.world, shard.rank) == (world, rank)
+        opt = RiemannianSGD(list(emb.xs) + list(emb.scales), lr=0.01, max_grad_norm=20)
+        for _ in range(2):
+            opt.zero_grad()
+            md = sharded_compute_dists(emb, shard)
+            assert md.numel() == shard.num_pairs
+            loss = StressLoss()(shard.slice(target), md)
+            loss.backward()
+            opt.step()
+        torch.save({'xs': [x.data for x in emb.xs], 'scales': [s.data for s in emb.scales],
+                    'grads': [p.grad for p in list(emb.xs) + list(emb.scales)]}, f'{tmp}/{key}_{rank}.pt')
+    finally:
+        dist.destroy_process_group()
+
+
+def test_pair_sharding_over_gloo_matches_single_process(tmp_path):
+    """world_size 2 on CPU: each rank evaluates only its row range of the pair list; one
+    all-reduce leaves the full gradient on both ranks; replicas stay identical and equal to
+    the unsharded run."""
+    import socket
+    import torch.multiprocessing as mp
+    import cpu_double
+    from graphembed.modules import ManifoldEmbedding
+    from graphembed.objectives import StressLoss
+    from graphembed.optim import RiemannianSGD
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_sharded_worker, args=(2, port, str(tmp_path), 'w2'), nprocs=2, join=True)
+    r0, r1 = (torch.load(tmp_path / f'w2_{r}.pt') for r in range(2))
+    torch.manual_seed(0)
+    emb = ManifoldEmbedding(41, [cpu_double.make('lorentz', 6), cpu_double.make('spd', 3)]).double()
+    target = torch.rand(41 * 40 // 2, dtype=torch.float64)
+    opt = RiemannianSGD(list(emb.xs) + list(emb.scales), lr=0.01, max_grad_norm=20)
+    for _ in range(2):
+        opt.zero_grad()
+        StressLoss()(target, emb.compute_dists(None)).backward()
+        opt.step()
+    for k in range(2):
+        assert torch.equal(r0['xs'][k], r1['xs'][k])                       # replicas identical
+        np.testing.assert_allclose(r0['xs'][k].numpy(), emb.xs[k].data.numpy(), rtol=1e-10, atol=1e-12)
+        np.testing.assert_allclose(r0['scales'][k].numpy(), emb.scales[k].data.numpy(), rtol=1e-10)
+    ref_grads = [p.grad for p in list(emb.xs) + list(emb.scales)]
+    for a, b in zip(r0['grads'], ref_grads):
+        np.testing.assert_allclose(a.numpy(), b.numpy(), rtol=1e-9, atol=1e-12)

@@ -197,17 +197,24 @@ __device__ __forceinline__ void congr_full(const T (&f)[D * D], const T (&s)[Pac
 // the eigenvalues and (if WITH_V) the columns of v the eigenvectors,
 // A = V diag(w) V^T.
 //
-// The sweep loop is wave-uniform (runs while any lane of the wavefront is
-// unconverged) so there is no divergence; a lane that has converged applies
-// exact identity rotations (t = 0 -> c = 1, s = 0), which leave its registers
-// bit-for-bit unchanged.  A lane's result therefore depends only on its own
-// matrix, never on its wave-mates: results are reproducible under any tiling
-// or sharding of the pair list.
+// Rotation for the pair (p,q), written to need only two transcendental issues
+// (v_rsq_f32 costs ~3.5x a plain VALU op on gfx950, tools/micro/valu_rate.hip):
+//   h = aqq - app,  r = rsq(h^2 + 4 apq^2),  cos 2t = |h| r,
+//   c = cos t = sqrt((1 + cos 2t)/2) = x rsq(x),   s = sgn(h) apq r / c,   tan t = s / c
+// (|t| <= pi/4, the small-angle root).  |h| carries a +1e-15 so that h = apq = 0
+// yields exactly the identity (c = 1, s = 0) with no branch; 1e-15 squares to a
+// normal float, so rsq never sees a flushed denormal.
 //
-// Convergence test: off(A)^2 <= eps^2 * ||diag(A)||^2 — the residual coupling
-// is then below the rounding error already committed when A was formed.
+// The sweep loop is wave-uniform: it runs while any lane of the wavefront has
+//   off(A)^2 > tol2 * ||diag(A)||^2 .
+// A lane that has converged keeps rotating by ~eps angles, which is harmless; which
+// lanes share a wavefront is fixed by the global column / point index alone (tiles
+// are anchored there), so results do not depend on how the pair list is sharded.
+// tol2 = eps^2 when eigenvectors are used (the residual coupling is then below the
+// rounding already committed in forming A); eigenvalue-only callers may pass eps,
+// because symmetric functions of the spectrum are second-order in the residual.
 template <typename T, int D, bool WITH_V>
-__device__ __forceinline__ void jacobi_eig(T (&a)[Packed<D>::NP], T (&v)[D][D]) {
+__device__ __forceinline__ void jacobi_eig(T (&a)[Packed<D>::NP], T (&v)[D][D], T tol2) {
   using N = Num<T>;
   if (WITH_V) {
 #pragma unroll
@@ -216,7 +223,6 @@ __device__ __forceinline__ void jacobi_eig(T (&a)[Packed<D>::NP], T (&v)[D][D]) 
       for (int c = 0; c < D; ++c) v[r][c] = (r == c) ? T(1) : T(0);
   }
   if (D == 1) return;
-  const T tol2 = N::eps() * N::eps();
   for (int sweep = 0; sweep < N::kMaxSweeps; ++sweep) {
     T off2 = T(0), dg2 = T(0);
 #pragma unroll
@@ -225,44 +231,95 @@ __device__ __forceinline__ void jacobi_eig(T (&a)[Packed<D>::NP], T (&v)[D][D]) 
 #pragma unroll
       for (int c = 0; c < r; ++c) off2 = N::fma(a[pidx(r, c)], a[pidx(r, c)], off2);
     }
-    const bool active = off2 > tol2 * dg2;
-    if (!__any(active)) break;
+    if (!__any(off2 > tol2 * dg2)) break;
 #pragma unroll
     for (int p = 0; p < D - 1; ++p) {
 #pragma unroll
       for (int q = p + 1; q < D; ++q) {
         const T apq = a[pidx(q, p)];
         const T h = a[pidx(q, q)] - a[pidx(p, p)];
-        // t = sgn(h) 2 apq / (|h| + sqrt(h^2 + 4 apq^2))  (smaller root)
-        const T two_apq = apq + apq;
-        const T den = N::abs(h) + N::sqrt(N::fma(h, h, two_apq * two_apq));
-        // (sgn(0) := +1 gives the 45-degree rotation when app == aqq; apq == 0
-        //  gives t = 0 because den >= tiny.)
-        T t = ((h < T(0)) ? -two_apq : two_apq) * N::rcp(N::max(den, N::tiny()));
-        t = active ? t : T(0);
-        const T c = N::rsqrt(N::fma(t, t, T(1)));
-        const T s = t * c;
+        const T ah = N::abs(h) + T(1e-15);
+        const T sa_ = (h < T(0)) ? -apq : apq;         // sgn(h) apq   (h = 0 counts as +)
+        const T sa2 = sa_ + sa_;
+        const T r = N::rsqrt(N::fma(ah, ah, sa2 * sa2));
+        const T x = N::fma(ah * r, T(0.5), T(0.5));     // cos^2 t
+        const T ci = N::rsqrt(x);
+        const T c = x * ci;
+        const T s = (sa_ * r) * ci;
+        const T t = s * ci;
         a[pidx(p, p)] = N::fma(-t, apq, a[pidx(p, p)]);
         a[pidx(q, q)] = N::fma(t, apq, a[pidx(q, q)]);
-        a[pidx(q, p)] = active ? T(0) : apq;
+        a[pidx(q, p)] = T(0);
 #pragma unroll
-        for (int r = 0; r < D; ++r) {
-          if (r == p || r == q) continue;
-          const T arp = a[pidx(r, p)], arq = a[pidx(r, q)];
-          a[pidx(r, p)] = N::fma(c, arp, -s * arq);
-          a[pidx(r, q)] = N::fma(s, arp, c * arq);
+        for (int r2 = 0; r2 < D; ++r2) {
+          if (r2 == p || r2 == q) continue;
+          const T arp = a[pidx(r2, p)], arq = a[pidx(r2, q)];
+          a[pidx(r2, p)] = N::fma(c, arp, -s * arq);
+          a[pidx(r2, q)] = N::fma(s, arp, c * arq);
         }
         if (WITH_V) {
 #pragma unroll
-          for (int r = 0; r < D; ++r) {
-            const T vrp = v[r][p], vrq = v[r][q];
-            v[r][p] = N::fma(c, vrp, -s * vrq);
-            v[r][q] = N::fma(s, vrp, c * vrq);
+          for (int r2 = 0; r2 < D; ++r2) {
+            const T vrp = v[r2][p], vrq = v[r2][q];
+            v[r2][p] = N::fma(c, vrp, -s * vrq);
+            v[r2][q] = N::fma(s, vrp, c * vrq);
           }
         }
       }
     }
   }
+}
+template <typename T, int D, bool WITH_V>
+__device__ __forceinline__ void jacobi_eig(T (&a)[Packed<D>::NP], T (&v)[D][D]) {
+  jacobi_eig<T, D, WITH_V>(a, v, Num<T>::eps() * Num<T>::eps());
+}
+
+// ------------------------------------------ closed-form eigenvalues, 3x3 (fp32)
+// Trigonometric solution of the characteristic cubic (the method of the reference's
+// fast.symeig3x3, linalg/fast.py:75-91, without its eps fudge terms): q = tr/3,
+// B = (A - qI)/p with p^2 = ||A - qI||_F^2 / 6, phi = acos(det(B)/2)/3,
+// w = q + p {2cos(phi), -cos(phi) + sqrt3 sin(phi), -cos(phi) - sqrt3 sin(phi)}.
+// acos / cos / sin are polynomials (abs err < 5e-8) — no libm calls, ~75 VALU ops
+// in all versus ~200 for Jacobi.  Eigenvalues come out with ABSOLUTE error
+// ~eps*||A||; callers needing small eigenvalues to high RELATIVE accuracy (wide
+// spectra) must fall back to Jacobi — see spd_pdist_fwd_kernel.
+__device__ __forceinline__ void eig3_trig(const float (&a)[6], float (&w)[3]) {
+  const float q = (a[pidx(0, 0)] + a[pidx(1, 1)] + a[pidx(2, 2)]) * (1.f / 3.f);
+  const float b00 = a[pidx(0, 0)] - q, b11 = a[pidx(1, 1)] - q, b22 = a[pidx(2, 2)] - q;
+  const float o10 = a[pidx(1, 0)], o20 = a[pidx(2, 0)], o21 = a[pidx(2, 1)];
+  float p2 = fmaf(b00, b00, fmaf(b11, b11, b22 * b22));
+  p2 = fmaf(2.f, fmaf(o10, o10, fmaf(o20, o20, o21 * o21)), p2) * (1.f / 6.f);
+  const float ip = __builtin_amdgcn_rsqf(fmaxf(p2, 1e-30f));
+  const float p = p2 * ip;
+  const float c00 = b00 * ip, c11 = b11 * ip, c22 = b22 * ip, c10 = o10 * ip, c20 = o20 * ip, c21 = o21 * ip;
+  float hd = c00 * fmaf(c11, c22, -c21 * c21) - c10 * fmaf(c10, c22, -c21 * c20) + c20 * fmaf(c10, c21, -c11 * c20);
+  hd = fminf(fmaxf(0.5f * hd, -1.f), 1.f);
+  // acos(|x|) = sqrt(1-|x|) P7(|x|)   (Abramowitz & Stegun 4.4.46, |err| <= 2e-8)
+  const float ax = fabsf(hd);
+  float pa = fmaf(-0.0012624911f, ax, 0.0066700901f);
+  pa = fmaf(pa, ax, -0.0170881256f);
+  pa = fmaf(pa, ax, 0.0308918810f);
+  pa = fmaf(pa, ax, -0.0501743046f);
+  pa = fmaf(pa, ax, 0.0889789874f);
+  pa = fmaf(pa, ax, -0.2145988016f);
+  pa = fmaf(pa, ax, 1.5707963050f);
+  const float ac = __builtin_amdgcn_sqrtf(1.f - ax) * pa;
+  const float phi = ((hd < 0.f) ? 3.14159265358979f - ac : ac) * (1.f / 3.f);   // in [0, pi/3]
+  const float z = phi * phi;
+  float cs = fmaf(z, -2.7557319e-7f, 2.4801587e-5f);
+  cs = fmaf(cs, z, -1.3888889e-3f);
+  cs = fmaf(cs, z, 4.1666667e-2f);
+  cs = fmaf(cs, z, -0.5f);
+  cs = fmaf(cs, z, 1.f);
+  float sn = fmaf(z, -2.5052108e-8f, 2.7557319e-6f);
+  sn = fmaf(sn, z, -1.9841270e-4f);
+  sn = fmaf(sn, z, 8.3333333e-3f);
+  sn = fmaf(sn, z, -1.6666667e-1f);
+  sn = fmaf(sn * z, phi, phi);
+  const float r3s = 1.7320508f * sn;
+  w[2] = fmaf(p, cs + cs, q);
+  w[1] = fmaf(p, r3s - cs, q);
+  w[0] = fmaf(p, -r3s - cs, q);
 }
 
 // out (packed) = V diag(f) V^T

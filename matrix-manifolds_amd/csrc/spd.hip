@@ -21,6 +21,9 @@
 
 #include "../../include/mm_manifolds.h"
 #include "prof.hpp"
+#include <cstdlib>
+#include <type_traits>
+
 #include "smallmat.hpp"
 
 namespace mm {
@@ -78,7 +81,8 @@ __device__ __forceinline__ T pair_core(const TL (&li)[Packed<D>::NP], const T (&
                                        T (&w)[D], T (&lw)[D], T (&v)[D][D]) {
   T a[Packed<D>::NP];
   congr_lower<T, D>(li, xj, a);
-  jacobi_eig<T, D, WITH_V>(a, v);
+  // eigenvalues only: sum log^2 w is second-order in the residual coupling -> tol2 = eps
+  jacobi_eig<T, D, WITH_V>(a, v, WITH_V ? Num<T>::eps() * Num<T>::eps() : Num<T>::eps());
   T s = T(0);
 #pragma unroll
   for (int k = 0; k < D; ++k) {
@@ -89,6 +93,67 @@ __device__ __forceinline__ T pair_core(const TL (&li)[Packed<D>::NP], const T (&
   return s;
 }
 
+// Forward-only value of one pair.  SPD(3) in fp32 takes the closed-form (trigonometric)
+// eigenvalues; a wavefront in which any pair has a wide spectrum (w_max > 32 w_min, where
+// the closed form's absolute error would show in log w_min) re-solves with Jacobi.
+template <typename T, int D, typename TL>
+__device__ __forceinline__ T pair_value(const TL (&li)[Packed<D>::NP], const T (&xj)[Packed<D>::NP], T wmin, T wmax) {
+  if constexpr (D == 3 && std::is_same<T, float>::value) {
+    float a[6], w[3], v[3][3];
+    congr_lower<float, 3>(li, xj, a);
+    eig3_trig(a, w);
+    const bool wide = !(w[0] * 32.f > w[2]);  // true for NaN / non-positive spectra too
+    if (__any(wide)) {
+      jacobi_eig<float, 3, false>(a, v, Num<float>::eps());
+      w[0] = a[pidx(0, 0)]; w[1] = a[pidx(1, 1)]; w[2] = a[pidx(2, 2)];
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const float l = Num<float>::log(fminf(fmaxf(w[k], wmin), wmax));
+      s = fmaf(l, l, s);
+    }
+    return s;
+  } else {
+    T w[D], lw[D], v[D][D];
+    return pair_core<T, D, false>(li, xj, wmin, wmax, w, lw, v);
+  }
+}
+
+// Folded triangular grid.  Row tile y needs the column blocks from the one holding its
+// first super-diagonal entry to the last; pairing tile y with tile gy-1-y makes every
+// grid row about equally long, so (almost) no launched workgroup is empty.
+struct TileId { int i0, jbase; bool ok; };
+template <int TI> __device__ __forceinline__ TileId fold_tile(int n, int row_begin, int row_end) {
+  const int gy = (row_end - row_begin + TI - 1) / TI;
+  const int nJB = (n + kBlock - 1) / kBlock;
+  int y = blockIdx.y, x = blockIdx.x;
+  int cb0 = (row_begin + y * TI + 1) / kBlock;
+  int cnt = nJB - cb0;
+  if (x >= cnt) {
+    x -= cnt;
+    const int y2 = gy - 1 - y;
+    if (y2 <= y) return {0, 0, false};
+    y = y2;
+    cb0 = (row_begin + y * TI + 1) / kBlock;
+    cnt = nJB - cb0;
+    if (x >= cnt) return {0, 0, false};
+  }
+  return {row_begin + y * TI, (cb0 + x) * kBlock, true};
+}
+template <int TI> inline dim3 fold_grid(int64_t n, int64_t rb, int64_t re) {
+  const int gy = int((re - rb + TI - 1) / TI);
+  const int nJB = int((n + kBlock - 1) / kBlock);
+  int gx = 0;
+  for (int y = 0; y < (gy + 1) / 2; ++y) {
+    const int y2 = gy - 1 - y;
+    int c = nJB - int((rb + int64_t(y) * TI + 1) / kBlock);
+    if (y2 > y) c += nJB - int((rb + int64_t(y2) * TI + 1) / kBlock);
+    gx = c > gx ? c : gx;
+  }
+  return dim3(gx > 0 ? gx : 1, (gy + 1) / 2 > 0 ? (gy + 1) / 2 : 1);
+}
+
 // ------------------------------------------------------------------ forward
 template <typename T, int D, int TI>
 __global__ __launch_bounds__(kBlock) void spd_pdist_fwd_kernel(const T* __restrict__ nodeL,
@@ -96,11 +161,9 @@ __global__ __launch_bounds__(kBlock) void spd_pdist_fwd_kernel(const T* __restri
                                                                int row_end, int squared, T wmin, T wmax,
                                                                T* __restrict__ out) {
   constexpr int NP = Packed<D>::NP;
-  const int i0 = row_begin + blockIdx.y * TI;
-  const int i1 = min(i0 + TI, row_end);
-  const int jblk = (i0 + 1) / kBlock + blockIdx.x;
-  const int jbase = jblk * kBlock;
-  if (jbase >= n) return;
+  const TileId tile = fold_tile<TI>(n, row_begin, row_end);
+  if (!tile.ok) return;
+  const int i0 = tile.i0, i1 = min(i0 + TI, row_end), jbase = tile.jbase;
   const int wave_j0 = jbase + (threadIdx.x & ~63);
   if (wave_j0 + 63 <= i0) return;  // whole wavefront below the diagonal
   const int j = jbase + threadIdx.x;
@@ -120,9 +183,7 @@ __global__ __launch_bounds__(kBlock) void spd_pdist_fwd_kernel(const T* __restri
     T li[NP];
 #pragma unroll
     for (int k = 0; k < NP; ++k) li[k] = nodeL[size_t(i) * NP + k];  // wave-uniform -> s_load
-    T w[D], lw[D], v[D][D];
-    T s = pair_core<T, D, false>(li, xj, wmin, wmax, w, lw, v);
-    s = Num<T>::max(s, wmin);
+    T s = Num<T>::max(pair_value<T, D>(li, xj, wmin, wmax), wmin);
     if (!squared) s = Num<T>::sqrt(s);
     if (jin && j > i) out[pair_off(n, i) - base + (j - i - 1)] = s;
   }
@@ -137,11 +198,9 @@ __global__ __launch_bounds__(kBlock) void spd_pdist_bwd_kernel(const T* __restri
                                                                T* __restrict__ accM, T* __restrict__ accN) {
   constexpr int NP = Packed<D>::NP;
   __shared__ T redM[kBlock / 64][TI][NP];
-  const int i0 = row_begin + blockIdx.y * TI;
-  const int i1 = min(i0 + TI, row_end);
-  const int jblk = (i0 + 1) / kBlock + blockIdx.x;
-  const int jbase = jblk * kBlock;
-  if (jbase >= n) return;  // block-uniform
+  const TileId tile = fold_tile<TI>(n, row_begin, row_end);
+  if (!tile.ok) return;  // block-uniform
+  const int i0 = tile.i0, i1 = min(i0 + TI, row_end), jbase = tile.jbase;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wave_j0 = jbase + wave * 64;
   const bool wave_live = wave_j0 + 63 > i0;  // else no pair of this wave is above the diagonal
@@ -237,9 +296,7 @@ __global__ void spd_dist_fwd_kernel(const T* __restrict__ x, const T* __restrict
   load_sym_packed<T, D>(y + k * D * D, ys);
   cholesky<T, D>(xs, l);
   invert_lower<T, D>(l, li);
-  T w[D], lw[D], v[D][D];
-  T s = pair_core<T, D, false>(li, ys, wmin, wmax, w, lw, v);
-  s = Num<T>::max(s, wmin);
+  T s = Num<T>::max(pair_value<T, D>(li, ys, wmin, wmax), wmin);
   if (!squared) s = Num<T>::sqrt(s);
   if (in) out[k] = s;
 }
@@ -442,24 +499,45 @@ int spd_pdist_prepare(const T* x, int64_t n, Ws<T>& ws, int flags, hipStream_t s
   return MM_OK;
 }
 
-template <int D> struct Tile { static constexpr int TI = 16; };
+inline int tile_rows() {  // MM_SPD_TI = 8 | 16 | 32 (tuning knob; default chosen on MI355X)
+  static const int v = [] { const char* e = std::getenv("MM_SPD_TI"); const int t = e ? std::atoi(e) : 16;
+                            return (t == 8 || t == 32) ? t : 16; }();
+  return v;
+}
+
+template <typename T, int D, int TI>
+int spd_pdist_fwd_ti(Ws<T>& ws, int64_t n, int64_t rb, int64_t re, int squared, double wmin, double wmax, T* out,
+                     hipStream_t st) {
+  {
+    ProfScope prof(PROF_SPD_FWD, st);
+    spd_pdist_fwd_kernel<T, D, TI><<<fold_grid<TI>(n, rb, re), dim3(kBlock), 0, st>>>(
+        ws.nodeL, ws.nodeX, int(n), int(rb), int(re), squared, T(wmin), T(wmax), out);
+  }
+  MM_CHECK_LAUNCH();
+  return MM_OK;
+}
 
 template <typename T, int D>
 int spd_pdist_fwd_t(const T* x, int64_t n, int64_t rb, int64_t re, int squared, double wmin, double wmax, T* out,
                     void* wsp, int flags, hipStream_t st) {
-  constexpr int TI = Tile<D>::TI;
   Ws<T> ws(wsp, n, Packed<D>::NP);
   int rc = spd_pdist_prepare<T, D>(x, n, ws, flags, st);
   if (rc) return rc;
-  if (re <= rb) return MM_OK;
-  const int nJB = int((n + kBlock - 1) / kBlock);
-  const int gx = nJB - int((rb + 1) / kBlock);
-  const int gy = int((re - rb + TI - 1) / TI);
-  if (gx <= 0) return MM_OK;
+  if (re <= rb || pair_off(n, re) == pair_off(n, rb)) return MM_OK;
+  switch (tile_rows()) {
+    case 8: return spd_pdist_fwd_ti<T, D, 8>(ws, n, rb, re, squared, wmin, wmax, out, st);
+    case 32: return spd_pdist_fwd_ti<T, D, 32>(ws, n, rb, re, squared, wmin, wmax, out, st);
+    default: return spd_pdist_fwd_ti<T, D, 16>(ws, n, rb, re, squared, wmin, wmax, out, st);
+  }
+}
+
+template <typename T, int D, int TI>
+int spd_pdist_bwd_ti(Ws<T>& ws, const T* g, int64_t n, int64_t rb, int64_t re, int squared, double wmin, double wmax,
+                     hipStream_t st) {
   {
-    ProfScope prof(PROF_SPD_FWD, st);
-    spd_pdist_fwd_kernel<T, D, TI><<<dim3(gx, gy), dim3(kBlock), 0, st>>>(ws.nodeL, ws.nodeX, int(n), int(rb),
-                                                                         int(re), squared, T(wmin), T(wmax), out);
+    ProfScope prof(PROF_SPD_BWD, st);
+    spd_pdist_bwd_kernel<T, D, TI><<<fold_grid<TI>(n, rb, re), dim3(kBlock), 0, st>>>(
+        ws.nodeL, ws.nodeX, g, int(n), int(rb), int(re), squared, T(wmin), T(wmax), ws.accM, ws.accN);
   }
   MM_CHECK_LAUNCH();
   return MM_OK;
@@ -468,23 +546,19 @@ int spd_pdist_fwd_t(const T* x, int64_t n, int64_t rb, int64_t re, int squared, 
 template <typename T, int D>
 int spd_pdist_bwd_t(const T* x, const T* g, int64_t n, int64_t rb, int64_t re, int squared, double wmin, double wmax,
                     T* grad, void* wsp, int flags, hipStream_t st) {
-  constexpr int TI = Tile<D>::TI;
   constexpr int NP = Packed<D>::NP;
   Ws<T> ws(wsp, n, NP);
   int rc = spd_pdist_prepare<T, D>(x, n, ws, flags, st);
   if (rc) return rc;
   hipError_t e = hipMemsetAsync(ws.accM, 0, sizeof(T) * size_t(n) * NP * 2, st);
   if (e != hipSuccess) return int(e);
-  const int nJB = int((n + kBlock - 1) / kBlock);
-  const int gx = nJB - int((rb + 1) / kBlock);
-  const int gy = int((re - rb + TI - 1) / TI);
-  if (re > rb && gx > 0) {
-    {
-      ProfScope prof(PROF_SPD_BWD, st);
-      spd_pdist_bwd_kernel<T, D, TI><<<dim3(gx, gy), dim3(kBlock), 0, st>>>(
-          ws.nodeL, ws.nodeX, g, int(n), int(rb), int(re), squared, T(wmin), T(wmax), ws.accM, ws.accN);
+  if (re > rb && pair_off(n, re) > pair_off(n, rb)) {
+    switch (tile_rows()) {
+      case 8: rc = spd_pdist_bwd_ti<T, D, 8>(ws, g, n, rb, re, squared, wmin, wmax, st); break;
+      case 32: rc = spd_pdist_bwd_ti<T, D, 32>(ws, g, n, rb, re, squared, wmin, wmax, st); break;
+      default: rc = spd_pdist_bwd_ti<T, D, 16>(ws, g, n, rb, re, squared, wmin, wmax, st); break;
     }
-    MM_CHECK_LAUNCH();
+    if (rc) return rc;
   }
   spd_pdist_finalize_kernel<T, D><<<dim3((n + 127) / 128), dim3(128), 0, st>>>(ws.nodeL, ws.accM, ws.accN, int(n),
                                                                                grad);

@@ -227,3 +227,31 @@ def test_edge_cases():
     bad = torch.stack([eye, -eye])
     with pytest.raises(torch.linalg.LinAlgError):
         SPD(3, check_pd=True).pdist(bad)
+
+
+@pytest.mark.parametrize('dname', list(DT))
+def test_wide_spectra_take_the_jacobi_path(dname):
+    """SPD(3) fp32 forward uses closed-form eigenvalues unless a wavefront holds a pair with
+    w_max > 32 w_min; points spread over ||log X|| up to ~4 exercise both paths and the switch."""
+    from graphembed.manifolds import SymmetricPositiveDefinite as SPD
+    from oracle import ref_port as rp
+    gen = torch.Generator().manual_seed(9)
+    port = rp.SPD(3)
+    n = 400
+    scale = torch.linspace(0.05, 4.0, n, dtype=torch.float64).reshape(n, 1)
+    u = torch.randn(n, 6, dtype=torch.float64, generator=gen)
+    u = u / u.norm(dim=-1, keepdim=True) * scale
+    x64 = port.exp(port.zero(n, dtype=torch.float64), port.from_vec(u))
+    xr = x64.clone().requires_grad_()
+    w, v = torch.linalg.eigh(torch.linalg.solve(torch.linalg.cholesky(x64)[0:1], x64))  # placeholder use
+    # exact fp64 evaluation (eigh), free of the reference's eps fudges
+    l = torch.linalg.cholesky(x64)
+    li = torch.linalg.inv(l)
+    i, j = torch.triu_indices(n, n, 1)
+    a = li[i] @ x64[j] @ li[i].transpose(1, 2)
+    ref = torch.linalg.eigvalsh(a).log().pow(2).sum(-1)
+    d2 = SPD(3).pdist(x64.to(DT[dname]).cuda(), squared=True)
+    got = d2.double().cpu()
+    tol = (1e-6, 3e-5) if dname == 'f32' else (1e-12, 1e-10)
+    bad = (got - ref).abs() - (tol[0] + tol[1] * ref.abs())
+    assert bad.max() <= 0, f'worst excess {bad.max():.3e} at d2={ref[bad.argmax()]:.3f}'

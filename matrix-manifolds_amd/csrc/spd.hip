@@ -82,7 +82,7 @@ __device__ __forceinline__ T pair_core(const TL (&li)[Packed<D>::NP], const T (&
   T a[Packed<D>::NP];
   congr_lower<T, D>(li, xj, a);
   // eigenvalues only: sum log^2 w is second-order in the residual coupling -> tol2 = eps
-  jacobi_eig<T, D, WITH_V>(a, v, WITH_V ? Num<T>::eps() * Num<T>::eps() : Num<T>::eps());
+  jacobi_eig<T, D, WITH_V, true>(a, v, WITH_V ? Num<T>::eps() * Num<T>::eps() : Num<T>::eps());
   T s = T(0);
 #pragma unroll
   for (int k = 0; k < D; ++k) {
@@ -104,7 +104,7 @@ __device__ __forceinline__ T pair_value(const TL (&li)[Packed<D>::NP], const T (
     eig3_trig(a, w);
     const bool wide = !(w[0] * 32.f > w[2]);  // true for NaN / non-positive spectra too
     if (__any(wide)) {
-      jacobi_eig<float, 3, false>(a, v, Num<float>::eps());
+      jacobi_eig<float, 3, false, true>(a, v, Num<float>::eps());
       w[0] = a[pidx(0, 0)]; w[1] = a[pidx(1, 1)]; w[2] = a[pidx(2, 2)];
     }
     float s = 0.f;
@@ -499,9 +499,9 @@ int spd_pdist_prepare(const T* x, int64_t n, Ws<T>& ws, int flags, hipStream_t s
   return MM_OK;
 }
 
-inline int tile_rows() {  // MM_SPD_TI = 8 | 16 | 32 (tuning knob; default chosen on MI355X)
-  static const int v = [] { const char* e = std::getenv("MM_SPD_TI"); const int t = e ? std::atoi(e) : 16;
-                            return (t == 8 || t == 32) ? t : 16; }();
+inline int tile_rows() {  // MM_SPD_TI = 8 | 16 | 32 (tuning knob; 8 measured fastest on MI355X at n = 5000)
+  static const int v = [] { const char* e = std::getenv("MM_SPD_TI"); const int t = e ? std::atoi(e) : 8;
+                            return (t == 16 || t == 32) ? t : 8; }();
   return v;
 }
 

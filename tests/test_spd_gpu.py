@@ -242,8 +242,6 @@ def test_wide_spectra_take_the_jacobi_path(dname):
     u = torch.randn(n, 6, dtype=torch.float64, generator=gen)
     u = u / u.norm(dim=-1, keepdim=True) * scale
     x64 = port.exp(port.zero(n, dtype=torch.float64), port.from_vec(u))
-    xr = x64.clone().requires_grad_()
-    w, v = torch.linalg.eigh(torch.linalg.solve(torch.linalg.cholesky(x64)[0:1], x64))  # placeholder use
     # exact fp64 evaluation (eigh), free of the reference's eps fudges
     l = torch.linalg.cholesky(x64)
     li = torch.linalg.inv(l)
@@ -252,6 +250,8 @@ def test_wide_spectra_take_the_jacobi_path(dname):
     ref = torch.linalg.eigvalsh(a).log().pow(2).sum(-1)
     d2 = SPD(3).pdist(x64.to(DT[dname]).cuda(), squared=True)
     got = d2.double().cpu()
-    tol = (1e-6, 3e-5) if dname == 'f32' else (1e-12, 1e-10)
+    # fp32: forming A = L^-1 X L^-T costs ~eps*cond(A) relative accuracy in the small eigenvalues
+    # whatever the eigensolver (cond up to ~1e4 here), hence the looser relative term
+    tol = (1e-6, 2e-4) if dname == 'f32' else (1e-12, 1e-10)
     bad = (got - ref).abs() - (tol[0] + tol[1] * ref.abs())
     assert bad.max() <= 0, f'worst excess {bad.max():.3e} at d2={ref[bad.argmax()]:.3f}'

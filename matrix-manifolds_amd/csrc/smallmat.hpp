@@ -226,9 +226,15 @@ __device__ __forceinline__ void jacobi_eig(T (&a)[Packed<D>::NP], T (&v)[D][D], 
       for (int c = 0; c < D; ++c) v[r][c] = (r == c) ? T(1) : T(0);
   }
   if (D == 1) return;
+  // Fully unrolled (registers are renamed sweep to sweep instead of being copied around a
+  // loop back-edge: -16 % kernel time on MI355X), and no convergence test before the
+  // sweeps every 3x3+ matrix needs anyway (one sweep is exact only for D = 2).
+  constexpr int kMinSweeps = D >= 3 ? 2 : 1;
+#pragma unroll
   for (int sweep = 0; sweep < N::kMaxSweeps; ++sweep) {
-    bool active = false;
-    if (REL) {
+    bool active = sweep < kMinSweeps;
+    if (active) {
+    } else if (REL) {
       // Demmel-Veselic criterion for positive-definite matrices: every coupling small
       // relative to ITS OWN two diagonal entries, so small eigenvalues of a wide
       // spectrum come out with high relative accuracy (log w needs exactly that).
@@ -353,6 +359,20 @@ __device__ __forceinline__ void vdvt(const T (&v)[D][D], const T (&f)[D], T (&ou
 }
 
 // ------------------------------------------------------------ wave reductions
+// Sum N independent values over the 64 lanes, level by level: the N cross-lane moves of a
+// level are issued back to back and waited for once (a per-value butterfly serialises
+// 6 N dependent LDS-crossbar round trips — measured as 31 % of the wave time in bwd).
+template <typename T, int N> __device__ __forceinline__ void wave_sum_n(T (&r)[N]) {
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) {
+    T t[N];
+#pragma unroll
+    for (int k = 0; k < N; ++k) t[k] = __shfl_xor(r[k], m, 64);
+#pragma unroll
+    for (int k = 0; k < N; ++k) r[k] += t[k];
+  }
+}
+
 template <typename T> __device__ __forceinline__ T wave_sum(T x) {
 #pragma unroll
   for (int m = 32; m >= 1; m >>= 1) x += __shfl_xor(x, m, 64);

@@ -82,7 +82,14 @@ __device__ __forceinline__ T pair_core(const TL (&li)[Packed<D>::NP], const T (&
   T a[Packed<D>::NP];
   congr_lower<T, D>(li, xj, a);
   // eigenvalues only: sum log^2 w is second-order in the residual coupling -> tol2 = eps
+#if defined(MM_ABL) && MM_ABL == 3   // ablation: no eigensolve (timing only)
+#pragma unroll
+  for (int r = 0; r < D; ++r)
+#pragma unroll
+    for (int c = 0; c < D; ++c) v[r][c] = (r == c) ? T(1) : a[pidx(r, c)];
+#else
   jacobi_eig<T, D, WITH_V, true>(a, v, WITH_V ? Num<T>::eps() * Num<T>::eps() : Num<T>::eps());
+#endif
   T s = T(0);
 #pragma unroll
   for (int k = 0; k < D; ++k) {
@@ -179,10 +186,16 @@ __global__ __launch_bounds__(kBlock) void spd_pdist_fwd_kernel(const T* __restri
     for (int k = 0; k < NP; ++k) xj[k] = nodeX[size_t(j) * NP + k];
   }
   const int64_t base = pair_off(n, row_begin);
+  T li_next[NP];  // wave-uniform -> scalar loads, issued one row ahead
+#pragma unroll
+  for (int k = 0; k < NP; ++k) li_next[k] = nodeL[size_t(i0) * NP + k];
   for (int i = i0; i < i1; ++i) {
     T li[NP];
 #pragma unroll
-    for (int k = 0; k < NP; ++k) li[k] = nodeL[size_t(i) * NP + k];  // wave-uniform -> s_load
+    for (int k = 0; k < NP; ++k) li[k] = li_next[k];
+    const int inext = min(i + 1, i1 - 1);
+#pragma unroll
+    for (int k = 0; k < NP; ++k) li_next[k] = nodeL[size_t(inext) * NP + k];
     T s = Num<T>::max(pair_value<T, D>(li, xj, wmin, wmax), wmin);
     if (!squared) s = Num<T>::sqrt(s);
     if (jin && j > i) out[pair_off(n, i) - base + (j - i - 1)] = s;
@@ -218,12 +231,19 @@ __global__ __launch_bounds__(kBlock) void spd_pdist_bwd_kernel(const T* __restri
   }
   const int64_t base = pair_off(n, row_begin);
   if (wave_live) {
+    T li_next[NP];  // row operand is fetched one row ahead (scalar loads overlap the eigensolve)
+#pragma unroll
+    for (int k = 0; k < NP; ++k) li_next[k] = nodeL[size_t(i0) * NP + k];
+    T g_next = (jin && j > i0) ? g[pair_off(n, i0) - base + (j - i0 - 1)] : T(0);
     for (int i = i0; i < i1; ++i) {
       T li[NP];
 #pragma unroll
-      for (int k = 0; k < NP; ++k) li[k] = nodeL[size_t(i) * NP + k];
-      const bool valid = jin && j > i;
-      T gs = valid ? g[pair_off(n, i) - base + (j - i - 1)] : T(0);
+      for (int k = 0; k < NP; ++k) li[k] = li_next[k];
+      const int inext = min(i + 1, i1 - 1);
+#pragma unroll
+      for (int k = 0; k < NP; ++k) li_next[k] = nodeL[size_t(inext) * NP + k];
+      T gs = g_next;  // upstream gradient, fetched one row ahead as well (hides the HBM latency)
+      g_next = (jin && j > inext && inext > i) ? g[pair_off(n, inext) - base + (j - inext - 1)] : T(0);
       T w[D], lw[D], v[D][D];
       const T s = pair_core<T, D, true>(li, xj, wmin, wmax, w, lw, v);
       if (!squared) gs *= T(0.5) * Num<T>::rsqrt(Num<T>::max(s, wmin));
@@ -231,17 +251,23 @@ __global__ __launch_bounds__(kBlock) void spd_pdist_bwd_kernel(const T* __restri
 #pragma unroll
       for (int k = 0; k < D; ++k) {
         cm[k] = (gs + gs) * lw[k];
-        cn[k] = cm[k] / w[k];
+        cn[k] = cm[k] * Num<T>::rcp(w[k]);
       }
       T m[NP], nn[NP], cj[NP];
       vdvt<T, D>(v, cm, m);
       vdvt<T, D>(v, cn, nn);
       congr_lower_t<T, D>(li, nn, cj);
 #pragma unroll
-      for (int k = 0; k < NP; ++k) {
-        accJ[k] += cj[k];
-        const T r = wave_sum(m[k]);
-        if (lane == 0) redM[wave][i - i0][k] = r;
+      for (int k = 0; k < NP; ++k) accJ[k] += cj[k];
+#if !defined(MM_ABL) || MM_ABL == 0
+      wave_sum_n<T, NP>(m);
+#elif MM_ABL == 1   // ablation: per-value butterflies
+#pragma unroll
+      for (int k = 0; k < NP; ++k) m[k] = wave_sum(m[k]);
+#endif              // MM_ABL >= 2: no reduction (timing only, wrong results)
+      if (lane == 0) {
+#pragma unroll
+        for (int k = 0; k < NP; ++k) redM[wave][i - i0][k] = m[k];
       }
     }
   }

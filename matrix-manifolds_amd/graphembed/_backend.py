@@ -10,7 +10,8 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(_HERE), 'lib', 'libmm_manifolds.so')
+# MM_MANIFOLDS_LIB points at another build of the SAME library (kernel A/B experiments)
+LIB_PATH = os.environ.get('MM_MANIFOLDS_LIB') or os.path.join(os.path.dirname(_HERE), 'lib', 'libmm_manifolds.so')
 
 MM_F32, MM_F64 = 0, 1
 MM_WS_PREPARED = 1

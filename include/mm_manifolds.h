@@ -166,6 +166,33 @@ int mm_vec_norm(int dtype, int kind, const void* u, int64_t cnt, int m, int squa
 int mm_vec_rsgd_step(int dtype, int kind, const void* x, const void* egrad, int64_t cnt, int m,
                      double lr, double max_grad_norm, int exact, void* x_new, mm_stream_t stream);
 
+/* ---- Grassmann Gr(N,p) / Stiefel St(N,p): points are [cnt,N,p], N <= 9, p <= 4 ---- */
+enum { MM_GRASSMANN = 0, MM_STIEFEL = 1 };
+enum {
+  MM_MAT_PROJU = 0,    /* u - x x^T u (grassmann.py:49-53) / u - x sym(x^T u) (stiefel.py:40-45)   */
+  MM_MAT_PROJX = 1,    /* Q of QR(x) (grassmann.py:55-61); Stiefel: sign-fixed (stiefel.py:47-57)  */
+  MM_MAT_RETR_SVD = 2, /* polar factor U V^T of x+u (grassmann.py:76-80, stiefel.py:66-69)         */
+  MM_MAT_RETR_QR = 3,  /* Q of QR(x+u) (grassmann.py:71-74); Stiefel sign-fixed (stiefel.py:62-63) */
+  MM_MAT_EXP = 4,      /* x V cos(S) V^T + U sin(S) V^T, u = U S V^T (grassmann.py:63-69)          */
+  MM_MAT_LOG = 5       /* log_x(u) (grassmann.py:82-89)                                            */
+};
+int mm_mat_max_rows(void);
+int mm_mat_max_cols(void);
+int mm_mat_map(int dtype, int kind, int op, const void* x, const void* u, int64_t cnt, int N, int p,
+               void* out, mm_stream_t stream);
+/* Grassmann.dist — grassmann.py:91-96: sum_k acos^2 sigma_k(x^T y) [sqrt]; element-wise over
+ * cnt pairs; out / (grad_x,grad_y) optional as in mm_vec_dist.  (acos'(1), where the
+ * reference yields NaN, is replaced by its finite limit.) */
+int mm_grass_dist(int dtype, const void* x, const void* y, const void* g, int64_t cnt, int N, int p,
+                  int squared, void* out, void* grad_x, void* grad_y, mm_stream_t stream);
+/* Manifold.pdist default (base.py:59-63) with Grassmann.dist, row-range layout as above. */
+size_t mm_grass_pdist_ws_bytes(int dtype, int64_t n, int N, int p);
+int mm_grass_pdist_fwd(int dtype, const void* x, int64_t n, int N, int p, int64_t row_begin,
+                       int64_t row_end, int squared, void* out, mm_stream_t stream);
+int mm_grass_pdist_bwd(int dtype, const void* x, const void* g, int64_t n, int N, int p,
+                       int64_t row_begin, int64_t row_end, int squared, void* grad_x, void* ws,
+                       mm_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -48,7 +48,16 @@ SIGNATURES = {
     'mm_vec_map': (_i, [_i, _i, _i, _vp, _vp, _vp, _i64, _i, _vp, _vp]),
     'mm_vec_norm': (_i, [_i, _i, _vp, _i64, _i, _i, _vp, _vp]),
     'mm_vec_rsgd_step': (_i, [_i, _i, _vp, _vp, _i64, _i, _dbl, _dbl, _i, _vp, _vp]),
+    'mm_mat_max_rows': (_i, []),
+    'mm_mat_max_cols': (_i, []),
+    'mm_mat_map': (_i, [_i, _i, _i, _vp, _vp, _i64, _i, _i, _vp, _vp]),
+    'mm_grass_dist': (_i, [_i, _vp, _vp, _vp, _i64, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    'mm_grass_pdist_ws_bytes': (_sz, [_i, _i64, _i, _i]),
+    'mm_grass_pdist_fwd': (_i, [_i, _vp, _i64, _i, _i, _i64, _i64, _i, _vp, _vp]),
+    'mm_grass_pdist_bwd': (_i, [_i, _vp, _vp, _i64, _i, _i, _i64, _i64, _i, _vp, _vp, _vp]),
 }
+GRASSMANN, STIEFEL = 0, 1
+MAT_PROJU, MAT_PROJX, MAT_RETR_SVD, MAT_RETR_QR, MAT_EXP, MAT_LOG = range(6)
 VEC_EGRAD2RGRAD, VEC_PROJU, VEC_EXP, VEC_RETR, VEC_PROJX, VEC_TRANSP, VEC_LOG = range(7)
 
 

@@ -1,0 +1,166 @@
+"""GPU parity of Grassmann / Stiefel (csrc/mat.hip) vs golden vectors of the reference and the
+reference's own property tests (tests/test_ortho.py)."""
+import itertools
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+DT = {'f32': torch.float32, 'f64': torch.float64}
+
+
+def dev(a):
+    return torch.from_numpy(np.array(a)).cuda()
+
+
+def check_rel(got, ref, tol, what):
+    got = got.detach().double().cpu().numpy()
+    ref = np.asarray(ref, dtype=np.float64)
+    assert got.shape == ref.shape, (what, got.shape, ref.shape)
+    ok = np.isfinite(ref)
+    if ok.mean() < 0.5:
+        return
+    err = np.abs(got - ref)[ok].max() / max(np.abs(ref[ok]).max(), 1e-30)
+    assert err <= tol, f'{what}: {err:.3e} > {tol:.1e}'
+
+
+@pytest.mark.parametrize('key,N,p', [('grassmann52', 5, 2), ('grassmann63', 6, 3)])
+@pytest.mark.parametrize('dname,init', list(itertools.product(DT, ['rand', 'wide'])))
+def test_grassmann_vs_reference_golden(key, N, p, dname, init):
+    from graphembed.manifolds import Grassmann
+    G = load_golden(key)
+    man = Grassmann(N, p)
+    tag = f'{dname}/{init}/n33'
+    # at the reference's init sigma ~ 1 - 1e-4: acos amplifies an fp32 ulp of sigma ~100x, and
+    # the reference's own fp32 gradient there is NaN (acos'(1)); fp64 agrees to rounding
+    vt = {'f32': 5e-3 if init == 'rand' else 5e-5, 'f64': 1e-8}[dname]
+    gt = {'f32': 5e-2 if init == 'rand' else 3e-3, 'f64': 1e-6}[dname]
+    x = dev(G[f'{tag}/x']).requires_grad_()
+    g = dev(G[f'{tag}/g'])
+    d2 = man.pdist(x, squared=True)
+    check_rel(d2, G[f'{tag}/d2'], vt, 'd2')
+    gr, = torch.autograd.grad((d2 * g).sum(), x)
+    assert bool(torch.isfinite(gr).all())
+    check_rel(gr, G[f'{tag}/grad_d2'], gt, 'grad_d2')
+    d1 = man.pdist(x, squared=False)
+    check_rel(d1 * d1, np.asarray(G[f'{tag}/d1'], np.float64)**2, vt, 'd1^2')
+    if init == 'wide':
+        gr, = torch.autograd.grad((d1 * g).sum(), x)
+        check_rel(gr, G[f'{tag}/grad_d1'], gt, 'grad_d1')
+    check_rel(man.dist(x.detach(), x.detach().flip(0), squared=True), G[f'{tag}/dist_xy'], vt, 'dist_xy')
+    mt = {'f32': 5e-5, 'f64': 1e-10}[dname]
+    xd = x.detach()
+    with torch.no_grad():
+        u = dev(G[f'{tag}/u'])
+        pu = man.proju(xd, u)
+        check_rel(pu, G[f'{tag}/proju'], mt, 'proju')
+        check_rel(man.exp(xd, pu), G[f'{tag}/exp'], mt, 'exp')
+        check_rel(man.retr(xd, pu), G[f'{tag}/retr'], mt, 'retr (polar)')
+        check_rel(man.retr_qr_(xd, pu), G[f'{tag}/retr_qr'], mt, 'retr_qr')
+        check_rel(man.projx(dev(G[f'{tag}/projx_in'])), G[f'{tag}/projx'], mt, 'projx (QR)')
+        check_rel(man.transp(xd, man.retr(xd, pu), pu), G[f'{tag}/transp'], mt * 5, 'transp')
+        if init == 'wide':
+            check_rel(man.log(xd, xd.flip(0)), G[f'{tag}/log'], mt * 100, 'log')
+
+
+@pytest.mark.parametrize('dname,init', list(itertools.product(DT, ['rand', 'wide'])))
+def test_stiefel_vs_reference_golden(dname, init):
+    from graphembed.manifolds import Stiefel
+    G = load_golden('stiefel52')
+    man = Stiefel(5, 2)
+    tag = f'{dname}/{init}/n33'
+    mt = {'f32': 5e-5, 'f64': 1e-10}[dname]
+    x = dev(G[f'{tag}/x'])
+    with torch.no_grad():
+        check_rel(man.egrad2rgrad(x, dev(G[f'{tag}/egrad_in'])), G[f'{tag}/rgrad'], mt, 'egrad2rgrad')
+        u = dev(G[f'{tag}/u'])
+        pu = man.proju(x, u)
+        check_rel(pu, G[f'{tag}/proju'], mt, 'proju')
+        check_rel(man.retr(x, pu), G[f'{tag}/retr'], mt, 'retr (polar)')
+        check_rel(man.retr_qr_(x, pu), G[f'{tag}/retr_qr'], mt, 'retr_qr')
+        check_rel(man._orthonormalize(dev(G[f'{tag}/projx_in'])), G[f'{tag}/projx'], mt, 'orthonormalize')
+    assert man.exp(x, x) is NotImplementedError
+
+
+@pytest.mark.parametrize('key', ['grassmann52', 'stiefel52'])
+@pytest.mark.parametrize('dname', list(DT))
+def test_rsgd_vs_reference_golden(key, dname):
+    from graphembed import manifolds as M
+    from graphembed.modules import ManifoldParameter
+    from graphembed.optim import RiemannianSGD
+    G = load_golden(key)
+    man = M.Grassmann(5, 2) if key.startswith('grass') else M.Stiefel(5, 2)
+    base = f'{dname}/rsgd'
+    tol = 1e-4 if dname == 'f32' else 1e-9
+    for exact, clip, mom in itertools.product([0, 1], [0, 1], [0, 1]):
+        tag = f'{base}/exact{exact}_clip{clip}_mom{mom}'
+        if f'{tag}/x1' not in G:
+            continue
+        p = ManifoldParameter(dev(G[f'{base}/x0']), manifold=man)
+        opt = RiemannianSGD([p], lr=0.05, momentum=0.9 if mom else 0, dampening=0.1 if mom else 0,
+                            max_grad_norm=2.0 if clip else None, exact=bool(exact))
+        for step, gk in ((1, 'g1'), (2, 'g2')):
+            p.grad = dev(G[f'{base}/{gk}'])
+            opt.step()
+            check_rel(p.data, G[f'{tag}/x{step}'], tol, f'{tag}/x{step}')
+        if mom:
+            check_rel(opt.state[p]['momentum_buffer'], G[f'{tag}/buf2'], tol, tag + '/buf2')
+
+
+@pytest.mark.parametrize('n,p', list(itertools.product(range(5, 10), [2, 3, 4])))
+def test_reference_properties(n, p):
+    """tests/test_ortho.py:12-17 (dist == ||log||) and :28-36 (grad of d^2/2 == -log) of the
+    reference, fp64; plus orthonormality of every projection / retraction."""
+    from graphembed.manifolds import Grassmann
+    torch.manual_seed(n * 10 + p)
+    gras = Grassmann(n, p)
+    like = torch.empty(0, dtype=torch.float64, device='cuda')
+    x = gras.rand_uniform(64, out=like)
+    y = gras.rand_uniform(64, out=like)
+    eye = torch.eye(p, dtype=torch.float64, device='cuda')
+    assert (x.transpose(1, 2) @ x - eye).abs().max() < 1e-12
+    with torch.no_grad():
+        lg = gras.log(x, y)
+        np.testing.assert_allclose(gras.dist(x, y).cpu(), gras.norm(x, lg).cpu(), atol=1e-8)
+        for q in (gras.exp(x, 0.3 * lg), gras.retr(x, 0.3 * lg), gras.retr_qr_(x, 0.3 * lg)):
+            assert (q.transpose(1, 2) @ q - eye).abs().max() < 1e-12
+        # exp(log) reaches the subspace of y: principal angles to y vanish
+        # (for p = 2 the reference's eps-clamped closed form cannot report less than ~7e-3)
+        assert gras.dist(gras.exp(x, lg), y).max() < (1e-2 if p == 2 else 1e-6)
+    xr = x.clone().requires_grad_()
+    d = 0.5 * gras.dist(xr, y, squared=True)
+    ge, = torch.autograd.grad(d.sum(), xr)
+    with torch.no_grad():
+        np.testing.assert_allclose(gras.egrad2rgrad(x, ge).cpu(), (-lg).cpu(), atol=1e-7)
+
+
+def test_pdist_sizes_and_sharding():
+    from graphembed import _backend as B
+    from graphembed.manifolds import Grassmann
+    from oracle import ref_port as rp
+    torch.manual_seed(4)
+    n = 300
+    man = Grassmann(6, 3)
+    x = man.rand_uniform(n, out=torch.empty(0, dtype=torch.float64, device='cuda'))
+    g = torch.randn(n * (n - 1) // 2, dtype=torch.float64, device='cuda')
+    xr = x.clone().requires_grad_()
+    full = man.pdist(xr, squared=True)
+    gfull, = torch.autograd.grad((full * g).sum(), xr)
+    xc = x.cpu().clone().requires_grad_()
+    ref = rp.Grassmann(6, 3).pdist(xc, squared=True)
+    rg, = torch.autograd.grad((ref * g.cpu()).sum(), xc)
+    np.testing.assert_allclose(full.detach().cpu(), ref.detach(), rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(gfull.cpu(), rg, rtol=1e-5, atol=1e-7)
+    parts, gsum = [], torch.zeros_like(x)
+    for r in range(3):
+        rb, re = B.shard_rows(n, 3, r)
+        xr = x.clone().requires_grad_()
+        part = man.pdist(xr, squared=True, rows=(rb, re))
+        gp, = torch.autograd.grad((part * g[B.pair_offset(n, rb):B.pair_offset(n, re)]).sum(), xr)
+        parts.append(part.detach())
+        gsum += gp
+    assert torch.equal(torch.cat(parts), full.detach())
+    np.testing.assert_allclose(gsum.cpu(), gfull.cpu(), rtol=1e-10, atol=1e-12)

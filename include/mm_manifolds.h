@@ -87,9 +87,10 @@ int mm_spd_pdist_bwd(int dtype, const void* x, const void* g, int64_t n, int d,
                      int64_t row_begin, int64_t row_end, int squared, double wmin,
                      double wmax, void* grad_x, void* ws, int flags, mm_stream_t stream);
 
-/* Copies the workspace status word to *host_status (0 = all factorizations
- * succeeded).  Synchronises `stream` — the only blocking call of the ABI. */
-int mm_spd_status(const void* ws, int* host_status, mm_stream_t stream);
+/* Counts the points whose Cholesky factorisation failed in the last prepare of `ws`
+ * (n = the point count it was prepared for) into *host_status (0 = all succeeded).
+ * Synchronises `stream` — the only blocking call of the ABI. */
+int mm_spd_status(void* ws, int64_t n, int* host_status, mm_stream_t stream);
 
 /* SymmetricPositiveDefinite.dist — spd.py:171-173, element-wise over m pairs
  * (x[k], y[k]).  x,y [m,d,d]; out [m]. */

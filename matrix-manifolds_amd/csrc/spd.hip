@@ -34,22 +34,28 @@ constexpr int kSpdMaxD = 5;
 __host__ __device__ inline int64_t pair_off(int64_t n, int64_t row) { return row * (2 * n - row - 1) / 2; }
 
 // Workspace layout (T = element type, NP = d(d+1)/2):
-//   [0,64)            status words (int32[16]); word 0 = #non-PD points seen
+//   [0,64)            word 0 = number of non-PD points (written by mm_spd_status' reduction)
+//   bad    int[n]     per-point "Cholesky failed" flag, written unconditionally by prep
 //   nodeL  T[n][NP]   packed lower L_i^-1
 //   nodeX  T[n][NP]   packed sym(X_i)
 //   accM   T[NP][n]   row-side accumulators   (sum_j V diag(2 g log w) V^T)
 //   accN   T[NP][n]   column-side accumulators (sum_i L_i^-T N_ij L_i^-1)
+// No memset is ever needed: prep zeroes the accumulators of its point and finalize zeroes
+// them again after reading (the fill kernels cost more than prep itself at n = 5000).
 template <typename T> struct Ws {
   int* status;
+  int* bad;
   T* nodeL;
   T* nodeX;
   T* accM;
   T* accN;
-  static size_t bytes(int64_t n, int np) { return 64 + sizeof(T) * size_t(n) * np * 4; }
+  static size_t bad_bytes(int64_t n) { return (size_t(n) * sizeof(int) + 63) / 64 * 64; }
+  static size_t bytes(int64_t n, int np) { return 64 + bad_bytes(n) + sizeof(T) * size_t(n) * np * 4; }
   Ws(void* base, int64_t n, int np) {
     char* p = static_cast<char*>(base);
     status = reinterpret_cast<int*>(p);
-    nodeL = reinterpret_cast<T*>(p + 64);
+    bad = reinterpret_cast<int*>(p + 64);
+    nodeL = reinterpret_cast<T*>(p + 64 + bad_bytes(n));
     nodeX = nodeL + n * np;
     accM = nodeX + n * np;
     accN = accM + n * np;
@@ -59,7 +65,7 @@ template <typename T> struct Ws {
 // ------------------------------------------------------------------ prep
 template <typename T, int D>
 __global__ void spd_prep_kernel(const T* __restrict__ x, int n, T* __restrict__ nodeL, T* __restrict__ nodeX,
-                                int* __restrict__ status) {
+                                T* __restrict__ accM, T* __restrict__ accN, int* __restrict__ bad) {
   constexpr int NP = Packed<D>::NP;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
@@ -71,8 +77,24 @@ __global__ void spd_prep_kernel(const T* __restrict__ x, int n, T* __restrict__ 
   for (int k = 0; k < NP; ++k) {
     nodeL[size_t(i) * NP + k] = li[k];
     nodeX[size_t(i) * NP + k] = xs[k];
+    accM[size_t(k) * n + i] = T(0);
+    accN[size_t(k) * n + i] = T(0);
   }
-  if (!ok) atomicAdd(status, 1);
+  bad[i] = ok ? 0 : 1;
+}
+
+__global__ void spd_count_bad_kernel(const int* __restrict__ bad, int n, int* __restrict__ status) {
+  int c = 0;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) c += bad[i];
+  c = wave_sum(c);
+  __shared__ int part[16];
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = c;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int t = 0;
+    for (int w = 0; w < int(blockDim.x >> 6); ++w) t += part[w];
+    status[0] = t;
+  }
 }
 
 // A = Li X Li^T, eigen-decompose, return s = sum log^2 clamp(w).
@@ -292,8 +314,8 @@ __global__ __launch_bounds__(kBlock) void spd_pdist_bwd_kernel(const T* __restri
 
 // grad_x[i] = -L_i^-T accM_i L_i^-1 + accN_i   (symmetric, full DxD)
 template <typename T, int D>
-__global__ void spd_pdist_finalize_kernel(const T* __restrict__ nodeL, const T* __restrict__ accM,
-                                          const T* __restrict__ accN, int n, T* __restrict__ grad) {
+__global__ void spd_pdist_finalize_kernel(const T* __restrict__ nodeL, T* __restrict__ accM,
+                                          T* __restrict__ accN, int n, T* __restrict__ grad) {
   constexpr int NP = Packed<D>::NP;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
@@ -305,7 +327,11 @@ __global__ void spd_pdist_finalize_kernel(const T* __restrict__ nodeL, const T* 
   }
   congr_lower_t<T, D>(li, m, gi);
 #pragma unroll
-  for (int k = 0; k < NP; ++k) gi[k] = accN[size_t(k) * n + i] - gi[k];
+  for (int k = 0; k < NP; ++k) {
+    gi[k] = accN[size_t(k) * n + i] - gi[k];
+    accM[size_t(k) * n + i] = T(0);  // leave the accumulators clean for the next backward
+    accN[size_t(k) * n + i] = T(0);
+  }
   store_sym_full<T, D>(grad + size_t(i) * D * D, gi);
 }
 
@@ -517,9 +543,8 @@ __global__ void spd_rsgd_step_kernel(const T* __restrict__ x, const T* __restric
 template <typename T, int D>
 int spd_pdist_prepare(const T* x, int64_t n, Ws<T>& ws, int flags, hipStream_t st) {
   if (!(flags & MM_WS_PREPARED)) {
-    hipError_t e = hipMemsetAsync(ws.status, 0, 64, st);
-    if (e != hipSuccess) return int(e);
-    spd_prep_kernel<T, D><<<dim3((n + 127) / 128), dim3(128), 0, st>>>(x, int(n), ws.nodeL, ws.nodeX, ws.status);
+    spd_prep_kernel<T, D><<<dim3((n + 127) / 128), dim3(128), 0, st>>>(x, int(n), ws.nodeL, ws.nodeX, ws.accM,
+                                                                       ws.accN, ws.bad);
     MM_CHECK_LAUNCH();
   }
   return MM_OK;
@@ -576,8 +601,6 @@ int spd_pdist_bwd_t(const T* x, const T* g, int64_t n, int64_t rb, int64_t re, i
   Ws<T> ws(wsp, n, NP);
   int rc = spd_pdist_prepare<T, D>(x, n, ws, flags, st);
   if (rc) return rc;
-  hipError_t e = hipMemsetAsync(ws.accM, 0, sizeof(T) * size_t(n) * NP * 2, st);
-  if (e != hipSuccess) return int(e);
   if (re > rb && pair_off(n, re) > pair_off(n, rb)) {
     switch (tile_rows()) {
       case 8: rc = spd_pdist_bwd_ti<T, D, 8>(ws, g, n, rb, re, squared, wmin, wmax, st); break;
@@ -654,10 +677,15 @@ int mm_spd_pdist_bwd(int dtype, const void* x, const void* g, int64_t n, int d, 
                                      squared, wmin, wmax, static_cast<T*>(grad_x), ws, flags, st)));
 }
 
-int mm_spd_status(const void* ws, int* host_status, mm_stream_t stream) {
-  if (!ws || !host_status) return MM_ERR_ARG;
+int mm_spd_status(void* ws, int64_t n, int* host_status, mm_stream_t stream) {
+  if (!ws || !host_status || n < 0) return MM_ERR_ARG;
   hipStream_t st = static_cast<hipStream_t>(stream);
-  hipError_t e = hipMemcpyAsync(host_status, ws, sizeof(int), hipMemcpyDeviceToHost, st);
+  int* status = static_cast<int*>(ws);
+  const int* bad = reinterpret_cast<const int*>(static_cast<char*>(ws) + 64);
+  spd_count_bad_kernel<<<dim3(1), dim3(256), 0, st>>>(bad, int(n), status);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return int(e);
+  e = hipMemcpyAsync(host_status, status, sizeof(int), hipMemcpyDeviceToHost, st);
   if (e != hipSuccess) return int(e);
   e = hipStreamSynchronize(st);
   return e == hipSuccess ? MM_OK : int(e);

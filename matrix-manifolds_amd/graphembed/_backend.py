@@ -33,7 +33,7 @@ SIGNATURES = {
     'mm_spd_pdist_ws_bytes': (_sz, [_i, _i64, _i]),
     'mm_spd_pdist_fwd': (_i, [_i, _vp, _i64, _i, _i64, _i64, _i, _dbl, _dbl, _vp, _vp, _i, _vp]),
     'mm_spd_pdist_bwd': (_i, [_i, _vp, _vp, _i64, _i, _i64, _i64, _i, _dbl, _dbl, _vp, _vp, _i, _vp]),
-    'mm_spd_status': (_i, [_vp, _c.POINTER(_i), _vp]),
+    'mm_spd_status': (_i, [_vp, _i64, _c.POINTER(_i), _vp]),
     'mm_spd_dist_fwd': (_i, [_i, _vp, _vp, _i64, _i, _i, _dbl, _dbl, _vp, _vp]),
     'mm_spd_dist_bwd': (_i, [_i, _vp, _vp, _vp, _i64, _i, _i, _dbl, _dbl, _vp, _vp, _vp]),
     'mm_spd_map': (_i, [_i, _i, _vp, _vp, _i64, _i, _dbl, _dbl, _vp, _vp]),

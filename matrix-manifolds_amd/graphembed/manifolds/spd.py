@@ -50,7 +50,7 @@ class _SpdPdist(torch.autograd.Function):
             if check_pd:
                 import ctypes
                 st = ctypes.c_int(0)
-                lib.call('mm_spd_status', B.ptr(ws), ctypes.byref(st), B.stream_of(xc))
+                lib.call('mm_spd_status', B.ptr(ws), n, ctypes.byref(st), B.stream_of(xc))
                 if st.value:
                     raise torch.linalg.LinAlgError(
                         f'pdist: {st.value} input matrices are not positive-definite')

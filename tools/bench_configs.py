@@ -1,0 +1,104 @@
+#!/usr/bin/env python3
+"""Secondary measurements: fwd+bwd time of the hot path on every BASELINE.json configuration
+(synthetic inputs of the named sizes).  Prints one JSON object.
+Usage: python tools/bench_configs.py [--only NAME]"""
+import argparse
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, 'matrix-manifolds_amd')):
+    sys.path.insert(0, p)
+import torch  # noqa: E402
+from graphembed import manifolds as M  # noqa: E402
+from graphembed.modules import ManifoldEmbedding  # noqa: E402
+from graphembed.objectives import StressLoss  # noqa: E402
+from graphembed.optim import RiemannianSGD  # noqa: E402
+
+
+def timeit(fn, iters=20, warm=5):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(iters):
+        fn()
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) / iters * 1e3  # us
+
+
+def pdist_case(man, n, dtype, **kw):
+    torch.manual_seed(42)
+    x = man.rand(n, out=torch.empty(0, dtype=dtype, device='cuda'), **kw).requires_grad_()
+    P = n * (n - 1) // 2
+    g = torch.randn(P, dtype=dtype, device='cuda')
+    fwd = timeit(lambda: man.pdist(x, squared=True))
+
+    def both():
+        d2 = man.pdist(x, squared=True)
+        torch.autograd.grad(d2, x, g)
+    tot = timeit(both)
+    return {'n': n, 'pairs': P, 'dtype': str(dtype).split('.')[-1], 'fwd_us': fwd, 'fwd_bwd_us': tot,
+            'pairs_per_s': P / (tot * 1e-6), 'GBps_8B_per_pair': P * 2 * x.element_size() / (tot * 1e-6) / 1e9}
+
+
+def step_case(mans, n, dtype):
+    """full training step: compute_dists + stress loss + backward + fused RSGD (momentum 0)"""
+    torch.manual_seed(0)
+    torch.set_default_dtype(dtype)
+    try:
+        with torch.device('cuda'):
+            emb = ManifoldEmbedding(n, mans)
+    finally:
+        torch.set_default_dtype(torch.float32)
+    P = n * (n - 1) // 2
+    target = torch.rand(P, dtype=dtype, device='cuda') * 0.99 + 0.01
+    opt = RiemannianSGD(list(emb.xs), lr=1e-3, exact=True, max_grad_norm=20)
+    fn = StressLoss()
+
+    def step():
+        opt.zero_grad()
+        fn(target, emb.compute_dists(None)).backward()
+        opt.step()
+    t = timeit(step)
+    return {'n': n, 'pairs': P, 'dtype': str(dtype).split('.')[-1], 'step_us': t, 'pairs_per_s': P / (t * 1e-6)}
+
+
+CASES = {
+    'c1_tree40_euclidean10_f64': lambda: pdist_case(M.Euclidean(10), 40, torch.float64),
+    'c2_facebook_lorentz11_f32_gram': lambda: pdist_case(M.Lorentz(11), 4039, torch.float32),
+    'c2_facebook_lorentz11_f32_valu': lambda: pdist_case(_valu(M.Lorentz(11)), 4039, torch.float32),
+    'c2_facebook_lorentz11_f64_gram': lambda: pdist_case(M.Lorentz(11), 4039, torch.float64),
+    'c3_grqc_spd3_n5000_f32': lambda: pdist_case(M.SymmetricPositiveDefinite(3), 5000, torch.float32),
+    'c3_grqc_spd3_n4158_f32': lambda: pdist_case(M.SymmetricPositiveDefinite(3), 4158, torch.float32),
+    'c3_grqc_spd3_n5000_f64': lambda: pdist_case(M.SymmetricPositiveDefinite(3), 5000, torch.float64),
+    'c3_spd2_n5000_f32': lambda: pdist_case(M.SymmetricPositiveDefinite(2), 5000, torch.float32),
+    'c4_csphd_product_step_f32': lambda: step_case([M.Lorentz(6), M.Sphere(6), M.SymmetricPositiveDefinite(2)], 1025, torch.float32),
+    'c4_csphd_product_step_f64': lambda: step_case([M.Lorentz(6), M.Sphere(6), M.SymmetricPositiveDefinite(2)], 1025, torch.float64),
+    'c5_wormnet_spd4_n2274_f32': lambda: pdist_case(M.SymmetricPositiveDefinite(4), 2274, torch.float32),
+    'c5_wormnet_spd4_n16384_f32': lambda: pdist_case(M.SymmetricPositiveDefinite(4), 16384, torch.float32),
+    'c3_spd3_step_n5000_f32': lambda: step_case([M.SymmetricPositiveDefinite(3)], 5000, torch.float32),
+    'sphere6_n5000_f32': lambda: pdist_case(M.Sphere(6), 5000, torch.float32),
+    'euclidean10_n5000_f32': lambda: pdist_case(M.Euclidean(10), 5000, torch.float32),
+    'grassmann52_n2000_f32': lambda: pdist_case(M.Grassmann(5, 2), 2000, torch.float32),
+}
+
+
+def _valu(man):
+    man.use_gram = False
+    return man
+
+
+if __name__ == '__main__':
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--only', default=None)
+    a = ap.parse_args()
+    out = {}
+    for name, fn in CASES.items():
+        if a.only and a.only not in name:
+            continue
+        out[name] = fn()
+    print(json.dumps(out, indent=1))

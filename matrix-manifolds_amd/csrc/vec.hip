@@ -136,20 +136,30 @@ __global__ __launch_bounds__(kVBlock) void vec_pdist_bwd_kernel(const T* __restr
   for (int k = 0; k < MP; ++k) a[k] = T(0);
   T wsum = T(0);
   const int64_t base = vpair_off(n, row_begin);
-  for (int i = i0; i < i1; ++i) {
-    T xi[MP];
-    load_point<T, MP>(x, i, m, xi);
-    const bool up = i < j;  // pair (i,j) stored under row i, else under row j
-    const bool valid = jin && (up ? (i >= row_begin && i < row_end) : (jown && i > j));
-    const int lo = up ? i : j, hi = up ? j : i;
-    T w = T(0);
-    if (valid) w = g[vpair_off(n, lo) - base + (hi - lo - 1)];
-    const T q = pair_q<T, KIND, MP>(xi, xj);
-    w *= PairFn<T, KIND>::dq(q, squared);
-    w = valid ? w : T(0);
-    wsum += w;
+  // The per-pair arithmetic (~45 VALU ops) is far too short to hide the latency of the load
+  // of g it depends on, so the upstream gradients of UNR rows are fetched as one batch first.
+  constexpr int UNR = 8;
+  for (int ib = i0; ib < i1; ib += UNR) {
+    T wv[UNR];
 #pragma unroll
-    for (int k = 0; k < MP; ++k) a[k] = Num<T>::fma(w, xi[k], a[k]);
+    for (int u = 0; u < UNR; ++u) {
+      const int i = ib + u;
+      const bool up = i < j;  // pair (i,j) stored under row i, else under row j
+      const bool valid = jin && i < i1 && (up ? (i >= row_begin && i < row_end) : (jown && i > j));
+      const int lo = up ? i : j, hi = up ? j : i;
+      wv[u] = valid ? g[vpair_off(n, lo) - base + (hi - lo - 1)] : T(0);
+    }
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+      const int i = min(ib + u, i1 - 1);  // (rows past the tile carry wv = 0)
+      T xi[MP];
+      load_point<T, MP>(x, i, m, xi);
+      const T q = pair_q<T, KIND, MP>(xi, xj);
+      const T w = wv[u] * PairFn<T, KIND>::dq(q, squared);
+      wsum += w;
+#pragma unroll
+      for (int k = 0; k < MP; ++k) a[k] = Num<T>::fma(w, xi[k], a[k]);
+    }
   }
   if (jin) {
 #pragma unroll

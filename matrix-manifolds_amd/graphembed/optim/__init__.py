@@ -1,1 +1,2 @@
 from .rsgd import RiemannianSGD
+from .radam import RiemannianAdam

@@ -268,18 +268,39 @@ __global__ __launch_bounds__(kBlock) void spd_pdist_bwd_kernel(const T* __restri
       for (int k = 0; k < NP; ++k) li_next[k] = nodeL[size_t(inext) * NP + k];
       T gs = g_next;  // upstream gradient, fetched one row ahead as well (hides the HBM latency)
       g_next = (jin && j > inext && inext > i) ? g[pair_off(n, inext) - base + (j - inext - 1)] : T(0);
-      T w[D], lw[D], v[D][D];
-      const T s = pair_core<T, D, true>(li, xj, wmin, wmax, w, lw, v);
-      if (!squared) gs *= T(0.5) * Num<T>::rsqrt(Num<T>::max(s, wmin));
-      T cm[D], cn[D];
-#pragma unroll
-      for (int k = 0; k < D; ++k) {
-        cm[k] = (gs + gs) * lw[k];
-        cn[k] = cm[k] * Num<T>::rcp(w[k]);
-      }
       T m[NP], nn[NP], cj[NP];
-      vdvt<T, D>(v, cm, m);
-      vdvt<T, D>(v, cn, nn);
+      bool series = false;
+      if constexpr (D == 3 && std::is_same<T, float>::value) {
+        // Close pairs (||A - I||_F <= 0.3 for the whole wavefront): log(A) and log(A) A^-1 from
+        // the Cayley-Hamilton series — no eigensolve.  Anything else takes the Jacobi path below.
+        float a[6], m0[6], n0[6];
+        congr_lower<float, 3>(li, xj, a);
+        const float e2 = log_series3(a, m0, n0);
+        series = !__any(!(e2 <= 0.09f));
+        if (series) {
+          if (!squared) {
+            float s = fmaf(m0[0], m0[0], fmaf(m0[2], m0[2], m0[5] * m0[5]));
+            s = fmaf(2.f, fmaf(m0[1], m0[1], fmaf(m0[3], m0[3], m0[4] * m0[4])), s);
+            gs *= 0.5f * Num<float>::rsqrt(fmaxf(s, wmin));
+          }
+          const float g2 = gs + gs;
+#pragma unroll
+          for (int k = 0; k < 6; ++k) { m[k] = g2 * m0[k]; nn[k] = g2 * n0[k]; }
+        }
+      }
+      if (!series) {
+        T w[D], lw[D], v[D][D];
+        const T s = pair_core<T, D, true>(li, xj, wmin, wmax, w, lw, v);
+        if (!squared) gs *= T(0.5) * Num<T>::rsqrt(Num<T>::max(s, wmin));
+        T cm[D], cn[D];
+#pragma unroll
+        for (int k = 0; k < D; ++k) {
+          cm[k] = (gs + gs) * lw[k];
+          cn[k] = cm[k] * Num<T>::rcp(w[k]);
+        }
+        vdvt<T, D>(v, cm, m);
+        vdvt<T, D>(v, cn, nn);
+      }
       congr_lower_t<T, D>(li, nn, cj);
 #pragma unroll
       for (int k = 0; k < NP; ++k) accJ[k] += cj[k];

@@ -429,6 +429,27 @@ template <typename T, int N> __device__ __forceinline__ void wave_sum_n(T (&r)[N
   }
 }
 
+// fp32 wavefront sum on the VALU's data-parallel-primitive lanes (no LDS crossbar, no s_waitcnt):
+// quad swaps, half-row / row mirrors, then row_bcast15 / row_bcast31 fold the four 16-lane rows;
+// the total lands in lanes 48-63 and is read from lane 63.  (The ds_bpermute butterflies cost 30 %
+// of the backward's wave time in LDS waits.)
+template <int CTRL, int ROW_MASK> __device__ __forceinline__ float dpp_add(float v) {
+  return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xF, true));
+}
+__device__ __forceinline__ float wave_sum_dpp(float v) {
+  v = dpp_add<0xB1, 0xF>(v);    // quad_perm [1,0,3,2]
+  v = dpp_add<0x4E, 0xF>(v);    // quad_perm [2,3,0,1]
+  v = dpp_add<0x141, 0xF>(v);   // row_half_mirror
+  v = dpp_add<0x140, 0xF>(v);   // row_mirror
+  v = dpp_add<0x142, 0xA>(v);   // row_bcast15 -> rows 1,3
+  v = dpp_add<0x143, 0xC>(v);   // row_bcast31 -> rows 2,3
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+template <int N> __device__ __forceinline__ void wave_sum_n(float (&r)[N]) {
+#pragma unroll
+  for (int k = 0; k < N; ++k) r[k] = wave_sum_dpp(r[k]);
+}
+
 template <typename T> __device__ __forceinline__ T wave_sum(T x) {
 #pragma unroll
   for (int m = 32; m >= 1; m >>= 1) x += __shfl_xor(x, m, 64);

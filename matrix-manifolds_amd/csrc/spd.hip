@@ -305,7 +305,7 @@ __global__ __launch_bounds__(kBlock) void spd_pdist_bwd_kernel(const T* __restri
 #pragma unroll
       for (int k = 0; k < NP; ++k) accJ[k] += cj[k];
 #if !defined(MM_ABL) || MM_ABL == 0
-      wave_sum_n<T, NP>(m);
+      wave_sum_n(m);  // fp32: DPP lanes; fp64: LDS-crossbar butterflies
 #elif MM_ABL == 1   // ablation: per-value butterflies
 #pragma unroll
       for (int k = 0; k < NP; ++k) m[k] = wave_sum(m[k]);

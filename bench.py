@@ -127,8 +127,9 @@ def main():
         torch.cuda.synchronize()
 
     # Launch-bound regime (N > 1: each rank's kernels shrink to tens of microseconds, below the
-    # host's per-step dispatch cost): capture one whole step — forward, backward, all-reduce —
-    # into a hipGraph and replay it.  Falls back to eager launches if capture is unavailable.
+    # host's per-step dispatch cost): capture the step's kernels — forward + backward — into a
+    # hipGraph and replay it, then issue the all-reduce.  Falls back to eager launches if capture
+    # is unavailable.
     use_graph = args.graph == 'on' or (args.graph == 'auto' and world > 1)
     graph = None
     if use_graph:
@@ -145,8 +146,6 @@ def main():
             with torch.cuda.graph(graph):
                 d2 = man.pdist(x, squared=True, rows=(rb, re))
                 grad_static, = torch.autograd.grad(d2, x, g_local)
-                if world > 1:
-                    dist.all_reduce(grad_static)
             fence()
         except Exception as exc:  # noqa: BLE001 — report and measure eagerly instead
             if rank == 0:
@@ -154,7 +153,15 @@ def main():
                       file=sys.stderr)
             graph = None
             fence()
-    run = graph.replay if graph is not None else step
+    if graph is not None:
+        # the collective stays OUTSIDE the captured graph (issued eagerly on the same stream right
+        # after the replay): RCCL-in-graph capture cannot be validated on a 1-GPU box
+        def run():
+            graph.replay()
+            if world > 1:
+                dist.all_reduce(grad_static)
+    else:
+        run = step
 
     for _ in range(args.warmup):
         run()
@@ -202,7 +209,7 @@ def main():
             'config': {'workload': f'grqc-class graph, n={n} nodes -> SPD(3) affine-invariant, all '
                                    f'{P} pairs, squared distance + backward, reference init (||log X||=0.1)',
                        'pairs_per_step': P, 'parallelism': f'pair-rows sharded x{world}, 1 all-reduce',
-                       'launch': 'hipGraph replay' if graph is not None else 'eager'},
+                       'launch': 'hipGraph replay (fwd+bwd) + eager all-reduce' if graph is not None else 'eager'},
         }
         if kern['bwd']:
             # dominant kernel: spd_pdist_bwd.  Algorithmic HBM bytes per launch: read g (4 B per

@@ -94,11 +94,18 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', 1))
     if world != args.gpus:
         raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run')
-    torch.cuda.set_device(local_rank)
-    dev = torch.device('cuda', local_rank)
+    ndev = torch.cuda.device_count()
+    dev = torch.device('cuda', local_rank % max(ndev, 1))   # (one rank per GPU on the real node)
+    torch.cuda.set_device(dev)
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group('nccl', device_id=dev)
+        # "nccl" IS RCCL on ROCm.  MM_BENCH_BACKEND=gloo exists only to exercise the N > 1 code
+        # path on a single-GPU development box.
+        backend = os.environ.get('MM_BENCH_BACKEND', 'nccl')
+        if backend == 'nccl':
+            dist.init_process_group('nccl', device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     from graphembed import _backend as B
     from graphembed.manifolds import SymmetricPositiveDefinite

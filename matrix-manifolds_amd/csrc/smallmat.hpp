@@ -400,6 +400,79 @@ __device__ __forceinline__ float log_series3(const float (&a)[6], float (&m0)[6]
   return tr2;
 }
 
+// Same for 4x4: E^(k+1) = p I + q E + r E^2 + t E^3 with
+//   (p,q,r,t)_(k+1) = (-s4 t, p + s3 t, q - s2 t, r + s1 t),  E^4 = s1 E^3 - s2 E^2 + s3 E - s4 I,
+// s1..s4 from the power sums tr E^m (Newton's identities; tr E^3 = <E^2,E>, tr E^4 = ||E^2||_F^2).
+// WANT_N = false evaluates log(A) only (the forward uses ||log A||_F^2).
+template <bool WANT_N>
+__device__ __forceinline__ float log_series4(const float (&a)[10], float (&m0)[10], float (&n0)[10]) {
+  constexpr float kA[10] = {1.000000001e+00f, -5.000000067e-01f, 3.333326160e-01f, -2.499985265e-01f,
+                            2.000629482e-01f, -1.667570841e-01f, 1.409399919e-01f, -1.227561192e-01f,
+                            1.344425630e-01f, -1.238070491e-01f};
+  constexpr float kB[10] = {1.000000046e+00f, -1.500000263e+00f, 1.833308241e+00f, -2.083275579e+00f,
+                            2.285528564e+00f, -2.453533202e+00f, 2.526338709e+00f, -2.630612542e+00f,
+                            3.630254921e+00f, -3.845332518e+00f};
+  float e[10], e2[10], e3[10];
+#pragma unroll
+  for (int k = 0; k < 10; ++k) e[k] = a[k];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) e[pidx(r, r)] -= 1.f;
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+#pragma unroll
+    for (int c = 0; c <= r; ++c) {
+      float acc = e[pidx(r, 0)] * e[pidx(0, c)];
+#pragma unroll
+      for (int k = 1; k < 4; ++k) acc = fmaf(e[pidx(r, k)], e[pidx(k, c)], acc);
+      e2[pidx(r, c)] = acc;
+    }
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+#pragma unroll
+    for (int c = 0; c <= r; ++c) {
+      float acc = e2[pidx(r, 0)] * e[pidx(0, c)];
+#pragma unroll
+      for (int k = 1; k < 4; ++k) acc = fmaf(e2[pidx(r, k)], e[pidx(k, c)], acc);
+      e3[pidx(r, c)] = acc;
+    }
+  float p1 = 0.f, p2 = 0.f, p3 = 0.f, p4 = 0.f;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    p1 += e[pidx(r, r)];
+    p2 += e2[pidx(r, r)];
+    p3 += e3[pidx(r, r)];
+    p4 = fmaf(e2[pidx(r, r)], e2[pidx(r, r)], p4);
+#pragma unroll
+    for (int c = 0; c < r; ++c) p4 = fmaf(2.f * e2[pidx(r, c)], e2[pidx(r, c)], p4);
+  }
+  const float s1 = p1;
+  const float s2 = 0.5f * fmaf(s1, p1, -p2);
+  const float s3 = (1.f / 3.f) * (fmaf(s2, p1, -s1 * p2) + p3);
+  const float s4 = 0.25f * (fmaf(s3, p1, -s2 * p2) + fmaf(s1, p3, -p4));
+  float p = 0.f, q = 1.f, r = 0.f, t = 0.f;
+  float al[4] = {0.f, 0.f, 0.f, 0.f}, be[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int k = 0; k < 10; ++k) {
+    al[0] = fmaf(kA[k], p, al[0]); al[1] = fmaf(kA[k], q, al[1]); al[2] = fmaf(kA[k], r, al[2]); al[3] = fmaf(kA[k], t, al[3]);
+    if (WANT_N) {
+      be[0] = fmaf(kB[k], p, be[0]); be[1] = fmaf(kB[k], q, be[1]); be[2] = fmaf(kB[k], r, be[2]); be[3] = fmaf(kB[k], t, be[3]);
+    }
+    const float pn = -s4 * t, qn = fmaf(s3, t, p), rn = fmaf(-s2, t, q), tn = fmaf(s1, t, r);
+    p = pn; q = qn; r = rn; t = tn;
+  }
+#pragma unroll
+  for (int k = 0; k < 10; ++k) {
+    m0[k] = fmaf(al[3], e3[k], fmaf(al[2], e2[k], al[1] * e[k]));
+    if (WANT_N) n0[k] = fmaf(be[3], e3[k], fmaf(be[2], e2[k], be[1] * e[k]));
+  }
+#pragma unroll
+  for (int rr = 0; rr < 4; ++rr) {
+    m0[pidx(rr, rr)] += al[0];
+    if (WANT_N) n0[pidx(rr, rr)] += be[0];
+  }
+  return p2;  // ||E||_F^2
+}
+
 // out (packed) = V diag(f) V^T
 template <typename T, int D>
 __device__ __forceinline__ void vdvt(const T (&v)[D][D], const T (&f)[D], T (&out)[Packed<D>::NP]) {

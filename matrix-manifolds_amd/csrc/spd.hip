@@ -145,6 +145,23 @@ __device__ __forceinline__ T pair_value(const TL (&li)[Packed<D>::NP], const T (
       s = fmaf(l, l, s);
     }
     return s;
+  } else if constexpr (D == 4 && std::is_same<T, float>::value) {
+    // close pairs: ||log A||_F^2 from the Cayley-Hamilton series (no eigensolve); else Jacobi
+    float a[10], m0[10], n0[10];
+    congr_lower<float, 4>(li, xj, a);
+    const float e2 = log_series4<false>(a, m0, n0);
+    if (!__any(!(e2 <= 0.09f))) {
+      float s = 0.f;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        s = fmaf(m0[pidx(r, r)], m0[pidx(r, r)], s);
+#pragma unroll
+        for (int c = 0; c < r; ++c) s = fmaf(2.f * m0[pidx(r, c)], m0[pidx(r, c)], s);
+      }
+      return s;
+    }
+    float w[4], lw[4], v[4][4];
+    return pair_core<float, 4, false>(li, xj, wmin, wmax, w, lw, v);
   } else {
     T w[D], lw[D], v[D][D];
     return pair_core<T, D, false>(li, xj, wmin, wmax, w, lw, v);
@@ -286,6 +303,26 @@ __global__ __launch_bounds__(kBlock) void spd_pdist_bwd_kernel(const T* __restri
           const float g2 = gs + gs;
 #pragma unroll
           for (int k = 0; k < 6; ++k) { m[k] = g2 * m0[k]; nn[k] = g2 * n0[k]; }
+        }
+      } else if constexpr (D == 4 && std::is_same<T, float>::value) {
+        float a[10], m0[10], n0[10];
+        congr_lower<float, 4>(li, xj, a);
+        const float e2 = log_series4<true>(a, m0, n0);
+        series = !__any(!(e2 <= 0.09f));
+        if (series) {
+          if (!squared) {
+            float s = 0.f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              s = fmaf(m0[pidx(r, r)], m0[pidx(r, r)], s);
+#pragma unroll
+              for (int c = 0; c < r; ++c) s = fmaf(2.f * m0[pidx(r, c)], m0[pidx(r, c)], s);
+            }
+            gs *= 0.5f * Num<float>::rsqrt(fmaxf(s, wmin));
+          }
+          const float g2 = gs + gs;
+#pragma unroll
+          for (int k = 0; k < 10; ++k) { m[k] = g2 * m0[k]; nn[k] = g2 * n0[k]; }
         }
       }
       if (!series) {

@@ -257,18 +257,19 @@ def test_wide_spectra_take_the_jacobi_path(dname):
     assert bad.max() <= 0, f'worst excess {bad.max():.3e} at d2={ref[bad.argmax()]:.3f}'
 
 
-def test_close_pair_gate_is_seamless():
-    """SPD(3) fp32 backward switches per wavefront between the eigen-free close-pair series
+@pytest.mark.parametrize('d', [3, 4])
+def test_close_pair_gate_is_seamless(d):
+    """SPD(3)/SPD(4) fp32 kernels switch per wavefront between the eigen-free close-pair series
     (||A - I||_F <= 0.3) and the Jacobi path.  Points at mixed distances, shuffled so that wavefronts
     of both kinds (and pairs right at the gate) occur; distances and gradients vs the fp64 checker."""
     from graphembed.manifolds import SymmetricPositiveDefinite as SPD
     from oracle import exact
     from oracle import ref_port as rp
     gen = torch.Generator().manual_seed(21)
-    port = rp.SPD(3)
+    port = rp.SPD(d)
     n = 640
     scale = torch.cat([torch.full((n // 2, ), 0.1), torch.linspace(0.12, 1.5, n // 2)])[torch.randperm(n, generator=gen)]
-    u = torch.randn(n, 6, dtype=torch.float64, generator=gen)
+    u = torch.randn(n, d * (d + 1) // 2, dtype=torch.float64, generator=gen)
     u = u / u.norm(dim=-1, keepdim=True) * scale.double().reshape(n, 1)
     x32 = port.exp(port.zero(n, dtype=torch.float64), port.from_vec(u)).float()
     g32 = torch.randn(n * (n - 1) // 2, generator=gen)
@@ -276,14 +277,14 @@ def test_close_pair_gate_is_seamless():
     ref_g = exact.spd_pdist_grad(x32.double().numpy(), g32.double().numpy())
     x = x32.cuda().requires_grad_()
     for squared in (True, False):
-        out = SPD(3).pdist(x, squared=squared)
+        out = SPD(d).pdist(x, squared=squared)
         d2 = (out if squared else out * out).detach().double().cpu().numpy()
         bad = np.abs(d2 - ref_d2) - (1e-6 + 3e-5 * np.abs(ref_d2))
         assert bad.max() <= 0, f'd2 worst excess {bad.max():.3e}'
-    gr, = torch.autograd.grad(SPD(3).pdist(x, squared=True), x, g32.cuda())
+    gr, = torch.autograd.grad(SPD(d).pdist(x, squared=True), x, g32.cuda())
     err = np.abs(gr.double().cpu().numpy() - ref_g).max() / np.abs(ref_g).max()
     assert err <= 3e-5, err
     ref_g1 = exact.spd_pdist_grad(x32.double().numpy(), g32.double().numpy(), squared=False)
-    gr, = torch.autograd.grad(SPD(3).pdist(x, squared=False), x, g32.cuda())
+    gr, = torch.autograd.grad(SPD(d).pdist(x, squared=False), x, g32.cuda())
     err = np.abs(gr.double().cpu().numpy() - ref_g1).max() / np.abs(ref_g1).max()
     assert err <= 5e-5, err

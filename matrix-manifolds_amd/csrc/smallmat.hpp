@@ -400,6 +400,34 @@ __device__ __forceinline__ float log_series3(const float (&a)[6], float (&m0)[6]
   return tr2;
 }
 
+// d^2 = ||log A||_F^2 of a close pair (||A - I||_F <= 0.3), 3x3, straight from the invariants of
+// E = A - I:  sum_k log^2(1 + e_k) = sum_m c_m tr(E^m), with the power sums from Newton's recurrence
+// t_m = s1 t_(m-1) - s2 t_(m-2) + s3 t_(m-3) and c_m from a degree-11 economised polynomial of
+// log^2(1+e) (max abs error 8e-10).  ~90 VALU ops, no transcendental.  *e2 receives ||E||_F^2.
+__device__ __forceinline__ float logsq_series3(const float (&a)[6], float* e2) {
+  constexpr float kL2[10] = {1.000000007e+00f, -1.000000039e+00f, 9.166626393e-01f, -8.333247760e-01f,
+                             7.614642417e-01f, -7.005246665e-01f, 6.374742114e-01f, -5.909650236e-01f,
+                             6.961358894e-01f, -6.701311000e-01f};
+  const float e00 = a[pidx(0, 0)] - 1.f, e11 = a[pidx(1, 1)] - 1.f, e22 = a[pidx(2, 2)] - 1.f;
+  const float e10 = a[pidx(1, 0)], e20 = a[pidx(2, 0)], e21 = a[pidx(2, 1)];
+  float t2 = fmaf(e00, e00, fmaf(e11, e11, e22 * e22));
+  t2 = fmaf(2.f, fmaf(e10, e10, fmaf(e20, e20, e21 * e21)), t2);
+  const float s1 = e00 + e11 + e22;
+  const float s2 = 0.5f * fmaf(s1, s1, -t2);
+  const float s3 = e00 * fmaf(e11, e22, -e21 * e21) - e10 * fmaf(e10, e22, -e21 * e20) +
+                   e20 * fmaf(e10, e21, -e11 * e20);
+  float tm3 = 3.f, tm2 = s1, tm1 = t2;
+  float acc = kL2[0] * t2;
+#pragma unroll
+  for (int k = 1; k < 10; ++k) {
+    const float t = fmaf(s1, tm1, fmaf(-s2, tm2, s3 * tm3));
+    acc = fmaf(kL2[k], t, acc);
+    tm3 = tm2; tm2 = tm1; tm1 = t;
+  }
+  *e2 = t2;
+  return acc;
+}
+
 // Same for 4x4: E^(k+1) = p I + q E + r E^2 + t E^3 with
 //   (p,q,r,t)_(k+1) = (-s4 t, p + s3 t, q - s2 t, r + s1 t),  E^4 = s1 E^3 - s2 E^2 + s3 E - s4 I,
 // s1..s4 from the power sums tr E^m (Newton's identities; tr E^3 = <E^2,E>, tr E^4 = ||E^2||_F^2).

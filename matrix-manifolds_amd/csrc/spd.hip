@@ -132,6 +132,11 @@ __device__ __forceinline__ T pair_value(const TL (&li)[Packed<D>::NP], const T (
   if constexpr (D == 3 && std::is_same<T, float>::value) {
     float a[6], w[3], v[3][3];
     congr_lower<float, 3>(li, xj, a);
+    {  // close pairs (whole wavefront within ||A - I||_F <= 0.3): invariants-only series
+      float e2;
+      const float sq = logsq_series3(a, &e2);
+      if (!__any(!(e2 <= 0.09f))) return sq;
+    }
     eig3_trig(a, w);
     const bool wide = !(w[0] * 32.f > w[2]);  // true for NaN / non-positive spectra too
     if (__any(wide)) {

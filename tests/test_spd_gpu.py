@@ -196,7 +196,9 @@ def test_properties_at_full_size():
     keep = i < j
     i, j = i[keep], j[keep]
     k = i * (2 * n - i - 1) // 2 + (j - i - 1)
-    assert torch.equal(d2.detach()[k], man.dist(x.detach()[i], x.detach()[j], squared=True))
+    # (which closed form a pair takes is decided per wavefront, so the two kernels may differ by rounding)
+    ref = man.dist(x.detach()[i], x.detach()[j], squared=True)
+    assert (d2.detach()[k] - ref).abs().max().item() <= 1e-7 + 1e-5 * ref.max().item()
 
 
 def test_no_nan_dists():

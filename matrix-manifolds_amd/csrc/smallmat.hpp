@@ -169,6 +169,33 @@ __device__ __forceinline__ void congr_lower_t(const TL (&lw)[Packed<D>::NP], con
     }
 }
 
+// out (full DxD, not symmetric) = Li^T M Lc^T  for packed lower Li, Lc and packed symmetric M.
+// With Li = L^-1 and Lc = L of the row point this is L^-T M L^T, the column-side gradient of a
+// pair up to the right factor X_j^-1 that is common to a whole column (spd.hip).
+template <typename T, int D, typename TL>
+__device__ __forceinline__ void lt_m_lt(const TL (&li)[Packed<D>::NP], const TL (&lc)[Packed<D>::NP],
+                                        const T (&m)[Packed<D>::NP], T (&out)[D][D]) {
+  T b[D][D];  // B = Li^T M : B[r][c] = sum_{k>=r} Li[k][r] M[k][c]
+#pragma unroll
+  for (int r = 0; r < D; ++r)
+#pragma unroll
+    for (int c = 0; c < D; ++c) {
+      T acc = li[pidx(r, r)] * m[pidx(r, c)];
+#pragma unroll
+      for (int k = r + 1; k < D; ++k) acc = Num<T>::fma(li[pidx(k, r)], m[pidx(k, c)], acc);
+      b[r][c] = acc;
+    }
+#pragma unroll
+  for (int r = 0; r < D; ++r)  // out = B Lc^T : out[r][c] = sum_{k<=c} B[r][k] Lc[c][k]
+#pragma unroll
+    for (int c = 0; c < D; ++c) {
+      T acc = b[r][0] * lc[pidx(c, 0)];
+#pragma unroll
+      for (int k = 1; k <= c; ++k) acc = Num<T>::fma(b[r][k], lc[pidx(c, k)], acc);
+      out[r][c] = acc;
+    }
+}
+
 // out = F S F^T for a full row-major DxD matrix F (symmetric result, packed).
 template <typename T, int D>
 __device__ __forceinline__ void congr_full(const T (&f)[D * D], const T (&s)[Packed<D>::NP],
@@ -355,6 +382,7 @@ __device__ __forceinline__ void eig3_trig(const float (&a)[6], float (&w)[3]) {
 // so both functions are alpha0 I + alpha1 E + alpha2 E^2 with coefficients from 10 three-term
 // recurrences on scalars.  ~175 VALU ops, branch-free, no transcendental; measured relative error
 // 5e-7 in fp32 (tools/micro/README).  Returns ||E||_F^2 for the caller's gate.
+template <bool WANT_N>
 __device__ __forceinline__ float log_series3(const float (&a)[6], float (&m0)[6], float (&n0)[6]) {
   constexpr float kA[10] = {1.000000001e+00f, -5.000000067e-01f, 3.333326160e-01f, -2.499985265e-01f,
                             2.000629482e-01f, -1.667570841e-01f, 1.409399919e-01f, -1.227561192e-01f,
@@ -381,7 +409,7 @@ __device__ __forceinline__ float log_series3(const float (&a)[6], float (&m0)[6]
 #pragma unroll
   for (int k = 0; k < 10; ++k) {
     a0 = fmaf(kA[k], p, a0); a1 = fmaf(kA[k], q, a1); a2 = fmaf(kA[k], r, a2);
-    b0 = fmaf(kB[k], p, b0); b1 = fmaf(kB[k], q, b1); b2 = fmaf(kB[k], r, b2);
+    if (WANT_N) { b0 = fmaf(kB[k], p, b0); b1 = fmaf(kB[k], q, b1); b2 = fmaf(kB[k], r, b2); }
     const float pn = s3 * r, qn = fmaf(-s2, r, p), rn = fmaf(s1, r, q);
     p = pn; q = qn; r = rn;
   }
@@ -391,6 +419,7 @@ __device__ __forceinline__ float log_series3(const float (&a)[6], float (&m0)[6]
   m0[pidx(1, 0)] = fmaf(a2, f10, a1 * e10);
   m0[pidx(2, 0)] = fmaf(a2, f20, a1 * e20);
   m0[pidx(2, 1)] = fmaf(a2, f21, a1 * e21);
+  if (!WANT_N) return tr2;
   n0[pidx(0, 0)] = fmaf(b2, f00, fmaf(b1, e00, b0));
   n0[pidx(1, 1)] = fmaf(b2, f11, fmaf(b1, e11, b0));
   n0[pidx(2, 2)] = fmaf(b2, f22, fmaf(b1, e22, b0));

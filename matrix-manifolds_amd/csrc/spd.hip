@@ -38,8 +38,12 @@ __host__ __device__ inline int64_t pair_off(int64_t n, int64_t row) { return row
 //   bad    int[n]     per-point "Cholesky failed" flag, written unconditionally by prep
 //   nodeL  T[n][NP]   packed lower L_i^-1
 //   nodeX  T[n][NP]   packed sym(X_i)
-//   accM   T[NP][n]   row-side accumulators   (sum_j V diag(2 g log w) V^T)
-//   accN   T[NP][n]   column-side accumulators (sum_i L_i^-T N_ij L_i^-1)
+//   nodeC  T[n][NP]   packed lower Cholesky factor L_i
+//   accM   T[NP][n]   row-side accumulators     sum_j M_ij,            M_ij = 2 g log(A_ij)
+//   accS   T[D*D][n]  column-side accumulators  sum_i L_i^-T M_ij L_i^T
+// The gradient w.r.t. the column point is L_i^-T [M A^-1] L_i^-1 with A^-1 = L_i^T X_j^-1 L_i, i.e.
+// (L_i^-T M L_i^T) X_j^-1: the factor X_j^-1 is common to the whole column, so only M is formed per
+// pair and X_j^-1 is applied once per point in finalize.
 // No memset is ever needed: prep zeroes the accumulators of its point and finalize zeroes
 // them again after reading (the fill kernels cost more than prep itself at n = 5000).
 template <typename T> struct Ws {
@@ -47,25 +51,32 @@ template <typename T> struct Ws {
   int* bad;
   T* nodeL;
   T* nodeX;
+  T* nodeC;
   T* accM;
-  T* accN;
+  T* accS;
   static size_t bad_bytes(int64_t n) { return (size_t(n) * sizeof(int) + 63) / 64 * 64; }
-  static size_t bytes(int64_t n, int np) { return 64 + bad_bytes(n) + sizeof(T) * size_t(n) * np * 4; }
-  Ws(void* base, int64_t n, int np) {
+  static size_t bytes(int64_t n, int d) {
+    const int np = d * (d + 1) / 2;
+    return 64 + bad_bytes(n) + sizeof(T) * size_t(n) * (4 * np + d * d);
+  }
+  Ws(void* base, int64_t n, int d) {
+    const int np = d * (d + 1) / 2;
     char* p = static_cast<char*>(base);
     status = reinterpret_cast<int*>(p);
     bad = reinterpret_cast<int*>(p + 64);
     nodeL = reinterpret_cast<T*>(p + 64 + bad_bytes(n));
     nodeX = nodeL + n * np;
-    accM = nodeX + n * np;
-    accN = accM + n * np;
+    nodeC = nodeX + n * np;
+    accM = nodeC + n * np;
+    accS = accM + n * np;
   }
 };
 
 // ------------------------------------------------------------------ prep
 template <typename T, int D>
 __global__ void spd_prep_kernel(const T* __restrict__ x, int n, T* __restrict__ nodeL, T* __restrict__ nodeX,
-                                T* __restrict__ accM, T* __restrict__ accN, int* __restrict__ bad) {
+                                T* __restrict__ nodeC, T* __restrict__ accM, T* __restrict__ accS,
+                                int* __restrict__ bad) {
   constexpr int NP = Packed<D>::NP;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
@@ -77,9 +88,11 @@ __global__ void spd_prep_kernel(const T* __restrict__ x, int n, T* __restrict__ 
   for (int k = 0; k < NP; ++k) {
     nodeL[size_t(i) * NP + k] = li[k];
     nodeX[size_t(i) * NP + k] = xs[k];
+    nodeC[size_t(i) * NP + k] = l[k];
     accM[size_t(k) * n + i] = T(0);
-    accN[size_t(k) * n + i] = T(0);
   }
+#pragma unroll
+  for (int k = 0; k < D * D; ++k) accS[size_t(k) * n + i] = T(0);
   bad[i] = ok ? 0 : 1;
 }
 
@@ -252,9 +265,10 @@ __global__ __launch_bounds__(kBlock) void spd_pdist_fwd_kernel(const T* __restri
 template <typename T, int D, int TI>
 __global__ __launch_bounds__(kBlock) void spd_pdist_bwd_kernel(const T* __restrict__ nodeL,
                                                                const T* __restrict__ nodeX,
+                                                               const T* __restrict__ nodeC,
                                                                const T* __restrict__ g, int n, int row_begin,
                                                                int row_end, int squared, T wmin, T wmax,
-                                                               T* __restrict__ accM, T* __restrict__ accN) {
+                                                               T* __restrict__ accM, T* __restrict__ accS) {
   constexpr int NP = Packed<D>::NP;
   __shared__ T redM[kBlock / 64][TI][NP];
   const TileId tile = fold_tile<TI>(n, row_begin, row_end);
@@ -266,9 +280,13 @@ __global__ __launch_bounds__(kBlock) void spd_pdist_bwd_kernel(const T* __restri
   const int j = jbase + threadIdx.x;
   const bool jin = j < n;
 
-  T xj[NP], accJ[NP];
+  T xj[NP], accJ[D][D];
 #pragma unroll
-  for (int k = 0; k < NP; ++k) { xj[k] = T(0); accJ[k] = T(0); }
+  for (int k = 0; k < NP; ++k) xj[k] = T(0);
+#pragma unroll
+  for (int r = 0; r < D; ++r)
+#pragma unroll
+    for (int c = 0; c < D; ++c) accJ[r][c] = T(0);
 #pragma unroll
   for (int k = 0; k < D; ++k) xj[pidx(k, k)] = T(1);
   if (jin) {
@@ -277,27 +295,30 @@ __global__ __launch_bounds__(kBlock) void spd_pdist_bwd_kernel(const T* __restri
   }
   const int64_t base = pair_off(n, row_begin);
   if (wave_live) {
-    T li_next[NP];  // row operand is fetched one row ahead (scalar loads overlap the eigensolve)
+    T li_next[NP], lc_next[NP];  // row operands are fetched one row ahead (scalar loads overlap the math)
 #pragma unroll
-    for (int k = 0; k < NP; ++k) li_next[k] = nodeL[size_t(i0) * NP + k];
+    for (int k = 0; k < NP; ++k) { li_next[k] = nodeL[size_t(i0) * NP + k]; lc_next[k] = nodeC[size_t(i0) * NP + k]; }
     T g_next = (jin && j > i0) ? g[pair_off(n, i0) - base + (j - i0 - 1)] : T(0);
     for (int i = i0; i < i1; ++i) {
-      T li[NP];
+      T li[NP], lc[NP];
 #pragma unroll
-      for (int k = 0; k < NP; ++k) li[k] = li_next[k];
+      for (int k = 0; k < NP; ++k) { li[k] = li_next[k]; lc[k] = lc_next[k]; }
       const int inext = min(i + 1, i1 - 1);
 #pragma unroll
-      for (int k = 0; k < NP; ++k) li_next[k] = nodeL[size_t(inext) * NP + k];
+      for (int k = 0; k < NP; ++k) {
+        li_next[k] = nodeL[size_t(inext) * NP + k];
+        lc_next[k] = nodeC[size_t(inext) * NP + k];
+      }
       T gs = g_next;  // upstream gradient, fetched one row ahead as well (hides the HBM latency)
       g_next = (jin && j > inext && inext > i) ? g[pair_off(n, inext) - base + (j - inext - 1)] : T(0);
-      T m[NP], nn[NP], cj[NP];
+      T m[NP];
       bool series = false;
       if constexpr (D == 3 && std::is_same<T, float>::value) {
-        // Close pairs (||A - I||_F <= 0.3 for the whole wavefront): log(A) and log(A) A^-1 from
-        // the Cayley-Hamilton series — no eigensolve.  Anything else takes the Jacobi path below.
+        // Close pairs (||A - I||_F <= 0.3 for the whole wavefront): log(A) from the
+        // Cayley-Hamilton series — no eigensolve.  Anything else takes the Jacobi path below.
         float a[6], m0[6], n0[6];
         congr_lower<float, 3>(li, xj, a);
-        const float e2 = log_series3(a, m0, n0);
+        const float e2 = log_series3<false>(a, m0, n0);
         series = !__any(!(e2 <= 0.09f));
         if (series) {
           if (!squared) {
@@ -307,12 +328,12 @@ __global__ __launch_bounds__(kBlock) void spd_pdist_bwd_kernel(const T* __restri
           }
           const float g2 = gs + gs;
 #pragma unroll
-          for (int k = 0; k < 6; ++k) { m[k] = g2 * m0[k]; nn[k] = g2 * n0[k]; }
+          for (int k = 0; k < 6; ++k) m[k] = g2 * m0[k];
         }
       } else if constexpr (D == 4 && std::is_same<T, float>::value) {
         float a[10], m0[10], n0[10];
         congr_lower<float, 4>(li, xj, a);
-        const float e2 = log_series4<true>(a, m0, n0);
+        const float e2 = log_series4<false>(a, m0, n0);
         series = !__any(!(e2 <= 0.09f));
         if (series) {
           if (!squared) {
@@ -327,25 +348,24 @@ __global__ __launch_bounds__(kBlock) void spd_pdist_bwd_kernel(const T* __restri
           }
           const float g2 = gs + gs;
 #pragma unroll
-          for (int k = 0; k < 10; ++k) { m[k] = g2 * m0[k]; nn[k] = g2 * n0[k]; }
+          for (int k = 0; k < 10; ++k) m[k] = g2 * m0[k];
         }
       }
       if (!series) {
         T w[D], lw[D], v[D][D];
         const T s = pair_core<T, D, true>(li, xj, wmin, wmax, w, lw, v);
         if (!squared) gs *= T(0.5) * Num<T>::rsqrt(Num<T>::max(s, wmin));
-        T cm[D], cn[D];
+        T cm[D];
 #pragma unroll
-        for (int k = 0; k < D; ++k) {
-          cm[k] = (gs + gs) * lw[k];
-          cn[k] = cm[k] * Num<T>::rcp(w[k]);
-        }
+        for (int k = 0; k < D; ++k) cm[k] = (gs + gs) * lw[k];
         vdvt<T, D>(v, cm, m);
-        vdvt<T, D>(v, cn, nn);
       }
-      congr_lower_t<T, D>(li, nn, cj);
+      T cj[D][D];
+      lt_m_lt<T, D>(li, lc, m, cj);
 #pragma unroll
-      for (int k = 0; k < NP; ++k) accJ[k] += cj[k];
+      for (int r = 0; r < D; ++r)
+#pragma unroll
+        for (int c = 0; c < D; ++c) accJ[r][c] += cj[r][c];
 #if !defined(MM_ABL) || MM_ABL == 0
       wave_sum_n(m);  // fp32: DPP lanes; fp64: LDS-crossbar butterflies
 #elif MM_ABL == 1   // ablation: per-value butterflies
@@ -373,30 +393,55 @@ __global__ __launch_bounds__(kBlock) void spd_pdist_bwd_kernel(const T* __restri
   // column side: lanes hold consecutive j -> 256-B contiguous atomics per k
   if (jin && wave_live) {
 #pragma unroll
-    for (int k = 0; k < NP; ++k) atomic_add(&accN[size_t(k) * n + j], accJ[k]);
+    for (int r = 0; r < D; ++r)
+#pragma unroll
+      for (int c = 0; c < D; ++c) atomic_add(&accS[size_t(r * D + c) * n + j], accJ[r][c]);
   }
 }
 
-// grad_x[i] = -L_i^-T accM_i L_i^-1 + accN_i   (symmetric, full DxD)
+// grad_x[i] = sym(accS_i X_i^-1) - L_i^-T accM_i L_i^-1   (symmetric, full DxD)
 template <typename T, int D>
 __global__ void spd_pdist_finalize_kernel(const T* __restrict__ nodeL, T* __restrict__ accM,
-                                          T* __restrict__ accN, int n, T* __restrict__ grad) {
+                                          T* __restrict__ accS, int n, T* __restrict__ grad) {
   constexpr int NP = Packed<D>::NP;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  T li[NP], m[NP], gi[NP];
+  T li[NP], m[NP], gi[NP], xinv[NP], sc[D][D];
 #pragma unroll
   for (int k = 0; k < NP; ++k) {
     li[k] = nodeL[size_t(i) * NP + k];
     m[k] = accM[size_t(k) * n + i];
-  }
-  congr_lower_t<T, D>(li, m, gi);
-#pragma unroll
-  for (int k = 0; k < NP; ++k) {
-    gi[k] = accN[size_t(k) * n + i] - gi[k];
     accM[size_t(k) * n + i] = T(0);  // leave the accumulators clean for the next backward
-    accN[size_t(k) * n + i] = T(0);
   }
+#pragma unroll
+  for (int r = 0; r < D; ++r)
+#pragma unroll
+    for (int c = 0; c < D; ++c) {
+      sc[r][c] = accS[size_t(r * D + c) * n + i];
+      accS[size_t(r * D + c) * n + i] = T(0);
+    }
+  congr_lower_t<T, D>(li, m, gi);   // L^-T M L^-1
+#pragma unroll
+  for (int r = 0; r < D; ++r)       // X^-1 = L^-T L^-1
+#pragma unroll
+    for (int c = 0; c <= r; ++c) {
+      T acc = T(0);
+#pragma unroll
+      for (int k = r; k < D; ++k) acc = Num<T>::fma(li[pidx(k, r)], li[pidx(k, c)], acc);
+      xinv[pidx(r, c)] = acc;
+    }
+#pragma unroll
+  for (int r = 0; r < D; ++r)
+#pragma unroll
+    for (int c = 0; c <= r; ++c) {
+      T a = T(0), b = T(0);         // (S X^-1)[r][c] and (S X^-1)[c][r]
+#pragma unroll
+      for (int k = 0; k < D; ++k) {
+        a = Num<T>::fma(sc[r][k], xinv[pidx(k, c)], a);
+        b = Num<T>::fma(sc[c][k], xinv[pidx(k, r)], b);
+      }
+      gi[pidx(r, c)] = T(0.5) * (a + b) - gi[pidx(r, c)];
+    }
   store_sym_full<T, D>(grad + size_t(i) * D * D, gi);
 }
 
@@ -608,8 +653,8 @@ __global__ void spd_rsgd_step_kernel(const T* __restrict__ x, const T* __restric
 template <typename T, int D>
 int spd_pdist_prepare(const T* x, int64_t n, Ws<T>& ws, int flags, hipStream_t st) {
   if (!(flags & MM_WS_PREPARED)) {
-    spd_prep_kernel<T, D><<<dim3((n + 127) / 128), dim3(128), 0, st>>>(x, int(n), ws.nodeL, ws.nodeX, ws.accM,
-                                                                       ws.accN, ws.bad);
+    spd_prep_kernel<T, D><<<dim3((n + 127) / 128), dim3(128), 0, st>>>(x, int(n), ws.nodeL, ws.nodeX, ws.nodeC,
+                                                                       ws.accM, ws.accS, ws.bad);
     MM_CHECK_LAUNCH();
   }
   return MM_OK;
@@ -636,7 +681,7 @@ int spd_pdist_fwd_ti(Ws<T>& ws, int64_t n, int64_t rb, int64_t re, int squared, 
 template <typename T, int D>
 int spd_pdist_fwd_t(const T* x, int64_t n, int64_t rb, int64_t re, int squared, double wmin, double wmax, T* out,
                     void* wsp, int flags, hipStream_t st) {
-  Ws<T> ws(wsp, n, Packed<D>::NP);
+  Ws<T> ws(wsp, n, D);
   int rc = spd_pdist_prepare<T, D>(x, n, ws, flags, st);
   if (rc) return rc;
   if (re <= rb || pair_off(n, re) == pair_off(n, rb)) return MM_OK;
@@ -653,7 +698,7 @@ int spd_pdist_bwd_ti(Ws<T>& ws, const T* g, int64_t n, int64_t rb, int64_t re, i
   {
     ProfScope prof(PROF_SPD_BWD, st);
     spd_pdist_bwd_kernel<T, D, TI><<<fold_grid<TI>(n, rb, re), dim3(kBlock), 0, st>>>(
-        ws.nodeL, ws.nodeX, g, int(n), int(rb), int(re), squared, T(wmin), T(wmax), ws.accM, ws.accN);
+        ws.nodeL, ws.nodeX, ws.nodeC, g, int(n), int(rb), int(re), squared, T(wmin), T(wmax), ws.accM, ws.accS);
   }
   MM_CHECK_LAUNCH();
   return MM_OK;
@@ -663,7 +708,7 @@ template <typename T, int D>
 int spd_pdist_bwd_t(const T* x, const T* g, int64_t n, int64_t rb, int64_t re, int squared, double wmin, double wmax,
                     T* grad, void* wsp, int flags, hipStream_t st) {
   constexpr int NP = Packed<D>::NP;
-  Ws<T> ws(wsp, n, NP);
+  Ws<T> ws(wsp, n, D);
   int rc = spd_pdist_prepare<T, D>(x, n, ws, flags, st);
   if (rc) return rc;
   if (re > rb && pair_off(n, re) > pair_off(n, rb)) {
@@ -674,7 +719,7 @@ int spd_pdist_bwd_t(const T* x, const T* g, int64_t n, int64_t rb, int64_t re, i
     }
     if (rc) return rc;
   }
-  spd_pdist_finalize_kernel<T, D><<<dim3((n + 127) / 128), dim3(128), 0, st>>>(ws.nodeL, ws.accM, ws.accN, int(n),
+  spd_pdist_finalize_kernel<T, D><<<dim3((n + 127) / 128), dim3(128), 0, st>>>(ws.nodeL, ws.accM, ws.accS, int(n),
                                                                                grad);
   MM_CHECK_LAUNCH();
   return MM_OK;
@@ -715,8 +760,7 @@ extern "C" {
 int mm_spd_max_dim(void) { return kSpdMaxD; }
 
 size_t mm_spd_pdist_ws_bytes(int dtype, int64_t n, int d) {
-  const int np = d * (d + 1) / 2;
-  return dtype == MM_F64 ? Ws<double>::bytes(n, np) : Ws<float>::bytes(n, np);
+  return dtype == MM_F64 ? Ws<double>::bytes(n, d) : Ws<float>::bytes(n, d);
 }
 
 int mm_spd_pdist_fwd(int dtype, const void* x, int64_t n, int d, int64_t row_begin, int64_t row_end, int squared,

@@ -580,6 +580,79 @@ template <int N> __device__ __forceinline__ void wave_sum_n(float (&r)[N]) {
   for (int k = 0; k < N; ++k) r[k] = wave_sum_dpp(r[k]);
 }
 
+// ---- transposing reduction: N values per lane -> one total per lane --------------------------
+// Summing N values over 64 lanes one value at a time costs 6 cross-lane steps each.  Instead the
+// values are halved at every butterfly level: at level s (partner = lane ^ 2^s) a lane with bit s
+// clear keeps the lower half of its values and SENDS the upper half (and vice versa), so after
+// log2(W) levels (W = N rounded up to a power of two) each lane owns ONE value — the partial sum
+// of index  idx = sum_s bit_s(lane) * W / 2^(s+1)  over its 2^log2(W)-lane group — and the remaining
+// levels are plain butterflies on that single value.  6 values: 7 + 3 cross-lane adds instead of 36.
+// Cross-lane moves: xor 1, 2 = DPP quad_perm; xor 4 = DPP row_shl:4 / row_shr:4 on complementary
+// bank masks; xor 8 = DPP row_ror:8; xor 16 / 32 = v_permlane16_swap / v_permlane32_swap (gfx950).
+// (primitives checked on hardware by tools/micro/t_perm.hip)
+template <int LEVEL> __device__ __forceinline__ float lane_xor(float x) {
+  const int xi = __float_as_int(x);
+  if constexpr (LEVEL == 0) return __int_as_float(__builtin_amdgcn_update_dpp(0, xi, 0xB1, 0xF, 0xF, false));
+  else if constexpr (LEVEL == 1) return __int_as_float(__builtin_amdgcn_update_dpp(0, xi, 0x4E, 0xF, 0xF, false));
+  else if constexpr (LEVEL == 2) {
+    int t = __builtin_amdgcn_update_dpp(0, xi, 0x104, 0xF, 0x5, false);   // lanes with bit 2 clear <- lane + 4
+    t = __builtin_amdgcn_update_dpp(t, xi, 0x114, 0xF, 0xA, false);       // lanes with bit 2 set   <- lane - 4
+    return __int_as_float(t);
+  } else {
+    static_assert(LEVEL == 3, "xor 16 / 32 use the swap forms below");
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, xi, 0x128, 0xF, 0xF, false));  // row_ror:8
+  }
+}
+__device__ __forceinline__ float butterfly16(float x) {   // x + x[lane ^ 16]
+  const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ float butterfly32(float x) {   // x + x[lane ^ 32]
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+template <int W> __device__ __forceinline__ int transposed_index(int lane) {
+  int idx = 0;
+#pragma unroll
+  for (int s = 0; (W >> (s + 1)) > 0; ++s) idx += ((lane >> s) & 1) * (W >> (s + 1));
+  return idx;
+}
+template <int LEVEL, int H> __device__ __forceinline__ void halve_level(float (&r)[2 * H], float (&o)[H], int lane) {
+  const bool up = (lane >> LEVEL) & 1;
+#pragma unroll
+  for (int k = 0; k < H; ++k) {
+    const float keep = up ? r[H + k] : r[k];
+    const float send = up ? r[k] : r[H + k];
+    o[k] = keep + lane_xor<LEVEL>(send);
+  }
+}
+// N <= 8: returns the wavefront total of value transposed_index<8>(lane) (zero for indices >= N).
+template <int N> __device__ __forceinline__ float wave_sum_transposed8(const float (&v)[N], int lane) {
+  static_assert(N <= 8, "");
+  float r8[8], r4[4], r2[2], r1[1];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) r8[k] = (k < N) ? v[k < N ? k : 0] : 0.f;
+  halve_level<0, 4>(r8, r4, lane);
+  halve_level<1, 2>(r4, r2, lane);
+  halve_level<2, 1>(r2, r1, lane);
+  float x = r1[0];
+  x += lane_xor<3>(x);
+  x = butterfly16(x);
+  return butterfly32(x);
+}
+// N <= 16
+template <int N> __device__ __forceinline__ float wave_sum_transposed16(const float (&v)[N], int lane) {
+  static_assert(N <= 16, "");
+  float r16[16], r8[8], r4[4], r2[2], r1[1];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) r16[k] = (k < N) ? v[k < N ? k : 0] : 0.f;
+  halve_level<0, 8>(r16, r8, lane);
+  halve_level<1, 4>(r8, r4, lane);
+  halve_level<2, 2>(r4, r2, lane);
+  halve_level<3, 1>(r2, r1, lane);
+  return butterfly32(butterfly16(r1[0]));
+}
+
 template <typename T> __device__ __forceinline__ T wave_sum(T x) {
 #pragma unroll
   for (int m = 32; m >= 1; m >>= 1) x += __shfl_xor(x, m, 64);

@@ -190,31 +190,31 @@ __device__ __forceinline__ T pair_value(const TL (&li)[Packed<D>::NP], const T (
 // first super-diagonal entry to the last; pairing tile y with tile gy-1-y makes every
 // grid row about equally long, so (almost) no launched workgroup is empty.
 struct TileId { int i0, jbase; bool ok; };
-template <int TI> __device__ __forceinline__ TileId fold_tile(int n, int row_begin, int row_end) {
+template <int TI, int BW = kBlock> __device__ __forceinline__ TileId fold_tile(int n, int row_begin, int row_end) {
   const int gy = (row_end - row_begin + TI - 1) / TI;
-  const int nJB = (n + kBlock - 1) / kBlock;
+  const int nJB = (n + BW - 1) / BW;
   int y = blockIdx.y, x = blockIdx.x;
-  int cb0 = (row_begin + y * TI + 1) / kBlock;
+  int cb0 = (row_begin + y * TI + 1) / BW;
   int cnt = nJB - cb0;
   if (x >= cnt) {
     x -= cnt;
     const int y2 = gy - 1 - y;
     if (y2 <= y) return {0, 0, false};
     y = y2;
-    cb0 = (row_begin + y * TI + 1) / kBlock;
+    cb0 = (row_begin + y * TI + 1) / BW;
     cnt = nJB - cb0;
     if (x >= cnt) return {0, 0, false};
   }
-  return {row_begin + y * TI, (cb0 + x) * kBlock, true};
+  return {row_begin + y * TI, (cb0 + x) * BW, true};
 }
-template <int TI> inline dim3 fold_grid(int64_t n, int64_t rb, int64_t re) {
+template <int TI, int BW = kBlock> inline dim3 fold_grid(int64_t n, int64_t rb, int64_t re) {
   const int gy = int((re - rb + TI - 1) / TI);
-  const int nJB = int((n + kBlock - 1) / kBlock);
+  const int nJB = int((n + BW - 1) / BW);
   int gx = 0;
   for (int y = 0; y < (gy + 1) / 2; ++y) {
     const int y2 = gy - 1 - y;
-    int c = nJB - int((rb + int64_t(y) * TI + 1) / kBlock);
-    if (y2 > y) c += nJB - int((rb + int64_t(y2) * TI + 1) / kBlock);
+    int c = nJB - int((rb + int64_t(y) * TI + 1) / BW);
+    if (y2 > y) c += nJB - int((rb + int64_t(y2) * TI + 1) / BW);
     gx = c > gx ? c : gx;
   }
   return dim3(gx > 0 ? gx : 1, (gy + 1) / 2 > 0 ? (gy + 1) / 2 : 1);
@@ -270,14 +270,21 @@ __global__ __launch_bounds__(kBlock) void spd_pdist_bwd_kernel(const T* __restri
                                                                int row_end, int squared, T wmin, T wmax,
                                                                T* __restrict__ accM, T* __restrict__ accS) {
   constexpr int NP = Packed<D>::NP;
-  __shared__ T redM[kBlock / 64][TI][NP];
-  const TileId tile = fold_tile<TI>(n, row_begin, row_end);
+  constexpr int NW = kBlock / 64;
+  // Workgroup tile: 64 columns x (4 waves x TI rows).  The four wavefronts share the columns, so
+  // their column-side partial sums are combined through LDS and flushed with ONE set of atomics:
+  // float atomics are a per-CU serial resource (~50 ns per wave instruction) and at TI = 8 the
+  // 36 column-side atomics of the old 256-column tile cost as much CU time as its arithmetic.
+  __shared__ T redM[NW][TI][NP];
+  __shared__ T colS[NW][D * D][64];
+  const TileId tile = fold_tile<NW * TI, 64>(n, row_begin, row_end);
   if (!tile.ok) return;  // block-uniform
-  const int i0 = tile.i0, i1 = min(i0 + TI, row_end), jbase = tile.jbase;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int wave_j0 = jbase + wave * 64;
-  const bool wave_live = wave_j0 + 63 > i0;  // else no pair of this wave is above the diagonal
-  const int j = jbase + threadIdx.x;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform -> row operands stay scalar loads
+  const int jbase = tile.jbase;
+  const int i0 = tile.i0 + wave * TI, i1 = max(i0, min(i0 + TI, min(tile.i0 + NW * TI, row_end)));
+  const bool wave_live = i0 < i1 && jbase + 63 > i0;  // else no pair of this wave is above the diagonal
+  const int j = jbase + lane;
   const bool jin = j < n;
 
   T xj[NP], accJ[D][D];
@@ -366,36 +373,49 @@ __global__ __launch_bounds__(kBlock) void spd_pdist_bwd_kernel(const T* __restri
       for (int r = 0; r < D; ++r)
 #pragma unroll
         for (int c = 0; c < D; ++c) accJ[r][c] += cj[r][c];
-#if !defined(MM_ABL) || MM_ABL == 0
-      wave_sum_n(m);  // fp32: DPP lanes; fp64: LDS-crossbar butterflies
-#elif MM_ABL == 1   // ablation: per-value butterflies
+      if constexpr (std::is_same<T, float>::value && NP <= 16) {
+        // transposing reduction: every lane ends up with the wavefront total of ONE entry of M
+        constexpr int W = NP <= 8 ? 8 : 16;
+        float tot;
+        if constexpr (NP <= 8) tot = wave_sum_transposed8<NP>(m, lane); else tot = wave_sum_transposed16<NP>(m, lane);
+        const int k = transposed_index<W>(lane);
+        if (lane < W && k < NP) redM[wave][i - i0][k] = tot;
+      } else {
+        wave_sum_n(m);  // fp64: LDS-crossbar butterflies
+        if (lane == 0) {
 #pragma unroll
-      for (int k = 0; k < NP; ++k) m[k] = wave_sum(m[k]);
-#endif              // MM_ABL >= 2: no reduction (timing only, wrong results)
-      if (lane == 0) {
-#pragma unroll
-        for (int k = 0; k < NP; ++k) redM[wave][i - i0][k] = m[k];
+          for (int k = 0; k < NP; ++k) redM[wave][i - i0][k] = m[k];
+        }
       }
     }
   }
-  __syncthreads();
-  // row side: sum the live wavefronts' partials, one coalesced atomic per (k, row)
-  for (int t = threadIdx.x; t < TI * NP; t += kBlock) {
-    const int k = t / TI, il = t % TI;
-    if (i0 + il < i1) {
-      T sum = T(0);
-#pragma unroll
-      for (int wv = 0; wv < kBlock / 64; ++wv)
-        if (jbase + wv * 64 + 63 > i0) sum += redM[wv][il][k];
-      atomic_add(&accM[size_t(k) * n + i0 + il], sum);
+  // row side: each wavefront owns its TI rows
+  if (wave_live) {
+    __builtin_amdgcn_wave_barrier();
+    for (int t = lane; t < TI * NP; t += 64) {
+      const int k = t / TI, il = t % TI;
+#if !defined(MM_ABL) || (MM_ABL != 7 && MM_ABL != 9)
+      if (i0 + il < i1) atomic_add(&accM[size_t(k) * n + i0 + il], redM[wave][il][k]);
+#endif
     }
   }
-  // column side: lanes hold consecutive j -> 256-B contiguous atomics per k
-  if (jin && wave_live) {
+  // column side: combine the four wavefronts, then 256-B contiguous atomics per entry
 #pragma unroll
-    for (int r = 0; r < D; ++r)
+  for (int r = 0; r < D; ++r)
 #pragma unroll
-      for (int c = 0; c < D; ++c) atomic_add(&accS[size_t(r * D + c) * n + j], accJ[r][c]);
+    for (int c = 0; c < D; ++c) colS[wave][r * D + c][lane] = accJ[r][c];
+  __syncthreads();
+  if (jin) {
+    for (int k = wave; k < D * D; k += NW) {
+      T sum = colS[0][k][lane];
+#pragma unroll
+      for (int wv = 1; wv < NW; ++wv) sum += colS[wv][k][lane];
+#if !defined(MM_ABL) || (MM_ABL != 7 && MM_ABL != 9)
+      atomic_add(&accS[size_t(k) * n + j], sum);
+#else
+      if (sum == T(12345.678)) accS[j] = sum;
+#endif
+    }
   }
 }
 
@@ -697,7 +717,7 @@ int spd_pdist_bwd_ti(Ws<T>& ws, const T* g, int64_t n, int64_t rb, int64_t re, i
                      hipStream_t st) {
   {
     ProfScope prof(PROF_SPD_BWD, st);
-    spd_pdist_bwd_kernel<T, D, TI><<<fold_grid<TI>(n, rb, re), dim3(kBlock), 0, st>>>(
+    spd_pdist_bwd_kernel<T, D, TI><<<fold_grid<(kBlock / 64) * TI, 64>(n, rb, re), dim3(kBlock), 0, st>>>(
         ws.nodeL, ws.nodeX, ws.nodeC, g, int(n), int(rb), int(re), squared, T(wmin), T(wmax), ws.accM, ws.accS);
   }
   MM_CHECK_LAUNCH();

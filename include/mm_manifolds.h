@@ -87,6 +87,26 @@ int mm_spd_pdist_bwd(int dtype, const void* x, const void* g, int64_t n, int d,
                      int64_t row_begin, int64_t row_end, int squared, double wmin,
                      double wmax, void* grad_x, void* ws, int flags, mm_stream_t stream);
 
+/* Fused objective + gradients for a single-factor SPD embedding: ONE pass over the pairs
+ * evaluates  m_k = softplus(*scale_raw) * d2_k  (ManifoldEmbedding.compute_dists,
+ * modules.py:84-88), the loss against target[k] (objectives.py:16-45), and both gradients —
+ * what `loss = objective_fn(gdists, compute_dists()); loss.backward()` computes in the reference
+ * (train.py:213-217) without ever writing the pair vector of distances (4 B/pair of HBM traffic
+ * instead of >= 40 B/pair through the framework's element-wise ops).
+ *   loss_kind  MM_LOSS_STRESS    sum (m - target)^2                         objectives.py:39-45
+ *              MM_LOSS_QUOTIENT  terms bit0: sum |m/(alpha target) - 1|
+ *                                terms bit1: sum |alpha target/(m + eps) - 1|,  eps = 1/(epoch+1)
+ *                                                                            objectives.py:16-36
+ *   target     pair vector (layout of mm_spd_pdist_fwd's `out`) of squared graph distances
+ *   scale_raw  device scalar (the raw scale parameter) or NULL for scale 1
+ *   loss_out   device [2]: { loss of this shard, d loss / d scale_raw of this shard }
+ *   grad_x     [n,d,d], OVERWRITTEN with this shard's partial d loss / d x. */
+enum { MM_LOSS_NONE = 0, MM_LOSS_STRESS = 1, MM_LOSS_QUOTIENT = 2 };
+int mm_spd_pdist_loss(int dtype, int loss_kind, const void* x, const void* target,
+                      const void* scale_raw, int64_t n, int d, int64_t row_begin, int64_t row_end,
+                      double alpha, double eps, int terms, double wmin, double wmax,
+                      void* loss_out, void* grad_x, void* ws, int flags, mm_stream_t stream);
+
 /* Counts the points whose Cholesky factorisation failed in the last prepare of `ws`
  * (n = the point count it was prepared for) into *host_status (0 = all succeeded).
  * Synchronises `stream` — the only blocking call of the ABI. */

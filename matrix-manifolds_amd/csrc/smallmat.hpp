@@ -429,6 +429,98 @@ __device__ __forceinline__ float log_series3(const float (&a)[6], float (&m0)[6]
   return tr2;
 }
 
+// ---- Cayley-transform logarithm: the general eigen-free path (3x3) ------------------------------
+// log A = log(mu) I + 2 atanh(Z),  Z = (A - mu I)(A + mu I)^-1  (spectrum z = (l - mu)/(l + mu), |z| < 1
+// for every SPD A), atanh(Z) = Z P(Z^2) with P a near-minimax polynomial of atanh(sqrt w)/sqrt w on
+// w in [0, 0.36] (degree 6 in fp32: 3.4e-8, degree 13 in fp64: 4e-15; tools/design/cayley_fit.py).
+// P(W) is evaluated through the Cayley-Hamilton reduction of W = Z^2 (scalar three-term recurrences),
+// the inverse is the adjugate of a 3x3, and mu = 2^k (the power of two next to tr A / 3) so that
+// log(mu) = k ln 2 carries no transcendental error and A ~ I gives log(mu) = 0 exactly.  Z is formed
+// as (A - mu I) adj(A + mu I) / det — a product of commuting symmetric matrices — which keeps its
+// RELATIVE accuracy when A is close to mu I (measured max error 7e-7 of max|log A| in fp32, 4e-13 in
+// fp64, spectra of any spread inside the gate).  ~170 ops, one division, no eigensolve, no iteration:
+// valid whenever tr(Z^2) <= 0.36, i.e. eigenvalue ratios up to ~16 — every pair of an embedding whose
+// distances are O(1).  Returns tr(Z^2) for the caller's (wave-uniform) gate.
+constexpr double kCayleyGate = 0.36;
+template <typename T> __device__ __forceinline__ T frexp_t(T x, int* k);
+template <> __device__ __forceinline__ float frexp_t<float>(float x, int* k) { return ::frexpf(x, k); }
+template <> __device__ __forceinline__ double frexp_t<double>(double x, int* k) { return ::frexp(x, k); }
+template <typename T> __device__ __forceinline__ T ldexp_t(T x, int k);
+template <> __device__ __forceinline__ float ldexp_t<float>(float x, int k) { return ::ldexpf(x, k); }
+template <> __device__ __forceinline__ double ldexp_t<double>(double x, int k) { return ::ldexp(x, k); }
+
+template <typename T> __device__ __forceinline__ void sym3_mul(const T (&x)[6], const T (&y)[6], T (&o)[6]) {
+  using N = Num<T>;  // product of two COMMUTING symmetric 3x3 (packed 00,10,11,20,21,22)
+  o[0] = N::fma(x[0], y[0], N::fma(x[1], y[1], x[3] * y[3]));
+  o[1] = N::fma(x[1], y[0], N::fma(x[2], y[1], x[4] * y[3]));
+  o[2] = N::fma(x[1], y[1], N::fma(x[2], y[2], x[4] * y[4]));
+  o[3] = N::fma(x[3], y[0], N::fma(x[4], y[1], x[5] * y[3]));
+  o[4] = N::fma(x[3], y[1], N::fma(x[4], y[2], x[5] * y[4]));
+  o[5] = N::fma(x[3], y[3], N::fma(x[4], y[4], x[5] * y[5]));
+}
+
+template <typename T> __device__ __forceinline__ T log_cayley3(const T (&a)[6], T (&m0)[6]) {
+  using N = Num<T>;
+  constexpr bool kF32 = std::is_same<T, float>::value;
+  constexpr int K = kF32 ? 6 : 13;
+  constexpr double kC32[7] = {1.00000002318570891e+00, 3.33327042495924375e-01, 2.00274867564608688e-01,
+                              1.38428695737667723e-01, 1.44240977093542333e-01, -3.05379184438951401e-02,
+                              2.73482843603638170e-01};
+  constexpr double kC64[14] = {9.99999999999997002e-01, 3.33333333336093829e-01, 1.99999999512113669e-01,
+                               1.42857176992888746e-01, 1.11109865194520263e-01, 9.09362522505209464e-02,
+                               7.65413194323763535e-02, 7.02835946952955759e-02, 3.51739351378960174e-02,
+                               1.60038305495638411e-01, -2.87332526616183470e-01, 7.35063731671786291e-01,
+                               -8.29196169410508666e-01, 5.70221868872885063e-01};
+  int k;
+  const T mant = frexp_t<T>((a[0] + a[2] + a[5]) * T(1.0 / 3.0), &k);  // mean eigenvalue = mant 2^k
+  if (mant < T(0.70710678118654752)) k -= 1;
+  const T mu = ldexp_t<T>(T(1), k), logmu = T(k) * T(0.69314718055994531);
+  // adj(B), B = A + mu I
+  const T b00 = a[0] + mu, b11 = a[2] + mu, b22 = a[5] + mu, b10 = a[1], b20 = a[3], b21 = a[4];
+  T adj[6], e[6], z[6], w[6], w2[6];
+  adj[0] = N::fma(b11, b22, -b21 * b21);
+  adj[1] = N::fma(b21, b20, -b10 * b22);
+  adj[2] = N::fma(b00, b22, -b20 * b20);
+  adj[3] = N::fma(b10, b21, -b11 * b20);
+  adj[4] = N::fma(b10, b20, -b00 * b21);
+  adj[5] = N::fma(b00, b11, -b10 * b10);
+  const T rdet = N::rcp(N::fma(b00, adj[0], N::fma(b10, adj[1], b20 * adj[3])));
+  e[0] = a[0] - mu; e[1] = a[1]; e[2] = a[2] - mu; e[3] = a[3]; e[4] = a[4]; e[5] = a[5] - mu;
+  sym3_mul<T>(e, adj, z);
+#pragma unroll
+  for (int i = 0; i < 6; ++i) z[i] *= rdet;
+  sym3_mul<T>(z, z, w);
+  sym3_mul<T>(w, w, w2);
+  const T t1 = w[0] + w[2] + w[5];
+  const T t2 = T(0.5) * N::fma(t1, t1, -(w2[0] + w2[2] + w2[5]));
+  const T t3 = w[0] * N::fma(w[2], w[5], -w[4] * w[4]) - w[1] * N::fma(w[1], w[5], -w[4] * w[3]) +
+               w[3] * N::fma(w[1], w[4], -w[2] * w[3]);
+  auto coef = [&](int i) -> T { return kF32 ? T(kC32[i < 7 ? i : 0]) : T(kC64[i]); };
+  T c0 = coef(0), c1 = coef(1), c2 = coef(2);
+  T p = T(0), q = T(0), r = T(1);  // W^2 = 0 I + 0 W + 1 W^2
+#pragma unroll
+  for (int i = 3; i <= K; ++i) {
+    const T pn = t3 * r, qn = N::fma(-t2, r, p), rn = N::fma(t1, r, q);
+    p = pn; q = qn; r = rn;
+    c0 = N::fma(coef(i), p, c0); c1 = N::fma(coef(i), q, c1); c2 = N::fma(coef(i), r, c2);
+  }
+  T pw[6];
+  pw[0] = N::fma(c2, w2[0], N::fma(c1, w[0], c0));
+  pw[1] = N::fma(c2, w2[1], c1 * w[1]);
+  pw[2] = N::fma(c2, w2[2], N::fma(c1, w[2], c0));
+  pw[3] = N::fma(c2, w2[3], c1 * w[3]);
+  pw[4] = N::fma(c2, w2[4], c1 * w[4]);
+  pw[5] = N::fma(c2, w2[5], N::fma(c1, w[5], c0));
+  sym3_mul<T>(z, pw, m0);
+  m0[0] = N::fma(T(2), m0[0], logmu);
+  m0[1] += m0[1];
+  m0[2] = N::fma(T(2), m0[2], logmu);
+  m0[3] += m0[3];
+  m0[4] += m0[4];
+  m0[5] = N::fma(T(2), m0[5], logmu);
+  return t1;
+}
+
 // d^2 = ||log A||_F^2 of a close pair (||A - I||_F <= 0.3), 3x3, straight from the invariants of
 // E = A - I:  sum_k log^2(1 + e_k) = sum_m c_m tr(E^m), with the power sums from Newton's recurrence
 // t_m = s1 t_(m-1) - s2 t_(m-2) + s3 t_(m-3) and c_m from a degree-11 economised polynomial of

@@ -30,6 +30,7 @@ namespace mm {
 
 constexpr int kBlock = 256;  // 4 wavefronts
 constexpr int kSpdMaxD = 5;
+constexpr int kLossSlots = 256;  // fused-loss partial sums are spread over this many addresses
 
 __host__ __device__ inline int64_t pair_off(int64_t n, int64_t row) { return row * (2 * n - row - 1) / 2; }
 
@@ -41,6 +42,7 @@ __host__ __device__ inline int64_t pair_off(int64_t n, int64_t row) { return row
 //   nodeC  T[n][NP]   packed lower Cholesky factor L_i
 //   accM   T[NP][n]   row-side accumulators     sum_j M_ij,            M_ij = 2 g log(A_ij)
 //   accS   T[D*D][n]  column-side accumulators  sum_i L_i^-T M_ij L_i^T
+//   loss   T[2][256]  fused-loss partial sums (loss, d loss / d softplus(scale)), spread over 256 slots
 // The gradient w.r.t. the column point is L_i^-T [M A^-1] L_i^-1 with A^-1 = L_i^T X_j^-1 L_i, i.e.
 // (L_i^-T M L_i^T) X_j^-1: the factor X_j^-1 is common to the whole column, so only M is formed per
 // pair and X_j^-1 is applied once per point in finalize.
@@ -54,10 +56,11 @@ template <typename T> struct Ws {
   T* nodeC;
   T* accM;
   T* accS;
+  T* loss;
   static size_t bad_bytes(int64_t n) { return (size_t(n) * sizeof(int) + 63) / 64 * 64; }
   static size_t bytes(int64_t n, int d) {
     const int np = d * (d + 1) / 2;
-    return 64 + bad_bytes(n) + sizeof(T) * size_t(n) * (4 * np + d * d);
+    return 64 + bad_bytes(n) + sizeof(T) * (size_t(n) * (4 * np + d * d) + 2 * kLossSlots);
   }
   Ws(void* base, int64_t n, int d) {
     const int np = d * (d + 1) / 2;
@@ -69,6 +72,7 @@ template <typename T> struct Ws {
     nodeC = nodeX + n * np;
     accM = nodeC + n * np;
     accS = accM + n * np;
+    loss = accS + n * d * d;
   }
 };
 
@@ -76,9 +80,11 @@ template <typename T> struct Ws {
 template <typename T, int D>
 __global__ void spd_prep_kernel(const T* __restrict__ x, int n, T* __restrict__ nodeL, T* __restrict__ nodeX,
                                 T* __restrict__ nodeC, T* __restrict__ accM, T* __restrict__ accS,
-                                int* __restrict__ bad) {
+                                T* __restrict__ loss, int* __restrict__ bad) {
   constexpr int NP = Packed<D>::NP;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (blockIdx.x == 0)
+    for (int t = threadIdx.x; t < 2 * kLossSlots; t += blockDim.x) loss[t] = T(0);
   if (i >= n) return;
   T xs[NP], l[NP], li[NP];
   load_sym_packed<T, D>(x + size_t(i) * D * D, xs);
@@ -180,6 +186,18 @@ __device__ __forceinline__ T pair_value(const TL (&li)[Packed<D>::NP], const T (
     }
     float w[4], lw[4], v[4][4];
     return pair_core<float, 4, false>(li, xj, wmin, wmax, w, lw, v);
+  } else if constexpr (D == 3) {
+    // fp64: ||log A||_F^2 from the Cayley-transform logarithm (no eigensolve) unless a pair of the
+    // wavefront has a very wide spectrum
+    T a[6], m0[6];
+    congr_lower<T, 3>(li, xj, a);
+    const T gate = log_cayley3<T>(a, m0);
+    if (!__any(!(gate <= T(kCayleyGate)))) {
+      T s = Num<T>::fma(m0[0], m0[0], Num<T>::fma(m0[2], m0[2], m0[5] * m0[5]));
+      return Num<T>::fma(T(2), Num<T>::fma(m0[1], m0[1], Num<T>::fma(m0[3], m0[3], m0[4] * m0[4])), s);
+    }
+    T w[D], lw[D], v[D][D];
+    return pair_core<T, D, false>(li, xj, wmin, wmax, w, lw, v);
   } else {
     T w[D], lw[D], v[D][D];
     return pair_core<T, D, false>(li, xj, wmin, wmax, w, lw, v);
@@ -261,16 +279,77 @@ __global__ __launch_bounds__(kBlock) void spd_pdist_fwd_kernel(const T* __restri
   }
 }
 
+// ---- fused loss epilogue (objectives.py:16-45 evaluated per pair in registers) -------------------
+// m = softplus(scale) * d2 (modules.py:84-88); returns the loss term and d loss / d m.
+template <typename T> struct LossArgs {
+  const T* scale_raw;  // device scalar: raw scale parameter (softplus applied here); null -> 1
+  T alpha, eps;        // quotient loss: target * alpha, 1 / (epoch + 1)
+  int terms;           // quotient loss: bit 0 = |m/(a g) - 1|, bit 1 = |a g/(m + eps) - 1|
+  T* slots;            // [2][kLossSlots]
+};
+template <typename T> __device__ __forceinline__ T softplus_of(const T* raw) {
+  if (!raw) return T(1);
+  const T v = *raw;  // torch.nn.functional.softplus: beta = 1, threshold = 20
+  if (std::is_same<T, float>::value) return v > T(20) ? v : T(::log1pf(::expf(float(v))));
+  return v > T(20) ? v : T(::log1p(::exp(double(v))));
+}
+template <typename T> __device__ __forceinline__ T sign_of(T q) { return q > T(0) ? T(1) : (q < T(0) ? T(-1) : T(0)); }
+template <typename T, int LOSS>
+__device__ __forceinline__ T loss_term(T m, T target, const LossArgs<T>& la, T& dldm) {
+  if constexpr (LOSS == MM_LOSS_STRESS) {
+    const T r = m - target;
+    dldm = r + r;
+    return r * r;
+  } else {
+    const T ag = target * la.alpha;
+    T l = T(0);
+    dldm = T(0);
+    if (la.terms & 1) {
+      const T inv = T(1) / ag, q = m * inv - T(1);
+      l += Num<T>::abs(q);
+      dldm += sign_of(q) * inv;
+    }
+    if (la.terms & 2) {
+      const T inv = T(1) / (m + la.eps), q = ag * inv - T(1);
+      l += Num<T>::abs(q);
+      dldm -= sign_of(q) * ag * inv * inv;
+    }
+    return l;
+  }
+}
+
+// The value loaded from the pair vector is the upstream gradient (LOSS == 0: of d2, or of d when
+// !squared) or the loss target; either way this returns d loss / d (d2) of the pair.
+template <typename T, int LOSS>
+__device__ __forceinline__ T upstream_of(T loaded, T dsq, bool valid, int squared, T wmin, T sp, const LossArgs<T>& la,
+                                         T& loss_acc, T& ds_acc) {
+  if constexpr (LOSS == MM_LOSS_NONE) {
+    if (__builtin_expect(!squared, 0)) loaded *= T(0.5) * Num<T>::rsqrt(Num<T>::max(dsq, wmin));  // d -> d2
+    return loaded;
+  } else {
+    T dldm;
+    const T l = loss_term<T, LOSS>(sp * dsq, loaded, la, dldm);
+    loss_acc += valid ? l : T(0);
+    ds_acc += valid ? dldm * dsq : T(0);
+    return valid ? dldm * sp : T(0);
+  }
+}
+
 // ------------------------------------------------------------------ backward
-template <typename T, int D, int TI>
+template <typename T, int D, int TI, int LOSS>
 __global__ __launch_bounds__(kBlock) void spd_pdist_bwd_kernel(const T* __restrict__ nodeL,
                                                                const T* __restrict__ nodeX,
                                                                const T* __restrict__ nodeC,
                                                                const T* __restrict__ g, int n, int row_begin,
                                                                int row_end, int squared, T wmin, T wmax,
-                                                               T* __restrict__ accM, T* __restrict__ accS) {
+                                                               T* __restrict__ accM, T* __restrict__ accS,
+                                                               LossArgs<T> la) {
   constexpr int NP = Packed<D>::NP;
   constexpr int NW = kBlock / 64;
+  // LOSS != 0: `g` holds the TARGET (graph) squared distances; the upstream gradient of each pair is
+  // derived in registers from the loss, and the loss / scale-gradient sums leave through la.slots.
+  T sp = T(1), loss_acc = T(0), ds_acc = T(0);
+  if constexpr (LOSS != MM_LOSS_NONE) sp = softplus_of(la.scale_raw);
   // Workgroup tile: 64 columns x (4 waves x TI rows).  The four wavefronts share the columns, so
   // their column-side partial sums are combined through LDS and flushed with ONE set of atomics:
   // float atomics are a per-CU serial resource (~50 ns per wave instruction) and at TI = 8 the
@@ -320,53 +399,76 @@ __global__ __launch_bounds__(kBlock) void spd_pdist_bwd_kernel(const T* __restri
       g_next = (jin && j > inext && inext > i) ? g[pair_off(n, inext) - base + (j - inext - 1)] : T(0);
       T m[NP];
       bool series = false;
-      if constexpr (D == 3 && std::is_same<T, float>::value) {
-        // Close pairs (||A - I||_F <= 0.3 for the whole wavefront): log(A) from the
-        // Cayley-Hamilton series — no eigensolve.  Anything else takes the Jacobi path below.
-        float a[6], m0[6], n0[6];
-        congr_lower<float, 3>(li, xj, a);
-        const float e2 = log_series3<false>(a, m0, n0);
-        series = !__any(!(e2 <= 0.09f));
-        if (series) {
-          if (!squared) {
-            float s = fmaf(m0[0], m0[0], fmaf(m0[2], m0[2], m0[5] * m0[5]));
-            s = fmaf(2.f, fmaf(m0[1], m0[1], fmaf(m0[3], m0[3], m0[4] * m0[4])), s);
-            gs *= 0.5f * Num<float>::rsqrt(fmaxf(s, wmin));
+      auto jacobi_path = [&]() {
+        T w[D], lw[D], v[D][D];
+        const T s = pair_core<T, D, true>(li, xj, wmin, wmax, w, lw, v);
+        gs = upstream_of<T, LOSS>(gs, s, jin && j > i, squared, wmin, sp, la, loss_acc, ds_acc);
+        T cm[D];
+#pragma unroll
+        for (int k = 0; k < D; ++k) cm[k] = (gs + gs) * lw[k];
+        vdvt<T, D>(v, cm, m);
+      };
+      if constexpr (D == 3) {
+        // Eigen-free paths, chosen per wavefront: close pairs (||A - I||_F <= 0.3, fp32) take the
+        // Cayley-Hamilton series of log(I + E); anything with tr(Z^2) <= 0.36 (eigenvalue ratios up
+        // to ~16: every pair of an embedding with O(1) distances) the Cayley-transform logarithm.
+        // What is left (very wide spectra, NaN, non-PD) goes to the Jacobi path.
+        // Written as an if / else-if / else chain with complete arms so that the likely arm is the
+        // fall-through (a taken branch per pair costs ~4 % of this kernel).
+        T a[6], m0[6];
+        congr_lower<T, 3>(li, xj, a);
+        auto finish = [&]() {
+          T s = T(0);
+          if (LOSS != MM_LOSS_NONE || !squared) {
+            s = Num<T>::fma(m0[0], m0[0], Num<T>::fma(m0[2], m0[2], m0[5] * m0[5]));
+            s = Num<T>::fma(T(2), Num<T>::fma(m0[1], m0[1], Num<T>::fma(m0[3], m0[3], m0[4] * m0[4])), s);
           }
-          const float g2 = gs + gs;
+          gs = upstream_of<T, LOSS>(gs, s, jin && j > i, squared, wmin, sp, la, loss_acc, ds_acc);
+          const T g2 = gs + gs;
 #pragma unroll
           for (int k = 0; k < 6; ++k) m[k] = g2 * m0[k];
+        };
+        bool close = false;
+        if constexpr (std::is_same<T, float>::value) {
+          // ||A - I||_F^2, written exactly as log_series3 forms it so the two share the arithmetic
+          const float e00 = a[0] - 1.f, e11 = a[2] - 1.f, e22 = a[5] - 1.f, e10 = a[1], e20 = a[3], e21 = a[4];
+          const float e2 = fmaf(e00, e00, fmaf(e10, e10, e20 * e20)) + fmaf(e10, e10, fmaf(e11, e11, e21 * e21)) +
+                           fmaf(e20, e20, fmaf(e21, e21, e22 * e22));
+          close = !__any(!(e2 <= 0.09f));
         }
+        if (__builtin_expect(close, 1)) {
+          if constexpr (std::is_same<T, float>::value) {
+            float n0[6];
+            log_series3<false>(a, m0, n0);
+          }
+          finish();
+        } else {
+          const T gate = log_cayley3<T>(a, m0);
+          if (__builtin_expect(!__any(!(gate <= T(kCayleyGate))), 1)) finish(); else jacobi_path();
+        }
+        series = true;
       } else if constexpr (D == 4 && std::is_same<T, float>::value) {
         float a[10], m0[10], n0[10];
         congr_lower<float, 4>(li, xj, a);
         const float e2 = log_series4<false>(a, m0, n0);
         series = !__any(!(e2 <= 0.09f));
         if (series) {
-          if (!squared) {
-            float s = 0.f;
+          float s = 0.f;
+          if (LOSS != MM_LOSS_NONE || !squared) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
               s = fmaf(m0[pidx(r, r)], m0[pidx(r, r)], s);
 #pragma unroll
               for (int c = 0; c < r; ++c) s = fmaf(2.f * m0[pidx(r, c)], m0[pidx(r, c)], s);
             }
-            gs *= 0.5f * Num<float>::rsqrt(fmaxf(s, wmin));
           }
+          gs = upstream_of<float, LOSS>(gs, s, jin && j > i, squared, wmin, sp, la, loss_acc, ds_acc);
           const float g2 = gs + gs;
 #pragma unroll
           for (int k = 0; k < 10; ++k) m[k] = g2 * m0[k];
         }
       }
-      if (!series) {
-        T w[D], lw[D], v[D][D];
-        const T s = pair_core<T, D, true>(li, xj, wmin, wmax, w, lw, v);
-        if (!squared) gs *= T(0.5) * Num<T>::rsqrt(Num<T>::max(s, wmin));
-        T cm[D];
-#pragma unroll
-        for (int k = 0; k < D; ++k) cm[k] = (gs + gs) * lw[k];
-        vdvt<T, D>(v, cm, m);
-      }
+      if (!series) jacobi_path();
       T cj[D][D];
       lt_m_lt<T, D>(li, lc, m, cj);
 #pragma unroll
@@ -404,7 +506,22 @@ __global__ __launch_bounds__(kBlock) void spd_pdist_bwd_kernel(const T* __restri
   for (int r = 0; r < D; ++r)
 #pragma unroll
     for (int c = 0; c < D; ++c) colS[wave][r * D + c][lane] = accJ[r][c];
+  __shared__ T lossW[NW][2];
+  if constexpr (LOSS != MM_LOSS_NONE) {
+    const T l = wave_sum(loss_acc), d = wave_sum(ds_acc);
+    if (lane == 0) { lossW[wave][0] = l; lossW[wave][1] = d; }
+  }
   __syncthreads();
+  if constexpr (LOSS != MM_LOSS_NONE) {
+    if (threadIdx.x == 0) {
+      T l = lossW[0][0], d = lossW[0][1];
+#pragma unroll
+      for (int wv = 1; wv < NW; ++wv) { l += lossW[wv][0]; d += lossW[wv][1]; }
+      const int slot = (blockIdx.x + blockIdx.y * gridDim.x) & (kLossSlots - 1);
+      atomic_add(&la.slots[slot], l);
+      atomic_add(&la.slots[kLossSlots + slot], d);
+    }
+  }
   if (jin) {
     for (int k = wave; k < D * D; k += NW) {
       T sum = colS[0][k][lane];
@@ -422,9 +539,26 @@ __global__ __launch_bounds__(kBlock) void spd_pdist_bwd_kernel(const T* __restri
 // grad_x[i] = sym(accS_i X_i^-1) - L_i^-T accM_i L_i^-1   (symmetric, full DxD)
 template <typename T, int D>
 __global__ void spd_pdist_finalize_kernel(const T* __restrict__ nodeL, T* __restrict__ accM,
-                                          T* __restrict__ accS, int n, T* __restrict__ grad) {
+                                          T* __restrict__ accS, int n, T* __restrict__ grad,
+                                          T* __restrict__ slots, const T* __restrict__ scale_raw,
+                                          T* __restrict__ loss_out) {
   constexpr int NP = Packed<D>::NP;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (slots && blockIdx.x == 0 && threadIdx.x < 64) {
+    // fused loss: loss_out[0] = sum of the loss terms, loss_out[1] = d loss / d scale_raw
+    // (= sum dl/dm * d2 * sigmoid(scale_raw)); the slots are left clean for the next call
+    double l = 0.0, d = 0.0;
+    for (int t = threadIdx.x; t < kLossSlots; t += 64) {
+      l += double(slots[t]); d += double(slots[kLossSlots + t]);
+      slots[t] = T(0); slots[kLossSlots + t] = T(0);
+    }
+    l = wave_sum(l); d = wave_sum(d);
+    if (threadIdx.x == 0) {
+      const double v = scale_raw ? double(*scale_raw) : 0.0;
+      loss_out[0] = T(l);
+      loss_out[1] = scale_raw ? T(d / (1.0 + ::exp(-v))) : T(0);
+    }
+  }
   if (i >= n) return;
   T li[NP], m[NP], gi[NP], xinv[NP], sc[D][D];
 #pragma unroll
@@ -674,7 +808,7 @@ template <typename T, int D>
 int spd_pdist_prepare(const T* x, int64_t n, Ws<T>& ws, int flags, hipStream_t st) {
   if (!(flags & MM_WS_PREPARED)) {
     spd_prep_kernel<T, D><<<dim3((n + 127) / 128), dim3(128), 0, st>>>(x, int(n), ws.nodeL, ws.nodeX, ws.nodeC,
-                                                                       ws.accM, ws.accS, ws.bad);
+                                                                       ws.accM, ws.accS, ws.loss, ws.bad);
     MM_CHECK_LAUNCH();
   }
   return MM_OK;
@@ -712,14 +846,36 @@ int spd_pdist_fwd_t(const T* x, int64_t n, int64_t rb, int64_t re, int squared, 
   }
 }
 
-template <typename T, int D, int TI>
+template <typename T, int D, int TI, int LOSS = MM_LOSS_NONE>
 int spd_pdist_bwd_ti(Ws<T>& ws, const T* g, int64_t n, int64_t rb, int64_t re, int squared, double wmin, double wmax,
-                     hipStream_t st) {
+                     hipStream_t st, LossArgs<T> la = LossArgs<T>{nullptr, T(1), T(0), 0, nullptr}) {
   {
     ProfScope prof(PROF_SPD_BWD, st);
-    spd_pdist_bwd_kernel<T, D, TI><<<fold_grid<(kBlock / 64) * TI, 64>(n, rb, re), dim3(kBlock), 0, st>>>(
-        ws.nodeL, ws.nodeX, ws.nodeC, g, int(n), int(rb), int(re), squared, T(wmin), T(wmax), ws.accM, ws.accS);
+    spd_pdist_bwd_kernel<T, D, TI, LOSS><<<fold_grid<(kBlock / 64) * TI, 64>(n, rb, re), dim3(kBlock), 0, st>>>(
+        ws.nodeL, ws.nodeX, ws.nodeC, g, int(n), int(rb), int(re), squared, T(wmin), T(wmax), ws.accM, ws.accS, la);
   }
+  MM_CHECK_LAUNCH();
+  return MM_OK;
+}
+
+// loss + gradients in one pass over the pairs (no pair vector of distances is ever written)
+template <typename T, int D>
+int spd_pdist_loss_t(int kind, const T* x, const T* target, const T* scale_raw, int64_t n, int64_t rb, int64_t re,
+                     double alpha, double eps, int terms, double wmin, double wmax, T* loss_out, T* grad, void* wsp,
+                     int flags, hipStream_t st) {
+  Ws<T> ws(wsp, n, D);
+  int rc = spd_pdist_prepare<T, D>(x, n, ws, flags, st);
+  if (rc) return rc;
+  if (re > rb && pair_off(n, re) > pair_off(n, rb)) {
+    LossArgs<T> la{scale_raw, T(alpha), T(eps), terms, ws.loss};
+    if (kind == MM_LOSS_STRESS)
+      rc = spd_pdist_bwd_ti<T, D, 8, MM_LOSS_STRESS>(ws, target, n, rb, re, 1, wmin, wmax, st, la);
+    else
+      rc = spd_pdist_bwd_ti<T, D, 8, MM_LOSS_QUOTIENT>(ws, target, n, rb, re, 1, wmin, wmax, st, la);
+    if (rc) return rc;
+  }
+  spd_pdist_finalize_kernel<T, D><<<dim3((n + 127) / 128), dim3(128), 0, st>>>(ws.nodeL, ws.accM, ws.accS, int(n),
+                                                                               grad, ws.loss, scale_raw, loss_out);
   MM_CHECK_LAUNCH();
   return MM_OK;
 }
@@ -739,8 +895,9 @@ int spd_pdist_bwd_t(const T* x, const T* g, int64_t n, int64_t rb, int64_t re, i
     }
     if (rc) return rc;
   }
-  spd_pdist_finalize_kernel<T, D><<<dim3((n + 127) / 128), dim3(128), 0, st>>>(ws.nodeL, ws.accM, ws.accS, int(n),
-                                                                               grad);
+  spd_pdist_finalize_kernel<T, D><<<dim3((n + 127) / 128), dim3(128), 0, st>>>(
+      ws.nodeL, ws.accM, ws.accS, int(n), grad, static_cast<T*>(nullptr), static_cast<const T*>(nullptr),
+      static_cast<T*>(nullptr));
   MM_CHECK_LAUNCH();
   return MM_OK;
 }
@@ -804,6 +961,27 @@ int mm_spd_pdist_bwd(int dtype, const void* x, const void* g, int64_t n, int d, 
   MM_DISPATCH(dtype, d,
               (spd_pdist_bwd_t<T, D>(static_cast<const T*>(x), static_cast<const T*>(g), n, row_begin, row_end,
                                      squared, wmin, wmax, static_cast<T*>(grad_x), ws, flags, st)));
+}
+
+int mm_spd_pdist_loss(int dtype, int loss_kind, const void* x, const void* target, const void* scale_raw, int64_t n,
+                      int d, int64_t row_begin, int64_t row_end, double alpha, double eps, int terms, double wmin,
+                      double wmax, void* loss_out, void* grad_x, void* ws, int flags, mm_stream_t stream) {
+  if (!x || !ws || !grad_x || !loss_out || n < 0 || row_begin < 0 || row_end > n || row_begin > row_end ||
+      n > (1 << 30))
+    return MM_ERR_ARG;
+  if (loss_kind != MM_LOSS_STRESS && loss_kind != MM_LOSS_QUOTIENT) return MM_ERR_UNSUPPORTED;
+  if (loss_kind == MM_LOSS_QUOTIENT && !(terms & 3)) return MM_ERR_ARG;
+  if (!target && mm_pair_offset(n, row_end) > mm_pair_offset(n, row_begin)) return MM_ERR_ARG;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (n == 0) {
+    const size_t es = dtype == MM_F64 ? 8 : 4;
+    hipError_t e = hipMemsetAsync(loss_out, 0, 2 * es, st);
+    return e == hipSuccess ? MM_OK : int(e);
+  }
+  MM_DISPATCH(dtype, d,
+              (spd_pdist_loss_t<T, D>(loss_kind, static_cast<const T*>(x), static_cast<const T*>(target),
+                                      static_cast<const T*>(scale_raw), n, row_begin, row_end, alpha, eps, terms, wmin,
+                                      wmax, static_cast<T*>(loss_out), static_cast<T*>(grad_x), ws, flags, st)));
 }
 
 int mm_spd_status(void* ws, int64_t n, int* host_status, mm_stream_t stream) {

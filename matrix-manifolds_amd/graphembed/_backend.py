@@ -15,6 +15,7 @@ LIB_PATH = os.environ.get('MM_MANIFOLDS_LIB') or os.path.join(os.path.dirname(_H
 
 MM_F32, MM_F64 = 0, 1
 MM_WS_PREPARED = 1
+LOSS_STRESS, LOSS_QUOTIENT = 1, 2
 EUCLIDEAN, LORENTZ, SPHERE = 0, 1, 2
 SPD_EGRAD2RGRAD, SPD_EXP, SPD_RETR, SPD_LOG, SPD_PROJX, SPD_PROJU = range(6)
 
@@ -33,6 +34,8 @@ SIGNATURES = {
     'mm_spd_pdist_ws_bytes': (_sz, [_i, _i64, _i]),
     'mm_spd_pdist_fwd': (_i, [_i, _vp, _i64, _i, _i64, _i64, _i, _dbl, _dbl, _vp, _vp, _i, _vp]),
     'mm_spd_pdist_bwd': (_i, [_i, _vp, _vp, _i64, _i, _i64, _i64, _i, _dbl, _dbl, _vp, _vp, _i, _vp]),
+    'mm_spd_pdist_loss': (_i, [_i, _i, _vp, _vp, _vp, _i64, _i, _i64, _i64, _dbl, _dbl, _i, _dbl, _dbl, _vp, _vp,
+                                _vp, _i, _vp]),
     'mm_spd_status': (_i, [_vp, _i64, _c.POINTER(_i), _vp]),
     'mm_spd_dist_fwd': (_i, [_i, _vp, _vp, _i64, _i, _i, _dbl, _dbl, _vp, _vp]),
     'mm_spd_dist_bwd': (_i, [_i, _vp, _vp, _vp, _i64, _i, _i, _dbl, _dbl, _vp, _vp, _vp]),

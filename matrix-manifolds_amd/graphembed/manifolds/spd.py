@@ -76,6 +76,42 @@ class _SpdPdist(torch.autograd.Function):
         return grad, None, None, None, None, None, None, None
 
 
+class _SpdPdistLoss(torch.autograd.Function):
+    """loss(target, softplus(scale) * pdist(x)^2) and both gradients from ONE pass over the
+    pairs (mm_spd_pdist_loss): what train.py:213-217 + modules.py:84-88 + objectives.py:16-45
+    compute in the reference, without materialising the pair vector of distances."""
+
+    @staticmethod
+    def forward(ctx, x, scale, target, n_mat, spec, wmin, wmax, row_begin, row_end):
+        B.require_gpu(x, target)
+        lib = B.lib()
+        xc = x.detach().contiguous()
+        n = xc.shape[0]
+        dt = B.dtype_code(xc)
+        kind, alpha, eps, terms = spec
+        tc = target.detach().to(xc.dtype).contiguous()
+        npairs = B.pair_offset(n, row_end) - B.pair_offset(n, row_begin)
+        if tc.numel() != npairs:
+            raise ValueError(f'target has {tc.numel()} entries, the pair range has {npairs}')
+        sc = None if scale is None else scale.detach().to(xc.dtype).reshape(1).contiguous()
+        with torch.cuda.device(xc.device):
+            ws = torch.empty(lib.raw('mm_spd_pdist_ws_bytes')(dt, n, n_mat), dtype=torch.uint8,
+                             device=xc.device)
+            out = torch.empty(2, dtype=xc.dtype, device=xc.device)
+            grad = torch.empty_like(xc)
+            lib.call('mm_spd_pdist_loss', dt, B.LOSS_STRESS if kind == 'stress' else B.LOSS_QUOTIENT,
+                     B.ptr(xc), B.ptr(tc), B.ptr(sc), n, n_mat, row_begin, row_end, alpha, eps, terms,
+                     wmin, wmax, B.ptr(out), B.ptr(grad), B.ptr(ws), 0, B.stream_of(xc))
+        ctx.grad_x = grad
+        ctx.grad_s = None if scale is None else out[1].reshape(scale.shape).to(scale.dtype)
+        return out[0]
+
+    @staticmethod
+    def backward(ctx, up):
+        gs = None if ctx.grad_s is None else ctx.grad_s * up
+        return ctx.grad_x * up, gs, None, None, None, None, None, None, None
+
+
 class _SpdDist(torch.autograd.Function):
 
     @staticmethod
@@ -220,6 +256,14 @@ class SymmetricPositiveDefinite(Manifold):
         assert x.ndim == 3
         rb, re = (0, x.shape[0]) if rows is None else rows
         return _SpdPdist.apply(x, self.n, squared, self.wmin, self.wmax, rb, re, self.check_pd)
+
+    def pdist_loss(self, x, scale, target, spec, rows=None):
+        """Fused `objective(target, softplus(scale) * pdist(x, squared=True))` with its gradients
+        in one pass; `spec` comes from `objective_fn.fused_spec(epoch=, alpha=)`.  Returns the
+        scalar loss of the pair range `rows` (all pairs by default)."""
+        assert x.ndim == 3
+        rb, re = (0, x.shape[0]) if rows is None else rows
+        return _SpdPdistLoss.apply(x, scale, target, self.n, spec, self.wmin, self.wmax, rb, re)
 
     def transp(self, x, y, u):  # spd.py:196-199
         return u

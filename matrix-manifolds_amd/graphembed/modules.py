@@ -74,6 +74,19 @@ class ManifoldEmbedding(torch.nn.Module):
             softplus(s) * man.pdist(x if i is None else x[i], squared=True)
             for x, s, man in zip(self.xs, self.scales, self.manifolds))
 
+    def fused_objective(self, objective_fn, gdists, i=None, rows=None, **kwargs):
+        """`objective_fn(gdists, self.compute_dists(i), **kwargs)` evaluated by ONE pair kernel
+        that also produces the gradients (no pair vector of distances, no element-wise passes),
+        or None when this embedding / objective has no fused kernel (several factors, a
+        manifold without `pdist_loss`, a loss without `fused_spec`)."""
+        if self.n_components != 1 or not hasattr(self.manifolds[0], 'pdist_loss'):
+            return None
+        if not hasattr(objective_fn, 'fused_spec') or not self.xs[0].is_cuda:
+            return None
+        spec = objective_fn.fused_spec(**kwargs)
+        x = self.xs[0] if i is None else self.xs[0][i]
+        return self.manifolds[0].pdist_loss(x, self.scales[0], gdists, spec, rows=rows)
+
     def __len__(self):
         return self.n
 
@@ -81,12 +94,17 @@ class ManifoldEmbedding(torch.nn.Module):
 class BatchedObjective(torch.nn.Module):
     """loss(dataset[idx], embedding.compute_dists(idx)) — modules.py:94-105."""
 
-    def __init__(self, objective_fn, dataset, embedding):
+    def __init__(self, objective_fn, dataset, embedding, fused=True):
         super().__init__()
         self.objective_fn = objective_fn
         self.dataset = dataset
         self.embedding = embedding
+        self.fused = fused  # use the one-pass loss+gradient kernel when the configuration has one
 
     def forward(self, indices, *args, **kwargs):
-        return self.objective_fn(self.dataset[indices].to(self.embedding.device),
-                                 self.embedding.compute_dists(indices), *args, **kwargs)
+        gdists = self.dataset[indices].to(self.embedding.device)
+        if self.fused and not args:
+            loss = self.embedding.fused_objective(self.objective_fn, gdists, indices, **kwargs)
+            if loss is not None:
+                return loss
+        return self.objective_fn(gdists, self.embedding.compute_dists(indices), *args, **kwargs)

@@ -31,6 +31,10 @@ class QuotientLoss(ObjectiveFunction):
             loss = loss + (gdists / (mdists + 1.0 / (epoch + 1)) - 1.0).abs().sum()
         return loss
 
+    def fused_spec(self, *, epoch, alpha):
+        """(kind, alpha, eps, terms) for the fused loss+gradient kernels (mm_*_pdist_loss)."""
+        return ('quotient', float(alpha), 1.0 / (epoch + 1), int(self.inc_l1) | (int(self.inc_l2) << 1))
+
     def __str__(self):
         return 'quotient_loss'
 
@@ -40,6 +44,9 @@ class StressLoss(ObjectiveFunction):
 
     def __call__(self, gdists, mdists, *, epoch=None, alpha=None):
         return torch.pow(mdists - gdists, 2).sum()
+
+    def fused_spec(self, *, epoch=None, alpha=None):
+        return ('stress', 1.0, 0.0, 0)
 
     def __str__(self):
         return 'stress_loss'

@@ -29,6 +29,16 @@ class _Flat:
 _default_manifold = _Flat()
 
 
+def _assign(x, new):
+    """`x.set_(new)` as in the reference (rsgd.py:80-82); while a HIP graph is being captured the
+    value is copied into x's own storage instead, so a replayed step keeps advancing the same
+    parameter memory."""
+    if x.is_cuda and torch.cuda.is_current_stream_capturing():
+        x.copy_(new)
+    else:
+        x.set_(new)
+
+
 class RiemannianSGD(torch.optim.Optimizer):
 
     def __init__(self, params, lr=required, momentum=0, dampening=0, max_grad_norm=None,
@@ -66,7 +76,7 @@ class RiemannianSGD(torch.optim.Optimizer):
             # one fused kernel per parameter when the manifold offers it
             fused = getattr(manifold, 'rsgd_step', None)
             if momentum == 0 and fused is not None:
-                x.set_(fused(x, grad, lr=lr, max_grad_norm=max_grad_norm, exact=group['exact']))
+                _assign(x, fused(x, grad, lr=lr, max_grad_norm=max_grad_norm, exact=group['exact']))
                 continue
 
             retr = manifold.exp if group['exact'] else manifold.retr
@@ -79,7 +89,7 @@ class RiemannianSGD(torch.optim.Optimizer):
                 buf.mul_(momentum).add_(grad, alpha=1 - dampening)
                 new_x = retr(x, -lr * buf)
                 new_buf = manifold.transp(x, new_x, buf)
-                x.set_(new_x)
-                buf.set_(new_buf)
+                _assign(x, new_x)
+                _assign(buf, new_buf)
             else:
-                x.set_(retr(x, -lr * grad))
+                _assign(x, retr(x, -lr * grad))

@@ -259,6 +259,40 @@ def test_wide_spectra_take_the_jacobi_path(dname):
     assert bad.max() <= 0, f'worst excess {bad.max():.3e} at d2={ref[bad.argmax()]:.3f}'
 
 
+@pytest.mark.parametrize('dname', list(DT))
+def test_eigenfree_paths_vs_exact_oracle(dname):
+    """SPD(3): close-pair series (fp32), Cayley-transform logarithm (both dtypes) and Jacobi are chosen
+    per wavefront.  Points spread over ||log X|| in [0.02, 2.5], shuffled, so every path and every
+    switch occurs; distances, gradients and the fused loss vs the fp64 checker (no eps fudges)."""
+    from graphembed.manifolds import SymmetricPositiveDefinite as SPD
+    from oracle import exact
+    from oracle import ref_port as rp
+    gen = torch.Generator().manual_seed(5)
+    port = rp.SPD(3)
+    n = 768
+    scale = torch.cat([torch.full((n // 4, ), 0.1), torch.linspace(0.02, 1.0, n // 2),
+                       torch.linspace(1.0, 2.5, n // 4)])[torch.randperm(n, generator=gen)]
+    u = torch.randn(n, 6, dtype=torch.float64, generator=gen)
+    u = u / u.norm(dim=-1, keepdim=True) * scale.double().reshape(n, 1)
+    x64 = port.exp(port.zero(n, dtype=torch.float64), port.from_vec(u)).to(DT[dname]).double()
+    g64 = torch.randn(n * (n - 1) // 2, dtype=torch.float64, generator=gen)
+    ref_d2 = exact.spd_pdist(x64.numpy())
+    ref_g = exact.spd_pdist_grad(x64.numpy(), g64.numpy())
+    x = x64.to(DT[dname]).cuda().requires_grad_()
+    d2 = SPD(3).pdist(x, squared=True)
+    a, r = (1e-6, 3e-5) if dname == 'f32' else (1e-13, 1e-10)
+    bad = np.abs(d2.detach().double().cpu().numpy() - ref_d2) - (a + r * np.abs(ref_d2))
+    assert bad.max() <= 0, f'd2 worst excess {bad.max():.3e}'
+    gr, = torch.autograd.grad(d2, x, g64.to(DT[dname]).cuda())
+    err = np.abs(gr.double().cpu().numpy() - ref_g).max() / np.abs(ref_g).max()
+    assert err <= (3e-5 if dname == 'f32' else 1e-10), err
+    # element-wise kernel agrees with the pair kernel
+    i, j = torch.triu_indices(n, n, 1)[:, ::37]
+    dd = SPD(3).dist(x.detach()[i.cuda()], x.detach()[j.cuda()], squared=True)
+    bad = np.abs(dd.double().cpu().numpy() - ref_d2[::37]) - (a + r * np.abs(ref_d2[::37]))
+    assert bad.max() <= 0, f'dist worst excess {bad.max():.3e}'
+
+
 @pytest.mark.parametrize('d', [3, 4])
 def test_close_pair_gate_is_seamless(d):
     """SPD(3)/SPD(4) fp32 kernels switch per wavefront between the eigen-free close-pair series
@@ -290,3 +324,144 @@ def test_close_pair_gate_is_seamless(d):
     gr, = torch.autograd.grad(SPD(d).pdist(x, squared=False), x, g32.cuda())
     err = np.abs(gr.double().cpu().numpy() - ref_g1).max() / np.abs(ref_g1).max()
     assert err <= 5e-5, err
+
+
+# ------------------------------------------------------------------ fused loss + gradients
+def _losses():
+    from graphembed.objectives import QuotientLoss, StressLoss
+    return {'stress': (StressLoss(), {}), 'quotient': (QuotientLoss(), dict(epoch=3, alpha=1.7)),
+            'quotient_l1': (QuotientLoss(inc_l2=False), dict(epoch=0, alpha=0.9)),
+            'quotient_l2': (QuotientLoss(inc_l1=False), dict(epoch=7, alpha=1.0))}
+
+
+@pytest.mark.parametrize('d,n', [(2, 257), (3, 300), (3, 1000), (4, 130), (5, 70)])
+@pytest.mark.parametrize('dname', list(DT))
+@pytest.mark.parametrize('loss_name', ['stress', 'quotient', 'quotient_l1', 'quotient_l2'])
+def test_fused_loss_vs_oracle_seeded(d, n, dname, loss_name):
+    """mm_spd_pdist_loss (one pass: loss, d/dx, d/dscale) vs the oracle port's
+    objective(target, softplus(s) * pdist(x)^2) + autograd, close and wide inputs."""
+    from graphembed.manifolds import SymmetricPositiveDefinite as SPD
+    from oracle import ref_port as rp
+    fn, kw = _losses()[loss_name]
+    gen = torch.Generator().manual_seed(7 * d + n)
+    port = rp.SPD(d)
+    for init in ('rand', 'wide'):
+        if init == 'rand':
+            x64 = port.rand(n, dtype=torch.float64, generator=gen)
+        else:
+            a = torch.rand(n, d, d, dtype=torch.float64, generator=gen)
+            x64 = a @ a.transpose(1, 2) + torch.eye(d, dtype=torch.float64)
+        xr = x64.clone().requires_grad_()
+        sr = torch.tensor(0.3, dtype=torch.float64, requires_grad=True)
+        md = torch.nn.functional.softplus(sr) * port.pdist(xr, squared=True)
+        # targets of the size of the distances, kept away from the |.| kinks of the quotient terms
+        # (a pair sitting on a kink may legitimately take either sign in two implementations)
+        tgt = (md.detach() * (0.5 + torch.rand(md.shape, dtype=torch.float64, generator=gen))).clamp_min(1e-3)
+        if kw:
+            for _ in range(8):
+                ag = tgt * kw['alpha']
+                near = ((md.detach() / ag - 1).abs() < 0.05) | ((ag / (md.detach() + 1 / (kw['epoch'] + 1)) - 1).abs() < 0.05)
+                tgt = torch.where(near, tgt * 1.25, tgt)
+            assert not near.any()
+        ref = fn(tgt, md, **kw)
+        ref_gx, ref_gs = torch.autograd.grad(ref, [xr, sr])
+        x = x64.to(DT[dname]).cuda().requires_grad_()
+        s = torch.tensor(0.3, dtype=DT[dname], device='cuda', requires_grad=True)
+        loss = SPD(d).pdist_loss(x, s, tgt.to(DT[dname]).cuda(), fn.fused_spec(**kw))
+        gx, gs = torch.autograd.grad(loss * 2.0, [x, s])   # upstream factor must propagate
+        rel = 2e-5 if dname == 'f32' else 2e-6
+        assert abs(loss.item() - ref.item()) <= rel * abs(ref.item()), (loss.item(), ref.item())
+        # close pairs (d2 ~ 1e-2): the port carries the reference's eps-fudged eigenvalues (bias up to
+        # ~1e-7 absolute on d2, DESIGN.md §5), which the loss residual m - target amplifies
+        check_rel(gx, 2 * sym(ref_gx.numpy()), 2e-4 if dname == 'f32' else 5e-5, f'grad_x {init}')
+        # d loss / d scale = sum of signed terms (cancellation): the fp32 error and the reference's
+        # eps bias (fp64) are relative to sum |term|, not to the net sum
+        assert abs(gs.item() - 2 * ref_gs.item()) <= (1e-3 if dname == 'f32' else 5e-4) * abs(2 * ref_gs.item())
+
+
+@pytest.mark.parametrize('dname', list(DT))
+def test_fused_loss_equals_unfused_path_and_shards(dname):
+    """Same numbers as compute_dists -> objective -> backward of this library; row shards of the
+    fused call sum to the unsharded one; a node subset goes through the gather."""
+    from graphembed import _backend as B
+    from graphembed.data import GraphDataset
+    from graphembed.manifolds import SymmetricPositiveDefinite as SPD
+    from graphembed.modules import BatchedObjective, ManifoldEmbedding
+    from graphembed.objectives import QuotientLoss
+    torch.manual_seed(11)
+    n = 600
+    torch.set_default_dtype(DT[dname])
+    try:
+        with torch.device('cuda'):
+            emb = ManifoldEmbedding(n, [SPD(3)])
+            target = torch.rand(n * (n - 1) // 2) * 0.05 + 0.01
+    finally:
+        torch.set_default_dtype(torch.float32)
+    fn = QuotientLoss()
+    kw = dict(epoch=2, alpha=1.3)
+    tol = 2e-5 if dname == 'f32' else 1e-11
+    ref = fn(target, emb.compute_dists(None), **kw)
+    rgx, rgs = torch.autograd.grad(ref, [emb.xs[0], emb.scales[0]])
+    loss = emb.fused_objective(fn, target, None, **kw)
+    gx, gs = torch.autograd.grad(loss, [emb.xs[0], emb.scales[0]])
+    assert abs(loss.item() - ref.item()) <= tol * abs(ref.item())
+    check_rel(gx, rgx.cpu().numpy(), tol, 'fused vs unfused grad_x')
+    assert abs(gs.item() - rgs.item()) <= 5 * tol * abs(rgs.item())
+    for world in (2, 5):
+        tot, gsum, ssum = 0.0, torch.zeros_like(gx), 0.0
+        for r in range(world):
+            rows = B.shard_rows(n, world, r)
+            lo, hi = B.pair_offset(n, rows[0]), B.pair_offset(n, rows[1])
+            part = emb.fused_objective(fn, target[lo:hi], None, rows=rows, **kw)
+            pgx, pgs = torch.autograd.grad(part, [emb.xs[0], emb.scales[0]])
+            tot, gsum, ssum = tot + part.item(), gsum + pgx, ssum + pgs.item()
+        assert abs(tot - ref.item()) <= tol * abs(ref.item())
+        check_rel(gsum, rgx.cpu().numpy(), tol, 'sum of fused shard grads')
+        assert abs(ssum - rgs.item()) <= 5 * tol * abs(rgs.item())
+    # BatchedObjective on a node subset (train.py:203-213): gather -> fused kernel -> scatter-add
+    ds = GraphDataset(target)
+    idx = torch.randperm(n, device='cuda')[:257]
+    obj_f, obj_u = BatchedObjective(fn, ds, emb), BatchedObjective(fn, ds, emb, fused=False)
+    lf, lu = obj_f(idx, **kw), obj_u(idx, **kw)
+    gf = torch.autograd.grad(lf, [emb.xs[0], emb.scales[0]])
+    gu = torch.autograd.grad(lu, [emb.xs[0], emb.scales[0]])
+    assert abs(lf.item() - lu.item()) <= tol * abs(lu.item())
+    check_rel(gf[0], gu[0].cpu().numpy(), tol, 'subset grad_x')
+    assert abs(gf[1].item() - gu[1].item()) <= 5 * tol * abs(gu[1].item())
+
+
+@pytest.mark.parametrize('loss_name', ['stress', 'quotient'])
+def test_tree40_training_trace_fused(loss_name):
+    """The reference's 20-epoch tree40 SPD(3) loss trace (golden), driven through the fused
+    loss+gradient kernel and the fused RSGD step."""
+    from graphembed import manifolds as M
+    from graphembed.modules import ManifoldEmbedding
+    from graphembed.objectives import QuotientLoss, StressLoss
+    from graphembed.optim import RiemannianSGD
+    G = load_golden('callers')
+    base = f'tree40/spd3/{loss_name}'
+    torch.set_default_dtype(torch.float64)
+    try:
+        with torch.device('cuda'):
+            emb = ManifoldEmbedding(40, [M.SymmetricPositiveDefinite(3)])
+        with torch.no_grad():
+            emb.xs[0].copy_(dev(G[f'{base}/x0_0']))
+        target = dev(G['tree40/target'])
+        opt = RiemannianSGD(list(emb.xs), lr=0.01, exact=True, max_grad_norm=20)
+        opt_s = RiemannianSGD(list(emb.scales), lr=1e-4, max_grad_norm=500)
+        fn = StressLoss() if loss_name == 'stress' else QuotientLoss()
+        losses = []
+        for epoch in range(20):
+            loss = emb.fused_objective(fn, target, None, epoch=epoch, alpha=1.0)
+            assert loss is not None
+            opt.zero_grad()
+            opt_s.zero_grad()
+            loss.backward()
+            opt.step()
+            opt_s.step()
+            losses.append(loss.item())
+    finally:
+        torch.set_default_dtype(torch.float32)
+    check_rel(np.array(losses), G[f'{base}/losses'], 2e-5, 'loss trace')
+    check_rel(emb.xs[0].data, G[f'{base}/x20_0'], 2e-4, 'x20')
+    check_rel(np.array([s.item() for s in emb.scales]), G[f'{base}/scales20'], 1e-6, 'scales')

@@ -45,7 +45,7 @@ def pdist_case(man, n, dtype, **kw):
             'pairs_per_s': P / (tot * 1e-6), 'GBps_8B_per_pair': P * 2 * x.element_size() / (tot * 1e-6) / 1e9}
 
 
-def step_case(mans, n, dtype):
+def step_case(mans, n, dtype, fused=False, graph=False):
     """full training step: compute_dists + stress loss + backward + fused RSGD (momentum 0)"""
     torch.manual_seed(0)
     torch.set_default_dtype(dtype)
@@ -59,11 +59,31 @@ def step_case(mans, n, dtype):
     opt = RiemannianSGD(list(emb.xs), lr=1e-3, exact=True, max_grad_norm=20)
     fn = StressLoss()
 
+    opt_s = RiemannianSGD(list(emb.scales), lr=1e-4, max_grad_norm=500)
+
     def step():
-        opt.zero_grad()
-        fn(target, emb.compute_dists(None)).backward()
+        opt.zero_grad(set_to_none=False)
+        opt_s.zero_grad(set_to_none=False)
+        if fused:
+            emb.fused_objective(fn, target, None).backward()
+        else:
+            fn(target, emb.compute_dists(None)).backward()
         opt.step()
-    t = timeit(step)
+        opt_s.step()
+    if graph:  # whole training step replayed as one hipGraph (static shapes, no host sync inside)
+        for p in list(emb.xs) + list(emb.scales):
+            p.grad = torch.zeros_like(p)
+        side = torch.cuda.Stream()
+        with torch.cuda.stream(side):
+            for _ in range(3):
+                step()
+        torch.cuda.current_stream().wait_stream(side)
+        gr = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(gr):
+            step()
+        t = timeit(gr.replay)
+    else:
+        t = timeit(step)
     return {'n': n, 'pairs': P, 'dtype': str(dtype).split('.')[-1], 'step_us': t, 'pairs_per_s': P / (t * 1e-6)}
 
 
@@ -75,12 +95,19 @@ CASES = {
     'c3_grqc_spd3_n5000_f32': lambda: pdist_case(M.SymmetricPositiveDefinite(3), 5000, torch.float32),
     'c3_grqc_spd3_n4158_f32': lambda: pdist_case(M.SymmetricPositiveDefinite(3), 4158, torch.float32),
     'c3_grqc_spd3_n5000_f64': lambda: pdist_case(M.SymmetricPositiveDefinite(3), 5000, torch.float64),
+    # "mid-training" spread: ||log X|| = 0.35 -> pair distances ~0.5 (targets are normalised to max 1)
+    'c3_grqc_spd3_n5000_f32_mid': lambda: pdist_case(M.SymmetricPositiveDefinite(3), 5000, torch.float32, ir=0.35),
+    'c3_grqc_spd3_n5000_f64_mid': lambda: pdist_case(M.SymmetricPositiveDefinite(3), 5000, torch.float64, ir=0.35),
     'c3_spd2_n5000_f32': lambda: pdist_case(M.SymmetricPositiveDefinite(2), 5000, torch.float32),
     'c4_csphd_product_step_f32': lambda: step_case([M.Lorentz(6), M.Sphere(6), M.SymmetricPositiveDefinite(2)], 1025, torch.float32),
     'c4_csphd_product_step_f64': lambda: step_case([M.Lorentz(6), M.Sphere(6), M.SymmetricPositiveDefinite(2)], 1025, torch.float64),
     'c5_wormnet_spd4_n2274_f32': lambda: pdist_case(M.SymmetricPositiveDefinite(4), 2274, torch.float32),
     'c5_wormnet_spd4_n16384_f32': lambda: pdist_case(M.SymmetricPositiveDefinite(4), 16384, torch.float32),
     'c3_spd3_step_n5000_f32': lambda: step_case([M.SymmetricPositiveDefinite(3)], 5000, torch.float32),
+    'c3_spd3_step_n5000_f32_fused': lambda: step_case([M.SymmetricPositiveDefinite(3)], 5000, torch.float32, fused=True),
+    'c3_spd3_step_n5000_f32_fused_graph': lambda: step_case([M.SymmetricPositiveDefinite(3)], 5000, torch.float32, fused=True, graph=True),
+    'c3_spd3_step_n5000_f32_graph': lambda: step_case([M.SymmetricPositiveDefinite(3)], 5000, torch.float32, graph=True),
+    'c5_spd4_step_n2274_f32_fused': lambda: step_case([M.SymmetricPositiveDefinite(4)], 2274, torch.float32, fused=True),
     'sphere6_n5000_f32': lambda: pdist_case(M.Sphere(6), 5000, torch.float32),
     'euclidean10_n5000_f32': lambda: pdist_case(M.Euclidean(10), 5000, torch.float32),
     'grassmann52_n2000_f32': lambda: pdist_case(M.Grassmann(5, 2), 2000, torch.float32),

@@ -40,6 +40,7 @@ def _assign(x, new):
 
 
 class RiemannianSGD(torch.optim.Optimizer):
+    graph_safe = True  # no host-side per-step state: a captured step can be replayed (graphembed.graphed)
 
     def __init__(self, params, lr=required, momentum=0, dampening=0, max_grad_norm=None,
                  exact=False):

@@ -99,3 +99,59 @@ def test_spd4_stress_size_properties():
     # (the number of Jacobi sweeps is decided per wavefront, so the two kernels may differ by rounding)
     ref = man.dist(x.detach()[i], x.detach()[j], squared=True)
     assert (d2.detach()[k] - ref).abs().max().item() <= 1e-7 + 1e-5 * ref.max().item()
+
+
+@pytest.mark.parametrize('case', ['spd3_fused', 'product'])
+def test_graphed_train_step_matches_eager(case):
+    """A training step captured as one HIP graph (graphembed.graphed) advances the parameters
+    exactly like the eager loop; capture itself does not advance them."""
+    from graphembed import manifolds as M
+    from graphembed.graphed import GraphedTrainStep
+    from graphembed.modules import ManifoldEmbedding
+    from graphembed.objectives import StressLoss
+    from graphembed.optim import RiemannianAdam, RiemannianSGD
+    n = 200
+    mans = {'spd3_fused': lambda: [M.SymmetricPositiveDefinite(3)],
+            'product': lambda: [M.Lorentz(6), M.Sphere(6), M.SymmetricPositiveDefinite(2)]}[case]
+    torch.set_default_dtype(torch.float64)
+    try:
+        def build():
+            torch.manual_seed(5)
+            with torch.device('cuda'):
+                emb = ManifoldEmbedding(n, mans())
+            opts = [RiemannianSGD(list(emb.xs), lr=0.01, exact=True, max_grad_norm=20),
+                    RiemannianSGD(list(emb.scales), lr=1e-4, max_grad_norm=500)]
+            return emb, opts
+        torch.manual_seed(1)
+        target = torch.rand(n * (n - 1) // 2, device='cuda') * 0.9 + 0.1
+        fn = StressLoss()
+
+        def loss_of(emb):
+            if case == 'spd3_fused':
+                return emb.fused_objective(fn, target, None)
+            return fn(target, emb.compute_dists(None))
+        emb_e, opts_e = build()
+        losses_e = []
+        for _ in range(6):
+            for o in opts_e:
+                o.zero_grad()
+            loss = loss_of(emb_e)
+            loss.backward()
+            for o in opts_e:
+                o.step()
+            losses_e.append(loss.item())
+        emb_g, opts_g = build()
+        x0 = [x.detach().clone() for x in emb_g.xs]
+        step = GraphedTrainStep(lambda: loss_of(emb_g), opts_g).capture()
+        for x, x_ in zip(emb_g.xs, x0):
+            assert torch.equal(x.detach(), x_), 'capture must not advance the parameters'
+        losses_g = [step().item() for _ in range(6)]
+        np.testing.assert_allclose(losses_g, losses_e, rtol=1e-9)
+        for a, b in zip(emb_g.xs, emb_e.xs):
+            np.testing.assert_allclose(a.detach().cpu().numpy(), b.detach().cpu().numpy(), rtol=1e-8, atol=1e-10)
+        for a, b in zip(emb_g.scales, emb_e.scales):
+            assert abs(a.item() - b.item()) <= 1e-10
+        with pytest.raises(TypeError):
+            GraphedTrainStep(lambda: loss_of(emb_g), [RiemannianAdam(list(emb_g.xs), lr=1e-3)])
+    finally:
+        torch.set_default_dtype(torch.float32)

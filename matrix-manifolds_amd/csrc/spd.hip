@@ -143,6 +143,48 @@ __device__ __forceinline__ T pair_core(const TL (&li)[Packed<D>::NP], const T (&
   return s;
 }
 
+// ---- eigen-free matrix logarithm, D = 3, 4 (smallmat.hpp) -----------------------------------
+// ||M||_F^2 of a packed symmetric matrix
+template <typename T, int D> __device__ __forceinline__ T frob2(const T (&m)[Packed<D>::NP]) {
+  T s = T(0);
+#pragma unroll
+  for (int r = 0; r < D; ++r) {
+    s = Num<T>::fma(m[pidx(r, r)], m[pidx(r, r)], s);
+#pragma unroll
+    for (int c = 0; c < r; ++c) s = Num<T>::fma(T(2) * m[pidx(r, c)], m[pidx(r, c)], s);
+  }
+  return s;
+}
+// ||A - I||_F^2 with the arithmetic of log_series3/4 (so the gate shares it with the series)
+template <int D> __device__ __forceinline__ float close_gate(const float (&a)[Packed<D>::NP]) {
+  float e[Packed<D>::NP];
+#pragma unroll
+  for (int k = 0; k < Packed<D>::NP; ++k) e[k] = a[k];
+#pragma unroll
+  for (int r = 0; r < D; ++r) e[pidx(r, r)] -= 1.f;
+  if constexpr (D == 3) {
+    return fmaf(e[0], e[0], fmaf(e[1], e[1], e[3] * e[3])) + fmaf(e[1], e[1], fmaf(e[2], e[2], e[4] * e[4])) +
+           fmaf(e[3], e[3], fmaf(e[4], e[4], e[5] * e[5]));
+  } else {
+    float p2 = 0.f;
+#pragma unroll
+    for (int r = 0; r < D; ++r) {
+      float acc = e[pidx(r, 0)] * e[pidx(0, r)];
+#pragma unroll
+      for (int k = 1; k < D; ++k) acc = fmaf(e[pidx(r, k)], e[pidx(k, r)], acc);
+      p2 += acc;
+    }
+    return p2;
+  }
+}
+template <int D> __device__ __forceinline__ void log_close(const float (&a)[Packed<D>::NP], float (&m0)[Packed<D>::NP]) {
+  float n0[Packed<D>::NP];
+  if constexpr (D == 3) log_series3<false>(a, m0, n0); else log_series4<false>(a, m0, n0);
+}
+template <typename T, int D> __device__ __forceinline__ T log_cayley(const T (&a)[Packed<D>::NP], T (&m0)[Packed<D>::NP]) {
+  if constexpr (D == 3) return log_cayley3<T>(a, m0); else return log_cayley4<T>(a, m0);
+}
+
 // Forward-only value of one pair.  SPD(3) in fp32 takes the closed-form (trigonometric)
 // eigenvalues; a wavefront in which any pair has a wide spectrum (w_max > 32 w_min, where
 // the closed form's absolute error would show in log w_min) re-solves with Jacobi.
@@ -169,33 +211,20 @@ __device__ __forceinline__ T pair_value(const TL (&li)[Packed<D>::NP], const T (
       s = fmaf(l, l, s);
     }
     return s;
-  } else if constexpr (D == 4 && std::is_same<T, float>::value) {
-    // close pairs: ||log A||_F^2 from the Cayley-Hamilton series (no eigensolve); else Jacobi
-    float a[10], m0[10], n0[10];
-    congr_lower<float, 4>(li, xj, a);
-    const float e2 = log_series4<false>(a, m0, n0);
-    if (!__any(!(e2 <= 0.09f))) {
-      float s = 0.f;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        s = fmaf(m0[pidx(r, r)], m0[pidx(r, r)], s);
-#pragma unroll
-        for (int c = 0; c < r; ++c) s = fmaf(2.f * m0[pidx(r, c)], m0[pidx(r, c)], s);
-      }
-      return s;
+  } else if constexpr (D == 3 || D == 4) {
+    // SPD(4), and SPD(3) in fp64: ||log A||_F^2 without an eigensolve — close-pair series (fp32), then
+    // the Cayley-transform logarithm; Jacobi only if a pair of the wavefront has a very wide spectrum
+    constexpr int NP = Packed<D>::NP;
+    T a[NP], m0[NP];
+    congr_lower<T, D>(li, xj, a);
+    bool close = false;
+    if constexpr (std::is_same<T, float>::value) close = !__any(!(close_gate<D>(a) <= 0.09f));
+    if (__builtin_expect(close, 1)) {
+      if constexpr (std::is_same<T, float>::value) log_close<D>(a, m0);
+      return frob2<T, D>(m0);
     }
-    float w[4], lw[4], v[4][4];
-    return pair_core<float, 4, false>(li, xj, wmin, wmax, w, lw, v);
-  } else if constexpr (D == 3) {
-    // fp64: ||log A||_F^2 from the Cayley-transform logarithm (no eigensolve) unless a pair of the
-    // wavefront has a very wide spectrum
-    T a[6], m0[6];
-    congr_lower<T, 3>(li, xj, a);
-    const T gate = log_cayley3<T>(a, m0);
-    if (!__any(!(gate <= T(kCayleyGate)))) {
-      T s = Num<T>::fma(m0[0], m0[0], Num<T>::fma(m0[2], m0[2], m0[5] * m0[5]));
-      return Num<T>::fma(T(2), Num<T>::fma(m0[1], m0[1], Num<T>::fma(m0[3], m0[3], m0[4] * m0[4])), s);
-    }
+    const T gate = log_cayley<T, D>(a, m0);
+    if (__builtin_expect(!__any(!(gate <= T(kCayleyGate))), 1)) return frob2<T, D>(m0);
     T w[D], lw[D], v[D][D];
     return pair_core<T, D, false>(li, xj, wmin, wmax, w, lw, v);
   } else {
@@ -408,65 +437,33 @@ __global__ __launch_bounds__(kBlock) void spd_pdist_bwd_kernel(const T* __restri
         for (int k = 0; k < D; ++k) cm[k] = (gs + gs) * lw[k];
         vdvt<T, D>(v, cm, m);
       };
-      if constexpr (D == 3) {
+      if constexpr (D == 3 || D == 4) {
         // Eigen-free paths, chosen per wavefront: close pairs (||A - I||_F <= 0.3, fp32) take the
         // Cayley-Hamilton series of log(I + E); anything with tr(Z^2) <= 0.36 (eigenvalue ratios up
         // to ~16: every pair of an embedding with O(1) distances) the Cayley-transform logarithm.
         // What is left (very wide spectra, NaN, non-PD) goes to the Jacobi path.
         // Written as an if / else-if / else chain with complete arms so that the likely arm is the
         // fall-through (a taken branch per pair costs ~4 % of this kernel).
-        T a[6], m0[6];
-        congr_lower<T, 3>(li, xj, a);
+        T a[NP], m0[NP];
+        congr_lower<T, D>(li, xj, a);
         auto finish = [&]() {
           T s = T(0);
-          if (LOSS != MM_LOSS_NONE || !squared) {
-            s = Num<T>::fma(m0[0], m0[0], Num<T>::fma(m0[2], m0[2], m0[5] * m0[5]));
-            s = Num<T>::fma(T(2), Num<T>::fma(m0[1], m0[1], Num<T>::fma(m0[3], m0[3], m0[4] * m0[4])), s);
-          }
+          if (LOSS != MM_LOSS_NONE || __builtin_expect(!squared, 0)) s = frob2<T, D>(m0);
           gs = upstream_of<T, LOSS>(gs, s, jin && j > i, squared, wmin, sp, la, loss_acc, ds_acc);
           const T g2 = gs + gs;
 #pragma unroll
-          for (int k = 0; k < 6; ++k) m[k] = g2 * m0[k];
+          for (int k = 0; k < NP; ++k) m[k] = g2 * m0[k];
         };
         bool close = false;
-        if constexpr (std::is_same<T, float>::value) {
-          // ||A - I||_F^2, written exactly as log_series3 forms it so the two share the arithmetic
-          const float e00 = a[0] - 1.f, e11 = a[2] - 1.f, e22 = a[5] - 1.f, e10 = a[1], e20 = a[3], e21 = a[4];
-          const float e2 = fmaf(e00, e00, fmaf(e10, e10, e20 * e20)) + fmaf(e10, e10, fmaf(e11, e11, e21 * e21)) +
-                           fmaf(e20, e20, fmaf(e21, e21, e22 * e22));
-          close = !__any(!(e2 <= 0.09f));
-        }
+        if constexpr (std::is_same<T, float>::value) close = !__any(!(close_gate<D>(a) <= 0.09f));
         if (__builtin_expect(close, 1)) {
-          if constexpr (std::is_same<T, float>::value) {
-            float n0[6];
-            log_series3<false>(a, m0, n0);
-          }
+          if constexpr (std::is_same<T, float>::value) log_close<D>(a, m0);
           finish();
         } else {
-          const T gate = log_cayley3<T>(a, m0);
+          const T gate = log_cayley<T, D>(a, m0);
           if (__builtin_expect(!__any(!(gate <= T(kCayleyGate))), 1)) finish(); else jacobi_path();
         }
         series = true;
-      } else if constexpr (D == 4 && std::is_same<T, float>::value) {
-        float a[10], m0[10], n0[10];
-        congr_lower<float, 4>(li, xj, a);
-        const float e2 = log_series4<false>(a, m0, n0);
-        series = !__any(!(e2 <= 0.09f));
-        if (series) {
-          float s = 0.f;
-          if (LOSS != MM_LOSS_NONE || !squared) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              s = fmaf(m0[pidx(r, r)], m0[pidx(r, r)], s);
-#pragma unroll
-              for (int c = 0; c < r; ++c) s = fmaf(2.f * m0[pidx(r, c)], m0[pidx(r, c)], s);
-            }
-          }
-          gs = upstream_of<float, LOSS>(gs, s, jin && j > i, squared, wmin, sp, la, loss_acc, ds_acc);
-          const float g2 = gs + gs;
-#pragma unroll
-          for (int k = 0; k < 10; ++k) m[k] = g2 * m0[k];
-        }
       }
       if (!series) jacobi_path();
       T cj[D][D];

@@ -259,27 +259,28 @@ def test_wide_spectra_take_the_jacobi_path(dname):
     assert bad.max() <= 0, f'worst excess {bad.max():.3e} at d2={ref[bad.argmax()]:.3f}'
 
 
+@pytest.mark.parametrize('d', [3, 4])
 @pytest.mark.parametrize('dname', list(DT))
-def test_eigenfree_paths_vs_exact_oracle(dname):
-    """SPD(3): close-pair series (fp32), Cayley-transform logarithm (both dtypes) and Jacobi are chosen
-    per wavefront.  Points spread over ||log X|| in [0.02, 2.5], shuffled, so every path and every
-    switch occurs; distances, gradients and the fused loss vs the fp64 checker (no eps fudges)."""
+def test_eigenfree_paths_vs_exact_oracle(dname, d):
+    """SPD(d), SPD(4): close-pair series (fp32), Cayley-transform logarithm (both dtypes) and Jacobi are
+    chosen per wavefront.  Points spread over ||log X|| in [0.02, 2.5], shuffled, so every path and
+    every switch occurs; distances and gradients vs the fp64 checker (no eps fudges)."""
     from graphembed.manifolds import SymmetricPositiveDefinite as SPD
     from oracle import exact
     from oracle import ref_port as rp
     gen = torch.Generator().manual_seed(5)
-    port = rp.SPD(3)
+    port = rp.SPD(d)
     n = 768
     scale = torch.cat([torch.full((n // 4, ), 0.1), torch.linspace(0.02, 1.0, n // 2),
                        torch.linspace(1.0, 2.5, n // 4)])[torch.randperm(n, generator=gen)]
-    u = torch.randn(n, 6, dtype=torch.float64, generator=gen)
+    u = torch.randn(n, d * (d + 1) // 2, dtype=torch.float64, generator=gen)
     u = u / u.norm(dim=-1, keepdim=True) * scale.double().reshape(n, 1)
     x64 = port.exp(port.zero(n, dtype=torch.float64), port.from_vec(u)).to(DT[dname]).double()
     g64 = torch.randn(n * (n - 1) // 2, dtype=torch.float64, generator=gen)
     ref_d2 = exact.spd_pdist(x64.numpy())
     ref_g = exact.spd_pdist_grad(x64.numpy(), g64.numpy())
     x = x64.to(DT[dname]).cuda().requires_grad_()
-    d2 = SPD(3).pdist(x, squared=True)
+    d2 = SPD(d).pdist(x, squared=True)
     a, r = (1e-6, 3e-5) if dname == 'f32' else (1e-13, 1e-10)
     bad = np.abs(d2.detach().double().cpu().numpy() - ref_d2) - (a + r * np.abs(ref_d2))
     assert bad.max() <= 0, f'd2 worst excess {bad.max():.3e}'
@@ -288,7 +289,7 @@ def test_eigenfree_paths_vs_exact_oracle(dname):
     assert err <= (3e-5 if dname == 'f32' else 1e-10), err
     # element-wise kernel agrees with the pair kernel
     i, j = torch.triu_indices(n, n, 1)[:, ::37]
-    dd = SPD(3).dist(x.detach()[i.cuda()], x.detach()[j.cuda()], squared=True)
+    dd = SPD(d).dist(x.detach()[i.cuda()], x.detach()[j.cuda()], squared=True)
     bad = np.abs(dd.double().cpu().numpy() - ref_d2[::37]) - (a + r * np.abs(ref_d2[::37]))
     assert bad.max() <= 0, f'dist worst excess {bad.max():.3e}'
 

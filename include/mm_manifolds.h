@@ -163,6 +163,13 @@ int mm_vec_pdist_fwd_gram(int dtype, int kind, const void* x, int64_t n, int m, 
 int mm_vec_pdist_bwd(int dtype, int kind, const void* x, const void* g, int64_t n, int m,
                      int64_t row_begin, int64_t row_end, int squared, void* grad_x, void* ws,
                      mm_stream_t stream);
+
+/* Fused objective + gradients for a single-factor vector-manifold embedding — the counterpart of
+ * mm_spd_pdist_loss (same loss kinds, arguments and outputs; squared distances). */
+int mm_vec_pdist_loss(int dtype, int kind, int loss_kind, const void* x, const void* target,
+                      const void* scale_raw, int64_t n, int m, int64_t row_begin, int64_t row_end,
+                      double alpha, double eps, int terms, void* loss_out, void* grad_x, void* ws,
+                      mm_stream_t stream);
 /* Element-wise dist over cnt pairs (x[k],y[k]).  out may be NULL (backward only);
  * grad_x/grad_y may both be NULL (forward only), else g [cnt] is required. */
 int mm_vec_dist(int dtype, int kind, const void* x, const void* y, const void* g, int64_t cnt, int m,

@@ -25,12 +25,12 @@
 #include <type_traits>
 
 #include "smallmat.hpp"
+#include "loss.hpp"
 
 namespace mm {
 
 constexpr int kBlock = 256;  // 4 wavefronts
 constexpr int kSpdMaxD = 5;
-constexpr int kLossSlots = 256;  // fused-loss partial sums are spread over this many addresses
 
 __host__ __device__ inline int64_t pair_off(int64_t n, int64_t row) { return row * (2 * n - row - 1) / 2; }
 
@@ -308,45 +308,6 @@ __global__ __launch_bounds__(kBlock) void spd_pdist_fwd_kernel(const T* __restri
   }
 }
 
-// ---- fused loss epilogue (objectives.py:16-45 evaluated per pair in registers) -------------------
-// m = softplus(scale) * d2 (modules.py:84-88); returns the loss term and d loss / d m.
-template <typename T> struct LossArgs {
-  const T* scale_raw;  // device scalar: raw scale parameter (softplus applied here); null -> 1
-  T alpha, eps;        // quotient loss: target * alpha, 1 / (epoch + 1)
-  int terms;           // quotient loss: bit 0 = |m/(a g) - 1|, bit 1 = |a g/(m + eps) - 1|
-  T* slots;            // [2][kLossSlots]
-};
-template <typename T> __device__ __forceinline__ T softplus_of(const T* raw) {
-  if (!raw) return T(1);
-  const T v = *raw;  // torch.nn.functional.softplus: beta = 1, threshold = 20
-  if (std::is_same<T, float>::value) return v > T(20) ? v : T(::log1pf(::expf(float(v))));
-  return v > T(20) ? v : T(::log1p(::exp(double(v))));
-}
-template <typename T> __device__ __forceinline__ T sign_of(T q) { return q > T(0) ? T(1) : (q < T(0) ? T(-1) : T(0)); }
-template <typename T, int LOSS>
-__device__ __forceinline__ T loss_term(T m, T target, const LossArgs<T>& la, T& dldm) {
-  if constexpr (LOSS == MM_LOSS_STRESS) {
-    const T r = m - target;
-    dldm = r + r;
-    return r * r;
-  } else {
-    const T ag = target * la.alpha;
-    T l = T(0);
-    dldm = T(0);
-    if (la.terms & 1) {
-      const T inv = T(1) / ag, q = m * inv - T(1);
-      l += Num<T>::abs(q);
-      dldm += sign_of(q) * inv;
-    }
-    if (la.terms & 2) {
-      const T inv = T(1) / (m + la.eps), q = ag * inv - T(1);
-      l += Num<T>::abs(q);
-      dldm -= sign_of(q) * ag * inv * inv;
-    }
-    return l;
-  }
-}
-
 // The value loaded from the pair vector is the upstream gradient (LOSS == 0: of d2, or of d when
 // !squared) or the loss target; either way this returns d loss / d (d2) of the pair.
 template <typename T, int LOSS>
@@ -541,21 +502,7 @@ __global__ void spd_pdist_finalize_kernel(const T* __restrict__ nodeL, T* __rest
                                           T* __restrict__ loss_out) {
   constexpr int NP = Packed<D>::NP;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (slots && blockIdx.x == 0 && threadIdx.x < 64) {
-    // fused loss: loss_out[0] = sum of the loss terms, loss_out[1] = d loss / d scale_raw
-    // (= sum dl/dm * d2 * sigmoid(scale_raw)); the slots are left clean for the next call
-    double l = 0.0, d = 0.0;
-    for (int t = threadIdx.x; t < kLossSlots; t += 64) {
-      l += double(slots[t]); d += double(slots[kLossSlots + t]);
-      slots[t] = T(0); slots[kLossSlots + t] = T(0);
-    }
-    l = wave_sum(l); d = wave_sum(d);
-    if (threadIdx.x == 0) {
-      const double v = scale_raw ? double(*scale_raw) : 0.0;
-      loss_out[0] = T(l);
-      loss_out[1] = scale_raw ? T(d / (1.0 + ::exp(-v))) : T(0);
-    }
-  }
+  if (slots && blockIdx.x == 0 && threadIdx.x < 64) loss_finalize<T>(slots, scale_raw, loss_out);
   if (i >= n) return;
   T li[NP], m[NP], gi[NP], xinv[NP], sc[D][D];
 #pragma unroll

@@ -17,6 +17,7 @@
 #include "../../include/mm_manifolds.h"
 #include "prof.hpp"
 #include "smallmat.hpp"
+#include "loss.hpp"
 
 namespace mm {
 
@@ -122,10 +123,13 @@ __global__ __launch_bounds__(kVBlock) void vec_pdist_fwd_kernel(const T* __restr
 // ------------------------------------------------------------------ backward
 // acc[k][j] += sum_i g_ij * dq_ij * (coefficient vector of x_i); finalize applies
 // the manifold-specific linear map (2(x_j - .) / -J / identity).
-template <typename T, int KIND, int MP, int TI>
+// LOSS != 0 (mm_vec_pdist_loss): `g` holds the TARGET squared distances; the upstream gradient of a
+// pair is derived in registers from the loss (loss.hpp) and the loss / scale-gradient sums (counted
+// once per unordered pair, in its i < j visit) leave through la.slots.
+template <typename T, int KIND, int MP, int TI, int LOSS>
 __global__ __launch_bounds__(kVBlock) void vec_pdist_bwd_kernel(const T* __restrict__ x, const T* __restrict__ g, int n,
                                                                 int m, int row_begin, int row_end, int squared,
-                                                                T* __restrict__ acc /* [MP+1][n] */) {
+                                                                T* __restrict__ acc /* [MP+1][n] */, LossArgs<T> la) {
   const int j = blockIdx.x * kVBlock + threadIdx.x;
   const int i0 = blockIdx.y * TI, i1 = min(i0 + TI, n);
   const bool jin = j < n;
@@ -134,19 +138,22 @@ __global__ __launch_bounds__(kVBlock) void vec_pdist_bwd_kernel(const T* __restr
   load_point<T, MP>(x, jin ? j : 0, m, xj);
 #pragma unroll
   for (int k = 0; k < MP; ++k) a[k] = T(0);
-  T wsum = T(0);
+  T wsum = T(0), sp = T(1), loss_acc = T(0), ds_acc = T(0);
+  if constexpr (LOSS != MM_LOSS_NONE) sp = softplus_of(la.scale_raw);
   const int64_t base = vpair_off(n, row_begin);
   // The per-pair arithmetic (~45 VALU ops) is far too short to hide the latency of the load
   // of g it depends on, so the upstream gradients of UNR rows are fetched as one batch first.
   constexpr int UNR = 8;
   for (int ib = i0; ib < i1; ib += UNR) {
     T wv[UNR];
+    bool ok[UNR];
 #pragma unroll
     for (int u = 0; u < UNR; ++u) {
       const int i = ib + u;
       const bool up = i < j;  // pair (i,j) stored under row i, else under row j
       const bool valid = jin && i < i1 && (up ? (i >= row_begin && i < row_end) : (jown && i > j));
       const int lo = up ? i : j, hi = up ? j : i;
+      ok[u] = valid;
       wv[u] = valid ? g[vpair_off(n, lo) - base + (hi - lo - 1)] : T(0);
     }
 #pragma unroll
@@ -155,7 +162,18 @@ __global__ __launch_bounds__(kVBlock) void vec_pdist_bwd_kernel(const T* __restr
       T xi[MP];
       load_point<T, MP>(x, i, m, xi);
       const T q = pair_q<T, KIND, MP>(xi, xj);
-      const T w = wv[u] * PairFn<T, KIND>::dq(q, squared);
+      T w;
+      if constexpr (LOSS == MM_LOSS_NONE) {
+        w = wv[u] * PairFn<T, KIND>::dq(q, squared);
+      } else {
+        const T d2 = PairFn<T, KIND>::value(q, 1);
+        T dldm;
+        const T l = loss_term<T, LOSS>(sp * d2, wv[u], la, dldm);
+        const bool once = ok[u] && ib + u < j;
+        loss_acc += once ? l : T(0);
+        ds_acc += once ? dldm * d2 : T(0);
+        w = ok[u] ? dldm * sp * PairFn<T, KIND>::dq(q, 1) : T(0);
+      }
       wsum += w;
 #pragma unroll
       for (int k = 0; k < MP; ++k) a[k] = Num<T>::fma(w, xi[k], a[k]);
@@ -167,12 +185,28 @@ __global__ __launch_bounds__(kVBlock) void vec_pdist_bwd_kernel(const T* __restr
       if (k < m) atomic_add(&acc[size_t(k) * n + j], a[k]);
     if (KIND == MM_EUCLIDEAN) atomic_add(&acc[size_t(MP) * n + j], wsum);
   }
+  if constexpr (LOSS != MM_LOSS_NONE) {
+    __shared__ T lossW[kVBlock / 64][2];
+    const T l = wave_sum(loss_acc), d = wave_sum(ds_acc);
+    if ((threadIdx.x & 63) == 0) { lossW[threadIdx.x >> 6][0] = l; lossW[threadIdx.x >> 6][1] = d; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      T ls = T(0), dsum = T(0);
+#pragma unroll
+      for (int wv = 0; wv < kVBlock / 64; ++wv) { ls += lossW[wv][0]; dsum += lossW[wv][1]; }
+      const int slot = (blockIdx.x + blockIdx.y * gridDim.x) & (kLossSlots - 1);
+      atomic_add(&la.slots[slot], ls);
+      atomic_add(&la.slots[kLossSlots + slot], dsum);
+    }
+  }
 }
 
 template <typename T, int KIND, int MP>
 __global__ void vec_pdist_finalize_kernel(const T* __restrict__ x, const T* __restrict__ acc, int n, int m,
-                                          T* __restrict__ grad) {
+                                          T* __restrict__ grad, T* __restrict__ slots,
+                                          const T* __restrict__ scale_raw, T* __restrict__ loss_out) {
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (slots && blockIdx.x == 0 && threadIdx.x < 64) loss_finalize<T>(slots, scale_raw, loss_out);
   if (j >= n) return;
   for (int k = 0; k < m; ++k) {
     const T s = acc[size_t(k) * n + j];
@@ -387,23 +421,35 @@ int vec_fwd_t(const T* x, int64_t n, int m, int64_t rb, int64_t re, int squared,
   return MM_OK;
 }
 
-template <typename T, int KIND, int MP>
+template <typename T, int KIND, int MP, int LOSS = MM_LOSS_NONE>
 int vec_bwd_t(const T* x, const T* g, int64_t n, int m, int64_t rb, int64_t re, int squared, T* grad, void* ws,
-              hipStream_t st) {
+              hipStream_t st, LossArgs<T> la = LossArgs<T>{nullptr, T(1), T(0), 0, nullptr}, T* loss_out = nullptr) {
   constexpr int TI = 64;
   T* acc = static_cast<T*>(ws);
-  hipError_t e = hipMemsetAsync(acc, 0, sizeof(T) * size_t(n) * (MP + 1), st);
+  T* slots = acc + size_t(n) * (MP + 1);
+  hipError_t e = hipMemsetAsync(acc, 0, sizeof(T) * (size_t(n) * (MP + 1) + 2 * kLossSlots), st);
   if (e != hipSuccess) return int(e);
+  la.slots = slots;
   if (re > rb) {
     ProfScope prof(PROF_VEC_BWD, st);
-    vec_pdist_bwd_kernel<T, KIND, MP, TI>
+    vec_pdist_bwd_kernel<T, KIND, MP, TI, LOSS>
         <<<dim3(int((n + kVBlock - 1) / kVBlock), int((n + TI - 1) / TI)), dim3(kVBlock), 0, st>>>(
-            x, g, int(n), m, int(rb), int(re), squared, acc);
+            x, g, int(n), m, int(rb), int(re), squared, acc, la);
   }
   MMV_CHECK();
-  vec_pdist_finalize_kernel<T, KIND, MP><<<dim3(int((n + 127) / 128)), dim3(128), 0, st>>>(x, acc, int(n), m, grad);
+  vec_pdist_finalize_kernel<T, KIND, MP><<<dim3(int((n + 127) / 128)), dim3(128), 0, st>>>(
+      x, acc, int(n), m, grad, LOSS != MM_LOSS_NONE ? slots : static_cast<T*>(nullptr), la.scale_raw, loss_out);
   MMV_CHECK();
   return MM_OK;
+}
+
+template <typename T, int KIND, int MP>
+int vec_loss_t(int loss_kind, const T* x, const T* target, const T* scale_raw, int64_t n, int m, int64_t rb, int64_t re,
+               double alpha, double eps, int terms, T* loss_out, T* grad, void* ws, hipStream_t st) {
+  LossArgs<T> la{scale_raw, T(alpha), T(eps), terms, nullptr};
+  if (loss_kind == MM_LOSS_STRESS)
+    return vec_bwd_t<T, KIND, MP, MM_LOSS_STRESS>(x, target, n, m, rb, re, 1, grad, ws, st, la, loss_out);
+  return vec_bwd_t<T, KIND, MP, MM_LOSS_QUOTIENT>(x, target, n, m, rb, re, 1, grad, ws, st, la, loss_out);
 }
 
 constexpr int pad_dim(int m) { return m <= 4 ? 4 : m <= 8 ? 8 : m <= 12 ? 12 : m <= 16 ? 16 : m <= 24 ? 24 : 32; }
@@ -440,7 +486,7 @@ extern "C" {
 int mm_vec_max_dim(void) { return kVecMaxDim; }
 
 size_t mm_vec_pdist_ws_bytes(int dtype, int64_t n, int m) {
-  return (dtype == MM_F64 ? 8 : 4) * size_t(n) * (pad_dim(m) + 1);
+  return (dtype == MM_F64 ? 8 : 4) * (size_t(n) * (pad_dim(m) + 1) + 2 * kLossSlots);
 }
 
 int mm_vec_pdist_fwd(int dtype, int kind, const void* x, int64_t n, int m, int64_t row_begin, int64_t row_end,
@@ -463,6 +509,22 @@ int mm_vec_pdist_bwd(int dtype, int kind, const void* x, const void* g, int64_t 
   MMV_DISPATCH_T(dtype, MMV_DISPATCH_KIND(kind, MMV_DISPATCH_MP(m, (vec_bwd_t<T, KIND, MP>(
       static_cast<const T*>(x), static_cast<const T*>(g), n, m, row_begin, row_end, squared,
       static_cast<T*>(grad_x), ws, st)))))
+}
+
+int mm_vec_pdist_loss(int dtype, int kind, int loss_kind, const void* x, const void* target, const void* scale_raw,
+                      int64_t n, int m, int64_t row_begin, int64_t row_end, double alpha, double eps, int terms,
+                      void* loss_out, void* grad_x, void* ws, mm_stream_t stream) {
+  if (!x || !grad_x || !ws || !loss_out || n < 1 || m < 1 || row_begin < 0 || row_end > n || row_begin > row_end ||
+      n > (1 << 30))
+    return MM_ERR_ARG;
+  if (m > kVecMaxDim) return MM_ERR_UNSUPPORTED;
+  if (loss_kind != MM_LOSS_STRESS && loss_kind != MM_LOSS_QUOTIENT) return MM_ERR_UNSUPPORTED;
+  if (loss_kind == MM_LOSS_QUOTIENT && !(terms & 3)) return MM_ERR_ARG;
+  if (!target && mm_pair_offset(n, row_end) > mm_pair_offset(n, row_begin)) return MM_ERR_ARG;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  MMV_DISPATCH_T(dtype, MMV_DISPATCH_KIND(kind, MMV_DISPATCH_MP(m, (vec_loss_t<T, KIND, MP>(
+      loss_kind, static_cast<const T*>(x), static_cast<const T*>(target), static_cast<const T*>(scale_raw), n, m,
+      row_begin, row_end, alpha, eps, terms, static_cast<T*>(loss_out), static_cast<T*>(grad_x), ws, st)))))
 }
 
 int mm_vec_dist(int dtype, int kind, const void* x, const void* y, const void* g, int64_t cnt, int m, int squared,

@@ -48,6 +48,41 @@ class _VecPdist(torch.autograd.Function):
         return grad.reshape(shape), None, None, None, None, None, None
 
 
+class _VecPdistLoss(torch.autograd.Function):
+    """loss(target, softplus(scale) * pdist(x)^2) with both gradients from one pass over the
+    pairs (mm_vec_pdist_loss) — see graphembed.manifolds.spd._SpdPdistLoss."""
+
+    @staticmethod
+    def forward(ctx, x, scale, target, kind, m, spec, row_begin, row_end):
+        B.require_gpu(x, target)
+        lib = B.lib()
+        n = x.shape[0]
+        xc = x.detach().reshape(n, m).contiguous()
+        dt = B.dtype_code(xc)
+        lkind, alpha, eps, terms = spec
+        tc = target.detach().to(xc.dtype).contiguous()
+        npairs = B.pair_offset(n, row_end) - B.pair_offset(n, row_begin)
+        if tc.numel() != npairs:
+            raise ValueError(f'target has {tc.numel()} entries, the pair range has {npairs}')
+        sc = None if scale is None else scale.detach().to(xc.dtype).reshape(1).contiguous()
+        with torch.cuda.device(xc.device):
+            ws = torch.empty(lib.raw('mm_vec_pdist_ws_bytes')(dt, n, m), dtype=torch.uint8,
+                             device=xc.device)
+            out = torch.empty(2, dtype=xc.dtype, device=xc.device)
+            grad = torch.empty_like(xc)
+            lib.call('mm_vec_pdist_loss', dt, kind, B.LOSS_STRESS if lkind == 'stress' else B.LOSS_QUOTIENT,
+                     B.ptr(xc), B.ptr(tc), B.ptr(sc), n, m, row_begin, row_end, alpha, eps, terms,
+                     B.ptr(out), B.ptr(grad), B.ptr(ws), B.stream_of(xc))
+        ctx.grad_x = grad.reshape(x.shape)
+        ctx.grad_s = None if scale is None else out[1].reshape(scale.shape).to(scale.dtype)
+        return out[0]
+
+    @staticmethod
+    def backward(ctx, up):
+        gs = None if ctx.grad_s is None else ctx.grad_s * up
+        return ctx.grad_x * up, gs, None, None, None, None, None, None
+
+
 class _VecDist(torch.autograd.Function):
 
     @staticmethod
@@ -178,3 +213,10 @@ class VectorManifold(Manifold):
         assert x.ndim == self.ndim + 1
         rb, re = (0, x.shape[0]) if rows is None else rows
         return _VecPdist.apply(x, self._kind, self._m, squared, rb, re, self.use_gram)
+
+    def pdist_loss(self, x, scale, target, spec, rows=None):
+        """Fused `objective(target, softplus(scale) * pdist(x, squared=True))` with its gradients in
+        one pass; `spec` comes from `objective_fn.fused_spec(epoch=, alpha=)`."""
+        assert x.ndim == self.ndim + 1
+        rb, re = (0, x.shape[0]) if rows is None else rows
+        return _VecPdistLoss.apply(x, scale, target, self._kind, self._m, spec, rb, re)

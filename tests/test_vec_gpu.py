@@ -325,3 +325,94 @@ def test_optim_sphere_dominant_eigenvector():
         assert abs(x.detach().norm().item() - 1) < 1e-6
     w, v = torch.linalg.eigh(a)
     assert abs(abs((v[:, -1] @ x.detach()).item()) - 1) < 1e-3
+
+
+@pytest.mark.parametrize('case', ['euclidean10', 'lorentz11', 'sphere6', 'lorentz3'])
+@pytest.mark.parametrize('dname', ['f32', 'f64'])
+@pytest.mark.parametrize('loss_name', ['stress', 'quotient'])
+def test_fused_loss_equals_unfused_path(case, dname, loss_name):
+    """mm_vec_pdist_loss (one pass: loss, d/dx, d/dscale) vs compute_dists -> objective -> backward
+    of this library (itself checked against the reference above); row shards sum to the whole."""
+    from graphembed import _backend as B
+    from graphembed import manifolds as M
+    from graphembed.modules import ManifoldEmbedding
+    from graphembed.objectives import QuotientLoss, StressLoss
+    mk = {'euclidean10': lambda: M.Euclidean(10), 'lorentz11': lambda: M.Lorentz(11),
+          'sphere6': lambda: M.Sphere(6), 'lorentz3': lambda: M.Lorentz(3)}[case]
+    dt = {'f32': torch.float32, 'f64': torch.float64}[dname]
+    n = 700
+    torch.manual_seed(3)
+    torch.set_default_dtype(dt)
+    try:
+        with torch.device('cuda'):
+            emb = ManifoldEmbedding(n, [mk()])
+            with torch.no_grad():  # spread the points: at the reference init every distance is ~0.1
+                emb.perturb(0.5)
+    finally:
+        torch.set_default_dtype(torch.float32)
+    fn, kw = (StressLoss(), {}) if loss_name == 'stress' else (QuotientLoss(), dict(epoch=2, alpha=1.3))
+    md = emb.compute_dists(None).detach()
+    gen = torch.Generator(device='cuda').manual_seed(1)
+    target = md * (0.5 + torch.rand(md.shape, dtype=dt, device='cuda', generator=gen))
+    if kw:  # keep away from the |.| kinks
+        for _ in range(8):
+            ag = target * kw['alpha']
+            near = ((md / ag - 1).abs() < 0.05) | ((ag / (md + 1 / (kw['epoch'] + 1)) - 1).abs() < 0.05)
+            target = torch.where(near, target * 1.25, target)
+        assert not near.any()
+    ref = fn(target, emb.compute_dists(None), **kw)
+    rgx, rgs = torch.autograd.grad(ref, [emb.xs[0], emb.scales[0]])
+    loss = emb.fused_objective(fn, target, None, **kw)
+    assert loss is not None
+    gx, gs = torch.autograd.grad(loss * 3.0, [emb.xs[0], emb.scales[0]])
+    tol = 5e-5 if dname == 'f32' else 1e-10
+    assert abs(loss.item() - ref.item()) <= tol * abs(ref.item())
+    check_rel(gx, 3 * rgx.double().cpu().numpy(), tol * 4, 'fused vs unfused grad_x')
+    assert abs(gs.item() - 3 * rgs.item()) <= (2e-3 if dname == 'f32' else 1e-9) * abs(3 * rgs.item())
+    tot, gsum, ssum = 0.0, torch.zeros_like(gx), 0.0
+    for r in range(3):
+        rows = B.shard_rows(n, 3, r)
+        lo, hi = B.pair_offset(n, rows[0]), B.pair_offset(n, rows[1])
+        part = emb.fused_objective(fn, target[lo:hi], None, rows=rows, **kw)
+        pgx, pgs = torch.autograd.grad(part, [emb.xs[0], emb.scales[0]])
+        tot, gsum, ssum = tot + part.item(), gsum + pgx, ssum + pgs.item()
+    assert abs(tot - ref.item()) <= tol * abs(ref.item())
+    check_rel(gsum, rgx.double().cpu().numpy(), tol * 4, 'sum of fused shard grads')
+
+
+@pytest.mark.parametrize('case', ['euclidean10', 'lorentz11'])
+@pytest.mark.parametrize('loss_name', ['stress', 'quotient'])
+def test_tree40_training_trace_fused(case, loss_name):
+    """The reference's 20-epoch tree40 loss traces (golden) driven through the fused kernel."""
+    from graphembed import manifolds as M
+    from graphembed.modules import ManifoldEmbedding
+    from graphembed.objectives import QuotientLoss, StressLoss
+    from graphembed.optim import RiemannianSGD
+    G = load_golden('callers')
+    mk = {'euclidean10': lambda: [M.Euclidean(10)], 'lorentz11': lambda: [M.Lorentz(11)]}[case]
+    base = f'tree40/{case}/{loss_name}'
+    torch.set_default_dtype(torch.float64)
+    try:
+        with torch.device('cuda'):
+            emb = ManifoldEmbedding(40, mk())
+        with torch.no_grad():
+            emb.xs[0].copy_(dev(G[f'{base}/x0_0']))
+        target = dev(G['tree40/target'])
+        opt = RiemannianSGD(list(emb.xs), lr=0.01, exact=True, max_grad_norm=20)
+        opt_s = RiemannianSGD(list(emb.scales), lr=1e-4, max_grad_norm=500)
+        fn = StressLoss() if loss_name == 'stress' else QuotientLoss()
+        losses = []
+        for epoch in range(20):
+            loss = emb.fused_objective(fn, target, None, epoch=epoch, alpha=1.0)
+            assert loss is not None
+            opt.zero_grad()
+            opt_s.zero_grad()
+            loss.backward()
+            opt.step()
+            opt_s.step()
+            losses.append(loss.item())
+    finally:
+        torch.set_default_dtype(torch.float32)
+    check_rel(np.array(losses), G[f'{base}/losses'], 1e-7, 'loss trace')
+    check_rel(emb.xs[0].data, G[f'{base}/x20_0'], 1e-6, 'x20')
+    check_rel(np.array([s.item() for s in emb.scales]), G[f'{base}/scales20'], 1e-6, 'scales')

@@ -86,7 +86,8 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-prof', action='store_true', help='no HIP-event bracketing of the kernels')
     ap.add_argument('--graph', choices=['auto', 'on', 'off'], default='auto',
-                    help='replay the step from a captured hipGraph (auto: when N > 1)')
+                    help='replay the step from a captured hipGraph (auto = on; falls back to eager launches '
+                         'if capture is unavailable)')
     args = ap.parse_args()
 
     rank = int(os.environ.get('RANK', 0))
@@ -133,11 +134,13 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # Launch-bound regime (N > 1: each rank's kernels shrink to tens of microseconds, below the
-    # host's per-step dispatch cost): capture the step's kernels — forward + backward — into a
-    # hipGraph and replay it, then issue the all-reduce.  Falls back to eager launches if capture
-    # is unavailable.
-    use_graph = args.graph == 'on' or (args.graph == 'auto' and world > 1)
+    # The step is 4 kernels of 4-70 us: through Python autograd the host needs 130-170 us to issue
+    # them (rocprofv3 shows a 44 us host gap between the forward and the backward kernel alone), i.e.
+    # eager launches measure the host, at any N.  So the step's kernels — forward + backward — are
+    # captured once into a hipGraph and replayed; the all-reduce is issued eagerly after the replay.
+    # Falls back to eager launches if capture is unavailable.  The per-kernel HIP-event durations
+    # (roofline) and `eager_ms_per_step` come from an eager pass right after the timed region.
+    use_graph = args.graph in ('on', 'auto')
     graph = None
     if use_graph:
         try:
@@ -182,12 +185,17 @@ def main():
     elapsed = time.perf_counter() - t0
     lib.call('mm_prof_enable', 0)
     roofline_pass = 'timed region'
+    eager_ms = None
     if graph is not None and not args.no_prof:
         # per-kernel durations: a short eager pass right after the timed region
         lib.call('mm_prof_enable', 1)
-        for _ in range(min(args.steps, 20)):
+        k_eager = min(args.steps, 20)
+        fence()
+        te = time.perf_counter()
+        for _ in range(k_eager):
             step()
         fence()
+        eager_ms = (time.perf_counter() - te) / k_eager * 1e3
         lib.call('mm_prof_enable', 0)
         roofline_pass = 'eager pass after the (graph-replayed) timed region'
 
@@ -218,12 +226,14 @@ def main():
                        'pairs_per_step': P, 'parallelism': f'pair-rows sharded x{world}, 1 all-reduce',
                        'launch': 'hipGraph replay (fwd+bwd) + eager all-reduce' if graph is not None else 'eager'},
         }
+        if eager_ms is not None:
+            out['eager_ms_per_step'] = eager_ms   # same step issued through Python autograd (host-bound)
         if kern['bwd']:
             # dominant kernel: spd_pdist_bwd.  Algorithmic HBM bytes per launch: read g (4 B per
             # pair) + node factors in (2*6 floats) + accumulators out (2*6 floats) per node.
             by = pairs_local * esz + n * 24 * esz
             # VALU instructions per 64-pair wave iteration and HBM bytes per launch measured with
-            # rocprofv3 --pmc on this exact workload (profiles/r01_v4_pmc_summary.txt); the plain
+            # rocprofv3 --pmc on this exact workload (profiles/r01_v6_pmc_summary.txt); the plain
             # v_fma_f32 issue rate is 2.44 cycles per wave instruction per SIMD (tools/micro/valu_rate.hip)
             iters = pairs_local / 64.0
             issue_s = lambda instr, t: instr * iters * 2.44 / (1024 * 2.4e9) / t
@@ -231,12 +241,12 @@ def main():
             out['roofline'] = {'bound': 'hbm', 'kernel': 'spd_pdist_bwd_kernel<float,3,8>',
                                'achieved': by / kern['bwd'] / 1e9, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                                'frac': by / kern['bwd'] / 1e9 / HBM_PEAK_GBS,
-                               'traffic': 96.4e6 if ref_shape else None,
+                               'traffic': 94.7e6 if ref_shape else None,
                                'traffic_source': 'rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE, '
-                                                 'profiles/r01_v4_pmc_summary.txt' if ref_shape else None,
+                                                 'profiles/r01_v6_pmc_summary.txt' if ref_shape else None,
                                'algorithmic_bytes': by,
                                'avg_launch_us': kern['bwd'] * 1e6, 'measured_in': roofline_pass,
-                               'valu_issue_frac': issue_s(231, kern['bwd'])}
+                               'valu_issue_frac': issue_s(213, kern['bwd'])}
             if kern['fwd']:
                 byf = pairs_local * esz + n * 12 * esz
                 out['roofline_fwd'] = {'bound': 'hbm', 'kernel': 'spd_pdist_fwd_kernel<float,3,8>',
@@ -244,7 +254,7 @@ def main():
                                        'unit': 'GB/s', 'frac': byf / kern['fwd'] / 1e9 / HBM_PEAK_GBS,
                                        'traffic': 50.3e6 if ref_shape else None, 'algorithmic_bytes': byf,
                                        'avg_launch_us': kern['fwd'] * 1e6,
-                                       'valu_issue_frac': issue_s(100, kern['fwd'])}
+                                       'valu_issue_frac': issue_s(91, kern['fwd'])}
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(42)
         print(json.dumps(out), flush=True)

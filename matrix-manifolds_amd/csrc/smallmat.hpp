@@ -144,6 +144,33 @@ __device__ __forceinline__ void congr_lower(const TL (&lw)[Packed<D>::NP], const
     }
 }
 
+// out = (Li Lj)(Li Lj)^T for packed lower-triangular Li, Lj: with Li = chol(X_i)^-1 and Lj = chol(X_j) this
+// is L_i^-1 X_j L_i^-T in 2 x D(D+1)(D+2)/6 FMAs (20 for D = 3, 40 for D = 4) instead of 28 / 60 through
+// the full product with X_j, and symmetric positive semi-definite by construction.
+template <typename T, int D, typename TL>
+__device__ __forceinline__ void congr_chol(const TL (&li)[Packed<D>::NP], const T (&lj)[Packed<D>::NP],
+                                           T (&out)[Packed<D>::NP]) {
+  T b[Packed<D>::NP];  // B = Li Lj (lower): B[r][c] = sum_{c<=k<=r} Li[r][k] Lj[k][c]
+#pragma unroll
+  for (int r = 0; r < D; ++r)
+#pragma unroll
+    for (int c = 0; c <= r; ++c) {
+      T acc = li[pidx(r, c)] * lj[pidx(c, c)];
+#pragma unroll
+      for (int k = c + 1; k <= r; ++k) acc = Num<T>::fma(li[pidx(r, k)], lj[pidx(k, c)], acc);
+      b[pidx(r, c)] = acc;
+    }
+#pragma unroll
+  for (int r = 0; r < D; ++r)
+#pragma unroll
+    for (int c = 0; c <= r; ++c) {
+      T acc = b[pidx(r, 0)] * b[pidx(c, 0)];
+#pragma unroll
+      for (int k = 1; k <= c; ++k) acc = Num<T>::fma(b[pidx(r, k)], b[pidx(c, k)], acc);
+      out[pidx(r, c)] = acc;
+    }
+}
+
 // out = Lw^T S Lw  (Lw lower-triangular packed, S symmetric packed).
 template <typename T, int D, typename TL>
 __device__ __forceinline__ void congr_lower_t(const TL (&lw)[Packed<D>::NP], const T (&s)[Packed<D>::NP],
@@ -371,25 +398,23 @@ __device__ __forceinline__ void eig3_trig(const float (&a)[6], float (&w)[3]) {
   w[0] = fmaf(p, -r3s - cs, q);
 }
 
-// ------------------------------ log(A) and log(A) A^-1 near the identity, 3x3 (fp32)
+// ------------------------------ log(A) near the identity, 3x3 / 4x4 (fp32)
 // For ||A - I||_F <= 0.3 (the two points of the pair are closer than ~0.3 — every pair at the
-// reference's initialisation) the two matrix functions the backward needs,
-//     M0 = log(A)            and      N0 = log(A) A^-1,
-// are evaluated WITHOUT an eigen-decomposition: with E = A - I, degree-10 economised polynomials
-// a(e) ~ log(1+e), b(e) ~ log(1+e)/(1+e) on [-0.3,0.3] (max abs error 4.6e-10 / 1.7e-8), and the
-// Cayley-Hamilton reduction E^(k+1) = p_k I + q_k E + r_k E^2,
-//     (p,q,r)_(k+1) = (s3 r_k, p_k - s2 r_k, q_k + s1 r_k),   E^3 = s1 E^2 - s2 E + s3 I,
-// so both functions are alpha0 I + alpha1 E + alpha2 E^2 with coefficients from 10 three-term
-// recurrences on scalars.  ~175 VALU ops, branch-free, no transcendental; measured relative error
-// 5e-7 in fp32 (tools/micro/README).  Returns ||E||_F^2 for the caller's gate.
-template <bool WANT_N>
-__device__ __forceinline__ float log_series3(const float (&a)[6], float (&m0)[6], float (&n0)[6]) {
-  constexpr float kA[10] = {1.000000001e+00f, -5.000000067e-01f, 3.333326160e-01f, -2.499985265e-01f,
-                            2.000629482e-01f, -1.667570841e-01f, 1.409399919e-01f, -1.227561192e-01f,
-                            1.344425630e-01f, -1.238070491e-01f};
-  constexpr float kB[10] = {1.000000046e+00f, -1.500000263e+00f, 1.833308241e+00f, -2.083275579e+00f,
-                            2.285528564e+00f, -2.453533202e+00f, 2.526338709e+00f, -2.630612542e+00f,
-                            3.630254921e+00f, -3.845332518e+00f};
+// reference's initialisation) log(A) is evaluated WITHOUT an eigen-decomposition: with E = A - I, an
+// economised polynomial a(e) ~ log(1+e) on [-0.3,0.3] and the Cayley-Hamilton reduction
+//     E^(k+1) = p_k I + q_k E + r_k E^2,   (p,q,r)_(k+1) = (s3 r_k, p_k - s2 r_k, q_k + s1 r_k),
+//     E^3 = s1 E^2 - s2 E + s3 I,
+// so log(A) = alpha0 I + alpha1 E + alpha2 E^2 with coefficients from three-term recurrences on
+// scalars: ~95 VALU ops, branch-free, no transcendental.  Returns ||E||_F^2 for the caller's gate.
+// log(1+x) = x p(x), p of degree 7 interpolated at Chebyshev nodes of |x| <= 0.3 (max error 9.1e-8 |x|,
+// tools/design/series_fit.py): the close-pair gate bounds the spectral radius of E by 0.3.
+#define MM_LOG_SERIES_COEFS                                                                              \
+  {9.999999337e-01f, -4.999999402e-01f, 3.333568549e-01f, -2.500212282e-01f, 1.987095623e-01f,           \
+   -1.655023071e-01f, 1.650813480e-01f, -1.450413880e-01f}
+constexpr int kLogSeriesTerms = 8;
+
+__device__ __forceinline__ float log_series3(const float (&a)[6], float (&m0)[6]) {
+  constexpr float kA[kLogSeriesTerms] = MM_LOG_SERIES_COEFS;
   const float e00 = a[pidx(0, 0)] - 1.f, e11 = a[pidx(1, 1)] - 1.f, e22 = a[pidx(2, 2)] - 1.f;
   const float e10 = a[pidx(1, 0)], e20 = a[pidx(2, 0)], e21 = a[pidx(2, 1)];
   // E^2 (symmetric)
@@ -405,11 +430,10 @@ __device__ __forceinline__ float log_series3(const float (&a)[6], float (&m0)[6]
   const float s3 = e00 * fmaf(e11, e22, -e21 * e21) - e10 * fmaf(e10, e22, -e21 * e20) +
                    e20 * fmaf(e10, e21, -e11 * e20);
   float p = 0.f, q = 1.f, r = 0.f;                       // E^1
-  float a0 = 0.f, a1 = 0.f, a2 = 0.f, b0 = 0.f, b1 = 0.f, b2 = 0.f;
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f;
 #pragma unroll
-  for (int k = 0; k < 10; ++k) {
+  for (int k = 0; k < kLogSeriesTerms; ++k) {
     a0 = fmaf(kA[k], p, a0); a1 = fmaf(kA[k], q, a1); a2 = fmaf(kA[k], r, a2);
-    if (WANT_N) { b0 = fmaf(kB[k], p, b0); b1 = fmaf(kB[k], q, b1); b2 = fmaf(kB[k], r, b2); }
     const float pn = s3 * r, qn = fmaf(-s2, r, p), rn = fmaf(s1, r, q);
     p = pn; q = qn; r = rn;
   }
@@ -419,13 +443,6 @@ __device__ __forceinline__ float log_series3(const float (&a)[6], float (&m0)[6]
   m0[pidx(1, 0)] = fmaf(a2, f10, a1 * e10);
   m0[pidx(2, 0)] = fmaf(a2, f20, a1 * e20);
   m0[pidx(2, 1)] = fmaf(a2, f21, a1 * e21);
-  if (!WANT_N) return tr2;
-  n0[pidx(0, 0)] = fmaf(b2, f00, fmaf(b1, e00, b0));
-  n0[pidx(1, 1)] = fmaf(b2, f11, fmaf(b1, e11, b0));
-  n0[pidx(2, 2)] = fmaf(b2, f22, fmaf(b1, e22, b0));
-  n0[pidx(1, 0)] = fmaf(b2, f10, b1 * e10);
-  n0[pidx(2, 0)] = fmaf(b2, f20, b1 * e20);
-  n0[pidx(2, 1)] = fmaf(b2, f21, b1 * e21);
   return tr2;
 }
 
@@ -627,9 +644,10 @@ template <typename T> __device__ __forceinline__ T log_cayley4(const T (&a)[10],
 // t_m = s1 t_(m-1) - s2 t_(m-2) + s3 t_(m-3) and c_m from a degree-11 economised polynomial of
 // log^2(1+e) (max abs error 8e-10).  ~90 VALU ops, no transcendental.  *e2 receives ||E||_F^2.
 __device__ __forceinline__ float logsq_series3(const float (&a)[6], float* e2) {
-  constexpr float kL2[10] = {1.000000007e+00f, -1.000000039e+00f, 9.166626393e-01f, -8.333247760e-01f,
-                             7.614642417e-01f, -7.005246665e-01f, 6.374742114e-01f, -5.909650236e-01f,
-                             6.961358894e-01f, -6.701311000e-01f};
+  constexpr int kTerms = 9;  // log^2(1+x) = x^2 q(x), q of degree 8 on |x| <= 0.3: max error 6.9e-8 x^2
+  constexpr float kL2[kTerms] = {9.999999990e-01f, -9.999985182e-01f, 9.166654125e-01f, -8.335515341e-01f,
+                                 7.613116690e-01f, -6.914147801e-01f, 6.401787542e-01f, -7.263483416e-01f,
+                                 6.811261199e-01f};
   const float e00 = a[pidx(0, 0)] - 1.f, e11 = a[pidx(1, 1)] - 1.f, e22 = a[pidx(2, 2)] - 1.f;
   const float e10 = a[pidx(1, 0)], e20 = a[pidx(2, 0)], e21 = a[pidx(2, 1)];
   float t2 = fmaf(e00, e00, fmaf(e11, e11, e22 * e22));
@@ -641,7 +659,7 @@ __device__ __forceinline__ float logsq_series3(const float (&a)[6], float* e2) {
   float tm3 = 3.f, tm2 = s1, tm1 = t2;
   float acc = kL2[0] * t2;
 #pragma unroll
-  for (int k = 1; k < 10; ++k) {
+  for (int k = 1; k < kTerms; ++k) {
     const float t = fmaf(s1, tm1, fmaf(-s2, tm2, s3 * tm3));
     acc = fmaf(kL2[k], t, acc);
     tm3 = tm2; tm2 = tm1; tm1 = t;
@@ -653,15 +671,8 @@ __device__ __forceinline__ float logsq_series3(const float (&a)[6], float* e2) {
 // Same for 4x4: E^(k+1) = p I + q E + r E^2 + t E^3 with
 //   (p,q,r,t)_(k+1) = (-s4 t, p + s3 t, q - s2 t, r + s1 t),  E^4 = s1 E^3 - s2 E^2 + s3 E - s4 I,
 // s1..s4 from the power sums tr E^m (Newton's identities; tr E^3 = <E^2,E>, tr E^4 = ||E^2||_F^2).
-// WANT_N = false evaluates log(A) only (the forward uses ||log A||_F^2).
-template <bool WANT_N>
-__device__ __forceinline__ float log_series4(const float (&a)[10], float (&m0)[10], float (&n0)[10]) {
-  constexpr float kA[10] = {1.000000001e+00f, -5.000000067e-01f, 3.333326160e-01f, -2.499985265e-01f,
-                            2.000629482e-01f, -1.667570841e-01f, 1.409399919e-01f, -1.227561192e-01f,
-                            1.344425630e-01f, -1.238070491e-01f};
-  constexpr float kB[10] = {1.000000046e+00f, -1.500000263e+00f, 1.833308241e+00f, -2.083275579e+00f,
-                            2.285528564e+00f, -2.453533202e+00f, 2.526338709e+00f, -2.630612542e+00f,
-                            3.630254921e+00f, -3.845332518e+00f};
+__device__ __forceinline__ float log_series4(const float (&a)[10], float (&m0)[10]) {
+  constexpr float kA[kLogSeriesTerms] = MM_LOG_SERIES_COEFS;
   float e[10], e2[10], e3[10];
 #pragma unroll
   for (int k = 0; k < 10; ++k) e[k] = a[k];
@@ -700,26 +711,17 @@ __device__ __forceinline__ float log_series4(const float (&a)[10], float (&m0)[1
   const float s3 = (1.f / 3.f) * (fmaf(s2, p1, -s1 * p2) + p3);
   const float s4 = 0.25f * (fmaf(s3, p1, -s2 * p2) + fmaf(s1, p3, -p4));
   float p = 0.f, q = 1.f, r = 0.f, t = 0.f;
-  float al[4] = {0.f, 0.f, 0.f, 0.f}, be[4] = {0.f, 0.f, 0.f, 0.f};
+  float al[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-  for (int k = 0; k < 10; ++k) {
+  for (int k = 0; k < kLogSeriesTerms; ++k) {
     al[0] = fmaf(kA[k], p, al[0]); al[1] = fmaf(kA[k], q, al[1]); al[2] = fmaf(kA[k], r, al[2]); al[3] = fmaf(kA[k], t, al[3]);
-    if (WANT_N) {
-      be[0] = fmaf(kB[k], p, be[0]); be[1] = fmaf(kB[k], q, be[1]); be[2] = fmaf(kB[k], r, be[2]); be[3] = fmaf(kB[k], t, be[3]);
-    }
     const float pn = -s4 * t, qn = fmaf(s3, t, p), rn = fmaf(-s2, t, q), tn = fmaf(s1, t, r);
     p = pn; q = qn; r = rn; t = tn;
   }
 #pragma unroll
-  for (int k = 0; k < 10; ++k) {
-    m0[k] = fmaf(al[3], e3[k], fmaf(al[2], e2[k], al[1] * e[k]));
-    if (WANT_N) n0[k] = fmaf(be[3], e3[k], fmaf(be[2], e2[k], be[1] * e[k]));
-  }
+  for (int k = 0; k < 10; ++k) m0[k] = fmaf(al[3], e3[k], fmaf(al[2], e2[k], al[1] * e[k]));
 #pragma unroll
-  for (int rr = 0; rr < 4; ++rr) {
-    m0[pidx(rr, rr)] += al[0];
-    if (WANT_N) n0[pidx(rr, rr)] += be[0];
-  }
+  for (int rr = 0; rr < 4; ++rr) m0[pidx(rr, rr)] += al[0];
   return p2;  // ||E||_F^2
 }
 

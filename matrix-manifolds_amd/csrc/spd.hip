@@ -117,11 +117,19 @@ __global__ void spd_count_bad_kernel(const int* __restrict__ bad, int n, int* __
 }
 
 // A = Li X Li^T, eigen-decompose, return s = sum log^2 clamp(w).
-template <typename T, int D, bool WITH_V, typename TL>
+// The second operand of a pair is X_j (CHOL = false: element-wise kernels) or its Cholesky factor
+// (CHOL = true: the all-pairs kernels, which have it in the node tables — cheaper congruence).
+template <typename T, int D, bool CHOL, typename TL>
+__device__ __forceinline__ void pair_a(const TL (&li)[Packed<D>::NP], const T (&yj)[Packed<D>::NP],
+                                       T (&a)[Packed<D>::NP]) {
+  if constexpr (CHOL) congr_chol<T, D>(li, yj, a); else congr_lower<T, D>(li, yj, a);
+}
+
+template <typename T, int D, bool WITH_V, bool CHOL = false, typename TL>
 __device__ __forceinline__ T pair_core(const TL (&li)[Packed<D>::NP], const T (&xj)[Packed<D>::NP], T wmin, T wmax,
                                        T (&w)[D], T (&lw)[D], T (&v)[D][D]) {
   T a[Packed<D>::NP];
-  congr_lower<T, D>(li, xj, a);
+  pair_a<T, D, CHOL>(li, xj, a);
   // eigenvalues only: sum log^2 w is second-order in the residual coupling -> tol2 = eps;
   // with eigenvectors: residual coupling <= 8 eps relative (gradient error ~1e-6, a quarter of
   // the wavefronts at the reference init would otherwise run a 4th sweep for the last bit)
@@ -178,8 +186,7 @@ template <int D> __device__ __forceinline__ float close_gate(const float (&a)[Pa
   }
 }
 template <int D> __device__ __forceinline__ void log_close(const float (&a)[Packed<D>::NP], float (&m0)[Packed<D>::NP]) {
-  float n0[Packed<D>::NP];
-  if constexpr (D == 3) log_series3<false>(a, m0, n0); else log_series4<false>(a, m0, n0);
+  if constexpr (D == 3) log_series3(a, m0); else log_series4(a, m0);
 }
 template <typename T, int D> __device__ __forceinline__ T log_cayley(const T (&a)[Packed<D>::NP], T (&m0)[Packed<D>::NP]) {
   if constexpr (D == 3) return log_cayley3<T>(a, m0); else return log_cayley4<T>(a, m0);
@@ -188,11 +195,11 @@ template <typename T, int D> __device__ __forceinline__ T log_cayley(const T (&a
 // Forward-only value of one pair.  SPD(3) in fp32 takes the closed-form (trigonometric)
 // eigenvalues; a wavefront in which any pair has a wide spectrum (w_max > 32 w_min, where
 // the closed form's absolute error would show in log w_min) re-solves with Jacobi.
-template <typename T, int D, typename TL>
+template <typename T, int D, bool CHOL = false, typename TL>
 __device__ __forceinline__ T pair_value(const TL (&li)[Packed<D>::NP], const T (&xj)[Packed<D>::NP], T wmin, T wmax) {
   if constexpr (D == 3 && std::is_same<T, float>::value) {
     float a[6], w[3], v[3][3];
-    congr_lower<float, 3>(li, xj, a);
+    pair_a<float, 3, CHOL>(li, xj, a);
     {  // close pairs (whole wavefront within ||A - I||_F <= 0.3): invariants-only series
       float e2;
       const float sq = logsq_series3(a, &e2);
@@ -216,7 +223,7 @@ __device__ __forceinline__ T pair_value(const TL (&li)[Packed<D>::NP], const T (
     // the Cayley-transform logarithm; Jacobi only if a pair of the wavefront has a very wide spectrum
     constexpr int NP = Packed<D>::NP;
     T a[NP], m0[NP];
-    congr_lower<T, D>(li, xj, a);
+    pair_a<T, D, CHOL>(li, xj, a);
     bool close = false;
     if constexpr (std::is_same<T, float>::value) close = !__any(!(close_gate<D>(a) <= 0.09f));
     if (__builtin_expect(close, 1)) {
@@ -226,10 +233,10 @@ __device__ __forceinline__ T pair_value(const TL (&li)[Packed<D>::NP], const T (
     const T gate = log_cayley<T, D>(a, m0);
     if (__builtin_expect(!__any(!(gate <= T(kCayleyGate))), 1)) return frob2<T, D>(m0);
     T w[D], lw[D], v[D][D];
-    return pair_core<T, D, false>(li, xj, wmin, wmax, w, lw, v);
+    return pair_core<T, D, false, CHOL>(li, xj, wmin, wmax, w, lw, v);
   } else {
     T w[D], lw[D], v[D][D];
-    return pair_core<T, D, false>(li, xj, wmin, wmax, w, lw, v);
+    return pair_core<T, D, false, CHOL>(li, xj, wmin, wmax, w, lw, v);
   }
 }
 
@@ -270,7 +277,7 @@ template <int TI, int BW = kBlock> inline dim3 fold_grid(int64_t n, int64_t rb, 
 // ------------------------------------------------------------------ forward
 template <typename T, int D, int TI>
 __global__ __launch_bounds__(kBlock) void spd_pdist_fwd_kernel(const T* __restrict__ nodeL,
-                                                               const T* __restrict__ nodeX, int n, int row_begin,
+                                                               const T* __restrict__ nodeY /* column operand: chol(X_j) */, int n, int row_begin,
                                                                int row_end, int squared, T wmin, T wmax,
                                                                T* __restrict__ out) {
   constexpr int NP = Packed<D>::NP;
@@ -289,7 +296,7 @@ __global__ __launch_bounds__(kBlock) void spd_pdist_fwd_kernel(const T* __restri
   for (int k = 0; k < D; ++k) xj[pidx(k, k)] = T(1);
   if (jin) {
 #pragma unroll
-    for (int k = 0; k < NP; ++k) xj[k] = nodeX[size_t(j) * NP + k];
+    for (int k = 0; k < NP; ++k) xj[k] = nodeY[size_t(j) * NP + k];
   }
   const int64_t base = pair_off(n, row_begin);
   T li_next[NP];  // wave-uniform -> scalar loads, issued one row ahead
@@ -302,7 +309,7 @@ __global__ __launch_bounds__(kBlock) void spd_pdist_fwd_kernel(const T* __restri
     const int inext = min(i + 1, i1 - 1);
 #pragma unroll
     for (int k = 0; k < NP; ++k) li_next[k] = nodeL[size_t(inext) * NP + k];
-    T s = Num<T>::max(pair_value<T, D>(li, xj, wmin, wmax), wmin);
+    T s = Num<T>::max(pair_value<T, D, true>(li, xj, wmin, wmax), wmin);
     if (!squared) s = Num<T>::sqrt(s);
     if (jin && j > i) out[pair_off(n, i) - base + (j - i - 1)] = s;
   }
@@ -328,7 +335,7 @@ __device__ __forceinline__ T upstream_of(T loaded, T dsq, bool valid, int square
 // ------------------------------------------------------------------ backward
 template <typename T, int D, int TI, int LOSS>
 __global__ __launch_bounds__(kBlock) void spd_pdist_bwd_kernel(const T* __restrict__ nodeL,
-                                                               const T* __restrict__ nodeX,
+                                                               const T* __restrict__ nodeY /* chol(X_j) */,
                                                                const T* __restrict__ nodeC,
                                                                const T* __restrict__ g, int n, int row_begin,
                                                                int row_end, int squared, T wmin, T wmax,
@@ -367,7 +374,7 @@ __global__ __launch_bounds__(kBlock) void spd_pdist_bwd_kernel(const T* __restri
   for (int k = 0; k < D; ++k) xj[pidx(k, k)] = T(1);
   if (jin) {
 #pragma unroll
-    for (int k = 0; k < NP; ++k) xj[k] = nodeX[size_t(j) * NP + k];
+    for (int k = 0; k < NP; ++k) xj[k] = nodeY[size_t(j) * NP + k];
   }
   const int64_t base = pair_off(n, row_begin);
   if (wave_live) {
@@ -391,7 +398,7 @@ __global__ __launch_bounds__(kBlock) void spd_pdist_bwd_kernel(const T* __restri
       bool series = false;
       auto jacobi_path = [&]() {
         T w[D], lw[D], v[D][D];
-        const T s = pair_core<T, D, true>(li, xj, wmin, wmax, w, lw, v);
+        const T s = pair_core<T, D, true, true>(li, xj, wmin, wmax, w, lw, v);
         gs = upstream_of<T, LOSS>(gs, s, jin && j > i, squared, wmin, sp, la, loss_acc, ds_acc);
         T cm[D];
 #pragma unroll
@@ -406,7 +413,7 @@ __global__ __launch_bounds__(kBlock) void spd_pdist_bwd_kernel(const T* __restri
         // Written as an if / else-if / else chain with complete arms so that the likely arm is the
         // fall-through (a taken branch per pair costs ~4 % of this kernel).
         T a[NP], m0[NP];
-        congr_lower<T, D>(li, xj, a);
+        congr_chol<T, D>(li, xj, a);
         auto finish = [&]() {
           T s = T(0);
           if (LOSS != MM_LOSS_NONE || __builtin_expect(!squared, 0)) s = frob2<T, D>(m0);
@@ -770,7 +777,7 @@ int spd_pdist_fwd_ti(Ws<T>& ws, int64_t n, int64_t rb, int64_t re, int squared, 
   {
     ProfScope prof(PROF_SPD_FWD, st);
     spd_pdist_fwd_kernel<T, D, TI><<<fold_grid<TI>(n, rb, re), dim3(kBlock), 0, st>>>(
-        ws.nodeL, ws.nodeX, int(n), int(rb), int(re), squared, T(wmin), T(wmax), out);
+        ws.nodeL, ws.nodeC, int(n), int(rb), int(re), squared, T(wmin), T(wmax), out);
   }
   MM_CHECK_LAUNCH();
   return MM_OK;
@@ -796,7 +803,7 @@ int spd_pdist_bwd_ti(Ws<T>& ws, const T* g, int64_t n, int64_t rb, int64_t re, i
   {
     ProfScope prof(PROF_SPD_BWD, st);
     spd_pdist_bwd_kernel<T, D, TI, LOSS><<<fold_grid<(kBlock / 64) * TI, 64>(n, rb, re), dim3(kBlock), 0, st>>>(
-        ws.nodeL, ws.nodeX, ws.nodeC, g, int(n), int(rb), int(re), squared, T(wmin), T(wmax), ws.accM, ws.accS, la);
+        ws.nodeL, ws.nodeC, ws.nodeC, g, int(n), int(rb), int(re), squared, T(wmin), T(wmax), ws.accM, ws.accS, la);
   }
   MM_CHECK_LAUNCH();
   return MM_OK;

@@ -30,6 +30,12 @@
 namespace mm {
 
 constexpr int kBlock = 256;  // 4 wavefronts
+#ifndef MM_BWD_WAVES
+#define MM_BWD_WAVES 4
+#endif
+// backward: wavefronts that share one 64-column tile (one column-side atomic flush per workgroup);
+// 4 where the LDS combine buffer of 8 would not fit (fp64, D = 5)
+template <typename T, int D> constexpr int bwd_waves() { return (sizeof(T) == 4 && D <= 4) ? MM_BWD_WAVES : 4; }
 constexpr int kSpdMaxD = 5;
 
 __host__ __device__ inline int64_t pair_off(int64_t n, int64_t row) { return row * (2 * n - row - 1) / 2; }
@@ -186,7 +192,12 @@ template <int D> __device__ __forceinline__ float close_gate(const float (&a)[Pa
   }
 }
 template <int D> __device__ __forceinline__ void log_close(const float (&a)[Packed<D>::NP], float (&m0)[Packed<D>::NP]) {
+#if defined(MM_ABL) && MM_ABL == 11  // ablation: no series (timing only)
+#pragma unroll
+  for (int k = 0; k < Packed<D>::NP; ++k) m0[k] = a[k];
+#else
   if constexpr (D == 3) log_series3(a, m0); else log_series4(a, m0);
+#endif
 }
 template <typename T, int D> __device__ __forceinline__ T log_cayley(const T (&a)[Packed<D>::NP], T (&m0)[Packed<D>::NP]) {
   if constexpr (D == 3) return log_cayley3<T>(a, m0); else return log_cayley4<T>(a, m0);
@@ -334,7 +345,7 @@ __device__ __forceinline__ T upstream_of(T loaded, T dsq, bool valid, int square
 
 // ------------------------------------------------------------------ backward
 template <typename T, int D, int TI, int LOSS>
-__global__ __launch_bounds__(kBlock) void spd_pdist_bwd_kernel(const T* __restrict__ nodeL,
+__global__ __launch_bounds__((64 * bwd_waves<T, D>())) void spd_pdist_bwd_kernel(const T* __restrict__ nodeL,
                                                                const T* __restrict__ nodeY /* chol(X_j) */,
                                                                const T* __restrict__ nodeC,
                                                                const T* __restrict__ g, int n, int row_begin,
@@ -342,12 +353,12 @@ __global__ __launch_bounds__(kBlock) void spd_pdist_bwd_kernel(const T* __restri
                                                                T* __restrict__ accM, T* __restrict__ accS,
                                                                LossArgs<T> la) {
   constexpr int NP = Packed<D>::NP;
-  constexpr int NW = kBlock / 64;
+  constexpr int NW = bwd_waves<T, D>();
   // LOSS != 0: `g` holds the TARGET (graph) squared distances; the upstream gradient of each pair is
   // derived in registers from the loss, and the loss / scale-gradient sums leave through la.slots.
   T sp = T(1), loss_acc = T(0), ds_acc = T(0);
   if constexpr (LOSS != MM_LOSS_NONE) sp = softplus_of(la.scale_raw);
-  // Workgroup tile: 64 columns x (4 waves x TI rows).  The four wavefronts share the columns, so
+  // Workgroup tile: 64 columns x (NW waves x TI rows).  The wavefronts share the columns, so
   // their column-side partial sums are combined through LDS and flushed with ONE set of atomics:
   // float atomics are a per-CU serial resource (~50 ns per wave instruction) and at TI = 8 the
   // 36 column-side atomics of the old 256-column tile cost as much CU time as its arithmetic.
@@ -435,7 +446,14 @@ __global__ __launch_bounds__(kBlock) void spd_pdist_bwd_kernel(const T* __restri
       }
       if (!series) jacobi_path();
       T cj[D][D];
+#if defined(MM_ABL) && MM_ABL == 10  // ablation: no column-side congruence (timing only)
+#pragma unroll
+      for (int r = 0; r < D; ++r)
+#pragma unroll
+        for (int c = 0; c < D; ++c) cj[r][c] = m[pidx(r, c)];
+#else
       lt_m_lt<T, D>(li, lc, m, cj);
+#endif
 #pragma unroll
       for (int r = 0; r < D; ++r)
 #pragma unroll
@@ -444,7 +462,13 @@ __global__ __launch_bounds__(kBlock) void spd_pdist_bwd_kernel(const T* __restri
         // transposing reduction: every lane ends up with the wavefront total of ONE entry of M
         constexpr int W = NP <= 8 ? 8 : 16;
         float tot;
+#if defined(MM_ABL) && MM_ABL == 8   // ablation: no cross-lane reduction (timing only)
+        tot = m[0];
+#pragma unroll
+        for (int k = 1; k < NP; ++k) tot += m[k];
+#else
         if constexpr (NP <= 8) tot = wave_sum_transposed8<NP>(m, lane); else tot = wave_sum_transposed16<NP>(m, lane);
+#endif
         const int k = transposed_index<W>(lane);
         if (lane < W && k < NP) redM[wave][i - i0][k] = tot;
       } else {
@@ -461,12 +485,12 @@ __global__ __launch_bounds__(kBlock) void spd_pdist_bwd_kernel(const T* __restri
     __builtin_amdgcn_wave_barrier();
     for (int t = lane; t < TI * NP; t += 64) {
       const int k = t / TI, il = t % TI;
-#if !defined(MM_ABL) || (MM_ABL != 7 && MM_ABL != 9)
+#if !defined(MM_ABL) || (MM_ABL != 7 && MM_ABL != 9 && MM_ABL != 12)
       if (i0 + il < i1) atomic_add(&accM[size_t(k) * n + i0 + il], redM[wave][il][k]);
 #endif
     }
   }
-  // column side: combine the four wavefronts, then 256-B contiguous atomics per entry
+  // column side: combine the wavefronts, then 256-B contiguous atomics per entry
 #pragma unroll
   for (int r = 0; r < D; ++r)
 #pragma unroll
@@ -492,7 +516,7 @@ __global__ __launch_bounds__(kBlock) void spd_pdist_bwd_kernel(const T* __restri
       T sum = colS[0][k][lane];
 #pragma unroll
       for (int wv = 1; wv < NW; ++wv) sum += colS[wv][k][lane];
-#if !defined(MM_ABL) || (MM_ABL != 7 && MM_ABL != 9)
+#if !defined(MM_ABL) || (MM_ABL != 7 && MM_ABL != 9 && MM_ABL != 13)
       atomic_add(&accS[size_t(k) * n + j], sum);
 #else
       if (sum == T(12345.678)) accS[j] = sum;
@@ -802,7 +826,7 @@ int spd_pdist_bwd_ti(Ws<T>& ws, const T* g, int64_t n, int64_t rb, int64_t re, i
                      hipStream_t st, LossArgs<T> la = LossArgs<T>{nullptr, T(1), T(0), 0, nullptr}) {
   {
     ProfScope prof(PROF_SPD_BWD, st);
-    spd_pdist_bwd_kernel<T, D, TI, LOSS><<<fold_grid<(kBlock / 64) * TI, 64>(n, rb, re), dim3(kBlock), 0, st>>>(
+    spd_pdist_bwd_kernel<T, D, TI, LOSS><<<fold_grid<bwd_waves<T, D>() * TI, 64>(n, rb, re), dim3(64 * bwd_waves<T, D>()), 0, st>>>(
         ws.nodeL, ws.nodeC, ws.nodeC, g, int(n), int(rb), int(re), squared, T(wmin), T(wmax), ws.accM, ws.accS, la);
   }
   MM_CHECK_LAUNCH();

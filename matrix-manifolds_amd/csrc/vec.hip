@@ -18,60 +18,13 @@
 #include "prof.hpp"
 #include "smallmat.hpp"
 #include "loss.hpp"
+#include "vecfn.hpp"
 
 namespace mm {
 
 constexpr int kVBlock = 256;
 constexpr int kVecMaxDim = 32;
-constexpr double kEps = 1e-8;  // utils.py:13 (both precisions)
-
 __host__ __device__ inline int64_t vpair_off(int64_t n, int64_t row) { return row * (2 * n - row - 1) / 2; }
-
-template <typename T> __device__ __forceinline__ T acos_t(T c);
-template <> __device__ __forceinline__ float acos_t<float>(float c) { return ::acosf(c); }
-template <> __device__ __forceinline__ double acos_t<double>(double c) { return ::acos(c); }
-
-// Forward value and d(out)/d(inner quantity) for one pair.
-//   Euclidean: q = sum (x_i - x_j)^2          out = max(q,eps) [sqrt]      base.py:29-33,56-57
-//   Lorentz  : q = -<x_i,x_j>_L               out = max(acosh(max(q,1)),eps)^2   lorentz.py:72-77
-//   Sphere   : q = <x_i,x_j>                  out = max(acos(clamp q),eps)^2     sphere.py:68-74
-template <typename T, int KIND> struct PairFn {
-  static __device__ __forceinline__ T value(T q, int squared) {
-    using N = Num<T>;
-    if (KIND == MM_EUCLIDEAN) {
-      const T s = N::max(q, T(kEps));
-      return squared ? s : N::sqrt(s);
-    } else if (KIND == MM_LORENTZ) {
-      const T t = N::max(q, T(1));
-      const T z = N::sqrt(N::fma(t, t, T(-1)));
-      const T d = N::max(N::log(t + z), T(kEps));
-      return squared ? d * d : d;
-    } else {
-      const T c = N::min(N::max(q, T(-1 + 1e-16)), T(1 - 1e-16));
-      const T th = N::max(acos_t<T>(c), T(kEps));
-      return squared ? th * th : th;
-    }
-  }
-  // d(out)/dq  (value clamps are gradient-transparent, as in the reference)
-  static __device__ __forceinline__ T dq(T q, int squared) {
-    using N = Num<T>;
-    if (KIND == MM_EUCLIDEAN) {
-      return squared ? T(1) : T(0.5) * N::rsqrt(N::max(q, T(kEps)));
-    } else if (KIND == MM_LORENTZ) {
-      const T t = N::max(q, T(1));
-      const T z = N::sqrt(N::fma(t, t, T(-1)));
-      const T d = N::max(N::log(t + z), T(kEps));
-      const T dz = T(1) / N::max(z, T(kEps));  // lorentz.py:134-138 (this clamp IS in the backward)
-      return squared ? (d + d) * dz : dz;
-    } else {
-      const T c = N::min(N::max(q, T(-1 + 1e-16)), T(1 - 1e-16));
-      const T th = N::max(acos_t<T>(c), T(kEps));
-      // the reference divides by sqrt(1-c^2) unguarded (inf at c = +-1); we floor it at eps
-      const T ds = T(-1) / N::max(N::sqrt(N::fma(-c, c, T(1))), T(kEps));
-      return squared ? (th + th) * ds : ds;
-    }
-  }
-};
 
 // q for one pair from register/scalar operands
 template <typename T, int KIND, int MP, typename TI>

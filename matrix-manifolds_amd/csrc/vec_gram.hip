@@ -18,6 +18,7 @@
 #include "../../include/mm_manifolds.h"
 #include "prof.hpp"
 #include "smallmat.hpp"
+#include "vecfn.hpp"
 
 namespace mm {
 
@@ -113,6 +114,205 @@ __global__ __launch_bounds__(64 * kGramWaves) void vec_gram_fwd_f64_kernel(const
   }
 }
 
+
+// ------------------------------------------------------------------ backward on the matrix cores
+// grad_j = sum_i w_ij * (d q_ij / d x_j) with w_ij = g_ij * dout/dq(q_ij): with W the (symmetric, zero-
+// diagonal) n x n matrix of the w_ij this is  ACC = W X  followed by the manifold's sign pattern
+// (Lorentz: -J, lorentz.py:72-77,134-138; sphere: identity, sphere.py:68-74) — two chained GEMMs with an
+// element-wise map between them, never materialising W:
+//   1. Q tile (32 i x 32 j) = (X_I S) X_J^T            v_mfma_f32_32x32x2_f32, K = m
+//   2. w = g * dout/dq(Q)                              on the accumulator registers (16 per lane)
+//   3. ACC_J (32 j x m) += W_IJ^T X_I                  v_mfma_f32_32x32x2_f32, K = 32 — the A operand is
+//      the accumulator of step 1 AS IT LIES: lane (j, h) holds W[i(s,h)][j] in register s, which is exactly
+//      A^T[j][k] for the k-order (s, h); the B operand is loaded in the same row order.  No shuffle, no LDS.
+// A wavefront owns one 32-column block J, keeps ACC_J in 16 accumulator registers and walks 32-row blocks
+// I; every ORDERED tile is visited (the mirrored tile feeds the other block's wavefront), so there is no
+// cross-lane reduction and a single flush per workgroup (4 wavefronts = 4 row sets, combined in LDS).
+// The upstream gradient of a tile is read in 128-B row segments of the pair vector: directly for tiles
+// above the diagonal (row i fixed per register), through a 32x33 LDS transpose for tiles below it (stored
+// under row j: contiguous in i).  Against the VALU kernel: per pair 2 x (m + m) FMAs and the strided
+// second read of g go away; what is left per pair is dout/dq (~15 VALU ops) and 4 B of HBM traffic.
+constexpr int kGramBwdWaves = 4;
+#ifndef MM_GRAM_BWD_MIN_WAVES
+#define MM_GRAM_BWD_MIN_WAVES 2   // measured: 2-3 wavefronts per SIMD (156 VGPRs) 39 us, 4 (128 VGPRs) 47 us
+#endif
+__device__ __forceinline__ int mfma_row(int q, int h) { return (q & 3) + 8 * (q >> 2) + 4 * h; }
+
+template <int KIND, int KS>  // KS = MFMA k-steps of the Gram = ceil(m / 2) rounded up to a dispatch class
+__global__ __launch_bounds__(64 * kGramBwdWaves) __attribute__((amdgpu_waves_per_eu(MM_GRAM_BWD_MIN_WAVES)))
+void vec_gram_bwd_f32_kernel(const float* __restrict__ x,
+                                                                            const float* __restrict__ g, int n, int m,
+                                                                            int row_begin, int row_end, int squared,
+                                                                            int tiles_per_wave, float* __restrict__ grad) {
+  __shared__ float sT[kGramBwdWaves][32][33];
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int r = lane & 31, h = lane >> 5;
+  const int nT = (n + 31) / 32;
+  const int jb = blockIdx.x, J = jb * 32;
+  // All loads are issued unconditionally from clamped addresses and masked afterwards: predicated loads
+  // compile to one exec-masked branch each and serialise the memory latency.  Element offsets are 32-bit
+  // (the launcher bounds n), so every load is base-SGPR + 32-bit VGPR offset.
+  using u32 = unsigned int;
+  const int rc = r < m ? r : m - 1;
+  float bJ[KS];  // B operand of the Gram: x[J + r][2 s + h]
+  {
+    const int jr = J + r;
+    const u32 xb = u32(jr < n ? jr : n - 1) * u32(m);
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      const int k = 2 * s + h;
+      const float v = x[xb + u32(k < m ? k : m - 1)];
+      bJ[s] = (jr < n && k < m) ? v : 0.f;
+    }
+  }
+  f32x16 accJ;
+#pragma unroll
+  for (int q = 0; q < 16; ++q) accJ[q] = 0.f;
+  const u32 base = u32(gpair_off(n, row_begin));
+  const u32 gmax = u32(gpair_off(n, row_end)) - base - 1u;  // last valid index of this shard's slice
+  auto goff = [&](int lo, int hi) -> u32 {  // pair (lo < hi) -> offset in this shard's slice, clamped
+    const u32 o = u32(lo) * u32(2 * n - lo - 1) / 2u - base + u32(hi - lo - 1);
+    return o > gmax ? gmax : o;   // (also catches the wrap-around of rows below row_begin)
+  };
+  const int j = J + r;
+  // Loads of a tile (operands of both GEMMs and the upstream gradients, in LOAD layout: for a tile below
+  // the diagonal the gradients arrive transposed), all issued before anything waits on them.
+  struct TileLoads { float xa[KS], bI[16], gr[16]; };
+  auto tile_block = [&](int t) { return (blockIdx.y * tiles_per_wave + t) * kGramBwdWaves + wave; };
+  // Offsets advance by additions: the rows of a tile in register order are row0 + {0,1,2,3, 8,...} (accumulator
+  // layout) or row0 + {0,2,4,...} (transposed load), and  off(row + 1) = off(row) + n - row - 2.
+  auto issue_xa = [&](int ib, TileLoads& L) {  // A operand of the Gram: rows of X_I, lane = row
+    const int ia = ib * 32 + r;
+    const u32 xo = u32(ia < n ? ia : n - 1) * u32(m);
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      const int k = 2 * s + h;
+      L.xa[s] = x[xo + u32(k < m ? k : m - 1)];
+    }
+  };
+  auto issue_bI = [&](int ib, TileLoads& L) {  // B operand of W^T X_I: rows I + mfma_row(s, h), lane = feature
+    const u32 xlast = u32(n - 1) * u32(m) + u32(rc);
+    u32 xo = u32(ib * 32 + 4 * h) * u32(m) + u32(rc);
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+      L.bI[s] = x[xo < xlast ? xo : xlast];
+      xo += u32((s & 3) == 3 ? 5 : 1) * u32(m);
+    }
+  };
+  auto issue_g = [&](int ib, TileLoads& L) {
+    const int I = ib * 32;
+    if (ib != jb) {
+      // above the diagonal (ib < jb): pair (i, j) lies in row i of the pair vector, contiguous in j — loaded
+      // straight into accumulator layout.  Below (ib > jb): pair (j', i) lies in row j', contiguous in i —
+      // loaded as the transposed tile (lane = i, register = j') and turned through LDS at use.
+      const bool upper = ib < jb;
+      const int A0 = upper ? I : J, B0 = upper ? J : I;  // row block / column block of the stored pairs
+      const int col = B0 + r < n ? B0 + r : n - 1;
+      int row = A0 + (upper ? 4 * h : h);
+      u32 o = u32(row) * u32(2 * n - row - 1) / 2u - base + u32(col - row - 1);
+#pragma unroll
+      for (int s = 0; s < 16; ++s) {
+        L.gr[s] = g[o > gmax ? gmax : o];  // (clamp: ragged edges and rows outside the shard, masked at use)
+        const int step = upper ? ((s & 3) == 3 ? 5 : 1) : 2;
+#pragma unroll
+        for (int d = 0; d < 5; ++d)
+          if (d < step) { o += u32(n - row - 2); ++row; }
+      }
+    } else {  // diagonal block: both orientations, element-wise gather (1 tile in nT)
+#pragma unroll
+      for (int s = 0; s < 16; ++s) {
+        const int i = I + mfma_row(s, h);
+        const int lo = i < j ? i : j, hi = i < j ? j : i;
+        L.gr[s] = g[goff(lo, hi < n ? (hi > lo ? hi : lo + 1) : n - 1)];
+      }
+    }
+  };
+  // (Requesting the next tile's operands while the current tile computes was measured SLOWER in both
+  // forms tried — a second register set: 240 VGPRs, 50 us; reusing each set right after its last use:
+  // 195 VGPRs, 42 us — against 37 us for this plain order at 162 VGPRs / 3 wavefronts per SIMD.)
+  for (int t = 0; t < tiles_per_wave; ++t) {
+    const int ib = tile_block(t);
+    if (ib >= nT) break;  // wave-uniform
+    const int I = ib * 32;
+    TileLoads cur;
+    issue_g(ib, cur);
+    issue_xa(ib, cur);
+    issue_bI(ib, cur);
+    // upstream gradients in accumulator layout: element (i = I + row(s,h), j = J + r).  Tiles that lie
+    // entirely inside the matrix and the shard (all but the ragged edges) need no masking at all.
+    const bool upper = ib < jb;
+    const int A0 = upper ? I : J;
+    const bool interior = ib != jb && I + 32 <= n && J + 32 <= n && A0 >= row_begin && A0 + 32 <= row_end;
+    float gv[16];
+    if (__builtin_expect(interior, 1)) {
+#pragma unroll
+      for (int s = 0; s < 16; ++s) gv[s] = cur.gr[s];
+    } else if (ib != jb) {
+      const int col = (upper ? J : I) + r;
+#pragma unroll
+      for (int s = 0; s < 16; ++s) {
+        const int row = A0 + (upper ? mfma_row(s, h) : 2 * s + h);
+        const bool valid = col < n && row >= row_begin && row < row_end;  // row < col always
+        gv[s] = valid ? cur.gr[s] : 0.f;
+      }
+    } else {
+#pragma unroll
+      for (int s = 0; s < 16; ++s) {
+        const int i = I + mfma_row(s, h);
+        const int lo = i < j ? i : j, hi = i < j ? j : i;
+        const bool valid = i != j && hi < n && lo >= row_begin && lo < row_end;
+        gv[s] = valid ? cur.gr[s] : 0.f;
+      }
+    }
+    if (ib > jb) {  // transposed load -> accumulator layout
+#pragma unroll
+      for (int u = 0; u < 16; ++u) sT[wave][2 * u + h][r] = gv[u];
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+      for (int s = 0; s < 16; ++s) gv[s] = sT[wave][r][mfma_row(s, h)];
+      __builtin_amdgcn_wave_barrier();
+    }
+    // 1. Gram tile
+    f32x16 q;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) q[k] = 0.f;
+    {
+      const bool ia_ok = I + r < n;
+#pragma unroll
+      for (int s = 0; s < KS; ++s) {
+        const int k = 2 * s + h;
+        float a = (ia_ok && k < m) ? cur.xa[s] : 0.f;
+        if (KIND == MM_LORENTZ && k != 0) a = -a;
+        q = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bJ[s], q, 0, 0, 0);
+      }
+    }
+    // 2.-3. w = g * dout/dq(Q) on the accumulator registers; ACC_J += W^T X_I
+    const bool rows_in = I + 32 <= n;
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+      const float w = gv[s] * PairFn<float, KIND>::dq(q[s], squared);
+      const float b = ((rows_in || I + mfma_row(s, h) < n) && r < m) ? cur.bI[s] : 0.f;
+      accJ = __builtin_amdgcn_mfma_f32_32x32x2f32(w, b, accJ, 0, 0, 0);
+    }
+  }
+  // combine the workgroup's wavefronts (same J, different rows) and flush once
+#pragma unroll
+  for (int q = 0; q < 16; ++q) sT[wave][mfma_row(q, h)][r] = accJ[q];
+  __syncthreads();
+  for (int e = threadIdx.x; e < 32 * 32; e += 64 * kGramBwdWaves) {
+    const int jj = e >> 5, c = e & 31;
+    if (c < m && J + jj < n) {
+      float sum = sT[0][jj][c];
+#pragma unroll
+      for (int w = 1; w < kGramBwdWaves; ++w) sum += sT[w][jj][c];
+      if (KIND == MM_LORENTZ && c != 0) sum = -sum;  // d q / d x_j = -J x_i
+      atomic_add(&grad[size_t(J + jj) * m + c], sum);
+    }
+  }
+}
+
 }  // namespace mm
 
 using namespace mm;
@@ -150,5 +350,49 @@ extern "C" int mm_vec_pdist_fwd_gram(int dtype, int kind, const void* x, int64_t
     }
   }
   hipError_t e = hipGetLastError();
+  return e == hipSuccess ? MM_OK : int(e);
+}
+
+extern "C" int mm_vec_pdist_bwd_gram(int dtype, int kind, const void* x, const void* g, int64_t n, int m,
+                                     int64_t row_begin, int64_t row_end, int squared, void* grad_x,
+                                     mm_stream_t stream) {
+  if (!x || !grad_x || n < 1 || m < 1 || row_begin < 0 || row_end > n || row_begin > row_end || n > (1 << 30))
+    return MM_ERR_ARG;
+  // 32-bit element offsets inside the kernel: n (n - 1) / 2 pairs and the row products must fit
+  if (dtype != MM_F32 || (kind != MM_LORENTZ && kind != MM_SPHERE) || m > 32 || n > 32768) return MM_ERR_UNSUPPORTED;
+  if (!g && mm_pair_offset(n, row_end) > mm_pair_offset(n, row_begin)) return MM_ERR_ARG;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  hipError_t e = hipMemsetAsync(grad_x, 0, sizeof(float) * size_t(n) * m, st);
+  if (e != hipSuccess) return int(e);
+  if (mm_pair_offset(n, row_end) == mm_pair_offset(n, row_begin)) return MM_OK;
+  const int nT = int((n + 31) / 32);
+  // 16 row blocks per workgroup (4 per wavefront) unless that leaves the chip under-filled
+  int tpw = 4;
+  while (tpw > 1 && int64_t(nT) * ((nT + kGramBwdWaves * tpw - 1) / (kGramBwdWaves * tpw)) < 768) tpw >>= 1;
+  const dim3 grid(nT, (nT + kGramBwdWaves * tpw - 1) / (kGramBwdWaves * tpw));
+  const dim3 block(64 * kGramBwdWaves);
+  auto* xp = static_cast<const float*>(x);
+  auto* gp = static_cast<const float*>(g);
+  auto* op = static_cast<float*>(grad_x);
+  {
+    ProfScope prof(PROF_VEC_BWD, st);
+#define MM_GRAM_BWD(KIND_, KS_)                                                                                  \
+  vec_gram_bwd_f32_kernel<KIND_, KS_><<<grid, block, 0, st>>>(xp, gp, int(n), m, int(row_begin), int(row_end), \
+                                                             squared, tpw, op)
+#define MM_GRAM_BWD_KS(KIND_)                        \
+  do {                                               \
+    const int ks = (m + 1) / 2;                      \
+    if (ks <= 2) MM_GRAM_BWD(KIND_, 2);              \
+    else if (ks <= 4) MM_GRAM_BWD(KIND_, 4);         \
+    else if (ks <= 6) MM_GRAM_BWD(KIND_, 6);         \
+    else if (ks <= 8) MM_GRAM_BWD(KIND_, 8);         \
+    else if (ks <= 12) MM_GRAM_BWD(KIND_, 12);       \
+    else MM_GRAM_BWD(KIND_, 16);                     \
+  } while (0)
+    if (kind == MM_LORENTZ) MM_GRAM_BWD_KS(MM_LORENTZ); else MM_GRAM_BWD_KS(MM_SPHERE);
+#undef MM_GRAM_BWD_KS
+#undef MM_GRAM_BWD
+  }
+  e = hipGetLastError();
   return e == hipSuccess ? MM_OK : int(e);
 }

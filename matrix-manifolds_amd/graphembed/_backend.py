@@ -47,6 +47,7 @@ SIGNATURES = {
     'mm_vec_pdist_fwd': (_i, [_i, _i, _vp, _i64, _i, _i64, _i64, _i, _vp, _vp]),
     'mm_vec_pdist_fwd_gram': (_i, [_i, _i, _vp, _i64, _i, _i64, _i64, _i, _vp, _vp]),
     'mm_vec_pdist_bwd': (_i, [_i, _i, _vp, _vp, _i64, _i, _i64, _i64, _i, _vp, _vp, _vp]),
+    'mm_vec_pdist_bwd_gram': (_i, [_i, _i, _vp, _vp, _i64, _i, _i64, _i64, _i, _vp, _vp]),
     'mm_vec_pdist_loss': (_i, [_i, _i, _i, _vp, _vp, _vp, _i64, _i, _i64, _i64, _dbl, _dbl, _i, _vp, _vp, _vp, _vp]),
     'mm_vec_dist': (_i, [_i, _i, _vp, _vp, _vp, _i64, _i, _i, _vp, _vp, _vp, _vp]),
     'mm_vec_map': (_i, [_i, _i, _i, _vp, _vp, _vp, _i64, _i, _vp, _vp]),

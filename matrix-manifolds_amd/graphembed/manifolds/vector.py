@@ -19,6 +19,7 @@ class _VecPdist(torch.autograd.Function):
         npairs = B.pair_offset(n, row_end) - B.pair_offset(n, row_begin)
         ctx.save_for_backward(xc)
         ctx.args = (kind, m, squared, row_begin, row_end, x.shape)
+        ctx.use_gram = use_gram
         ctx.empty = npairs == 0
         if ctx.empty:
             return xc.new_empty(0)
@@ -40,11 +41,16 @@ class _VecPdist(torch.autograd.Function):
         n = xc.shape[0]
         dt = B.dtype_code(xc)
         with torch.cuda.device(xc.device):
-            ws = torch.empty(lib.raw('mm_vec_pdist_ws_bytes')(dt, n, m), dtype=torch.uint8,
-                             device=xc.device)
             grad = torch.empty_like(xc)
-            lib.call('mm_vec_pdist_bwd', dt, kind, B.ptr(xc), B.ptr(g), n, m, row_begin, row_end,
-                     int(squared), B.ptr(grad), B.ptr(ws), B.stream_of(xc))
+            if ctx.use_gram and xc.dtype == torch.float32:
+                # matrix-core backward (inner-product manifolds, fp32): W^T X, no workspace
+                lib.call('mm_vec_pdist_bwd_gram', dt, kind, B.ptr(xc), B.ptr(g), n, m, row_begin,
+                         row_end, int(squared), B.ptr(grad), B.stream_of(xc))
+            else:
+                ws = torch.empty(lib.raw('mm_vec_pdist_ws_bytes')(dt, n, m), dtype=torch.uint8,
+                                 device=xc.device)
+                lib.call('mm_vec_pdist_bwd', dt, kind, B.ptr(xc), B.ptr(g), n, m, row_begin, row_end,
+                         int(squared), B.ptr(grad), B.ptr(ws), B.stream_of(xc))
         return grad.reshape(shape), None, None, None, None, None, None
 
 

@@ -14,6 +14,8 @@
 // The MFMA Gram form of the forward lives in vec_gram.hip.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "../../include/mm_manifolds.h"
 #include "prof.hpp"
 #include "smallmat.hpp"
@@ -430,6 +432,12 @@ constexpr int pad_dim(int m) { return m <= 4 ? 4 : m <= 8 ? 8 : m <= 12 ? 12 : m
   else if ((dtype) == MM_F64) { using T = double; __VA_ARGS__ }  \
   else return MM_ERR_ARG;
 
+// matrix-core path of the fused objective (vec_gram.hip)
+bool vec_gram_supports(int dtype, int kind, int64_t n, int m);
+int vec_gram_loss(int kind, int loss_kind, const float* x, const float* target, const float* scale_raw, int64_t n, int m,
+                  int64_t row_begin, int64_t row_end, double alpha, double eps, int terms, float* loss_out, float* grad,
+                  float* slots, hipStream_t st);
+
 }  // namespace mm
 
 using namespace mm;
@@ -475,6 +483,10 @@ int mm_vec_pdist_loss(int dtype, int kind, int loss_kind, const void* x, const v
   if (loss_kind == MM_LOSS_QUOTIENT && !(terms & 3)) return MM_ERR_ARG;
   if (!target && mm_pair_offset(n, row_end) > mm_pair_offset(n, row_begin)) return MM_ERR_ARG;
   hipStream_t st = static_cast<hipStream_t>(stream);
+  if (vec_gram_supports(dtype, kind, n, m) && !std::getenv("MM_VEC_LOSS_VALU"))  // inner-product manifolds, fp32: MFMA
+    return vec_gram_loss(kind, loss_kind, static_cast<const float*>(x), static_cast<const float*>(target),
+                         static_cast<const float*>(scale_raw), n, m, row_begin, row_end, alpha, eps, terms,
+                         static_cast<float*>(loss_out), static_cast<float*>(grad_x), static_cast<float*>(ws), st);
   MMV_DISPATCH_T(dtype, MMV_DISPATCH_KIND(kind, MMV_DISPATCH_MP(m, (vec_loss_t<T, KIND, MP>(
       loss_kind, static_cast<const T*>(x), static_cast<const T*>(target), static_cast<const T*>(scale_raw), n, m,
       row_begin, row_end, alpha, eps, terms, static_cast<T*>(loss_out), static_cast<T*>(grad_x), ws, st)))))

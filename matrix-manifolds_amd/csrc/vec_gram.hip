@@ -19,6 +19,7 @@
 #include "prof.hpp"
 #include "smallmat.hpp"
 #include "vecfn.hpp"
+#include "loss.hpp"
 
 namespace mm {
 
@@ -138,12 +139,14 @@ constexpr int kGramBwdWaves = 4;
 #endif
 __device__ __forceinline__ int mfma_row(int q, int h) { return (q & 3) + 8 * (q >> 2) + 4 * h; }
 
-template <int KIND, int KS>  // KS = MFMA k-steps of the Gram = ceil(m / 2) rounded up to a dispatch class
+// LOSS != 0 (mm_vec_pdist_loss): `g` holds the TARGET squared distances; the loss term, its derivative and
+// the upstream gradient of each pair are formed on the accumulator registers (loss.hpp).  Entries outside
+// the matrix / the shard carry a NaN sentinel instead of 0 through the layout change.
+template <int KIND, int KS, int LOSS>  // KS = MFMA k-steps of the Gram = ceil(m / 2) rounded up to a dispatch class
 __global__ __launch_bounds__(64 * kGramBwdWaves) __attribute__((amdgpu_waves_per_eu(MM_GRAM_BWD_MIN_WAVES)))
-void vec_gram_bwd_f32_kernel(const float* __restrict__ x,
-                                                                            const float* __restrict__ g, int n, int m,
-                                                                            int row_begin, int row_end, int squared,
-                                                                            int tiles_per_wave, float* __restrict__ grad) {
+void vec_gram_bwd_f32_kernel(const float* __restrict__ x, const float* __restrict__ g, int n, int m, int row_begin,
+                             int row_end, int squared, int tiles_per_wave, float* __restrict__ grad,
+                             LossArgs<float> la) {
   __shared__ float sT[kGramBwdWaves][32][33];
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int r = lane & 31, h = lane >> 5;
@@ -168,6 +171,9 @@ void vec_gram_bwd_f32_kernel(const float* __restrict__ x,
   f32x16 accJ;
 #pragma unroll
   for (int q = 0; q < 16; ++q) accJ[q] = 0.f;
+  float sp = 1.f, loss_acc = 0.f, ds_acc = 0.f;
+  if constexpr (LOSS != MM_LOSS_NONE) sp = softplus_of(la.scale_raw);
+  const float kInvalid = LOSS != MM_LOSS_NONE ? __builtin_nanf("") : 0.f;
   const u32 base = u32(gpair_off(n, row_begin));
   const u32 gmax = u32(gpair_off(n, row_end)) - base - 1u;  // last valid index of this shard's slice
   auto goff = [&](int lo, int hi) -> u32 {  // pair (lo < hi) -> offset in this shard's slice, clamped
@@ -253,7 +259,7 @@ void vec_gram_bwd_f32_kernel(const float* __restrict__ x,
       for (int s = 0; s < 16; ++s) {
         const int row = A0 + (upper ? mfma_row(s, h) : 2 * s + h);
         const bool valid = col < n && row >= row_begin && row < row_end;  // row < col always
-        gv[s] = valid ? cur.gr[s] : 0.f;
+        gv[s] = valid ? cur.gr[s] : kInvalid;
       }
     } else {
 #pragma unroll
@@ -261,7 +267,7 @@ void vec_gram_bwd_f32_kernel(const float* __restrict__ x,
         const int i = I + mfma_row(s, h);
         const int lo = i < j ? i : j, hi = i < j ? j : i;
         const bool valid = i != j && hi < n && lo >= row_begin && lo < row_end;
-        gv[s] = valid ? cur.gr[s] : 0.f;
+        gv[s] = valid ? cur.gr[s] : kInvalid;
       }
     }
     if (ib > jb) {  // transposed load -> accumulator layout
@@ -292,7 +298,19 @@ void vec_gram_bwd_f32_kernel(const float* __restrict__ x,
     const bool rows_in = I + 32 <= n;
 #pragma unroll
     for (int s = 0; s < 16; ++s) {
-      const float w = gv[s] * PairFn<float, KIND>::dq(q[s], squared);
+      float w;
+      if constexpr (LOSS == MM_LOSS_NONE) {
+        w = gv[s] * PairFn<float, KIND>::dq(q[s], squared);
+      } else {
+        const bool ok = gv[s] == gv[s];
+        const float d2 = PairFn<float, KIND>::value(q[s], 1);
+        float dldm;
+        const float l = loss_term<float, LOSS>(sp * d2, gv[s], la, dldm);
+        const bool once = ok && (ib < jb || (ib == jb && I + mfma_row(s, h) < j));  // each unordered pair once
+        loss_acc += once ? l : 0.f;
+        ds_acc += once ? dldm * d2 : 0.f;
+        w = ok ? dldm * sp * PairFn<float, KIND>::dq(q[s], 1) : 0.f;
+      }
       const float b = ((rows_in || I + mfma_row(s, h) < n) && r < m) ? cur.bI[s] : 0.f;
       accJ = __builtin_amdgcn_mfma_f32_32x32x2f32(w, b, accJ, 0, 0, 0);
     }
@@ -300,7 +318,22 @@ void vec_gram_bwd_f32_kernel(const float* __restrict__ x,
   // combine the workgroup's wavefronts (same J, different rows) and flush once
 #pragma unroll
   for (int q = 0; q < 16; ++q) sT[wave][mfma_row(q, h)][r] = accJ[q];
+  __shared__ float lossW[kGramBwdWaves][2];
+  if constexpr (LOSS != MM_LOSS_NONE) {
+    const float l = wave_sum(loss_acc), d = wave_sum(ds_acc);
+    if (lane == 0) { lossW[wave][0] = l; lossW[wave][1] = d; }
+  }
   __syncthreads();
+  if constexpr (LOSS != MM_LOSS_NONE) {
+    if (threadIdx.x == 0) {
+      float l = 0.f, d = 0.f;
+#pragma unroll
+      for (int w = 0; w < kGramBwdWaves; ++w) { l += lossW[w][0]; d += lossW[w][1]; }
+      const int slot = (blockIdx.x + blockIdx.y * gridDim.x) & (kLossSlots - 1);
+      atomic_add(&la.slots[slot], l);
+      atomic_add(&la.slots[kLossSlots + slot], d);
+    }
+  }
   for (int e = threadIdx.x; e < 32 * 32; e += 64 * kGramBwdWaves) {
     const int jj = e >> 5, c = e & 31;
     if (c < m && J + jj < n) {
@@ -353,16 +386,18 @@ extern "C" int mm_vec_pdist_fwd_gram(int dtype, int kind, const void* x, int64_t
   return e == hipSuccess ? MM_OK : int(e);
 }
 
-extern "C" int mm_vec_pdist_bwd_gram(int dtype, int kind, const void* x, const void* g, int64_t n, int m,
-                                     int64_t row_begin, int64_t row_end, int squared, void* grad_x,
-                                     mm_stream_t stream) {
-  if (!x || !grad_x || n < 1 || m < 1 || row_begin < 0 || row_end > n || row_begin > row_end || n > (1 << 30))
-    return MM_ERR_ARG;
-  // 32-bit element offsets inside the kernel: n (n - 1) / 2 pairs and the row products must fit
-  if (dtype != MM_F32 || (kind != MM_LORENTZ && kind != MM_SPHERE) || m > 32 || n > 32768) return MM_ERR_UNSUPPORTED;
-  if (!g && mm_pair_offset(n, row_end) > mm_pair_offset(n, row_begin)) return MM_ERR_ARG;
-  hipStream_t st = static_cast<hipStream_t>(stream);
-  hipError_t e = hipMemsetAsync(grad_x, 0, sizeof(float) * size_t(n) * m, st);
+namespace mm {
+
+__global__ void gram_loss_finalize_kernel(float* __restrict__ slots, const float* __restrict__ scale_raw,
+                                          float* __restrict__ loss_out) {
+  loss_finalize<float>(slots, scale_raw, loss_out);
+}
+
+// Shared launcher of the matrix-core backward: plain (loss_kind = MM_LOSS_NONE, `g` = upstream gradients)
+// or fused objective (`g` = targets; la.slots must be zeroed [2][kLossSlots] floats).
+int vec_gram_bwd_launch(int kind, int loss_kind, const float* xp, const float* gp, int64_t n, int m, int64_t row_begin,
+                        int64_t row_end, int squared, float* op, LossArgs<float> la, hipStream_t st) {
+  hipError_t e = hipMemsetAsync(op, 0, sizeof(float) * size_t(n) * m, st);
   if (e != hipSuccess) return int(e);
   if (mm_pair_offset(n, row_end) == mm_pair_offset(n, row_begin)) return MM_OK;
   const int nT = int((n + 31) / 32);
@@ -371,28 +406,64 @@ extern "C" int mm_vec_pdist_bwd_gram(int dtype, int kind, const void* x, const v
   while (tpw > 1 && int64_t(nT) * ((nT + kGramBwdWaves * tpw - 1) / (kGramBwdWaves * tpw)) < 768) tpw >>= 1;
   const dim3 grid(nT, (nT + kGramBwdWaves * tpw - 1) / (kGramBwdWaves * tpw));
   const dim3 block(64 * kGramBwdWaves);
-  auto* xp = static_cast<const float*>(x);
-  auto* gp = static_cast<const float*>(g);
-  auto* op = static_cast<float*>(grad_x);
   {
     ProfScope prof(PROF_VEC_BWD, st);
-#define MM_GRAM_BWD(KIND_, KS_)                                                                                  \
-  vec_gram_bwd_f32_kernel<KIND_, KS_><<<grid, block, 0, st>>>(xp, gp, int(n), m, int(row_begin), int(row_end), \
-                                                             squared, tpw, op)
-#define MM_GRAM_BWD_KS(KIND_)                        \
-  do {                                               \
-    const int ks = (m + 1) / 2;                      \
-    if (ks <= 2) MM_GRAM_BWD(KIND_, 2);              \
-    else if (ks <= 4) MM_GRAM_BWD(KIND_, 4);         \
-    else if (ks <= 6) MM_GRAM_BWD(KIND_, 6);         \
-    else if (ks <= 8) MM_GRAM_BWD(KIND_, 8);         \
-    else if (ks <= 12) MM_GRAM_BWD(KIND_, 12);       \
-    else MM_GRAM_BWD(KIND_, 16);                     \
+#define MM_GRAM_BWD(KIND_, KS_, LOSS_)                                                                        \
+  vec_gram_bwd_f32_kernel<KIND_, KS_, LOSS_><<<grid, block, 0, st>>>(xp, gp, int(n), m, int(row_begin),     \
+                                                                    int(row_end), squared, tpw, op, la)
+#define MM_GRAM_BWD_KS(KIND_, LOSS_)                        \
+  do {                                                      \
+    const int ks = (m + 1) / 2;                             \
+    if (ks <= 2) MM_GRAM_BWD(KIND_, 2, LOSS_);              \
+    else if (ks <= 4) MM_GRAM_BWD(KIND_, 4, LOSS_);         \
+    else if (ks <= 6) MM_GRAM_BWD(KIND_, 6, LOSS_);         \
+    else if (ks <= 8) MM_GRAM_BWD(KIND_, 8, LOSS_);         \
+    else if (ks <= 12) MM_GRAM_BWD(KIND_, 12, LOSS_);       \
+    else MM_GRAM_BWD(KIND_, 16, LOSS_);                     \
   } while (0)
-    if (kind == MM_LORENTZ) MM_GRAM_BWD_KS(MM_LORENTZ); else MM_GRAM_BWD_KS(MM_SPHERE);
+#define MM_GRAM_BWD_LOSS(KIND_)                                                  \
+  do {                                                                           \
+    if (loss_kind == MM_LOSS_NONE) MM_GRAM_BWD_KS(KIND_, MM_LOSS_NONE);          \
+    else if (loss_kind == MM_LOSS_STRESS) MM_GRAM_BWD_KS(KIND_, MM_LOSS_STRESS); \
+    else MM_GRAM_BWD_KS(KIND_, MM_LOSS_QUOTIENT);                                \
+  } while (0)
+    if (kind == MM_LORENTZ) MM_GRAM_BWD_LOSS(MM_LORENTZ); else MM_GRAM_BWD_LOSS(MM_SPHERE);
+#undef MM_GRAM_BWD_LOSS
 #undef MM_GRAM_BWD_KS
 #undef MM_GRAM_BWD
   }
   e = hipGetLastError();
   return e == hipSuccess ? MM_OK : int(e);
+}
+
+// mm_vec_pdist_loss on the matrix cores (called from vec.hip when the configuration qualifies)
+bool vec_gram_supports(int dtype, int kind, int64_t n, int m) {
+  return dtype == MM_F32 && (kind == MM_LORENTZ || kind == MM_SPHERE) && m <= 32 && n <= 32768;
+}
+int vec_gram_loss(int kind, int loss_kind, const float* x, const float* target, const float* scale_raw, int64_t n, int m,
+                  int64_t row_begin, int64_t row_end, double alpha, double eps, int terms, float* loss_out, float* grad,
+                  float* slots, hipStream_t st) {
+  hipError_t e = hipMemsetAsync(slots, 0, sizeof(float) * 2 * kLossSlots, st);
+  if (e != hipSuccess) return int(e);
+  LossArgs<float> la{scale_raw, float(alpha), float(eps), terms, slots};
+  const int rc = vec_gram_bwd_launch(kind, loss_kind, x, target, n, m, row_begin, row_end, 1, grad, la, st);
+  if (rc) return rc;
+  gram_loss_finalize_kernel<<<dim3(1), dim3(64), 0, st>>>(slots, scale_raw, loss_out);
+  e = hipGetLastError();
+  return e == hipSuccess ? MM_OK : int(e);
+}
+
+}  // namespace mm
+
+extern "C" int mm_vec_pdist_bwd_gram(int dtype, int kind, const void* x, const void* g, int64_t n, int m,
+                                     int64_t row_begin, int64_t row_end, int squared, void* grad_x,
+                                     mm_stream_t stream) {
+  if (!x || !grad_x || n < 1 || m < 1 || row_begin < 0 || row_end > n || row_begin > row_end || n > (1 << 30))
+    return MM_ERR_ARG;
+  // 32-bit element offsets inside the kernel: n (n - 1) / 2 pairs and the row products must fit
+  if (!vec_gram_supports(dtype, kind, n, m)) return MM_ERR_UNSUPPORTED;
+  if (!g && mm_pair_offset(n, row_end) > mm_pair_offset(n, row_begin)) return MM_ERR_ARG;
+  return vec_gram_bwd_launch(kind, MM_LOSS_NONE, static_cast<const float*>(x), static_cast<const float*>(g), n, m,
+                             row_begin, row_end, squared, static_cast<float*>(grad_x),
+                             LossArgs<float>{nullptr, 1.f, 0.f, 0, nullptr}, static_cast<hipStream_t>(stream));
 }

@@ -228,6 +228,20 @@ int mm_grass_pdist_bwd(int dtype, const void* x, const void* g, int64_t n, int N
                        int64_t row_begin, int64_t row_end, int squared, void* grad_x, void* ws,
                        mm_stream_t stream);
 
+/* ---- product embeddings ---------------------------------------------------- */
+/* Objective of a product embedding in one pass over the pair vectors (the element-wise part of
+ * train.py:213-217 for several factors): with d2[k] the squared pair distances of factor k,
+ *   m = sum_k softplus(*scale_raw[k]) * d2[k]      (modules.py:84-88)
+ *   loss = objective(target, m)                    (objectives.py:16-45; kinds as mm_spd_pdist_loss)
+ * writes g_out[k] = dloss/dm * softplus(scale_k) (the upstream gradient of factor k's pdist backward)
+ * and loss_out = { loss, dloss/dscale_raw[0], ..., dloss/dscale_raw[nf-1] }.
+ * d2, scale_raw, g_out are HOST arrays of nf device pointers (nf <= mm_product_max_factors()). */
+int mm_product_max_factors(void);
+size_t mm_product_loss_ws_bytes(int dtype, int nf);
+int mm_product_loss(int dtype, int loss_kind, int nf, const void* const* d2, const void* target,
+                    const void* const* scale_raw, int64_t npairs, double alpha, double eps, int terms,
+                    void* const* g_out, void* loss_out, void* ws, mm_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

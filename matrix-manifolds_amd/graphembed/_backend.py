@@ -30,6 +30,10 @@ SIGNATURES = {
     'mm_prof_collect': (_i, [_i, _c.POINTER(_i64), _c.POINTER(_dbl)]),
     'mm_pair_offset': (_i64, [_i64, _i64]),
     'mm_shard_rows': (_i, [_i64, _i, _i, _c.POINTER(_i64), _c.POINTER(_i64)]),
+    'mm_product_max_factors': (_i, []),
+    'mm_product_loss_ws_bytes': (_sz, [_i, _i]),
+    'mm_product_loss': (_i, [_i, _i, _i, _c.POINTER(_vp), _vp, _c.POINTER(_vp), _i64, _dbl, _dbl, _i,
+                              _c.POINTER(_vp), _vp, _vp, _vp]),
     'mm_spd_max_dim': (_i, []),
     'mm_spd_pdist_ws_bytes': (_sz, [_i, _i64, _i]),
     'mm_spd_pdist_fwd': (_i, [_i, _vp, _i64, _i, _i64, _i64, _i, _dbl, _dbl, _vp, _vp, _i, _vp]),
@@ -157,3 +161,12 @@ def shard_rows(n, world, rank):
     rb = 0 if rank == 0 else first_row_at_or_after(P * rank // world)
     re = n if rank == world - 1 else first_row_at_or_after(P * (rank + 1) // world)
     return rb, re
+
+
+def ptr_array(tensors):
+    """Host array of device pointers (the `const void* const*` arguments of the C ABI)."""
+    import ctypes
+    arr = (ctypes.c_void_p * len(tensors))()
+    for k, t in enumerate(tensors):
+        arr[k] = t.data_ptr()
+    return arr

@@ -5,6 +5,57 @@ import torch
 from torch.nn.functional import softplus
 
 
+def _max_product_factors():
+    from graphembed import _backend as B
+    return B.lib().raw('mm_product_max_factors')()
+
+
+class _ProductLoss(torch.autograd.Function):
+    """Objective of a product embedding with the element-wise part in ONE kernel (mm_product_loss):
+    per-factor pdist forward kernels -> loss, per-factor upstream gradients and scale gradients ->
+    per-factor pdist backward kernels.  Replaces ~25 framework kernels per step of
+    `objective_fn(gdists, embedding.compute_dists(idx)); loss.backward()` (modules.py:84-105)."""
+
+    @staticmethod
+    def forward(ctx, target, spec, rows, manifolds, *params):
+        from graphembed import _backend as B
+        k = len(manifolds)
+        xs, scales = params[:k], params[k:]
+        B.require_gpu(*xs)
+        lib = B.lib()
+        kind, alpha, eps, terms = spec
+        dtype = xs[0].dtype
+        with torch.enable_grad():
+            leaves = [x.detach().requires_grad_() for x in xs]
+            d2 = [man.pdist(x, squared=True, **({} if rows is None else {'rows': rows}))
+                  for man, x in zip(manifolds, leaves)]
+        npairs = d2[0].numel()
+        tc = target.detach().to(dtype).contiguous()
+        if tc.numel() != npairs:
+            raise ValueError(f'target has {tc.numel()} entries, the pair range has {npairs}')
+        sc = [s.detach().to(dtype).reshape(1).contiguous() for s in scales]
+        dev = xs[0].device
+        with torch.cuda.device(dev):
+            gs = [torch.empty(npairs, dtype=dtype, device=dev) for _ in range(k)]
+            out = torch.empty(1 + k, dtype=dtype, device=dev)
+            dt = B.dtype_code(xs[0])
+            ws = torch.empty(lib.raw('mm_product_loss_ws_bytes')(dt, k), dtype=torch.uint8, device=dev)
+            lib.call('mm_product_loss', dt, B.LOSS_STRESS if kind == 'stress' else B.LOSS_QUOTIENT, k,
+                     B.ptr_array([d.detach() for d in d2]), B.ptr(tc), B.ptr_array(sc), npairs, alpha, eps,
+                     terms, B.ptr_array(gs), B.ptr(out), B.ptr(ws), B.stream_of(xs[0]))
+            grads = [torch.autograd.grad(d, x, g)[0] for d, x, g in zip(d2, leaves, gs)]
+        ctx.grads = grads + [out[1 + i].reshape(s.shape).to(s.dtype) for i, s in enumerate(scales)]
+        return out[0]
+
+    @staticmethod
+    def backward(ctx, up):
+        try:  # one multi-tensor launch for all 2K gradients
+            grads = list(torch._foreach_mul(ctx.grads, up))
+        except (RuntimeError, TypeError):
+            grads = [g * up for g in ctx.grads]
+        return (None, None, None, None) + tuple(grads)
+
+
 class ManifoldParameter(torch.nn.Parameter):
     """A Parameter that knows the manifold it lives on (modules.py:9-23)."""
 
@@ -77,15 +128,19 @@ class ManifoldEmbedding(torch.nn.Module):
     def fused_objective(self, objective_fn, gdists, i=None, rows=None, **kwargs):
         """`objective_fn(gdists, self.compute_dists(i), **kwargs)` evaluated by ONE pair kernel
         that also produces the gradients (no pair vector of distances, no element-wise passes),
-        or None when this embedding / objective has no fused kernel (several factors, a
-        manifold without `pdist_loss`, a loss without `fused_spec`)."""
-        if self.n_components != 1 or not hasattr(self.manifolds[0], 'pdist_loss'):
-            return None
+        or None when the objective has no fused kernel (a loss without `fused_spec`, CPU tensors).
+        Single factors run the whole pair computation in one kernel; products run one forward and
+        one backward kernel per factor around a single loss kernel (`mm_product_loss`)."""
         if not hasattr(objective_fn, 'fused_spec') or not self.xs[0].is_cuda:
             return None
         spec = objective_fn.fused_spec(**kwargs)
-        x = self.xs[0] if i is None else self.xs[0][i]
-        return self.manifolds[0].pdist_loss(x, self.scales[0], gdists, spec, rows=rows)
+        if self.n_components == 1 and hasattr(self.manifolds[0], 'pdist_loss'):
+            x = self.xs[0] if i is None else self.xs[0][i]
+            return self.manifolds[0].pdist_loss(x, self.scales[0], gdists, spec, rows=rows)
+        if self.n_components > _max_product_factors():
+            return None
+        xs = [x if i is None else x[i] for x in self.xs]
+        return _ProductLoss.apply(gdists, spec, rows, tuple(self.manifolds), *xs, *self.scales)
 
     def __len__(self):
         return self.n

@@ -155,3 +155,60 @@ def test_graphed_train_step_matches_eager(case):
             GraphedTrainStep(lambda: loss_of(emb_g), [RiemannianAdam(list(emb_g.xs), lr=1e-3)])
     finally:
         torch.set_default_dtype(torch.float32)
+
+
+@pytest.mark.parametrize('dname', ['f32', 'f64'])
+@pytest.mark.parametrize('loss_name', ['stress', 'quotient'])
+def test_product_fused_objective_equals_unfused(dname, loss_name):
+    """csphd-style product (Lorentz x Sphere x SPD(2)) and a Grassmann single factor: the fused
+    objective (per-factor pair kernels around ONE loss kernel, mm_product_loss) gives the loss and all
+    gradients of compute_dists -> objective -> backward; row shards sum to the whole."""
+    from graphembed import _backend as B
+    from graphembed import manifolds as M
+    from graphembed.modules import ManifoldEmbedding
+    from graphembed.objectives import QuotientLoss, StressLoss
+    dt = {'f32': torch.float32, 'f64': torch.float64}[dname]
+    n = 300
+    fn, kw = (StressLoss(), {}) if loss_name == 'stress' else (QuotientLoss(), dict(epoch=1, alpha=1.2))
+    tol = 1e-4 if dname == 'f32' else 1e-10
+    for mans in ([M.Lorentz(6), M.Sphere(6), M.SymmetricPositiveDefinite(2)], [M.Grassmann(5, 2)]):
+        torch.manual_seed(4)
+        torch.set_default_dtype(dt)
+        try:
+            with torch.device('cuda'):
+                emb = ManifoldEmbedding(n, mans)
+                with torch.no_grad():
+                    emb.perturb(0.3)
+        finally:
+            torch.set_default_dtype(torch.float32)
+        params = list(emb.xs) + list(emb.scales)
+        md = emb.compute_dists(None).detach()
+        gen = torch.Generator(device='cuda').manual_seed(2)
+        target = md * (0.5 + torch.rand(md.shape, dtype=dt, device='cuda', generator=gen))
+        if kw:
+            for _ in range(8):
+                ag = target * kw['alpha']
+                near = ((md / ag - 1).abs() < 0.05) | ((ag / (md + 1 / (kw['epoch'] + 1)) - 1).abs() < 0.05)
+                target = torch.where(near, target * 1.25, target)
+            assert not near.any()
+        ref = fn(target, emb.compute_dists(None), **kw)
+        rg = torch.autograd.grad(ref, params)
+        loss = emb.fused_objective(fn, target, None, **kw)
+        assert loss is not None
+        g = torch.autograd.grad(loss * 2.0, params)
+        assert abs(loss.item() - ref.item()) <= tol * abs(ref.item())
+        for a, b in zip(g, rg):
+            err = (a - 2 * b).abs().max().item() / max(b.abs().max().item() * 2, 1e-30)
+            assert err <= 20 * tol, err
+        tot, gsum = 0.0, [torch.zeros_like(p) for p in params]
+        for r in range(3):
+            rows = B.shard_rows(n, 3, r)
+            lo, hi = B.pair_offset(n, rows[0]), B.pair_offset(n, rows[1])
+            part = emb.fused_objective(fn, target[lo:hi], None, rows=rows, **kw)
+            pg = torch.autograd.grad(part, params)
+            tot += part.item()
+            gsum = [s + p for s, p in zip(gsum, pg)]
+        assert abs(tot - ref.item()) <= tol * abs(ref.item())
+        for a, b in zip(gsum, rg):
+            err = (a - b).abs().max().item() / max(b.abs().max().item(), 1e-30)
+            assert err <= 20 * tol, err

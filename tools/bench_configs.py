@@ -103,6 +103,8 @@ CASES = {
     'c3_grqc_spd3_n5000_f64_mid': lambda: pdist_case(M.SymmetricPositiveDefinite(3), 5000, torch.float64, ir=0.35),
     'c3_spd2_n5000_f32': lambda: pdist_case(M.SymmetricPositiveDefinite(2), 5000, torch.float32),
     'c4_csphd_product_step_f32': lambda: step_case([M.Lorentz(6), M.Sphere(6), M.SymmetricPositiveDefinite(2)], 1025, torch.float32),
+    'c4_csphd_product_step_f32_fused': lambda: step_case([M.Lorentz(6), M.Sphere(6), M.SymmetricPositiveDefinite(2)], 1025, torch.float32, fused=True),
+    'c4_csphd_product_step_f32_fused_graph': lambda: step_case([M.Lorentz(6), M.Sphere(6), M.SymmetricPositiveDefinite(2)], 1025, torch.float32, fused=True, graph=True),
     'c4_csphd_product_step_f32_graph': lambda: step_case([M.Lorentz(6), M.Sphere(6), M.SymmetricPositiveDefinite(2)], 1025, torch.float32, graph=True),
     'c4_csphd_product_step_f64': lambda: step_case([M.Lorentz(6), M.Sphere(6), M.SymmetricPositiveDefinite(2)], 1025, torch.float64),
     'c5_wormnet_spd4_n2274_f32': lambda: pdist_case(M.SymmetricPositiveDefinite(4), 2274, torch.float32),

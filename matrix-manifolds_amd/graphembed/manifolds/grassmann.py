@@ -20,7 +20,7 @@ class _GrassPdist(torch.autograd.Function):
         ctx.empty = npairs == 0
         if ctx.empty:
             return xc.new_empty(0)
-        with torch.cuda.device(xc.device):
+        with B.on_device(xc.device):
             out = torch.empty(npairs, dtype=xc.dtype, device=xc.device)
             B.lib().call('mm_grass_pdist_fwd', B.dtype_code(xc), B.ptr(xc), n, N, p, row_begin, row_end,
                          int(squared), B.ptr(out), B.stream_of(xc))
@@ -36,7 +36,7 @@ class _GrassPdist(torch.autograd.Function):
         g = g.contiguous()
         n = xc.shape[0]
         dt = B.dtype_code(xc)
-        with torch.cuda.device(xc.device):
+        with B.on_device(xc.device):
             ws = torch.empty(lib.raw('mm_grass_pdist_ws_bytes')(dt, n, N, p), dtype=torch.uint8, device=xc.device)
             grad = torch.empty_like(xc)
             lib.call('mm_grass_pdist_bwd', dt, B.ptr(xc), B.ptr(g), n, N, p, row_begin, row_end, int(squared),
@@ -51,7 +51,7 @@ class _GrassDist(torch.autograd.Function):
         B.require_gpu(x, y)
         xc = x.detach().reshape(-1, N, p).contiguous()
         yc = y.detach().reshape(-1, N, p).contiguous()
-        with torch.cuda.device(xc.device):
+        with B.on_device(xc.device):
             out = torch.empty(xc.shape[0], dtype=xc.dtype, device=xc.device)
             B.lib().call('mm_grass_dist', B.dtype_code(xc), B.ptr(xc), B.ptr(yc), None, xc.shape[0], N, p,
                          int(squared), B.ptr(out), None, None, B.stream_of(xc))
@@ -64,7 +64,7 @@ class _GrassDist(torch.autograd.Function):
         xc, yc = ctx.saved_tensors
         N, p, squared, xs, ys = ctx.args
         g = g.reshape(-1).contiguous()
-        with torch.cuda.device(xc.device):
+        with B.on_device(xc.device):
             gx, gy = torch.empty_like(xc), torch.empty_like(yc)
             B.lib().call('mm_grass_dist', B.dtype_code(xc), B.ptr(xc), B.ptr(yc), B.ptr(g), xc.shape[0], N, p,
                          int(squared), None, B.ptr(gx), B.ptr(gy), B.stream_of(xc))
@@ -106,7 +106,7 @@ class _MatrixManifold(Manifold):
         shape = torch.broadcast_shapes(*[t.shape for t in ts])
         xc = x.expand(shape).reshape(-1, self.n, self.p).contiguous()
         uc = None if u is None else u.expand(shape).reshape(-1, self.n, self.p).contiguous()
-        with torch.cuda.device(xc.device):
+        with B.on_device(xc.device):
             out = torch.empty_like(xc)
             B.lib().call('mm_mat_map', B.dtype_code(xc), self._kind, op, B.ptr(xc), B.ptr(uc), xc.shape[0],
                          self.n, self.p, B.ptr(out), B.stream_of(xc))

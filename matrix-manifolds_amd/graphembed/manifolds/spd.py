@@ -41,7 +41,7 @@ class _SpdPdist(torch.autograd.Function):
         if ctx.empty:
             ctx.save_for_backward(xc)
             return xc.new_empty(0)
-        with torch.cuda.device(xc.device):
+        with B.on_device(xc.device):
             ws = torch.empty(lib.raw('mm_spd_pdist_ws_bytes')(dt, n, n_mat), dtype=torch.uint8,
                              device=xc.device)
             out = torch.empty(npairs, dtype=xc.dtype, device=xc.device)
@@ -68,7 +68,7 @@ class _SpdPdist(torch.autograd.Function):
         lib = B.lib()
         g = g.contiguous()
         n = xc.shape[0]
-        with torch.cuda.device(xc.device):
+        with B.on_device(xc.device):
             grad = torch.empty_like(xc)
             lib.call('mm_spd_pdist_bwd', B.dtype_code(xc), B.ptr(xc), B.ptr(g), n, n_mat, row_begin,
                      row_end, int(squared), wmin, wmax, B.ptr(grad), B.ptr(ctx.ws),
@@ -94,7 +94,7 @@ class _SpdPdistLoss(torch.autograd.Function):
         if tc.numel() != npairs:
             raise ValueError(f'target has {tc.numel()} entries, the pair range has {npairs}')
         sc = None if scale is None else scale.detach().to(xc.dtype).reshape(1).contiguous()
-        with torch.cuda.device(xc.device):
+        with B.on_device(xc.device):
             ws = torch.empty(lib.raw('mm_spd_pdist_ws_bytes')(dt, n, n_mat), dtype=torch.uint8,
                              device=xc.device)
             out = torch.empty(2, dtype=xc.dtype, device=xc.device)
@@ -119,7 +119,7 @@ class _SpdDist(torch.autograd.Function):
         B.require_gpu(x, y)
         xc, yc = _flat(x.detach(), n_mat), _flat(y.detach(), n_mat)
         m = xc.shape[0]
-        with torch.cuda.device(xc.device):
+        with B.on_device(xc.device):
             out = torch.empty(m, dtype=xc.dtype, device=xc.device)
             B.lib().call('mm_spd_dist_fwd', B.dtype_code(xc), B.ptr(xc), B.ptr(yc), m, n_mat,
                          int(squared), wmin, wmax, B.ptr(out), B.stream_of(xc))
@@ -132,7 +132,7 @@ class _SpdDist(torch.autograd.Function):
         xc, yc = ctx.saved_tensors
         n_mat, squared, wmin, wmax, xs, ys = ctx.args
         g = g.reshape(-1).contiguous()
-        with torch.cuda.device(xc.device):
+        with B.on_device(xc.device):
             gx, gy = torch.empty_like(xc), torch.empty_like(yc)
             B.lib().call('mm_spd_dist_bwd', B.dtype_code(xc), B.ptr(xc), B.ptr(yc), B.ptr(g),
                          xc.shape[0], n_mat, int(squared), wmin, wmax, B.ptr(gx), B.ptr(gy),
@@ -189,7 +189,7 @@ class SymmetricPositiveDefinite(Manifold):
         shape = torch.broadcast_shapes(x.shape, u.shape) if u is not None else x.shape
         xc = _flat(x.expand(shape), self.n)
         uc = _flat(u.expand(shape), self.n) if u is not None else None
-        with torch.cuda.device(xc.device):
+        with B.on_device(xc.device):
             out = torch.empty_like(xc)
             B.lib().call('mm_spd_map', B.dtype_code(xc), op, B.ptr(xc), B.ptr(uc), xc.shape[0],
                          self.n, self.wmin, self.wmax, B.ptr(out), B.stream_of(xc))
@@ -209,7 +209,7 @@ class SymmetricPositiveDefinite(Manifold):
         B.require_gpu(x, u)
         shape = torch.broadcast_shapes(x.shape, u.shape)
         xc, uc = _flat(x.detach().expand(shape), self.n), _flat(u.detach().expand(shape), self.n)
-        with torch.cuda.device(xc.device):
+        with B.on_device(xc.device):
             out = torch.empty(xc.shape[0], dtype=xc.dtype, device=xc.device)
             B.lib().call('mm_spd_norm', B.dtype_code(xc), B.ptr(xc), B.ptr(uc), xc.shape[0], self.n,
                          int(squared), B.ptr(out), B.stream_of(xc))
@@ -273,7 +273,7 @@ class SymmetricPositiveDefinite(Manifold):
         egrad2rgrad -> norm clip -> exp|retr in one kernel. Returns the new points."""
         B.require_gpu(x, egrad)
         xc, gc = _flat(x.detach(), self.n), _flat(egrad.detach(), self.n)
-        with torch.cuda.device(xc.device):
+        with B.on_device(xc.device):
             out = torch.empty_like(xc)
             B.lib().call('mm_spd_rsgd_step', B.dtype_code(xc), B.ptr(xc), B.ptr(gc), xc.shape[0],
                          self.n, float(lr), -1.0 if max_grad_norm is None else float(max_grad_norm),

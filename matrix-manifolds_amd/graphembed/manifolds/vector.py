@@ -23,7 +23,7 @@ class _VecPdist(torch.autograd.Function):
         ctx.empty = npairs == 0
         if ctx.empty:
             return xc.new_empty(0)
-        with torch.cuda.device(xc.device):
+        with B.on_device(xc.device):
             out = torch.empty(npairs, dtype=xc.dtype, device=xc.device)
             name = 'mm_vec_pdist_fwd_gram' if use_gram else 'mm_vec_pdist_fwd'
             lib.call(name, B.dtype_code(xc), kind, B.ptr(xc), n, m, row_begin, row_end, int(squared),
@@ -40,7 +40,7 @@ class _VecPdist(torch.autograd.Function):
         g = g.contiguous()
         n = xc.shape[0]
         dt = B.dtype_code(xc)
-        with torch.cuda.device(xc.device):
+        with B.on_device(xc.device):
             grad = torch.empty_like(xc)
             if ctx.use_gram and xc.dtype == torch.float32:
                 # matrix-core backward (inner-product manifolds, fp32): W^T X, no workspace
@@ -71,7 +71,7 @@ class _VecPdistLoss(torch.autograd.Function):
         if tc.numel() != npairs:
             raise ValueError(f'target has {tc.numel()} entries, the pair range has {npairs}')
         sc = None if scale is None else scale.detach().to(xc.dtype).reshape(1).contiguous()
-        with torch.cuda.device(xc.device):
+        with B.on_device(xc.device):
             ws = torch.empty(lib.raw('mm_vec_pdist_ws_bytes')(dt, n, m), dtype=torch.uint8,
                              device=xc.device)
             out = torch.empty(2, dtype=xc.dtype, device=xc.device)
@@ -97,7 +97,7 @@ class _VecDist(torch.autograd.Function):
         xc = x.detach().reshape(-1, m).contiguous()
         yc = y.detach().reshape(-1, m).contiguous()
         cnt = xc.shape[0]
-        with torch.cuda.device(xc.device):
+        with B.on_device(xc.device):
             out = torch.empty(cnt, dtype=xc.dtype, device=xc.device)
             B.lib().call('mm_vec_dist', B.dtype_code(xc), kind, B.ptr(xc), B.ptr(yc), None, cnt, m,
                          int(squared), B.ptr(out), None, None, B.stream_of(xc))
@@ -110,7 +110,7 @@ class _VecDist(torch.autograd.Function):
         xc, yc = ctx.saved_tensors
         kind, m, squared, xs, ys = ctx.args
         g = g.reshape(-1).contiguous()
-        with torch.cuda.device(xc.device):
+        with B.on_device(xc.device):
             gx, gy = torch.empty_like(xc), torch.empty_like(yc)
             B.lib().call('mm_vec_dist', B.dtype_code(xc), kind, B.ptr(xc), B.ptr(yc), B.ptr(g),
                          xc.shape[0], m, int(squared), None, B.ptr(gx), B.ptr(gy), B.stream_of(xc))
@@ -146,7 +146,7 @@ class VectorManifold(Manifold):
         m = self._m
         flat = [None if t is None else t.expand(shape).reshape(-1, m).contiguous() for t in (x, u, y)]
         xc = flat[0]
-        with torch.cuda.device(xc.device):
+        with B.on_device(xc.device):
             out = torch.empty_like(xc)
             B.lib().call('mm_vec_map', B.dtype_code(xc), self._kind, op, B.ptr(flat[0]), B.ptr(flat[1]),
                          B.ptr(flat[2]), xc.shape[0], m, B.ptr(out), B.stream_of(xc))
@@ -164,7 +164,7 @@ class VectorManifold(Manifold):
         B.require_gpu(u)
         m = self._m
         uc = u.detach().reshape(-1, m).contiguous()
-        with torch.cuda.device(uc.device):
+        with B.on_device(uc.device):
             out = torch.empty(uc.shape[0], dtype=uc.dtype, device=uc.device)
             B.lib().call('mm_vec_norm', B.dtype_code(uc), self._kind, B.ptr(uc), uc.shape[0], m,
                          int(squared), B.ptr(out), B.stream_of(uc))
@@ -198,7 +198,7 @@ class VectorManifold(Manifold):
         m = self._m
         xc = x.detach().reshape(-1, m).contiguous()
         gc = egrad.detach().reshape(-1, m).contiguous()
-        with torch.cuda.device(xc.device):
+        with B.on_device(xc.device):
             out = torch.empty_like(xc)
             B.lib().call('mm_vec_rsgd_step', B.dtype_code(xc), self._kind, B.ptr(xc), B.ptr(gc),
                          xc.shape[0], m, float(lr),

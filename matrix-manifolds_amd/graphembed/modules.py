@@ -35,7 +35,7 @@ class _ProductLoss(torch.autograd.Function):
             raise ValueError(f'target has {tc.numel()} entries, the pair range has {npairs}')
         sc = [s.detach().to(dtype).reshape(1).contiguous() for s in scales]
         dev = xs[0].device
-        with torch.cuda.device(dev):
+        with B.on_device(dev):
             gs = [torch.empty(npairs, dtype=dtype, device=dev) for _ in range(k)]
             out = torch.empty(1 + k, dtype=dtype, device=dev)
             dt = B.dtype_code(xs[0])

@@ -36,7 +36,7 @@ class _Flat:
             return None
         xc = x.detach().reshape(-1, m).contiguous()
         gc = egrad.detach().reshape(-1, m).to(xc.dtype).contiguous()
-        with torch.cuda.device(xc.device):
+        with B.on_device(xc.device):
             out = torch.empty_like(xc)
             B.lib().call('mm_vec_rsgd_step', B.dtype_code(xc), B.EUCLIDEAN, B.ptr(xc), B.ptr(gc),
                          xc.shape[0], m, float(lr),
@@ -77,6 +77,28 @@ class RiemannianSGD(torch.optim.Optimizer):
             for group in self.param_groups:
                 self._step(group)
         return loss
+
+    # torch.optim.Optimizer wraps `step` of every subclass in a profiler range plus pre/post hook
+    # dispatch (~25 us of host time per call) unless it is marked as hooked already: the update is
+    # one or two kernels of a few microseconds, so the wrapper alone would dominate an eager step.
+    # (Step hooks registered on the optimizer are therefore not run.)
+    step.hooked = True
+
+    def zero_grad(self, set_to_none=True):
+        """Lean version of Optimizer.zero_grad (same semantics; the foreach/profiler machinery of
+        the base class costs ~20 us per call for a handful of parameters)."""
+        for group in self.param_groups:
+            for p in group['params']:
+                if p.grad is None:
+                    continue
+                if set_to_none:
+                    p.grad = None
+                else:
+                    if p.grad.grad_fn is not None:
+                        p.grad.detach_()
+                    else:
+                        p.grad.requires_grad_(False)
+                    p.grad.zero_()
 
     def _step(self, group):
         lr, momentum, dampening = group['lr'], group['momentum'], group['dampening']

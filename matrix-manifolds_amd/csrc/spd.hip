@@ -30,6 +30,13 @@
 namespace mm {
 
 constexpr int kBlock = 256;  // 4 wavefronts
+// Tile-shape sweep on MI355X (SPD(3) fp32, n = 5000, backward): rows per wavefront 4 / 6 / 8 / 12 -> 90.7 / 81.5 /
+// 70.0 / 73.5 us; wavefronts per workgroup 8 -> +1.5 us.  Persistent workgroups (one launch-filling grid that
+// loops over tiles) were measured slower too: 118 us with a global atomic tile counter (same-address returning
+// atomics serialise at ~18 ns each), 75-81 us with a static round-robin (78 VGPRs -> 6 wavefronts per SIMD).
+#ifndef MM_BWD_TI
+#define MM_BWD_TI 8   // rows per wavefront of a backward tile (default of MM_SPD_TI)
+#endif
 #ifndef MM_BWD_WAVES
 #define MM_BWD_WAVES 4
 #endif
@@ -844,9 +851,9 @@ int spd_pdist_loss_t(int kind, const T* x, const T* target, const T* scale_raw, 
   if (re > rb && pair_off(n, re) > pair_off(n, rb)) {
     LossArgs<T> la{scale_raw, T(alpha), T(eps), terms, ws.loss};
     if (kind == MM_LOSS_STRESS)
-      rc = spd_pdist_bwd_ti<T, D, 8, MM_LOSS_STRESS>(ws, target, n, rb, re, 1, wmin, wmax, st, la);
+      rc = spd_pdist_bwd_ti<T, D, MM_BWD_TI, MM_LOSS_STRESS>(ws, target, n, rb, re, 1, wmin, wmax, st, la);
     else
-      rc = spd_pdist_bwd_ti<T, D, 8, MM_LOSS_QUOTIENT>(ws, target, n, rb, re, 1, wmin, wmax, st, la);
+      rc = spd_pdist_bwd_ti<T, D, MM_BWD_TI, MM_LOSS_QUOTIENT>(ws, target, n, rb, re, 1, wmin, wmax, st, la);
     if (rc) return rc;
   }
   spd_pdist_finalize_kernel<T, D><<<dim3((n + 127) / 128), dim3(128), 0, st>>>(ws.nodeL, ws.accM, ws.accS, int(n),
@@ -864,7 +871,7 @@ int spd_pdist_bwd_t(const T* x, const T* g, int64_t n, int64_t rb, int64_t re, i
   if (rc) return rc;
   if (re > rb && pair_off(n, re) > pair_off(n, rb)) {
     switch (tile_rows()) {
-      case 8: rc = spd_pdist_bwd_ti<T, D, 8>(ws, g, n, rb, re, squared, wmin, wmax, st); break;
+      case 8: rc = spd_pdist_bwd_ti<T, D, MM_BWD_TI>(ws, g, n, rb, re, squared, wmin, wmax, st); break;
       case 32: rc = spd_pdist_bwd_ti<T, D, 32>(ws, g, n, rb, re, squared, wmin, wmax, st); break;
       default: rc = spd_pdist_bwd_ti<T, D, 16>(ws, g, n, rb, re, squared, wmin, wmax, st); break;
     }

@@ -806,41 +806,67 @@ __device__ __forceinline__ float butterfly32(float x) {   // x + x[lane ^ 32]
   const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
   return __uint_as_float(r[0]) + __uint_as_float(r[1]);
 }
+// fp64: the same moves on the two 32-bit halves
+template <int LEVEL> __device__ __forceinline__ double lane_xor(double x) {
+  const long long b = __double_as_longlong(x);
+  const float lo = lane_xor<LEVEL>(__int_as_float(int(b & 0xffffffffLL)));
+  const float hi = lane_xor<LEVEL>(__int_as_float(int(b >> 32)));
+  return __longlong_as_double((static_cast<long long>(__float_as_int(hi)) << 32) |
+                              static_cast<long long>(static_cast<unsigned int>(__float_as_int(lo))));
+}
+template <int WHICH> __device__ __forceinline__ double swap_partner(double x) {  // value of lane ^ 16 (WHICH = 16) / ^ 32
+  const long long b = __double_as_longlong(x);
+  const unsigned lo = static_cast<unsigned>(b & 0xffffffffLL), hi = static_cast<unsigned>(b >> 32);
+  unsigned plo, phi;
+  if constexpr (WHICH == 16) {
+    const auto r0 = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+    const auto r1 = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+    plo = r0[0] ^ r0[1] ^ lo; phi = r1[0] ^ r1[1] ^ hi;  // {own, partner} in some order: xor out the own value
+  } else {
+    const auto r0 = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+    const auto r1 = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+    plo = r0[0] ^ r0[1] ^ lo; phi = r1[0] ^ r1[1] ^ hi;
+  }
+  return __longlong_as_double((static_cast<long long>(phi) << 32) | static_cast<long long>(plo));
+}
+__device__ __forceinline__ double butterfly16(double x) { return x + swap_partner<16>(x); }
+__device__ __forceinline__ double butterfly32(double x) { return x + swap_partner<32>(x); }
+
 template <int W> __device__ __forceinline__ int transposed_index(int lane) {
   int idx = 0;
 #pragma unroll
   for (int s = 0; (W >> (s + 1)) > 0; ++s) idx += ((lane >> s) & 1) * (W >> (s + 1));
   return idx;
 }
-template <int LEVEL, int H> __device__ __forceinline__ void halve_level(float (&r)[2 * H], float (&o)[H], int lane) {
+template <int LEVEL, int H, typename T> __device__ __forceinline__ void halve_level(T (&r)[2 * H], T (&o)[H], int lane) {
   const bool up = (lane >> LEVEL) & 1;
 #pragma unroll
   for (int k = 0; k < H; ++k) {
-    const float keep = up ? r[H + k] : r[k];
-    const float send = up ? r[k] : r[H + k];
+    const T keep = up ? r[H + k] : r[k];
+    const T send = up ? r[k] : r[H + k];
     o[k] = keep + lane_xor<LEVEL>(send);
   }
 }
 // N <= 8: returns the wavefront total of value transposed_index<8>(lane) (zero for indices >= N).
-template <int N> __device__ __forceinline__ float wave_sum_transposed8(const float (&v)[N], int lane) {
+template <int N, typename T> __device__ __forceinline__ T wave_sum_transposed8(const T (&v)[N], int lane) {
   static_assert(N <= 8, "");
-  float r8[8], r4[4], r2[2], r1[1];
+  T r8[8], r4[4], r2[2], r1[1];
 #pragma unroll
-  for (int k = 0; k < 8; ++k) r8[k] = (k < N) ? v[k < N ? k : 0] : 0.f;
+  for (int k = 0; k < 8; ++k) r8[k] = (k < N) ? v[k < N ? k : 0] : T(0);
   halve_level<0, 4>(r8, r4, lane);
   halve_level<1, 2>(r4, r2, lane);
   halve_level<2, 1>(r2, r1, lane);
-  float x = r1[0];
+  T x = r1[0];
   x += lane_xor<3>(x);
   x = butterfly16(x);
   return butterfly32(x);
 }
 // N <= 16
-template <int N> __device__ __forceinline__ float wave_sum_transposed16(const float (&v)[N], int lane) {
+template <int N, typename T> __device__ __forceinline__ T wave_sum_transposed16(const T (&v)[N], int lane) {
   static_assert(N <= 16, "");
-  float r16[16], r8[8], r4[4], r2[2], r1[1];
+  T r16[16], r8[8], r4[4], r2[2], r1[1];
 #pragma unroll
-  for (int k = 0; k < 16; ++k) r16[k] = (k < N) ? v[k < N ? k : 0] : 0.f;
+  for (int k = 0; k < 16; ++k) r16[k] = (k < N) ? v[k < N ? k : 0] : T(0);
   halve_level<0, 8>(r16, r8, lane);
   halve_level<1, 4>(r8, r4, lane);
   halve_level<2, 2>(r4, r2, lane);

@@ -465,10 +465,10 @@ __global__ __launch_bounds__((64 * bwd_waves<T, D>())) void spd_pdist_bwd_kernel
       for (int r = 0; r < D; ++r)
 #pragma unroll
         for (int c = 0; c < D; ++c) accJ[r][c] += cj[r][c];
-      if constexpr (std::is_same<T, float>::value && NP <= 16) {
+      if constexpr (NP <= 16) {
         // transposing reduction: every lane ends up with the wavefront total of ONE entry of M
         constexpr int W = NP <= 8 ? 8 : 16;
-        float tot;
+        T tot;
 #if defined(MM_ABL) && MM_ABL == 8   // ablation: no cross-lane reduction (timing only)
         tot = m[0];
 #pragma unroll

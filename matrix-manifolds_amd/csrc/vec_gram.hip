@@ -15,6 +15,8 @@
 // fp64: v_mfma_f64_16x16x4_f64, 16x16 tiles (its own C layout: row = (l>>4)+4q).
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "../../include/mm_manifolds.h"
 #include "prof.hpp"
 #include "smallmat.hpp"
@@ -402,8 +404,9 @@ int vec_gram_bwd_launch(int kind, int loss_kind, const float* xp, const float* g
   if (mm_pair_offset(n, row_end) == mm_pair_offset(n, row_begin)) return MM_OK;
   const int nT = int((n + 31) / 32);
   // 16 row blocks per workgroup (4 per wavefront) unless that leaves the chip under-filled
-  int tpw = 4;
-  while (tpw > 1 && int64_t(nT) * ((nT + kGramBwdWaves * tpw - 1) / (kGramBwdWaves * tpw)) < 768) tpw >>= 1;
+  static const int tpw_env = [] { const char* e = std::getenv("MM_GRAM_BWD_TPW"); return e ? std::atoi(e) : 0; }();
+  int tpw = tpw_env > 0 ? tpw_env : 4;
+  while (tpw_env <= 0 && tpw > 1 && int64_t(nT) * ((nT + kGramBwdWaves * tpw - 1) / (kGramBwdWaves * tpw)) < 768) tpw >>= 1;
   const dim3 grid(nT, (nT + kGramBwdWaves * tpw - 1) / (kGramBwdWaves * tpw));
   const dim3 block(64 * kGramBwdWaves);
   {

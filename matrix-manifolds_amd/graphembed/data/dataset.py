@@ -1,34 +1,44 @@
-"""Targets of the embedding problem — counterpart of graphembed/graphembed/data/dataset.py:7-30.
-Stores max-normalised SQUARED graph distances; indexing by a node subset returns the
-row-major upper-triangle pair vector of that subset (same order as Manifold.pdist)."""
+"""Targets of the embedding problem — counterpart of graphembed/graphembed/data/dataset.py:7-30:
+max-normalised SQUARED graph distances, indexable by a node subset.
+
+The full-batch step and the multi-GPU shards only ever need the condensed pair vector (same
+row-major upper-triangle order as `Manifold.pdist`), so that is what is stored; the dense n x n
+matrix the reference keeps is built on first use by a node mini-batch (`dataset[indices]`,
+train.py:203-213) and cached."""
 import torch
 from torch.utils.data import Dataset
 
-from graphembed.utils import squareform1
+from graphembed.utils import nnm1d2_to_n, squareform1
 
 
 class GraphDataset(Dataset):
 
     def __init__(self, pdists):
-        pdists = pdists.pow(2)
-        pdists = pdists / pdists.max()
-        self.condensed = pdists            # (P,) — what full-batch steps and shards read
-        self.pdists = squareform1(pdists)  # dense (n,n) for node mini-batches
+        sq = pdists.pow(2)
+        self.condensed = sq / sq.max()     # (P,)
+        self._dense = None                 # (n, n), lazily
+
+    @property
+    def pdists(self):
+        """Dense symmetric matrix of the targets (the reference's attribute name)."""
+        if self._dense is None:
+            self._dense = squareform1(self.condensed)
+        return self._dense
 
     @property
     def device(self):
-        return self.pdists.device
+        return self.condensed.device
+
+    def __len__(self):
+        return nnm1d2_to_n(self.condensed.numel())
 
     def __getitem__(self, node_indices=None):
+        """Pair vector of the sub-graph induced by `node_indices` (all nodes for None)."""
         if node_indices is None:
             return self.condensed
-        node_indices = node_indices.to(self.device)
-        sub = self.pdists[node_indices][:, node_indices]
-        return squareform1(sub)
+        idx = node_indices.to(self.device)
+        return squareform1(self.pdists.index_select(0, idx).index_select(1, idx))
 
     def pairs(self, shard):
         """The slice of the full pair vector owned by a `graphembed.parallel.PairShard`."""
         return self.condensed[shard.lo:shard.hi]
-
-    def __len__(self):
-        return len(self.pdists)

@@ -4,10 +4,12 @@ factor manifolds: ~60 kernel launches of a few microseconds each per step, train
 
 Everything on the path is capture-safe: the HIP entry points take the stream, allocate nothing and
 never synchronise; workspaces and outputs come from torch's caching allocator (graph-private pool
-during capture); `RiemannianSGD` / `RiemannianAdam` write parameters in place while capturing.
+during capture); `RiemannianSGD` / `RiemannianAdam` write parameters in place while capturing and keep
+all per-step state (momentum, moments, the Adam step counter) in device memory.
 
-    step = GraphedTrainStep(lambda: objective(None, epoch=0, alpha=1.0), optimizers)
-    for epoch in range(n_epochs):
+    step = GraphedTrainStep(lambda: objective(None, epoch=0, alpha=1.0), optimizers).capture()
+    # capture() has run `warmup` (default 3) ordinary steps: step.warmup_losses
+    for epoch in range(3, n_epochs):
         loss = step()            # one hipGraphLaunch; `loss` is a device scalar (no sync)
 
 Anything that changes between steps must live in device memory that the closure reads (targets,
@@ -24,10 +26,11 @@ class GraphedTrainStep:
         for o in self.optimizers:
             if not getattr(o, 'graph_safe', False):
                 raise TypeError(f'{type(o).__name__} keeps host-side step state and cannot be replayed '
-                                'from a captured graph (RiemannianSGD can)')
+                                'from a captured graph (RiemannianSGD and RiemannianAdam of this package can)')
         self.warmup = warmup
         self.graph = None
         self.loss = None
+        self.warmup_losses = []
 
     def _params(self):
         return [p for o in self.optimizers for g in o.param_groups for p in g['params']]
@@ -42,30 +45,23 @@ class GraphedTrainStep:
         return loss.detach()
 
     def capture(self):
+        """Runs `warmup` ordinary (eager) training steps — they COUNT as training steps: optimizer
+        state is created and advanced by them, and their losses are kept in `warmup_losses` — then
+        records the next step without executing it."""
         params = self._params()
         if not params or not all(p.is_cuda for p in params):
             raise RuntimeError('GraphedTrainStep needs parameters in GPU memory')
         for p in params:  # static gradient buffers: zero_grad(set_to_none=False) keeps them
             if p.grad is None:
                 p.grad = torch.zeros_like(p)
-        # parameters are restored after the warm-up iterations: capture must not advance training
-        saved = [p.detach().clone() for p in params]
-        states = [o.state_dict() for o in self.optimizers]
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
-            for _ in range(self.warmup):
-                self._eager_step()
+            self.warmup_losses = [self._eager_step() for _ in range(max(1, self.warmup))]
         torch.cuda.current_stream().wait_stream(side)
-        with torch.no_grad():
-            for p, s in zip(params, saved):
-                p.copy_(s)
-        for o, st in zip(self.optimizers, states):
-            o.load_state_dict(st)
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
             self.loss = self._eager_step()
-        # the capture pass itself does not execute: parameters are still the saved ones
         return self
 
     def __call__(self):

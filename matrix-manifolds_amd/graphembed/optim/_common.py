@@ -1,0 +1,118 @@
+"""Scaffolding shared by the Riemannian optimizers of this package.
+
+`ManifoldOptimizer` owns everything that is not the update rule itself: the lean `step` /
+`zero_grad` (no profiler ranges or hook dispatch around updates that are one or two kernels long),
+the lookup of a parameter's manifold (flat parameters — scales, curvatures — fall back to the
+Euclidean rule, as graphembed/graphembed/optim/rsgd.py:7,56-59 does with `Euclidean(1)`), the
+Riemannian gradient with its per-point norm clip, and assignment of new values in a way that
+survives HIP-graph capture.  Subclasses implement `_update(group, p, state, manifold)`.
+"""
+import torch
+
+from graphembed.modules import ManifoldParameter
+
+
+class FlatRule:
+    """Manifold-API subset for parameters that live in flat space, arithmetic in torch except for
+    the fused momentum-free step, which reuses the Euclidean RSGD kernel on GPU tensors."""
+
+    @staticmethod
+    def egrad2rgrad(x, u):
+        return u
+
+    @staticmethod
+    def norm(x, u, keepdim=False):
+        return (u * u).sum(-1, keepdim=keepdim).clamp(min=1e-8).sqrt()
+
+    @staticmethod
+    def exp(x, u):
+        return x + u
+
+    retr = exp
+
+    @staticmethod
+    def transp(x, y, u):
+        return u
+
+    @staticmethod
+    def rsgd_step(x, egrad, *, lr, max_grad_norm=None, exact=False):
+        """One kernel instead of ~12 scalar framework kernels per parameter; None when the tensor
+        is not eligible (CPU, wide last dimension), in which case the caller composes the step."""
+        if not x.is_cuda:
+            return None
+        width = x.shape[-1] if x.ndim else 1
+        if width > 32 or x.dtype not in (torch.float32, torch.float64):
+            return None
+        from graphembed import _backend as B
+        xc = x.detach().reshape(-1, width).contiguous()
+        gc = egrad.detach().reshape(-1, width).to(xc.dtype).contiguous()
+        with B.on_device(xc.device):
+            out = torch.empty_like(xc)
+            B.lib().call('mm_vec_rsgd_step', B.dtype_code(xc), B.EUCLIDEAN, B.ptr(xc), B.ptr(gc),
+                         xc.shape[0], width, float(lr),
+                         -1.0 if max_grad_norm is None else float(max_grad_norm), int(bool(exact)),
+                         B.ptr(out), B.stream_of(xc))
+        return out.reshape(x.shape)
+
+
+FLAT = FlatRule()
+
+
+def assign(t, new):
+    """`t.set_(new)` (what the reference does, rsgd.py:80-82) — except while a HIP graph is being
+    captured, where the value is copied into t's own storage so that a replayed step keeps
+    advancing the same memory."""
+    if t.is_cuda and torch.cuda.is_current_stream_capturing():
+        t.copy_(new)
+    else:
+        t.set_(new)
+
+
+class ManifoldOptimizer(torch.optim.Optimizer):
+
+    def step(self, closure=None):
+        loss = closure() if closure is not None else None
+        with torch.no_grad():
+            for group in self.param_groups:
+                for p in group['params']:
+                    if p.grad is not None:
+                        self._update(group, p, self.state[p], self.manifold_of(p))
+        return loss
+
+    # torch.optim.Optimizer wraps `step` of every subclass in a profiler range plus pre/post hook
+    # dispatch (~25 us of host time per call) unless it is marked as hooked already; the updates
+    # here are a few microseconds of GPU work.  (Step hooks registered on the optimizer do not run.)
+    step.hooked = True
+
+    def zero_grad(self, set_to_none=True):
+        for group in self.param_groups:
+            for p in group['params']:
+                g = p.grad
+                if g is None:
+                    continue
+                if set_to_none:
+                    p.grad = None
+                    continue
+                if g.grad_fn is not None:
+                    g.detach_()
+                else:
+                    g.requires_grad_(False)
+                g.zero_()
+
+    @staticmethod
+    def manifold_of(p):
+        if isinstance(p, ManifoldParameter) and p.manifold is not None:
+            return p.manifold
+        return FLAT
+
+    @staticmethod
+    def riemannian_gradient(manifold, p, max_grad_norm):
+        """(clipped Riemannian gradient, its norm BEFORE clipping or None if not needed)."""
+        rgrad = manifold.egrad2rgrad(p, p.grad)
+        if max_grad_norm is None:
+            return rgrad, None
+        norm = manifold.norm(p, rgrad, keepdim=True)
+        return rgrad * torch.clamp(max_grad_norm / norm, max=1.0), norm
+
+    def _update(self, group, p, state, manifold):
+        raise NotImplementedError

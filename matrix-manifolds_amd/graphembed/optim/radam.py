@@ -1,70 +1,60 @@
 """Riemannian Adam with one second-moment scalar per point — counterpart of
-graphembed/graphembed/optim/radam.py:12-98 (same param groups, same update order).
-All arithmetic goes through the Manifold API (HIP kernels) plus a few element-wise torch ops
-on [n, point] tensors."""
+graphembed/graphembed/optim/radam.py:12-98 (same constructor, param groups, state keys and update
+order), built on the shared scaffold of `_common.py`.
+
+Unlike the reference, the step counter lives in device memory and the bias corrections are computed
+there, so a captured HIP graph of a training step replays correctly (`graph_safe`)."""
 import logging
 
 import torch
 
-from graphembed.modules import ManifoldParameter
-from graphembed.optim.rsgd import _default_manifold
+from graphembed.optim._common import ManifoldOptimizer, assign
 from graphembed.utils import EPS
 
 logger = logging.getLogger(__name__)
 
 
-class RiemannianAdam(torch.optim.Optimizer):
+class RiemannianAdam(ManifoldOptimizer):
+    graph_safe = True
 
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), nc=False, max_grad_norm=None, exact=False):
         if nc and betas[1] is not None:
             logger.warning('beta1=%.5f will be ignored because `nc` is True', betas[1])
-        defaults = dict(lr=lr, betas=betas, nc=nc, max_grad_norm=max_grad_norm, exact=exact)
-        super().__init__(params, defaults)
+        super().__init__(params, dict(lr=lr, betas=betas, nc=nc, max_grad_norm=max_grad_norm, exact=exact))
 
-    def step(self, closure=None):
-        loss = None
-        if closure is not None:
-            loss = closure()
-        with torch.no_grad():
-            for group in self.param_groups:
-                self._step(group)
-        return loss
+    @staticmethod
+    def _counter(state, like):
+        """state['step'] as a 0-dim fp64 device tensor (a reference checkpoint stores a Python int)."""
+        t = state.get('step', 1)
+        if not torch.is_tensor(t):
+            t = torch.tensor(float(t), dtype=torch.float64, device=like.device)
+            state['step'] = t
+        return t
 
-    def _step(self, group):
-        lr = group['lr']
+    def _update(self, group, p, state, manifold):
+        if 'exp_avg' not in state:
+            state['exp_avg'] = torch.zeros_like(p)      # first moment, a tangent vector at p
+            state['exp_avg_sq'] = torch.zeros_like(p)   # ONE scalar per point, broadcast over it (radam.py:60)
+        t = self._counter(state, p)
+        m, v = state['exp_avg'], state['exp_avg_sq']
         beta1, beta2 = group['betas']
-        max_grad_norm = group['max_grad_norm']
-        for x in group['params']:
-            grad = x.grad
-            if grad is None:
-                continue
-            state = self.state[x]
-            if len(state) == 0:
-                state['step'] = 1
-                state['exp_avg'] = torch.zeros_like(x)
-                state['exp_avg_sq'] = torch.zeros_like(x)   # one scalar per point, broadcast (radam.py:60)
-            if isinstance(x, ManifoldParameter) and x.manifold is not None:
-                manifold = x.manifold
-            else:
-                manifold = _default_manifold
-            retr = manifold.exp if group['exact'] else manifold.retr
+        if group['nc']:
+            beta2 = 1.0 - 1.0 / t                        # AdamNc: the varying second-moment decay (radam.py:81-82)
 
-            grad = manifold.egrad2rgrad(x, grad)
-            grad_norm = manifold.norm(x, grad, keepdim=True)        # norm BEFORE clipping (radam.py:72-74)
-            if max_grad_norm is not None:
-                grad = grad * torch.clamp(max_grad_norm / grad_norm, max=1.0)
+        # the second moment sees the gradient norm BEFORE clipping (radam.py:72-74)
+        rgrad = manifold.egrad2rgrad(p, p.grad)
+        norm = manifold.norm(p, rgrad, keepdim=True)
+        if group['max_grad_norm'] is not None:
+            rgrad = rgrad * torch.clamp(group['max_grad_norm'] / norm, max=1.0)
 
-            step = state['step']
-            exp_avg, exp_avg_sq = state['exp_avg'], state['exp_avg_sq']
-            if group['nc']:
-                beta2 = 1 - 1 / step
-            exp_avg.mul_(beta1).add_(grad, alpha=1 - beta1)
-            exp_avg_sq.mul_(beta2).add_(grad_norm.pow(2) * (1 - beta2))
-            denom = exp_avg_sq.sqrt().add_(EPS[x.dtype])
-            alpha = lr * (1 - beta2**step)**0.5 / (1 - beta1**step)
-            direction = exp_avg / denom * (-alpha)
-            new_x = retr(x, direction)
-            exp_avg_new = manifold.transp(x, new_x, exp_avg)
-            x.set_(new_x)
-            exp_avg.set_(exp_avg_new)
-            state['step'] += 1
+        m.mul_(beta1).add_(rgrad, alpha=1 - beta1)
+        v.mul_(beta2).add_(norm.pow(2) * (1 - beta2))
+        bias = (1 - beta2**t)**0.5 / (1 - beta1**t)      # device scalars: no host round trip
+        stride = (-group['lr'] * bias).to(p.dtype)
+        direction = m / (v.sqrt() + EPS[p.dtype]) * stride
+        move = manifold.exp if group['exact'] else manifold.retr
+        new_p = move(p, direction)
+        carried = manifold.transp(p, new_p, m)
+        assign(p, new_p)
+        assign(m, carried)
+        t.add_(1)

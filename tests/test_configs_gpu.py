@@ -104,7 +104,7 @@ def test_spd4_stress_size_properties():
 @pytest.mark.parametrize('case', ['spd3_fused', 'product'])
 def test_graphed_train_step_matches_eager(case):
     """A training step captured as one HIP graph (graphembed.graphed) advances the parameters
-    exactly like the eager loop; capture itself does not advance them."""
+    exactly like the eager loop (warm-up steps are ordinary steps; recording a step does not execute it)."""
     from graphembed import manifolds as M
     from graphembed.graphed import GraphedTrainStep
     from graphembed.modules import ManifoldEmbedding
@@ -141,18 +141,37 @@ def test_graphed_train_step_matches_eager(case):
                 o.step()
             losses_e.append(loss.item())
         emb_g, opts_g = build()
-        x0 = [x.detach().clone() for x in emb_g.xs]
-        step = GraphedTrainStep(lambda: loss_of(emb_g), opts_g).capture()
-        for x, x_ in zip(emb_g.xs, x0):
-            assert torch.equal(x.detach(), x_), 'capture must not advance the parameters'
-        losses_g = [step().item() for _ in range(6)]
+        step = GraphedTrainStep(lambda: loss_of(emb_g), opts_g, warmup=2).capture()  # 2 eager steps, then record
+        after_capture = [x.detach().clone() for x in emb_g.xs]
+        torch.cuda.synchronize()
+        for x, x_ in zip(emb_g.xs, after_capture):
+            assert torch.equal(x.detach(), x_), 'recording a step must not execute it'
+        losses_g = [l.item() for l in step.warmup_losses] + [step().item() for _ in range(4)]
         np.testing.assert_allclose(losses_g, losses_e, rtol=1e-9)
         for a, b in zip(emb_g.xs, emb_e.xs):
             np.testing.assert_allclose(a.detach().cpu().numpy(), b.detach().cpu().numpy(), rtol=1e-8, atol=1e-10)
         for a, b in zip(emb_g.scales, emb_e.scales):
             assert abs(a.item() - b.item()) <= 1e-10
+        # RiemannianAdam keeps its step counter in device memory: graph replay == eager as well
+        emb_a, _ = build()
+        emb_b, _ = build()
+        opt_a = [RiemannianAdam(list(emb_a.xs), lr=1e-3, max_grad_norm=20)]
+        opt_b = [RiemannianAdam(list(emb_b.xs), lr=1e-3, max_grad_norm=20)]
+        for _ in range(5):
+            opt_a[0].zero_grad()
+            la = loss_of(emb_a)
+            la.backward()
+            opt_a[0].step()
+        step_b = GraphedTrainStep(lambda: loss_of(emb_b), opt_b, warmup=2).capture()
+        lb = [step_b().item() for _ in range(3)][-1]
+        assert abs(lb - la.item()) <= 1e-9 * abs(la.item())
+        for a, b in zip(emb_a.xs, emb_b.xs):
+            np.testing.assert_allclose(a.detach().cpu().numpy(), b.detach().cpu().numpy(), rtol=1e-8, atol=1e-10)
+
+        class _HostState(torch.optim.SGD):
+            pass
         with pytest.raises(TypeError):
-            GraphedTrainStep(lambda: loss_of(emb_g), [RiemannianAdam(list(emb_g.xs), lr=1e-3)])
+            GraphedTrainStep(lambda: loss_of(emb_g), [_HostState(list(emb_g.scales), lr=1e-3)])
     finally:
         torch.set_default_dtype(torch.float32)
 

@@ -34,9 +34,6 @@ constexpr int kBlock = 256;  // 4 wavefronts
 // 70.0 / 73.5 us; wavefronts per workgroup 8 -> +1.5 us.  Persistent workgroups (one launch-filling grid that
 // loops over tiles) were measured slower too: 118 us with a global atomic tile counter (same-address returning
 // atomics serialise at ~18 ns each), 75-81 us with a static round-robin (78 VGPRs -> 6 wavefronts per SIMD).
-#ifndef MM_BWD_TI
-#define MM_BWD_TI 8   // rows per wavefront of a backward tile (default of MM_SPD_TI)
-#endif
 #ifndef MM_BWD_WAVES
 #define MM_BWD_WAVES 4
 #endif
@@ -796,10 +793,22 @@ int spd_pdist_prepare(const T* x, int64_t n, Ws<T>& ws, int flags, hipStream_t s
   return MM_OK;
 }
 
-inline int tile_rows() {  // MM_SPD_TI = 8 | 16 | 32 (tuning knob; 8 measured fastest on MI355X at n = 5000)
-  static const int v = [] { const char* e = std::getenv("MM_SPD_TI"); const int t = e ? std::atoi(e) : 8;
-                            return (t == 16 || t == 32) ? t : 8; }();
-  return v;
+// Rows per wavefront of a tile.  Forward: 8 (MM_SPD_TI = 8 | 16 | 32 overrides).  Backward: 16 once the
+// launch still fills the machine at that height (>= 2048 workgroups of 64 x 64 pairs), else 8; measured at
+// n = 5000 (12.5 M pairs): 8 -> 70.8 us, 16 -> 67.9 us, 32 -> 74.4 us (MM_SPD_BWD_TI overrides).
+inline int env_tile_rows(const char* name) {
+  const char* e = std::getenv(name);
+  const int t = e ? std::atoi(e) : 0;
+  return (t == 8 || t == 16 || t == 32) ? t : 0;
+}
+inline int tile_rows() {
+  static const int v = env_tile_rows("MM_SPD_TI");
+  return v ? v : 8;
+}
+inline int bwd_tile_rows(int64_t pairs) {
+  static const int v = env_tile_rows("MM_SPD_BWD_TI");
+  if (v) return v;
+  return pairs >= int64_t(2048) * 64 * 64 ? 16 : 8;
 }
 
 template <typename T, int D, int TI>
@@ -850,10 +859,13 @@ int spd_pdist_loss_t(int kind, const T* x, const T* target, const T* scale_raw, 
   if (rc) return rc;
   if (re > rb && pair_off(n, re) > pair_off(n, rb)) {
     LossArgs<T> la{scale_raw, T(alpha), T(eps), terms, ws.loss};
+    const bool tall = bwd_tile_rows(pair_off(n, re) - pair_off(n, rb)) >= 16;
     if (kind == MM_LOSS_STRESS)
-      rc = spd_pdist_bwd_ti<T, D, MM_BWD_TI, MM_LOSS_STRESS>(ws, target, n, rb, re, 1, wmin, wmax, st, la);
+      rc = tall ? spd_pdist_bwd_ti<T, D, 16, MM_LOSS_STRESS>(ws, target, n, rb, re, 1, wmin, wmax, st, la)
+                : spd_pdist_bwd_ti<T, D, 8, MM_LOSS_STRESS>(ws, target, n, rb, re, 1, wmin, wmax, st, la);
     else
-      rc = spd_pdist_bwd_ti<T, D, MM_BWD_TI, MM_LOSS_QUOTIENT>(ws, target, n, rb, re, 1, wmin, wmax, st, la);
+      rc = tall ? spd_pdist_bwd_ti<T, D, 16, MM_LOSS_QUOTIENT>(ws, target, n, rb, re, 1, wmin, wmax, st, la)
+                : spd_pdist_bwd_ti<T, D, 8, MM_LOSS_QUOTIENT>(ws, target, n, rb, re, 1, wmin, wmax, st, la);
     if (rc) return rc;
   }
   spd_pdist_finalize_kernel<T, D><<<dim3((n + 127) / 128), dim3(128), 0, st>>>(ws.nodeL, ws.accM, ws.accS, int(n),
@@ -870,8 +882,8 @@ int spd_pdist_bwd_t(const T* x, const T* g, int64_t n, int64_t rb, int64_t re, i
   int rc = spd_pdist_prepare<T, D>(x, n, ws, flags, st);
   if (rc) return rc;
   if (re > rb && pair_off(n, re) > pair_off(n, rb)) {
-    switch (tile_rows()) {
-      case 8: rc = spd_pdist_bwd_ti<T, D, MM_BWD_TI>(ws, g, n, rb, re, squared, wmin, wmax, st); break;
+    switch (bwd_tile_rows(pair_off(n, re) - pair_off(n, rb))) {
+      case 8: rc = spd_pdist_bwd_ti<T, D, 8>(ws, g, n, rb, re, squared, wmin, wmax, st); break;
       case 32: rc = spd_pdist_bwd_ti<T, D, 32>(ws, g, n, rb, re, squared, wmin, wmax, st); break;
       default: rc = spd_pdist_bwd_ti<T, D, 16>(ws, g, n, rb, re, squared, wmin, wmax, st); break;
     }

@@ -233,20 +233,20 @@ def main():
             # pair) + node factors in (2*6 floats) + accumulators out (2*6 floats) per node.
             by = pairs_local * esz + n * 24 * esz
             # VALU instructions per 64-pair wave iteration and HBM bytes per launch measured with
-            # rocprofv3 --pmc on this exact workload (profiles/r01_v6_pmc_summary.txt); the plain
+            # rocprofv3 --pmc on this exact workload (profiles/r01_v8_pmc_summary.txt); the plain
             # v_fma_f32 issue rate is 2.44 cycles per wave instruction per SIMD (tools/micro/valu_rate.hip)
             iters = pairs_local / 64.0
             issue_s = lambda instr, t: instr * iters * 2.44 / (1024 * 2.4e9) / t
             ref_shape = (n == N_NODES and world == 1)
-            out['roofline'] = {'bound': 'hbm', 'kernel': 'spd_pdist_bwd_kernel<float,3,8>',
+            out['roofline'] = {'bound': 'hbm', 'kernel': 'spd_pdist_bwd_kernel<float,3,TI>',
                                'achieved': by / kern['bwd'] / 1e9, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                                'frac': by / kern['bwd'] / 1e9 / HBM_PEAK_GBS,
-                               'traffic': 94.7e6 if ref_shape else None,
+                               'traffic': 88.0e6 if ref_shape else None,
                                'traffic_source': 'rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE, '
-                                                 'profiles/r01_v6_pmc_summary.txt' if ref_shape else None,
+                                                 'profiles/r01_v8_pmc_summary.txt' if ref_shape else None,
                                'algorithmic_bytes': by,
                                'avg_launch_us': kern['bwd'] * 1e6, 'measured_in': roofline_pass,
-                               'valu_issue_frac': issue_s(213, kern['bwd'])}
+                               'valu_issue_frac': issue_s(209, kern['bwd'])}
             if kern['fwd']:
                 byf = pairs_local * esz + n * 12 * esz
                 out['roofline_fwd'] = {'bound': 'hbm', 'kernel': 'spd_pdist_fwd_kernel<float,3,8>',

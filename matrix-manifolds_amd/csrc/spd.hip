@@ -396,7 +396,14 @@ __global__ __launch_bounds__((64 * bwd_waves<T, D>())) void spd_pdist_bwd_kernel
     T li_next[NP], lc_next[NP];  // row operands are fetched one row ahead (scalar loads overlap the math)
 #pragma unroll
     for (int k = 0; k < NP; ++k) { li_next[k] = nodeL[size_t(i0) * NP + k]; lc_next[k] = nodeC[size_t(i0) * NP + k]; }
-    T g_next = (jin && j > i0) ? g[pair_off(n, i0) - base + (j - i0 - 1)] : T(0);
+    // The pair-vector loads are UNCONDITIONAL (clamped address, value masked at use): a predicated load
+    // compiles to an exec-masked branch, after which the compiler can no longer count outstanding loads
+    // and waits for vmcnt(0) right behind the prefetch — exposing the HBM latency it was meant to hide.
+    auto g_at = [&](int row) -> T {
+      const int64_t off = pair_off(n, row) - base + (j - row - 1);
+      return g[(jin && j > row) ? off : int64_t(0)];
+    };
+    T g_next = g_at(i0);
     for (int i = i0; i < i1; ++i) {
       T li[NP], lc[NP];
 #pragma unroll
@@ -407,8 +414,8 @@ __global__ __launch_bounds__((64 * bwd_waves<T, D>())) void spd_pdist_bwd_kernel
         li_next[k] = nodeL[size_t(inext) * NP + k];
         lc_next[k] = nodeC[size_t(inext) * NP + k];
       }
-      T gs = g_next;  // upstream gradient, fetched one row ahead as well (hides the HBM latency)
-      g_next = (jin && j > inext && inext > i) ? g[pair_off(n, inext) - base + (j - inext - 1)] : T(0);
+      T gs = (jin && j > i) ? g_next : T(0);  // upstream gradient, fetched one row ahead (hides the HBM latency)
+      g_next = g_at(inext);
       T m[NP];
       bool series = false;
       auto jacobi_path = [&]() {

@@ -231,3 +231,26 @@ def test_product_fused_objective_equals_unfused(dname, loss_name):
         for a, b in zip(gsum, rg):
             err = (a - b).abs().max().item() / max(b.abs().max().item(), 1e-30)
             assert err <= 20 * tol, err
+
+
+def test_fused_loss_full_size_tall_tiles():
+    """At >= 8.4 M pairs the backward / fused-loss kernels switch to 16-row tiles: same numbers as the
+    unfused path (forward kernel + framework loss + 16-row backward) at n = 4200, SPD(3) fp32."""
+    from graphembed.manifolds import SymmetricPositiveDefinite as SPD
+    from graphembed.modules import ManifoldEmbedding
+    from graphembed.objectives import QuotientLoss, StressLoss
+    n = 4200
+    torch.manual_seed(8)
+    with torch.device('cuda'):
+        emb = ManifoldEmbedding(n, [SPD(3)])
+        target = torch.rand(n * (n - 1) // 2) * 0.05 + 0.02
+    params = [emb.xs[0], emb.scales[0]]
+    for fn, kw in ((StressLoss(), {}), (QuotientLoss(), dict(epoch=2, alpha=1.1))):
+        ref = fn(target, emb.compute_dists(None), **kw)
+        rg = torch.autograd.grad(ref, params)
+        loss = emb.fused_objective(fn, target, None, **kw)
+        g = torch.autograd.grad(loss, params)
+        assert abs(loss.item() - ref.item()) <= 5e-5 * abs(ref.item()), (loss.item(), ref.item())
+        err = (g[0] - rg[0]).abs().max().item() / rg[0].abs().max().item()
+        assert err <= 2e-4, err
+        assert abs(g[1].item() - rg[1].item()) <= 2e-3 * abs(rg[1].item())

@@ -164,9 +164,10 @@ int mm_vec_pdist_bwd(int dtype, int kind, const void* x, const void* g, int64_t 
                      int64_t row_begin, int64_t row_end, int squared, void* grad_x, void* ws,
                      mm_stream_t stream);
 
-/* Backward of mm_vec_pdist_fwd(_gram) on the matrix cores (fp32; Lorentz and sphere): W^T X with
- * W = g * dout/dq(Gram) formed tile by tile in the MFMA accumulators (csrc/vec_gram.hip).  Same
- * result as mm_vec_pdist_bwd; needs no workspace.  MM_ERR_UNSUPPORTED for other dtypes / kinds. */
+/* Backward of mm_vec_pdist_fwd(_gram) on the matrix cores (fp32; Lorentz, sphere, and the SQUARED
+ * Euclidean distance): W^T X with W = g * dout/dq(Gram) formed tile by tile in the MFMA accumulators
+ * (csrc/vec_gram.hip; Euclidean: W = g, no Gram).  Same result as mm_vec_pdist_bwd; needs no
+ * workspace.  MM_ERR_UNSUPPORTED for other dtypes / kinds / sizes (n > 32768, m > 32). */
 int mm_vec_pdist_bwd_gram(int dtype, int kind, const void* x, const void* g, int64_t n, int m,
                           int64_t row_begin, int64_t row_end, int squared, void* grad_x,
                           mm_stream_t stream);

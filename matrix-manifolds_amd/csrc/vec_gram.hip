@@ -159,8 +159,12 @@ void vec_gram_bwd_f32_kernel(const float* __restrict__ x, const float* __restric
   // (the launcher bounds n), so every load is base-SGPR + 32-bit VGPR offset.
   using u32 = unsigned int;
   const int rc = r < m ? r : m - 1;
+  // Euclidean (squared distances only): dout/dq = 1, so W = g and no Gram is needed at all — the kernel is a
+  // symmetric packed matrix times X; a ones column appended to X delivers the row sums of W that the
+  // gradient 2 (x_j sum_i w_ij - sum_i w_ij x_i) needs.
+  constexpr bool kEuclid = KIND == MM_EUCLIDEAN;
   float bJ[KS];  // B operand of the Gram: x[J + r][2 s + h]
-  {
+  if constexpr (!kEuclid) {
     const int jr = J + r;
     const u32 xb = u32(jr < n ? jr : n - 1) * u32(m);
 #pragma unroll
@@ -244,7 +248,7 @@ void vec_gram_bwd_f32_kernel(const float* __restrict__ x, const float* __restric
     const int I = ib * 32;
     TileLoads cur;
     issue_g(ib, cur);
-    issue_xa(ib, cur);
+    if constexpr (!kEuclid) issue_xa(ib, cur);
     issue_bI(ib, cur);
     // upstream gradients in accumulator layout: element (i = I + row(s,h), j = J + r).  Tiles that lie
     // entirely inside the matrix and the shard (all but the ragged edges) need no masking at all.
@@ -286,7 +290,7 @@ void vec_gram_bwd_f32_kernel(const float* __restrict__ x, const float* __restric
     f32x16 q;
 #pragma unroll
     for (int k = 0; k < 16; ++k) q[k] = 0.f;
-    {
+    if constexpr (!kEuclid) {
       const bool ia_ok = I + r < n;
 #pragma unroll
       for (int s = 0; s < KS; ++s) {
@@ -301,7 +305,9 @@ void vec_gram_bwd_f32_kernel(const float* __restrict__ x, const float* __restric
 #pragma unroll
     for (int s = 0; s < 16; ++s) {
       float w;
-      if constexpr (LOSS == MM_LOSS_NONE) {
+      if constexpr (kEuclid) {
+        w = gv[s];
+      } else if constexpr (LOSS == MM_LOSS_NONE) {
         w = gv[s] * PairFn<float, KIND>::dq(q[s], squared);
       } else {
         const bool ok = gv[s] == gv[s];
@@ -313,7 +319,8 @@ void vec_gram_bwd_f32_kernel(const float* __restrict__ x, const float* __restric
         ds_acc += once ? dldm * d2 : 0.f;
         w = ok ? dldm * sp * PairFn<float, KIND>::dq(q[s], 1) : 0.f;
       }
-      const float b = ((rows_in || I + mfma_row(s, h) < n) && r < m) ? cur.bI[s] : 0.f;
+      float b = ((rows_in || I + mfma_row(s, h) < n) && r < m) ? cur.bI[s] : 0.f;
+      if (kEuclid && r == m) b = 1.f;  // ones column: accumulates sum_i w_ij (w is 0 for rows outside the matrix)
       accJ = __builtin_amdgcn_mfma_f32_32x32x2f32(w, b, accJ, 0, 0, 0);
     }
   }
@@ -343,6 +350,12 @@ void vec_gram_bwd_f32_kernel(const float* __restrict__ x, const float* __restric
 #pragma unroll
       for (int w = 1; w < kGramBwdWaves; ++w) sum += sT[w][jj][c];
       if (KIND == MM_LORENTZ && c != 0) sum = -sum;  // d q / d x_j = -J x_i
+      if constexpr (kEuclid) {                        // d q / d x_j = 2 (x_j - x_i)
+        float wsum = sT[0][jj][m];
+#pragma unroll
+        for (int w = 1; w < kGramBwdWaves; ++w) wsum += sT[w][jj][m];
+        sum = 2.f * fmaf(wsum, x[size_t(J + jj) * m + c], -sum);
+      }
       atomic_add(&grad[size_t(J + jj) * m + c], sum);
     }
   }
@@ -430,7 +443,9 @@ int vec_gram_bwd_launch(int kind, int loss_kind, const float* xp, const float* g
     else if (loss_kind == MM_LOSS_STRESS) MM_GRAM_BWD_KS(KIND_, MM_LOSS_STRESS); \
     else MM_GRAM_BWD_KS(KIND_, MM_LOSS_QUOTIENT);                                \
   } while (0)
-    if (kind == MM_LORENTZ) MM_GRAM_BWD_LOSS(MM_LORENTZ); else MM_GRAM_BWD_LOSS(MM_SPHERE);
+    if (kind == MM_LORENTZ) MM_GRAM_BWD_LOSS(MM_LORENTZ);
+    else if (kind == MM_SPHERE) MM_GRAM_BWD_LOSS(MM_SPHERE);
+    else MM_GRAM_BWD(MM_EUCLIDEAN, 2, MM_LOSS_NONE);
 #undef MM_GRAM_BWD_LOSS
 #undef MM_GRAM_BWD_KS
 #undef MM_GRAM_BWD
@@ -442,6 +457,11 @@ int vec_gram_bwd_launch(int kind, int loss_kind, const float* xp, const float* g
 // mm_vec_pdist_loss on the matrix cores (called from vec.hip when the configuration qualifies)
 bool vec_gram_supports(int dtype, int kind, int64_t n, int m) {
   return dtype == MM_F32 && (kind == MM_LORENTZ || kind == MM_SPHERE) && m <= 32 && n <= 32768;
+}
+// plain backward only: also the Euclidean squared distance (no Gram, one spare column for the row sums)
+bool vec_gram_bwd_supports(int dtype, int kind, int64_t n, int m, int squared) {
+  return vec_gram_supports(dtype, kind, n, m) ||
+         (dtype == MM_F32 && kind == MM_EUCLIDEAN && squared && m <= 31 && n <= 32768);
 }
 int vec_gram_loss(int kind, int loss_kind, const float* x, const float* target, const float* scale_raw, int64_t n, int m,
                   int64_t row_begin, int64_t row_end, double alpha, double eps, int terms, float* loss_out, float* grad,
@@ -464,7 +484,7 @@ extern "C" int mm_vec_pdist_bwd_gram(int dtype, int kind, const void* x, const v
   if (!x || !grad_x || n < 1 || m < 1 || row_begin < 0 || row_end > n || row_begin > row_end || n > (1 << 30))
     return MM_ERR_ARG;
   // 32-bit element offsets inside the kernel: n (n - 1) / 2 pairs and the row products must fit
-  if (!vec_gram_supports(dtype, kind, n, m)) return MM_ERR_UNSUPPORTED;
+  if (!vec_gram_bwd_supports(dtype, kind, n, m, squared)) return MM_ERR_UNSUPPORTED;
   if (!g && mm_pair_offset(n, row_end) > mm_pair_offset(n, row_begin)) return MM_ERR_ARG;
   return vec_gram_bwd_launch(kind, MM_LOSS_NONE, static_cast<const float*>(x), static_cast<const float*>(g), n, m,
                              row_begin, row_end, squared, static_cast<float*>(grad_x),

@@ -42,7 +42,9 @@ class _VecPdist(torch.autograd.Function):
         dt = B.dtype_code(xc)
         with B.on_device(xc.device):
             grad = torch.empty_like(xc)
-            if ctx.use_gram and xc.dtype == torch.float32 and n <= 32768:
+            mfma = xc.dtype == torch.float32 and n <= 32768 and (
+                ctx.use_gram or (kind == B.EUCLIDEAN and squared and m <= 31))
+            if mfma:
                 # matrix-core backward (inner-product manifolds, fp32): W^T X, no workspace
                 lib.call('mm_vec_pdist_bwd_gram', dt, kind, B.ptr(xc), B.ptr(g), n, m, row_begin,
                          row_end, int(squared), B.ptr(grad), B.stream_of(xc))

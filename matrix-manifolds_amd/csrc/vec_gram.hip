@@ -49,7 +49,9 @@ template <typename T, int KIND> __device__ __forceinline__ T gram_value(T q, int
 
 constexpr int kGramWaves = 4;
 
-// fp32: 32x32 tile per wavefront
+// fp32: 32x32 tiles, kGramFwdTiles consecutive column tiles per wavefront (the row-block operand stays in
+// registers; one tile per wavefront made the kernel wave-launch-bound: 8 k wavefronts of ~1 us each)
+constexpr int kGramFwdTiles = 4;
 template <int KIND>
 __global__ __launch_bounds__(64 * kGramWaves) void vec_gram_fwd_f32_kernel(const float* __restrict__ x, int n, int m,
                                                                          int row_begin, int row_end, int squared,
@@ -57,30 +59,52 @@ __global__ __launch_bounds__(64 * kGramWaves) void vec_gram_fwd_f32_kernel(const
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r = lane & 31, h = lane >> 5;
   const int i0 = row_begin + blockIdx.y * 32;
-  const int j0 = (((i0 + 1) / 32) + blockIdx.x * kGramWaves + wave) * 32;
-  if (j0 >= n) return;  // wave-uniform
-  const int ia = i0 + r, jb = j0 + r;
-  const bool ia_ok = ia < n, jb_ok = jb < n;
+  const int jt0 = ((i0 + 1) / 32) + (blockIdx.x * kGramWaves + wave) * kGramFwdTiles;
+  if (jt0 * 32 >= n) return;  // wave-uniform
+  const int ia = i0 + r;
+  const bool ia_ok = ia < n;
   const float* xa = x + size_t(ia_ok ? ia : 0) * m;
-  const float* xb = x + size_t(jb_ok ? jb : 0) * m;
-  f32x16 acc;
-#pragma unroll
-  for (int q = 0; q < 16; ++q) acc[q] = 0.f;
   const int ksteps = (m + 1) / 2;
-  for (int s = 0; s < ksteps; ++s) {
+  float av[16];  // A operand: x[i0 + r][2 s + h] (Lorentz: space-like part negated), m <= 32
+#pragma unroll
+  for (int s = 0; s < 16; ++s) {
     const int k = 2 * s + h;
-    float a = (ia_ok && k < m) ? xa[k] : 0.f;
-    const float b = (jb_ok && k < m) ? xb[k] : 0.f;
+    float a = (s < ksteps && ia_ok && k < m) ? xa[k < m ? k : 0] : 0.f;
     if (KIND == MM_LORENTZ && k != 0) a = -a;
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+    av[s] = a;
   }
   const int64_t base = gpair_off(n, row_begin);
-  const int j = j0 + r;
+  for (int t = 0; t < kGramFwdTiles; ++t) {
+    const int j0 = (jt0 + t) * 32;
+    if (j0 >= n) break;  // wave-uniform
+    const int jb = j0 + r;
+    const bool jb_ok = jb < n;
+    const float* xb = x + size_t(jb_ok ? jb : 0) * m;
+    f32x16 acc;
 #pragma unroll
-  for (int q = 0; q < 16; ++q) {
-    const int i = i0 + (q & 3) + 8 * (q >> 2) + 4 * h;
-    const float v = gram_value<float, KIND>(acc[q], squared);
-    if (i < row_end && j < n && j > i) out[gpair_off(n, i) - base + (j - i - 1)] = v;
+    for (int q = 0; q < 16; ++q) acc[q] = 0.f;
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+      if (s < ksteps) {
+        const int k = 2 * s + h;
+        const float b = (jb_ok && k < m) ? xb[k < m ? k : 0] : 0.f;
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s], b, acc, 0, 0, 0);
+      }
+    }
+    const int j = j0 + r;
+    // offsets advance by additions: rows in register order are i0 + 4h + {0,1,2,3, 8,...}, and
+    // off(row + 1) = off(row) + n - row - 2 (a 64-bit multiply per element cost more than the acosh)
+    int row = i0 + 4 * h;
+    int64_t o = gpair_off(n, row) - base + (j - row - 1);
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const float v = gram_value<float, KIND>(acc[q], squared);
+      if (row < row_end && j < n && j > row) out[o] = v;
+      const int step = (q & 3) == 3 ? 5 : 1;
+#pragma unroll
+      for (int d = 0; d < 5; ++d)
+        if (d < step) { o += n - row - 2; ++row; }
+    }
   }
 }
 
@@ -375,7 +399,8 @@ extern "C" int mm_vec_pdist_fwd_gram(int dtype, int kind, const void* x, int64_t
   const int tile = dtype == MM_F32 ? 32 : 16;
   const int ntile_cols = int((n + tile - 1) / tile) - int((row_begin + 1) / tile);
   if (ntile_cols <= 0) return MM_OK;
-  const dim3 grid((ntile_cols + kGramWaves - 1) / kGramWaves, int((row_end - row_begin + tile - 1) / tile));
+  const int per_wg = kGramWaves * (dtype == MM_F32 ? kGramFwdTiles : 1);
+  const dim3 grid((ntile_cols + per_wg - 1) / per_wg, int((row_end - row_begin + tile - 1) / tile));
   const dim3 block(64 * kGramWaves);
   {
     ProfScope prof(PROF_VEC_FWD, st);

@@ -34,6 +34,9 @@ constexpr int kBlock = 256;  // 4 wavefronts
 // 70.0 / 73.5 us; wavefronts per workgroup 8 -> +1.5 us.  Persistent workgroups (one launch-filling grid that
 // loops over tiles) were measured slower too: 118 us with a global atomic tile counter (same-address returning
 // atomics serialise at ~18 ns each), 75-81 us with a static round-robin (78 VGPRs -> 6 wavefronts per SIMD).
+#ifndef MM_BWD_G_AHEAD
+#define MM_BWD_G_AHEAD 3   // rows of the pair vector requested ahead of their use in the backward
+#endif
 #ifndef MM_BWD_WAVES
 #define MM_BWD_WAVES 4
 #endif
@@ -368,6 +371,10 @@ __global__ __launch_bounds__((64 * bwd_waves<T, D>())) void spd_pdist_bwd_kernel
   // 36 column-side atomics of the old 256-column tile cost as much CU time as its arithmetic.
   __shared__ T redM[NW][TI][NP];
   __shared__ T colS[NW][D * D][64];
+#if defined(MM_BWD_LDS_PAD)  // occupancy experiment (timing only): pad the workgroup's LDS footprint
+  __shared__ float lds_pad[MM_BWD_LDS_PAD / 4];
+  if (threadIdx.x == 0 && n < 0) lds_pad[0] = 1.f;
+#endif
   const TileId tile = fold_tile<NW * TI, 64>(n, row_begin, row_end);
   if (!tile.ok) return;  // block-uniform
   const int lane = threadIdx.x & 63;
@@ -403,7 +410,12 @@ __global__ __launch_bounds__((64 * bwd_waves<T, D>())) void spd_pdist_bwd_kernel
       const int64_t off = pair_off(n, row) - base + (j - row - 1);
       return g[(jin && j > row) ? off : int64_t(0)];
     };
-    T g_next = g_at(i0);
+    // ... and kGAhead rows ahead: with 8 wavefronts interleaved on a SIMD one row of work is ~1.7 us of wall
+    // time, the loaded HBM latency is longer than that (SQ_WAIT_INST_ANY was 36 % of the wave cycles).
+    constexpr int kGAhead = MM_BWD_G_AHEAD;
+    T gq[kGAhead];
+#pragma unroll
+    for (int a = 0; a < kGAhead; ++a) gq[a] = g_at(min(i0 + a, i1 - 1));
     for (int i = i0; i < i1; ++i) {
       T li[NP], lc[NP];
 #pragma unroll
@@ -414,8 +426,10 @@ __global__ __launch_bounds__((64 * bwd_waves<T, D>())) void spd_pdist_bwd_kernel
         li_next[k] = nodeL[size_t(inext) * NP + k];
         lc_next[k] = nodeC[size_t(inext) * NP + k];
       }
-      T gs = (jin && j > i) ? g_next : T(0);  // upstream gradient, fetched one row ahead (hides the HBM latency)
-      g_next = g_at(inext);
+      T gs = (jin && j > i) ? gq[0] : T(0);  // upstream gradient (or target) of this row
+#pragma unroll
+      for (int a = 0; a + 1 < kGAhead; ++a) gq[a] = gq[a + 1];
+      gq[kGAhead - 1] = g_at(min(i + kGAhead, i1 - 1));
       T m[NP];
       bool series = false;
       auto jacobi_path = [&]() {

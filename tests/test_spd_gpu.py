@@ -466,3 +466,59 @@ def test_tree40_training_trace_fused(loss_name):
     check_rel(np.array(losses), G[f'{base}/losses'], 2e-5, 'loss trace')
     check_rel(emb.xs[0].data, G[f'{base}/x20_0'], 2e-4, 'x20')
     check_rel(np.array([s.item() for s in emb.scales]), G[f'{base}/scales20'], 1e-6, 'scales')
+
+
+# ------------------------------------------------------------------ the reference's own property tests
+@pytest.mark.parametrize('d', [2, 3, 4, 5])
+@pytest.mark.parametrize('seed', [0, 1])
+def test_reference_property_suite(d, seed):
+    """The properties graphembed/tests/test_spd.py checks (unit distance, exp/log round trip, distance
+    formulas via the eigenvalues of Y^-1 X, inner vs norm, Riemannian gradient of half the squared
+    distance = -log), through the HIP kernels, with that file's tolerances (atol 1e-4)."""
+    from graphembed.manifolds import SymmetricPositiveDefinite as SPD
+    torch.manual_seed(seed)
+    spd = SPD(d)
+    f64 = dict(dtype=torch.float64, device='cuda')
+
+    def rand_spd(n):
+        a = torch.rand(n, d, d, **f64)
+        return a @ a.transpose(1, 2) + torch.eye(d, **f64)
+
+    def rand_sym(n):
+        a = torch.rand(n, d, d, **f64)
+        return 0.5 * (a + a.transpose(1, 2))
+
+    # test_dim
+    assert spd.dim == d * (d + 1) // 2
+    # test_unit_distance
+    u_vec = torch.randn(spd.dim, **f64)
+    u = SPD.from_vec(u_vec / u_vec.norm())
+    eye = torch.eye(d, **f64)
+    assert abs(spd.norm(eye, u).item() - 1.0) <= 1e-4
+    assert abs(spd.dist(eye, spd.exp(eye, u)).item() - 1.0) <= 1e-4
+    # test_exp_log
+    x, v = rand_spd(10), rand_sym(10)
+    y = spd.exp(x, v)
+    assert (spd.log(x, y) - v).abs().max().item() <= 1e-4
+    assert (spd.norm(x, v) - spd.dist(x, y)).abs().max().item() <= 1e-4
+    # test_distance_formulas: sqrt(sum log^2 eig(Y^-1 X)), both orders
+    a, b = rand_spd(2)
+    ref = spd.dist(a, b).item()
+    for p, q in ((a, b), (b, a)):
+        w = torch.linalg.eigvals(torch.linalg.solve(q.cpu(), p.cpu())).real
+        assert abs(w.log().pow(2).sum().sqrt().item() - ref) <= 1e-4
+    # test_inner_norm
+    xs = spd.rand(100, ir=1.0, out=torch.empty(0, **f64))
+    us = spd.randvec(xs)
+    assert (spd.inner(xs, us, us) ** 0.5 - spd.norm(xs, us)).abs().max().item() <= 1e-4
+    # test_gradient: rgrad of 0.5 d^2(x, y) at x is -log_x(y)
+    x2, y2 = spd.rand(2, ir=1.0, out=torch.empty(0, **f64))
+    x2 = x2.clone().requires_grad_()
+    half = 0.5 * spd.dist(x2, y2, squared=True)
+    ge, = torch.autograd.grad(half, x2)
+    with torch.no_grad():
+        rg = spd.egrad2rgrad(x2.detach(), ge)
+        assert (rg + spd.log(x2.detach(), y2)).abs().max().item() <= 1e-4
+    # test_no_nan_dists
+    big = rand_spd(1000 if d < 4 else 50).float()
+    assert not torch.isnan(spd.pdist(big)).any()

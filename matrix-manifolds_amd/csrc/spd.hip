@@ -762,8 +762,10 @@ __global__ void spd_norm_kernel(const T* __restrict__ x, const T* __restrict__ u
 }
 
 template <typename T, int D>
-__global__ void spd_rsgd_step_kernel(const T* __restrict__ x, const T* __restrict__ eg, int64_t m, T lr,
-                                     T max_grad_norm, int exact, T* __restrict__ xnew) {
+// (x and xnew are deliberately not __restrict__: the update may be done in place, xnew == x — every thread
+// reads its whole point before it writes it)
+__global__ void spd_rsgd_step_kernel(const T* x, const T* __restrict__ eg, int64_t m, T lr,
+                                     T max_grad_norm, int exact, T* xnew) {
   constexpr int NP = Packed<D>::NP;
   const int64_t k0 = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
   const bool in = k0 < m;

@@ -339,8 +339,9 @@ __global__ void vec_norm_kernel(const T* __restrict__ u, int64_t cnt, int m, int
 
 // fused momentum-free RSGD update (rsgd.py:63-68,82)
 template <typename T, int KIND>
-__global__ void vec_rsgd_step_kernel(const T* __restrict__ x, const T* __restrict__ eg, int64_t cnt, int m, T lr,
-                                     T max_grad_norm, int exact, T* __restrict__ xnew) {
+// (x and xnew are deliberately not __restrict__: the update may be done in place, xnew == x)
+__global__ void vec_rsgd_step_kernel(const T* x, const T* __restrict__ eg, int64_t cnt, int m, T lr,
+                                     T max_grad_norm, int exact, T* xnew) {
   const int64_t p = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
   if (p >= cnt) return;
   T r[kVecMaxDim], o[kVecMaxDim];

@@ -268,17 +268,20 @@ class SymmetricPositiveDefinite(Manifold):
     def transp(self, x, y, u):  # spd.py:196-199
         return u
 
-    def rsgd_step(self, x, egrad, *, lr, max_grad_norm=None, exact=False):
+    def rsgd_step(self, x, egrad, *, lr, max_grad_norm=None, exact=False, inplace=False):
         """Fused momentum-free RiemannianSGD update (optim/rsgd.py:63-68,82):
-        egrad2rgrad -> norm clip -> exp|retr in one kernel. Returns the new points."""
+        egrad2rgrad -> norm clip -> exp|retr in one kernel.  Returns the new points; with
+        `inplace=True` they are written over `x` (every thread reads its point before writing it)."""
         B.require_gpu(x, egrad)
-        xc, gc = _flat(x.detach(), self.n), _flat(egrad.detach(), self.n)
+        xd = x.detach()
+        inplace = inplace and xd.is_contiguous()
+        xc, gc = _flat(xd, self.n), _flat(egrad.detach(), self.n)
         with B.on_device(xc.device):
-            out = torch.empty_like(xc)
+            out = xc if inplace else torch.empty_like(xc)
             B.lib().call('mm_spd_rsgd_step', B.dtype_code(xc), B.ptr(xc), B.ptr(gc), xc.shape[0],
                          self.n, float(lr), -1.0 if max_grad_norm is None else float(max_grad_norm),
                          int(bool(exact)), B.ptr(out), B.stream_of(xc))
-        return out.reshape(x.shape)
+        return x if inplace else out.reshape(x.shape)
 
     def rand(self, *shape, out=None, ir=1e-1):  # spd.py:201-208
         eyes = self.zero(*shape, out=out)

@@ -194,19 +194,22 @@ class VectorManifold(Manifold):
     def transp(self, x, y, u):
         return self._map(B.VEC_TRANSP, x, u, y)
 
-    def rsgd_step(self, x, egrad, *, lr, max_grad_norm=None, exact=False):
-        """Fused momentum-free RiemannianSGD update (optim/rsgd.py:63-68,82)."""
+    def rsgd_step(self, x, egrad, *, lr, max_grad_norm=None, exact=False, inplace=False):
+        """Fused momentum-free RiemannianSGD update (optim/rsgd.py:63-68,82); `inplace=True` writes
+        the new points over `x` (each thread reads its whole point before writing it)."""
         B.require_gpu(x, egrad)
         m = self._m
-        xc = x.detach().reshape(-1, m).contiguous()
+        xd = x.detach()
+        inplace = inplace and xd.is_contiguous()
+        xc = xd.reshape(-1, m).contiguous()
         gc = egrad.detach().reshape(-1, m).contiguous()
         with B.on_device(xc.device):
-            out = torch.empty_like(xc)
+            out = xc if inplace else torch.empty_like(xc)
             B.lib().call('mm_vec_rsgd_step', B.dtype_code(xc), self._kind, B.ptr(xc), B.ptr(gc),
                          xc.shape[0], m, float(lr),
                          -1.0 if max_grad_norm is None else float(max_grad_norm), int(bool(exact)),
                          B.ptr(out), B.stream_of(xc))
-        return out.reshape(x.shape)
+        return x if inplace else out.reshape(x.shape)
 
     # -- distances -------------------------------------------------------------
     def dist(self, x, y, squared=False, keepdim=False):

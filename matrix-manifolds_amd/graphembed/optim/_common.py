@@ -35,7 +35,7 @@ class FlatRule:
         return u
 
     @staticmethod
-    def rsgd_step(x, egrad, *, lr, max_grad_norm=None, exact=False):
+    def rsgd_step(x, egrad, *, lr, max_grad_norm=None, exact=False, inplace=False):
         """One kernel instead of ~12 scalar framework kernels per parameter; None when the tensor
         is not eligible (CPU, wide last dimension), in which case the caller composes the step."""
         if not x.is_cuda:
@@ -44,25 +44,31 @@ class FlatRule:
         if width > 32 or x.dtype not in (torch.float32, torch.float64):
             return None
         from graphembed import _backend as B
-        xc = x.detach().reshape(-1, width).contiguous()
+        xd = x.detach()
+        inplace = inplace and xd.is_contiguous()
+        xc = xd.reshape(-1, width).contiguous()
         gc = egrad.detach().reshape(-1, width).to(xc.dtype).contiguous()
         with B.on_device(xc.device):
-            out = torch.empty_like(xc)
+            out = xc if inplace else torch.empty_like(xc)
             B.lib().call('mm_vec_rsgd_step', B.dtype_code(xc), B.EUCLIDEAN, B.ptr(xc), B.ptr(gc),
                          xc.shape[0], width, float(lr),
                          -1.0 if max_grad_norm is None else float(max_grad_norm), int(bool(exact)),
                          B.ptr(out), B.stream_of(xc))
-        return out.reshape(x.shape)
+        return x if inplace else out.reshape(x.shape)
 
 
 FLAT = FlatRule()
+
+
+def capturing(t):
+    return t.is_cuda and torch.cuda.is_current_stream_capturing()
 
 
 def assign(t, new):
     """`t.set_(new)` (what the reference does, rsgd.py:80-82) — except while a HIP graph is being
     captured, where the value is copied into t's own storage so that a replayed step keeps
     advancing the same memory."""
-    if t.is_cuda and torch.cuda.is_current_stream_capturing():
+    if capturing(t):
         t.copy_(new)
     else:
         t.set_(new)

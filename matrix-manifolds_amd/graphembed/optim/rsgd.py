@@ -3,7 +3,7 @@ graphembed/graphembed/optim/rsgd.py:10-82: same constructor and param-group keys
 order (egrad2rgrad -> per-point norm clip -> momentum with transport | plain exp/retr step)."""
 from torch.optim.optimizer import required
 
-from graphembed.optim._common import FLAT, ManifoldOptimizer, assign
+from graphembed.optim._common import FLAT, ManifoldOptimizer, assign, capturing
 
 _default_manifold = FLAT  # (kept under the reference's name for callers that import it)
 _assign = assign
@@ -24,6 +24,10 @@ class RiemannianSGD(ManifoldOptimizer):
         if momentum == 0:
             # one fused kernel per parameter when the manifold offers it (rsgd.py:63-68,82)
             fused = getattr(manifold, 'rsgd_step', None)
+            if fused is not None and capturing(p):
+                # while a HIP graph is recorded the kernel writes straight over the parameter
+                if fused(p, p.grad, lr=lr, max_grad_norm=clip, exact=group['exact'], inplace=True) is p:
+                    return
             new_p = None if fused is None else fused(p, p.grad, lr=lr, max_grad_norm=clip,
                                                      exact=group['exact'])
             if new_p is None:

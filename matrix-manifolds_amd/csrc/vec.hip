@@ -435,9 +435,9 @@ constexpr int pad_dim(int m) { return m <= 4 ? 4 : m <= 8 ? 8 : m <= 12 ? 12 : m
 
 // matrix-core path of the fused objective (vec_gram.hip)
 bool vec_gram_supports(int dtype, int kind, int64_t n, int m);
-int vec_gram_loss(int kind, int loss_kind, const float* x, const float* target, const float* scale_raw, int64_t n, int m,
-                  int64_t row_begin, int64_t row_end, double alpha, double eps, int terms, float* loss_out, float* grad,
-                  float* slots, hipStream_t st);
+int vec_gram_loss(int dtype, int kind, int loss_kind, const void* x, const void* target, const void* scale_raw, int64_t n,
+                  int m, int64_t row_begin, int64_t row_end, double alpha, double eps, int terms, void* loss_out,
+                  void* grad, void* slots, hipStream_t st);
 
 }  // namespace mm
 
@@ -484,10 +484,9 @@ int mm_vec_pdist_loss(int dtype, int kind, int loss_kind, const void* x, const v
   if (loss_kind == MM_LOSS_QUOTIENT && !(terms & 3)) return MM_ERR_ARG;
   if (!target && mm_pair_offset(n, row_end) > mm_pair_offset(n, row_begin)) return MM_ERR_ARG;
   hipStream_t st = static_cast<hipStream_t>(stream);
-  if (vec_gram_supports(dtype, kind, n, m) && !std::getenv("MM_VEC_LOSS_VALU"))  // inner-product manifolds, fp32: MFMA
-    return vec_gram_loss(kind, loss_kind, static_cast<const float*>(x), static_cast<const float*>(target),
-                         static_cast<const float*>(scale_raw), n, m, row_begin, row_end, alpha, eps, terms,
-                         static_cast<float*>(loss_out), static_cast<float*>(grad_x), static_cast<float*>(ws), st);
+  if (vec_gram_supports(dtype, kind, n, m) && !std::getenv("MM_VEC_LOSS_VALU"))  // inner-product manifolds: MFMA
+    return vec_gram_loss(dtype, kind, loss_kind, x, target, scale_raw, n, m, row_begin, row_end, alpha, eps, terms,
+                         loss_out, grad_x, ws, st);
   MMV_DISPATCH_T(dtype, MMV_DISPATCH_KIND(kind, MMV_DISPATCH_MP(m, (vec_loss_t<T, KIND, MP>(
       loss_kind, static_cast<const T*>(x), static_cast<const T*>(target), static_cast<const T*>(scale_raw), n, m,
       row_begin, row_end, alpha, eps, terms, static_cast<T*>(loss_out), static_cast<T*>(grad_x), ws, st)))))

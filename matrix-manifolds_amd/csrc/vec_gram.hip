@@ -385,6 +385,8 @@ void vec_gram_bwd_f32_kernel(const float* __restrict__ x, const float* __restric
   }
 }
 
+#include "vec_gram_bwd64.hpp"
+
 }  // namespace mm
 
 using namespace mm;
@@ -428,13 +430,13 @@ extern "C" int mm_vec_pdist_fwd_gram(int dtype, int kind, const void* x, int64_t
 
 namespace mm {
 
-__global__ void gram_loss_finalize_kernel(float* __restrict__ slots, const float* __restrict__ scale_raw,
-                                          float* __restrict__ loss_out) {
-  loss_finalize<float>(slots, scale_raw, loss_out);
+template <typename T>
+__global__ void gram_loss_finalize_kernel(T* __restrict__ slots, const T* __restrict__ scale_raw, T* __restrict__ loss_out) {
+  loss_finalize<T>(slots, scale_raw, loss_out);
 }
 
-// Shared launcher of the matrix-core backward: plain (loss_kind = MM_LOSS_NONE, `g` = upstream gradients)
-// or fused objective (`g` = targets; la.slots must be zeroed [2][kLossSlots] floats).
+// Shared launchers of the matrix-core backward: plain (loss_kind = MM_LOSS_NONE, `g` = upstream gradients)
+// or fused objective (`g` = targets; la.slots must be zeroed [2][kLossSlots]).
 int vec_gram_bwd_launch(int kind, int loss_kind, const float* xp, const float* gp, int64_t n, int m, int64_t row_begin,
                         int64_t row_end, int squared, float* op, LossArgs<float> la, hipStream_t st) {
   hipError_t e = hipMemsetAsync(op, 0, sizeof(float) * size_t(n) * m, st);
@@ -479,26 +481,81 @@ int vec_gram_bwd_launch(int kind, int loss_kind, const float* xp, const float* g
   return e == hipSuccess ? MM_OK : int(e);
 }
 
-// mm_vec_pdist_loss on the matrix cores (called from vec.hip when the configuration qualifies)
-bool vec_gram_supports(int dtype, int kind, int64_t n, int m) {
-  return dtype == MM_F32 && (kind == MM_LORENTZ || kind == MM_SPHERE) && m <= 32 && n <= 32768;
+int vec_gram_bwd_launch(int kind, int loss_kind, const double* xp, const double* gp, int64_t n, int m,
+                        int64_t row_begin, int64_t row_end, int squared, double* op, LossArgs<double> la,
+                        hipStream_t st) {
+  hipError_t e = hipMemsetAsync(op, 0, sizeof(double) * size_t(n) * m, st);
+  if (e != hipSuccess) return int(e);
+  if (mm_pair_offset(n, row_end) == mm_pair_offset(n, row_begin)) return MM_OK;
+  const int nT = int((n + 15) / 16);
+  int tpw = 8;  // 32 row blocks of 16 per workgroup
+  while (tpw > 1 && int64_t(nT) * ((nT + kGramBwdWaves * tpw - 1) / (kGramBwdWaves * tpw)) < 768) tpw >>= 1;
+  const dim3 grid(nT, (nT + kGramBwdWaves * tpw - 1) / (kGramBwdWaves * tpw));
+  const dim3 block(64 * kGramBwdWaves);
+  {
+    ProfScope prof(PROF_VEC_BWD, st);
+#define MM_GRAM_BWD64(KIND_, KS_, LOSS_)                                                                      \
+  vec_gram_bwd_f64_kernel<KIND_, KS_, LOSS_><<<grid, block, 0, st>>>(xp, gp, int(n), m, int(row_begin),     \
+                                                                    int(row_end), squared, tpw, op, la)
+#define MM_GRAM_BWD64_KS(KIND_, LOSS_)                      \
+  do {                                                      \
+    const int ks = (m + 3) / 4;                             \
+    if (ks <= 1) MM_GRAM_BWD64(KIND_, 1, LOSS_);            \
+    else if (ks <= 2) MM_GRAM_BWD64(KIND_, 2, LOSS_);       \
+    else if (ks <= 3) MM_GRAM_BWD64(KIND_, 3, LOSS_);       \
+    else MM_GRAM_BWD64(KIND_, 4, LOSS_);                    \
+  } while (0)
+#define MM_GRAM_BWD64_LOSS(KIND_)                                                  \
+  do {                                                                             \
+    if (loss_kind == MM_LOSS_NONE) MM_GRAM_BWD64_KS(KIND_, MM_LOSS_NONE);          \
+    else if (loss_kind == MM_LOSS_STRESS) MM_GRAM_BWD64_KS(KIND_, MM_LOSS_STRESS); \
+    else MM_GRAM_BWD64_KS(KIND_, MM_LOSS_QUOTIENT);                                \
+  } while (0)
+    if (kind == MM_LORENTZ) MM_GRAM_BWD64_LOSS(MM_LORENTZ); else MM_GRAM_BWD64_LOSS(MM_SPHERE);
+#undef MM_GRAM_BWD64_LOSS
+#undef MM_GRAM_BWD64_KS
+#undef MM_GRAM_BWD64
+  }
+  e = hipGetLastError();
+  return e == hipSuccess ? MM_OK : int(e);
 }
-// plain backward only: also the Euclidean squared distance (no Gram, one spare column for the row sums)
+
+// which configurations the matrix-core kernels take (32-bit element offsets: n <= 32768)
+bool vec_gram_supports(int dtype, int kind, int64_t n, int m) {
+  if (kind != MM_LORENTZ && kind != MM_SPHERE) return false;
+  if (n > 32768) return false;
+  return (dtype == MM_F32 && m <= 32) || (dtype == MM_F64 && m <= 16);
+}
+// plain backward only: also the Euclidean squared distance in fp32 (no Gram, one spare column for the row sums)
 bool vec_gram_bwd_supports(int dtype, int kind, int64_t n, int m, int squared) {
   return vec_gram_supports(dtype, kind, n, m) ||
          (dtype == MM_F32 && kind == MM_EUCLIDEAN && squared && m <= 31 && n <= 32768);
 }
-int vec_gram_loss(int kind, int loss_kind, const float* x, const float* target, const float* scale_raw, int64_t n, int m,
-                  int64_t row_begin, int64_t row_end, double alpha, double eps, int terms, float* loss_out, float* grad,
-                  float* slots, hipStream_t st) {
-  hipError_t e = hipMemsetAsync(slots, 0, sizeof(float) * 2 * kLossSlots, st);
+template <typename T>
+int vec_gram_loss_t(int kind, int loss_kind, const T* x, const T* target, const T* scale_raw, int64_t n, int m,
+                    int64_t row_begin, int64_t row_end, double alpha, double eps, int terms, T* loss_out, T* grad,
+                    T* slots, hipStream_t st) {
+  hipError_t e = hipMemsetAsync(slots, 0, sizeof(T) * 2 * kLossSlots, st);
   if (e != hipSuccess) return int(e);
-  LossArgs<float> la{scale_raw, float(alpha), float(eps), terms, slots};
+  LossArgs<T> la{scale_raw, T(alpha), T(eps), terms, slots};
   const int rc = vec_gram_bwd_launch(kind, loss_kind, x, target, n, m, row_begin, row_end, 1, grad, la, st);
   if (rc) return rc;
-  gram_loss_finalize_kernel<<<dim3(1), dim3(64), 0, st>>>(slots, scale_raw, loss_out);
+  gram_loss_finalize_kernel<T><<<dim3(1), dim3(64), 0, st>>>(slots, scale_raw, loss_out);
   e = hipGetLastError();
   return e == hipSuccess ? MM_OK : int(e);
+}
+// mm_vec_pdist_loss on the matrix cores (called from vec.hip when the configuration qualifies)
+int vec_gram_loss(int dtype, int kind, int loss_kind, const void* x, const void* target, const void* scale_raw, int64_t n,
+                  int m, int64_t row_begin, int64_t row_end, double alpha, double eps, int terms, void* loss_out,
+                  void* grad, void* slots, hipStream_t st) {
+  if (dtype == MM_F32)
+    return vec_gram_loss_t<float>(kind, loss_kind, static_cast<const float*>(x), static_cast<const float*>(target),
+                                  static_cast<const float*>(scale_raw), n, m, row_begin, row_end, alpha, eps, terms,
+                                  static_cast<float*>(loss_out), static_cast<float*>(grad), static_cast<float*>(slots), st);
+  return vec_gram_loss_t<double>(kind, loss_kind, static_cast<const double*>(x), static_cast<const double*>(target),
+                                 static_cast<const double*>(scale_raw), n, m, row_begin, row_end, alpha, eps, terms,
+                                 static_cast<double*>(loss_out), static_cast<double*>(grad), static_cast<double*>(slots),
+                                 st);
 }
 
 }  // namespace mm
@@ -511,7 +568,12 @@ extern "C" int mm_vec_pdist_bwd_gram(int dtype, int kind, const void* x, const v
   // 32-bit element offsets inside the kernel: n (n - 1) / 2 pairs and the row products must fit
   if (!vec_gram_bwd_supports(dtype, kind, n, m, squared)) return MM_ERR_UNSUPPORTED;
   if (!g && mm_pair_offset(n, row_end) > mm_pair_offset(n, row_begin)) return MM_ERR_ARG;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (dtype == MM_F64)
+    return vec_gram_bwd_launch(kind, MM_LOSS_NONE, static_cast<const double*>(x), static_cast<const double*>(g), n, m,
+                               row_begin, row_end, squared, static_cast<double*>(grad_x),
+                               LossArgs<double>{nullptr, 1.0, 0.0, 0, nullptr}, st);
   return vec_gram_bwd_launch(kind, MM_LOSS_NONE, static_cast<const float*>(x), static_cast<const float*>(g), n, m,
                              row_begin, row_end, squared, static_cast<float*>(grad_x),
-                             LossArgs<float>{nullptr, 1.f, 0.f, 0, nullptr}, static_cast<hipStream_t>(stream));
+                             LossArgs<float>{nullptr, 1.f, 0.f, 0, nullptr}, st);
 }

@@ -42,8 +42,9 @@ class _VecPdist(torch.autograd.Function):
         dt = B.dtype_code(xc)
         with B.on_device(xc.device):
             grad = torch.empty_like(xc)
-            mfma = xc.dtype == torch.float32 and n <= 32768 and (
-                ctx.use_gram or (kind == B.EUCLIDEAN and squared and m <= 31))
+            f32 = xc.dtype == torch.float32
+            mfma = n <= 32768 and ((ctx.use_gram and (f32 or m <= 16)) or
+                                   (f32 and kind == B.EUCLIDEAN and squared and m <= 31))
             if mfma:
                 # matrix-core backward (inner-product manifolds, fp32): W^T X, no workspace
                 lib.call('mm_vec_pdist_bwd_gram', dt, kind, B.ptr(xc), B.ptr(g), n, m, row_begin,

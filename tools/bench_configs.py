@@ -92,6 +92,7 @@ CASES = {
     'c2_facebook_lorentz11_f32_gram': lambda: pdist_case(M.Lorentz(11), 4039, torch.float32),
     'c2_facebook_lorentz11_f32_valu': lambda: pdist_case(_valu(M.Lorentz(11)), 4039, torch.float32),
     'c2_facebook_lorentz11_f64_gram': lambda: pdist_case(M.Lorentz(11), 4039, torch.float64),
+    'c2_facebook_lorentz11_f64_valu': lambda: pdist_case(_valu(M.Lorentz(11)), 4039, torch.float64),
     'c2_facebook_lorentz11_step_f32': lambda: step_case([M.Lorentz(11)], 4039, torch.float32),
     'c2_facebook_lorentz11_step_f32_fused': lambda: step_case([M.Lorentz(11)], 4039, torch.float32, fused=True),
     'c2_facebook_lorentz11_step_f32_fused_graph': lambda: step_case([M.Lorentz(11)], 4039, torch.float32, fused=True, graph=True),

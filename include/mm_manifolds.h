@@ -107,6 +107,22 @@ int mm_spd_pdist_loss(int dtype, int loss_kind, const void* x, const void* targe
                       double alpha, double eps, int terms, double wmin, double wmax,
                       void* loss_out, void* grad_x, void* ws, int flags, mm_stream_t stream);
 
+/* Stein divergence S(X,Y) = log det((X+Y)/2) - (log det X + log det Y)/2 — the second SPD "distance" of the
+ * reference (SymmetricPositiveDefinite(use_stein_div=True): spd.py:183-194 stein_div / stein_pdiv,
+ * 246-295 PairwiseSteinDivergence, linalg/torch_batch.py:173-197 PLogDet).  Value clamped >= wmin
+ * (gradient-transparent), sqrt of it if !squared.  Layouts, workspace (mm_spd_pdist_ws_bytes), row ranges and
+ * flags as mm_spd_pdist_fwd / mm_spd_pdist_bwd; mm_spd_stein_div is the element-wise form over m pairs
+ * (out and/or both gradients may be requested; g is the upstream gradient of out). */
+int mm_spd_stein_pdiv_fwd(int dtype, const void* x, int64_t n, int d, int64_t row_begin,
+                          int64_t row_end, int squared, double wmin, void* out, void* ws, int flags,
+                          mm_stream_t stream);
+int mm_spd_stein_pdiv_bwd(int dtype, const void* x, const void* g, int64_t n, int d,
+                          int64_t row_begin, int64_t row_end, int squared, double wmin,
+                          void* grad_x, void* ws, int flags, mm_stream_t stream);
+int mm_spd_stein_div(int dtype, const void* x, const void* y, const void* g, int64_t m, int d,
+                     int squared, double wmin, void* out, void* grad_x, void* grad_y,
+                     mm_stream_t stream);
+
 /* Counts the points whose Cholesky factorisation failed in the last prepare of `ws`
  * (n = the point count it was prepared for) into *host_status (0 = all succeeded).
  * Synchronises `stream` — the only blocking call of the ABI. */

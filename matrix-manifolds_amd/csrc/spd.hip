@@ -27,73 +27,15 @@
 #include "smallmat.hpp"
 #include "loss.hpp"
 
+#include "spd_ws.hpp"
+
 namespace mm {
-
-constexpr int kBlock = 256;  // 4 wavefronts
-// Tile-shape sweep on MI355X (SPD(3) fp32, n = 5000, backward): rows per wavefront 4 / 6 / 8 / 12 -> 90.7 / 81.5 /
-// 70.0 / 73.5 us; wavefronts per workgroup 8 -> +1.5 us.  Persistent workgroups (one launch-filling grid that
-// loops over tiles) were measured slower too: 118 us with a global atomic tile counter (same-address returning
-// atomics serialise at ~18 ns each), 75-81 us with a static round-robin (78 VGPRs -> 6 wavefronts per SIMD).
-#ifndef MM_BWD_G_AHEAD
-#define MM_BWD_G_AHEAD 3   // rows of the pair vector requested ahead of their use in the backward
-#endif
-#ifndef MM_BWD_WAVES
-#define MM_BWD_WAVES 4
-#endif
-// backward: wavefronts that share one 64-column tile (one column-side atomic flush per workgroup);
-// 4 where the LDS combine buffer of 8 would not fit (fp64, D = 5)
-template <typename T, int D> constexpr int bwd_waves() { return (sizeof(T) == 4 && D <= 4) ? MM_BWD_WAVES : 4; }
-constexpr int kSpdMaxD = 5;
-
-__host__ __device__ inline int64_t pair_off(int64_t n, int64_t row) { return row * (2 * n - row - 1) / 2; }
-
-// Workspace layout (T = element type, NP = d(d+1)/2):
-//   [0,64)            word 0 = number of non-PD points (written by mm_spd_status' reduction)
-//   bad    int[n]     per-point "Cholesky failed" flag, written unconditionally by prep
-//   nodeL  T[n][NP]   packed lower L_i^-1
-//   nodeX  T[n][NP]   packed sym(X_i)
-//   nodeC  T[n][NP]   packed lower Cholesky factor L_i
-//   accM   T[NP][n]   row-side accumulators     sum_j M_ij,            M_ij = 2 g log(A_ij)
-//   accS   T[D*D][n]  column-side accumulators  sum_i L_i^-T M_ij L_i^T
-//   loss   T[2][256]  fused-loss partial sums (loss, d loss / d softplus(scale)), spread over 256 slots
-// The gradient w.r.t. the column point is L_i^-T [M A^-1] L_i^-1 with A^-1 = L_i^T X_j^-1 L_i, i.e.
-// (L_i^-T M L_i^T) X_j^-1: the factor X_j^-1 is common to the whole column, so only M is formed per
-// pair and X_j^-1 is applied once per point in finalize.
-// No memset is ever needed: prep zeroes the accumulators of its point and finalize zeroes
-// them again after reading (the fill kernels cost more than prep itself at n = 5000).
-template <typename T> struct Ws {
-  int* status;
-  int* bad;
-  T* nodeL;
-  T* nodeX;
-  T* nodeC;
-  T* accM;
-  T* accS;
-  T* loss;
-  static size_t bad_bytes(int64_t n) { return (size_t(n) * sizeof(int) + 63) / 64 * 64; }
-  static size_t bytes(int64_t n, int d) {
-    const int np = d * (d + 1) / 2;
-    return 64 + bad_bytes(n) + sizeof(T) * (size_t(n) * (4 * np + d * d) + 2 * kLossSlots);
-  }
-  Ws(void* base, int64_t n, int d) {
-    const int np = d * (d + 1) / 2;
-    char* p = static_cast<char*>(base);
-    status = reinterpret_cast<int*>(p);
-    bad = reinterpret_cast<int*>(p + 64);
-    nodeL = reinterpret_cast<T*>(p + 64 + bad_bytes(n));
-    nodeX = nodeL + n * np;
-    nodeC = nodeX + n * np;
-    accM = nodeC + n * np;
-    accS = accM + n * np;
-    loss = accS + n * d * d;
-  }
-};
 
 // ------------------------------------------------------------------ prep
 template <typename T, int D>
 __global__ void spd_prep_kernel(const T* __restrict__ x, int n, T* __restrict__ nodeL, T* __restrict__ nodeX,
                                 T* __restrict__ nodeC, T* __restrict__ accM, T* __restrict__ accS,
-                                T* __restrict__ loss, int* __restrict__ bad) {
+                                T* __restrict__ loss, int* __restrict__ bad, T* __restrict__ nodeLd) {
   constexpr int NP = Packed<D>::NP;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (blockIdx.x == 0)
@@ -113,6 +55,10 @@ __global__ void spd_prep_kernel(const T* __restrict__ x, int n, T* __restrict__ 
 #pragma unroll
   for (int k = 0; k < D * D; ++k) accS[size_t(k) * n + i] = T(0);
   bad[i] = ok ? 0 : 1;
+  T ld = T(0);
+#pragma unroll
+  for (int k = 0; k < D; ++k) ld += Num<T>::log(l[pidx(k, k)]);
+  nodeLd[i] = ld + ld;
 }
 
 __global__ void spd_count_bad_kernel(const int* __restrict__ bad, int n, int* __restrict__ status) {
@@ -256,40 +202,6 @@ __device__ __forceinline__ T pair_value(const TL (&li)[Packed<D>::NP], const T (
     T w[D], lw[D], v[D][D];
     return pair_core<T, D, false, CHOL>(li, xj, wmin, wmax, w, lw, v);
   }
-}
-
-// Folded triangular grid.  Row tile y needs the column blocks from the one holding its
-// first super-diagonal entry to the last; pairing tile y with tile gy-1-y makes every
-// grid row about equally long, so (almost) no launched workgroup is empty.
-struct TileId { int i0, jbase; bool ok; };
-template <int TI, int BW = kBlock> __device__ __forceinline__ TileId fold_tile(int n, int row_begin, int row_end) {
-  const int gy = (row_end - row_begin + TI - 1) / TI;
-  const int nJB = (n + BW - 1) / BW;
-  int y = blockIdx.y, x = blockIdx.x;
-  int cb0 = (row_begin + y * TI + 1) / BW;
-  int cnt = nJB - cb0;
-  if (x >= cnt) {
-    x -= cnt;
-    const int y2 = gy - 1 - y;
-    if (y2 <= y) return {0, 0, false};
-    y = y2;
-    cb0 = (row_begin + y * TI + 1) / BW;
-    cnt = nJB - cb0;
-    if (x >= cnt) return {0, 0, false};
-  }
-  return {row_begin + y * TI, (cb0 + x) * BW, true};
-}
-template <int TI, int BW = kBlock> inline dim3 fold_grid(int64_t n, int64_t rb, int64_t re) {
-  const int gy = int((re - rb + TI - 1) / TI);
-  const int nJB = int((n + BW - 1) / BW);
-  int gx = 0;
-  for (int y = 0; y < (gy + 1) / 2; ++y) {
-    const int y2 = gy - 1 - y;
-    int c = nJB - int((rb + int64_t(y) * TI + 1) / BW);
-    if (y2 > y) c += nJB - int((rb + int64_t(y2) * TI + 1) / BW);
-    gx = c > gx ? c : gx;
-  }
-  return dim3(gx > 0 ? gx : 1, (gy + 1) / 2 > 0 ? (gy + 1) / 2 : 1);
 }
 
 // ------------------------------------------------------------------ forward
@@ -810,7 +722,7 @@ template <typename T, int D>
 int spd_pdist_prepare(const T* x, int64_t n, Ws<T>& ws, int flags, hipStream_t st) {
   if (!(flags & MM_WS_PREPARED)) {
     spd_prep_kernel<T, D><<<dim3((n + 127) / 128), dim3(128), 0, st>>>(x, int(n), ws.nodeL, ws.nodeX, ws.nodeC,
-                                                                       ws.accM, ws.accS, ws.loss, ws.bad);
+                                                                       ws.accM, ws.accS, ws.loss, ws.bad, ws.nodeLd);
     MM_CHECK_LAUNCH();
   }
   return MM_OK;
@@ -918,6 +830,8 @@ int spd_pdist_bwd_t(const T* x, const T* g, int64_t n, int64_t rb, int64_t re, i
   MM_CHECK_LAUNCH();
   return MM_OK;
 }
+
+#include "spd_stein.hpp"
 
 // dtype x D dispatch ---------------------------------------------------------
 #define MM_DISPATCH_D(T, d, CALL)                \
@@ -1061,6 +975,42 @@ int mm_spd_rsgd_step(int dtype, const void* x, const void* egrad, int64_t m, int
               (launch_pointwise<T, D>(spd_rsgd_step_kernel<T, D>, m, st, static_cast<const T*>(x),
                                       static_cast<const T*>(egrad), m, T(lr), T(max_grad_norm), exact,
                                       static_cast<T*>(x_new))));
+}
+
+int mm_spd_stein_pdiv_fwd(int dtype, const void* x, int64_t n, int d, int64_t row_begin, int64_t row_end, int squared,
+                          double wmin, void* out, void* ws, int flags, mm_stream_t stream) {
+  if (!x || !ws || n < 0 || row_begin < 0 || row_end > n || row_begin > row_end || n > (1 << 30)) return MM_ERR_ARG;
+  if (n == 0) return MM_OK;
+  if (!out && mm_pair_offset(n, row_end) > mm_pair_offset(n, row_begin)) return MM_ERR_ARG;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  MM_DISPATCH(dtype, d,
+              (spd_stein_fwd_t<T, D>(static_cast<const T*>(x), n, row_begin, row_end, squared, wmin,
+                                     static_cast<T*>(out), ws, flags, st)));
+}
+
+int mm_spd_stein_pdiv_bwd(int dtype, const void* x, const void* g, int64_t n, int d, int64_t row_begin, int64_t row_end,
+                          int squared, double wmin, void* grad_x, void* ws, int flags, mm_stream_t stream) {
+  if (!x || !ws || !grad_x || n < 0 || row_begin < 0 || row_end > n || row_begin > row_end || n > (1 << 30))
+    return MM_ERR_ARG;
+  if (n == 0) return MM_OK;
+  if (!g && mm_pair_offset(n, row_end) > mm_pair_offset(n, row_begin)) return MM_ERR_ARG;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  MM_DISPATCH(dtype, d,
+              (spd_stein_bwd_t<T, D>(static_cast<const T*>(x), static_cast<const T*>(g), n, row_begin, row_end, squared,
+                                     wmin, static_cast<T*>(grad_x), ws, flags, st)));
+}
+
+int mm_spd_stein_div(int dtype, const void* x, const void* y, const void* g, int64_t m, int d, int squared, double wmin,
+                     void* out, void* grad_x, void* grad_y, mm_stream_t stream) {
+  if (m < 0 || (m > 0 && (!x || !y)) || ((grad_x != nullptr) != (grad_y != nullptr)) || (grad_x && !g) ||
+      (!out && !grad_x))
+    return MM_ERR_ARG;
+  if (m == 0) return MM_OK;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  MM_DISPATCH(dtype, d,
+              (launch_pointwise<T, D>(spd_stein_div_kernel<T, D>, m, st, static_cast<const T*>(x),
+                                      static_cast<const T*>(y), static_cast<const T*>(g), m, squared, T(wmin),
+                                      static_cast<T*>(out), static_cast<T*>(grad_x), static_cast<T*>(grad_y))));
 }
 
 }  // extern "C"

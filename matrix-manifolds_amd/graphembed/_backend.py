@@ -40,6 +40,9 @@ SIGNATURES = {
     'mm_spd_pdist_bwd': (_i, [_i, _vp, _vp, _i64, _i, _i64, _i64, _i, _dbl, _dbl, _vp, _vp, _i, _vp]),
     'mm_spd_pdist_loss': (_i, [_i, _i, _vp, _vp, _vp, _i64, _i, _i64, _i64, _dbl, _dbl, _i, _dbl, _dbl, _vp, _vp,
                                 _vp, _i, _vp]),
+    'mm_spd_stein_pdiv_fwd': (_i, [_i, _vp, _i64, _i, _i64, _i64, _i, _dbl, _vp, _vp, _i, _vp]),
+    'mm_spd_stein_pdiv_bwd': (_i, [_i, _vp, _vp, _i64, _i, _i64, _i64, _i, _dbl, _vp, _vp, _i, _vp]),
+    'mm_spd_stein_div': (_i, [_i, _vp, _vp, _vp, _i64, _i, _i, _dbl, _vp, _vp, _vp, _vp]),
     'mm_spd_status': (_i, [_vp, _i64, _c.POINTER(_i), _vp]),
     'mm_spd_dist_fwd': (_i, [_i, _vp, _vp, _i64, _i, _i, _dbl, _dbl, _vp, _vp]),
     'mm_spd_dist_bwd': (_i, [_i, _vp, _vp, _vp, _i64, _i, _i, _dbl, _dbl, _vp, _vp, _vp]),

@@ -9,7 +9,8 @@ methods, shapes and clamps).  Differences, all documented in DESIGN.md §6:
 * the gradient of `pdist`/`dist` is the symmetric part of what the reference's
   autograd returns (the reference reads only one triangle and yields a
   non-symmetric matrix; everything downstream symmetrises it, spd.py:119-135);
-* the Stein-divergence path (`use_stein_div=True`) is not on this hot path.
+* `use_stein_div=True` rebinds `dist` / `pdist` to the Stein divergence (spd.py:51-53, 183-194, 246-295),
+  also on pair kernels (csrc/spd_stein.hpp); the reference's dense (n, n, d, d) backward is gone.
 """
 import math
 
@@ -140,17 +141,87 @@ class _SpdDist(torch.autograd.Function):
         return gx.reshape(xs), gy.reshape(ys), None, None, None, None
 
 
+class _SteinPdiv(torch.autograd.Function):
+    """Pairwise Stein divergence over the rows [row_begin, row_end) of the pair list —
+    PairwiseSteinDivergence (spd.py:246-295) + the value clamp / sqrt of stein_pdiv (191-194)."""
+
+    @staticmethod
+    def forward(ctx, x, n_mat, squared, wmin, row_begin, row_end):
+        B.require_gpu(x)
+        lib = B.lib()
+        xc = x.detach().contiguous()
+        n = xc.shape[0]
+        dt = B.dtype_code(xc)
+        npairs = B.pair_offset(n, row_end) - B.pair_offset(n, row_begin)
+        ctx.save_for_backward(xc)
+        ctx.empty = npairs == 0
+        if ctx.empty:
+            return xc.new_empty(0)
+        with B.on_device(xc.device):
+            ws = torch.empty(lib.raw('mm_spd_pdist_ws_bytes')(dt, n, n_mat), dtype=torch.uint8,
+                             device=xc.device)
+            out = torch.empty(npairs, dtype=xc.dtype, device=xc.device)
+            lib.call('mm_spd_stein_pdiv_fwd', dt, B.ptr(xc), n, n_mat, row_begin, row_end, int(squared),
+                     wmin, B.ptr(out), B.ptr(ws), 0, B.stream_of(xc))
+        ctx.ws = ws
+        ctx.args = (n_mat, squared, wmin, row_begin, row_end)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        xc, = ctx.saved_tensors
+        if ctx.empty:
+            return (torch.zeros_like(xc), ) + (None, ) * 5
+        n_mat, squared, wmin, row_begin, row_end = ctx.args
+        g = g.contiguous()
+        with B.on_device(xc.device):
+            grad = torch.empty_like(xc)
+            B.lib().call('mm_spd_stein_pdiv_bwd', B.dtype_code(xc), B.ptr(xc), B.ptr(g), xc.shape[0], n_mat,
+                         row_begin, row_end, int(squared), wmin, B.ptr(grad), B.ptr(ctx.ws),
+                         B.MM_WS_PREPARED, B.stream_of(xc))
+        return grad, None, None, None, None, None
+
+
+class _SteinDiv(torch.autograd.Function):
+    """Element-wise Stein divergence (spd.py:183-189)."""
+
+    @staticmethod
+    def forward(ctx, x, y, n_mat, squared, wmin):
+        B.require_gpu(x, y)
+        xc, yc = _flat(x.detach(), n_mat), _flat(y.detach(), n_mat)
+        with B.on_device(xc.device):
+            out = torch.empty(xc.shape[0], dtype=xc.dtype, device=xc.device)
+            B.lib().call('mm_spd_stein_div', B.dtype_code(xc), B.ptr(xc), B.ptr(yc), None, xc.shape[0], n_mat,
+                         int(squared), wmin, B.ptr(out), None, None, B.stream_of(xc))
+        ctx.save_for_backward(xc, yc)
+        ctx.args = (n_mat, squared, wmin, x.shape, y.shape)
+        return out.reshape(x.shape[:-2])
+
+    @staticmethod
+    def backward(ctx, g):
+        xc, yc = ctx.saved_tensors
+        n_mat, squared, wmin, xs, ys = ctx.args
+        g = g.reshape(-1).contiguous()
+        with B.on_device(xc.device):
+            gx, gy = torch.empty_like(xc), torch.empty_like(yc)
+            B.lib().call('mm_spd_stein_div', B.dtype_code(xc), B.ptr(xc), B.ptr(yc), B.ptr(g), xc.shape[0],
+                         n_mat, int(squared), wmin, None, B.ptr(gx), B.ptr(gy), B.stream_of(xc))
+        return gx.reshape(xs), gy.reshape(ys), None, None, None
+
+
 class SymmetricPositiveDefinite(Manifold):
 
     def __init__(self, n, *, fast_symeig=True, fast_chol=True, use_stein_div=False, wmin=1e-8,
                  wmax=1e8, check_pd=False):
-        if use_stein_div:
-            raise NotImplementedError(
-                'the Stein-divergence path (spd.py:183-194) is outside the accelerated hot path')
         self.n = n
         self.wmin = wmin
         self.wmax = wmax
         self.check_pd = check_pd
+        self.use_stein_div = use_stein_div
+        if use_stein_div:  # spd.py:51-53
+            self.dist = self.stein_div
+            self.pdist = self.stein_pdiv
+            self.pdist_loss = None  # the fused objective is the affine-invariant one
 
     # -- Vec(.) of Pennec et al. (spd.py:66-81)
     @staticmethod
@@ -264,6 +335,16 @@ class SymmetricPositiveDefinite(Manifold):
         assert x.ndim == 3
         rb, re = (0, x.shape[0]) if rows is None else rows
         return _SpdPdistLoss.apply(x, scale, target, self.n, spec, self.wmin, self.wmax, rb, re)
+
+    def stein_div(self, x, y, squared=False, keepdim=False):  # spd.py:183-189
+        shape = torch.broadcast_shapes(x.shape, y.shape)
+        d = _SteinDiv.apply(x.expand(shape), y.expand(shape), self.n, squared, self.wmin)
+        return d.reshape(*d.shape, 1, 1) if keepdim else d
+
+    def stein_pdiv(self, x, squared=False, rows=None):  # spd.py:191-194
+        assert x.ndim == 3
+        rb, re = (0, x.shape[0]) if rows is None else rows
+        return _SteinPdiv.apply(x, self.n, squared, self.wmin, rb, re)
 
     def transp(self, x, y, u):  # spd.py:196-199
         return u

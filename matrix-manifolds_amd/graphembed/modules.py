@@ -134,7 +134,7 @@ class ManifoldEmbedding(torch.nn.Module):
         if not hasattr(objective_fn, 'fused_spec') or not self.xs[0].is_cuda:
             return None
         spec = objective_fn.fused_spec(**kwargs)
-        if self.n_components == 1 and hasattr(self.manifolds[0], 'pdist_loss'):
+        if self.n_components == 1 and getattr(self.manifolds[0], 'pdist_loss', None) is not None:
             x = self.xs[0] if i is None else self.xs[0][i]
             return self.manifolds[0].pdist_loss(x, self.scales[0], gdists, spec, rows=rows)
         if self.n_components > _max_product_factors():

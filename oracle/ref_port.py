@@ -169,7 +169,7 @@ class Manifold:
 
 
 class SPD(Manifold):
-    """manifolds/spd.py:21-243 (affine-invariant metric; Stein path not ported)."""
+    """manifolds/spd.py:21-243 (affine-invariant metric; Stein divergence: stein_div / stein_pdiv)."""
 
     ndim = 2
 
@@ -265,6 +265,25 @@ class SPD(Manifold):
         l_inv, _ = self.invchol(x)
         i, j = triu_pairs(x.shape[0], x.device)
         return self._norm_log(axat(l_inv[i], x[j]), squared)
+
+    # -- Stein divergence (spd.py:183-194, 246-295; linalg/torch_batch.py:173-197) -------------------
+    def _logdet(self, x):
+        """2 sum log |diag chol(x)| — PLogDet.forward; autograd of this expression yields g X^-1."""
+        return 2 * self.chol(x).diagonal(dim1=-2, dim2=-1).abs().log().sum(-1)
+
+    def stein_div(self, x, y, squared=False, keepdim=False):
+        div = self._logdet(0.5 * (x + y)) - 0.5 * (self._logdet(x) + self._logdet(y))
+        div = vclamp(div, self.wmin)
+        div = div if squared else div.sqrt()
+        return div.reshape(*div.shape, 1, 1) if keepdim else div
+
+    def stein_pdiv(self, x, squared=False):
+        assert x.ndim == 3
+        i, j = triu_pairs(x.shape[0], x.device)
+        ld = self._logdet(x)
+        div = self._logdet(0.5 * (x[i] + x[j])) - 0.5 * (ld[i] + ld[j])
+        div = vclamp(div, self.wmin)
+        return div if squared else div.sqrt()
 
     def transp(self, x, y, u):  # spd.py:196-199
         return u

@@ -183,3 +183,30 @@ def test_tree40_training_trace(case, loss_name):
     close(np.array(losses), G[f'{base}/losses'], 1e-6, 'loss trace')
     for k in range(len(mans)):
         close(xs[k], G[f'{base}/x20_{k}'], 1e-6, f'x20_{k}')
+
+
+@pytest.mark.parametrize('d', [2, 3, 4])
+@pytest.mark.parametrize('dname', ['f32', 'f64'])
+def test_stein_divergence(d, dname):
+    """The port's Stein path (spd.py:183-194, 246-295) against vectors recorded from the reference's
+    PairwiseSteinDivergence / stein_div, values and autograd gradients."""
+    G = load_golden('stein')
+    man = rp.SPD(d)
+    tol = 2e-4 if dname == 'f32' else 1e-9
+    for init in ('rand', 'wide'):
+        for n in (33, 70):
+            tag = f'spd{d}/{dname}/{init}/n{n}'
+            x = T(G[f'{tag}/x']).requires_grad_()
+            g = T(G[f'{tag}/g'])
+            for squared, sfx in ((True, 'sq'), (False, 'rt')):
+                div = man.stein_pdiv(x, squared=squared)
+                close(div.detach(), G[f'{tag}/div_{sfx}'], tol, f'div {tag} {sfx}')
+                gr, = torch.autograd.grad((div * g).sum(), x)
+                close(sym(gr.numpy()), sym(G[f'{tag}/grad_{sfx}']), tol * 10, f'grad {tag} {sfx}')
+            xx = T(G[f'{tag}/x']).requires_grad_()
+            y = T(G[f'{tag}/x']).flip(0).clone().requires_grad_()
+            dd = man.stein_div(xx, y, squared=True)
+            close(dd.detach(), G[f'{tag}/dist_sq'], tol, f'dist {tag}')
+            gx, gy = torch.autograd.grad(dd.sum(), [xx, y])
+            close(sym(gx.numpy()), sym(G[f'{tag}/dist_gx']), tol * 10, f'dist gx {tag}')
+            close(sym(gy.numpy()), sym(G[f'{tag}/dist_gy']), tol * 10, f'dist gy {tag}')

@@ -522,3 +522,99 @@ def test_reference_property_suite(d, seed):
     # test_no_nan_dists
     big = rand_spd(1000 if d < 4 else 50).float()
     assert not torch.isnan(spd.pdist(big)).any()
+
+
+# ------------------------------------------------------------------ Stein divergence
+@pytest.mark.parametrize('d', [2, 3, 4])
+@pytest.mark.parametrize('dname', list(DT))
+def test_stein_vs_reference_golden(d, dname):
+    """SymmetricPositiveDefinite(use_stein_div=True): pdist / dist and gradients against vectors recorded
+    from the reference's PairwiseSteinDivergence / stein_div (tests/golden/gen_golden_stein.py)."""
+    from graphembed.manifolds import SymmetricPositiveDefinite as SPD
+    G = load_golden('stein')
+    man = SPD(d, use_stein_div=True)
+    vt = 2e-5 if dname == 'f32' else 1e-7
+    gt = 2e-4 if dname == 'f32' else 5e-7
+    for init in ('rand', 'wide'):
+        for n in (33, 70):
+            tag = f'spd{d}/{dname}/{init}/n{n}'
+            x = dev(G[f'{tag}/x']).requires_grad_()
+            g = dev(G[f'{tag}/g'])
+            for squared, sfx in ((True, 'sq'), (False, 'rt')):
+                div = man.pdist(x, squared=squared)
+                ref = np.asarray(G[f'{tag}/div_{sfx}'], dtype=np.float64)
+                err = np.abs(div.detach().double().cpu().numpy() - ref)
+                # close pairs: S ~ 1e-3 is a difference of O(1) log-determinants -> absolute fp32 noise
+                assert (err <= (2e-6 if dname == 'f32' else 1e-9) + vt * np.abs(ref)).all() or sfx == 'rt', err.max()
+                if sfx == 'rt':  # sqrt amplifies that noise: compare the squares
+                    sq = (div * div).detach().double().cpu().numpy()
+                    assert (np.abs(sq - ref * ref) <= (2e-6 if dname == 'f32' else 1e-9) + vt * ref * ref).all()
+                if dname == 'f32' and init == 'rand' and sfx == 'rt':
+                    continue  # d sqrt(S) at S ~ 1e-3 in fp32: ill-conditioned in both implementations
+                gr, = torch.autograd.grad((div * g).sum(), x)
+                check_rel(gr, sym(G[f'{tag}/grad_{sfx}']), gt * (20 if init == 'rand' and dname == 'f32' else 1),
+                          f'grad {tag} {sfx}')
+            xx = dev(G[f'{tag}/x']).requires_grad_()
+            y = dev(G[f'{tag}/x']).flip(0).clone().requires_grad_()
+            dd = man.dist(xx, y, squared=True)
+            ref = np.asarray(G[f'{tag}/dist_sq'], dtype=np.float64)
+            assert (np.abs(dd.detach().double().cpu().numpy() - ref) <= (2e-6 if dname == 'f32' else 1e-9) + vt * np.abs(ref)).all()
+            gx, gy = torch.autograd.grad(dd.sum(), [xx, y])
+            check_rel(gx, sym(G[f'{tag}/dist_gx']), gt * (20 if init == 'rand' and dname == 'f32' else 1), f'dist gx {tag}')
+            check_rel(gy, sym(G[f'{tag}/dist_gy']), gt * (20 if init == 'rand' and dname == 'f32' else 1), f'dist gy {tag}')
+
+
+@pytest.mark.parametrize('dname', list(DT))
+def test_stein_vs_oracle_seeded_and_shards(dname):
+    """Sizes that cross tiles and the diagonal blocks, against the oracle port; row shards reproduce the
+    unsharded forward bit for bit and sum to its backward; the embedding's fused objective falls back to
+    per-factor kernels + mm_product_loss for a Stein manifold."""
+    from graphembed import _backend as B
+    from graphembed.manifolds import SymmetricPositiveDefinite as SPD
+    from graphembed.modules import ManifoldEmbedding
+    from graphembed.objectives import StressLoss
+    from oracle import ref_port as rp
+    gen = torch.Generator().manual_seed(12)
+    for d, n in ((3, 700), (4, 150), (5, 80)):
+        port = rp.SPD(d)
+        a = torch.rand(n, d, d, dtype=torch.float64, generator=gen)
+        x64 = a @ a.transpose(1, 2) + torch.eye(d, dtype=torch.float64)
+        g64 = torch.randn(n * (n - 1) // 2, dtype=torch.float64, generator=gen)
+        xr = x64.clone().requires_grad_()
+        ref = port.stein_pdiv(xr, squared=True)
+        ref_g, = torch.autograd.grad((ref * g64).sum(), xr)
+        man = SPD(d, use_stein_div=True)
+        x = x64.to(DT[dname]).cuda().requires_grad_()
+        g = g64.to(DT[dname]).cuda()
+        div = man.pdist(x, squared=True)
+        tol = 2e-5 if dname == 'f32' else 1e-11
+        err = np.abs(div.detach().double().cpu().numpy() - ref.detach().numpy())
+        assert (err <= (2e-6 if dname == 'f32' else 1e-12) + tol * np.abs(ref.detach().numpy())).all(), err.max()
+        gr, = torch.autograd.grad((div * g).sum(), x)
+        check_rel(gr, sym(ref_g.numpy()), 5e-5 if dname == 'f32' else 1e-10, f'grad d={d}')
+        parts, gsum = [], torch.zeros_like(gr)
+        for r in range(3):
+            rb, re = B.shard_rows(n, 3, r)
+            lo, hi = B.pair_offset(n, rb), B.pair_offset(n, re)
+            xs = x.detach().clone().requires_grad_()
+            part = man.pdist(xs, squared=True, rows=(rb, re))
+            pg, = torch.autograd.grad((part * g[lo:hi]).sum(), xs)
+            parts.append(part.detach())
+            gsum += pg
+        assert torch.equal(torch.cat(parts), div.detach())
+        check_rel(gsum, gr.double().cpu().numpy(), 2e-5 if dname == 'f32' else 1e-12, 'sum of shard grads')
+    torch.manual_seed(2)
+    torch.set_default_dtype(DT[dname])
+    try:
+        with torch.device('cuda'):
+            emb = ManifoldEmbedding(300, [SPD(3, use_stein_div=True)])
+            target = torch.rand(300 * 299 // 2) * 0.01 + 0.001
+    finally:
+        torch.set_default_dtype(torch.float32)
+    fn = StressLoss()
+    ref = fn(target, emb.compute_dists(None))
+    rg = torch.autograd.grad(ref, [emb.xs[0], emb.scales[0]])
+    loss = emb.fused_objective(fn, target, None)
+    gg = torch.autograd.grad(loss, [emb.xs[0], emb.scales[0]])
+    assert abs(loss.item() - ref.item()) <= (1e-4 if dname == 'f32' else 1e-10) * abs(ref.item())
+    check_rel(gg[0], rg[0].double().cpu().numpy(), 1e-3 if dname == 'f32' else 1e-9, 'fused stein grad')

@@ -102,6 +102,7 @@ CASES = {
     # "mid-training" spread: ||log X|| = 0.35 -> pair distances ~0.5 (targets are normalised to max 1)
     'c3_grqc_spd3_n5000_f32_mid': lambda: pdist_case(M.SymmetricPositiveDefinite(3), 5000, torch.float32, ir=0.35),
     'c3_grqc_spd3_n5000_f64_mid': lambda: pdist_case(M.SymmetricPositiveDefinite(3), 5000, torch.float64, ir=0.35),
+    'c3_spd3_stein_n5000_f32': lambda: pdist_case(M.SymmetricPositiveDefinite(3, use_stein_div=True), 5000, torch.float32),
     'c3_spd2_n5000_f32': lambda: pdist_case(M.SymmetricPositiveDefinite(2), 5000, torch.float32),
     'c4_csphd_product_step_f32': lambda: step_case([M.Lorentz(6), M.Sphere(6), M.SymmetricPositiveDefinite(2)], 1025, torch.float32),
     'c4_csphd_product_step_f32_fused': lambda: step_case([M.Lorentz(6), M.Sphere(6), M.SymmetricPositiveDefinite(2)], 1025, torch.float32, fused=True),

@@ -259,6 +259,18 @@ int mm_product_loss(int dtype, int loss_kind, int nf, const void* const* d2, con
                     const void* const* scale_raw, int64_t npairs, double alpha, double eps, int terms,
                     void* const* g_out, void* loss_out, void* ws, mm_stream_t stream);
 
+/* ---- graph-reconstruction metric --------------------------------------------- */
+/* Per-node average precision of the embedding's neighbour ranking — what
+ * FastPrecision::MeanAveragePrecision (pyx/impl/precision.cpp) and py_mean_average_precision
+ * (metrics.py:61-96) average into the MAP score.
+ *   dist          [n,n] dense symmetric embedding distances (zeros on the diagonal)
+ *   indptr/indices  CSR adjacency of the (unweighted) graph, int32, device memory
+ *   rank_scratch  int[nnz] device scratch
+ *   ap_out        [n]: AP(u) = 1/deg(u) sum_{v in N(u)} (#neighbours ranked <= v) / rank(v); ties by node index. */
+int mm_graph_average_precision(int dtype, const void* dist, int64_t n, const int* indptr,
+                               const int* indices, int* rank_scratch, void* ap_out,
+                               mm_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -557,3 +557,24 @@ def make(name, *args):
     return {'spd': SPD, 'lorentz': Lorentz, 'sphere': Sphere,
             'euclidean': Euclidean, 'grassmann': Grassmann,
             'stiefel': Stiefel}[name](*args)
+
+
+# ---------------------------------------------------------------- metrics.py:61-96
+def mean_average_precision(dense, neighbours):
+    """py_mean_average_precision restated on plain numpy: `dense` is the (n, n) matrix of embedding
+    distances (zero diagonal), `neighbours[u]` the set of graph neighbours of node u."""
+    import numpy as np
+    n = dense.shape[0]
+    scores = []
+    for u in range(n):
+        order = np.argsort(dense[u], kind='stable')
+        nb = neighbours[u]
+        hits, psum = 0, 0.0
+        for i in range(1, n):
+            if order[i] in nb:
+                hits += 1
+                psum += hits / i
+                if hits == len(nb):
+                    break
+        scores.append(psum / len(nb))
+    return float(np.mean(scores))

@@ -1,0 +1,78 @@
+"""Metrics: the oracle's MAP restatement and this package's metric functions against
+values recorded from the reference's graphembed/metrics.py; the GPU average-precision kernel against
+both (the reference's own tests: tests/test_metrics.py:15-24)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+
+CASES = [f'er{n}_{p}_{s}' for n, p in ((50, 0.1), (100, 0.05), (100, 0.5), (300, 0.02)) for s in (0, 1)]
+
+
+def _graph(G, tag):
+    import networkx as nx
+    g = nx.Graph()
+    g.add_nodes_from(range(int(G[f'{tag}/n'])))
+    g.add_edges_from(np.asarray(G[f'{tag}/edges']).tolist())
+    return g
+
+
+@pytest.mark.parametrize('tag', CASES)
+def test_oracle_map_vs_reference(tag):
+    from scipy.spatial.distance import squareform
+    from oracle import ref_port as rp
+    G = load_golden('metrics')
+    g = _graph(G, tag)
+    nb = [set(g.neighbors(u)) for u in range(g.number_of_nodes())]
+    got = rp.mean_average_precision(squareform(np.asarray(G[f'{tag}/pdists'], dtype=np.float64)), nb)
+    assert abs(got - float(G[f'{tag}/map'])) <= 1e-12
+
+
+@pytest.mark.parametrize('tag', CASES[:4])
+def test_scalar_metrics_vs_reference(tag):
+    from graphembed import metrics as M
+    G = load_golden('metrics')
+    md, gd = torch.from_numpy(np.array(G[f'{tag}/md'])), torch.from_numpy(np.array(G[f'{tag}/gd']))
+    assert abs(M.average_distortion(md, gd).item() - float(G[f'{tag}/distortion'])) <= 1e-12
+    assert abs(M.pearsonr(md, gd).item() - float(G[f'{tag}/pearsonr'])) <= 1e-12
+    assert abs(M.average_pearsonr(md, gd).item() - float(G[f'{tag}/avg_pearsonr'])) <= 1e-10
+    vs = np.array(G['auc/vs'])
+    np.testing.assert_allclose(M.area_under_curve(vs), G['auc/full'], rtol=1e-12)
+    np.testing.assert_allclose(M.area_under_curve(vs, 4), G['auc/step4'], rtol=1e-12)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('tag', CASES)
+def test_gpu_map_vs_reference_golden(tag):
+    from graphembed.metrics import mean_average_precision
+    from graphembed.pyx import FastPrecision
+    G = load_golden('metrics')
+    g = _graph(G, tag)
+    pd = torch.from_numpy(np.array(G[f'{tag}/pdists']))
+    ref = float(G[f'{tag}/map'])
+    assert abs(FastPrecision(g).mean_average_precision(pd) - ref) <= 1e-6
+    assert abs(mean_average_precision(pd.double().cuda(), g) - ref) <= 1e-9
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('n,p', [(1000, 0.01), (1000, 0.5), (2500, 0.004)])
+def test_gpu_map_vs_oracle_seeded(n, p):
+    """The reference's test_cython_map sizes: random distances on Erdos-Renyi graphs; ties (duplicated
+    distances) resolve by node index like a stable argsort; the perfect embedding scores 1."""
+    import networkx as nx
+    from scipy.spatial.distance import squareform
+    from graphembed.data.graph import compute_graph_pdists
+    from graphembed.pyx import FastPrecision
+    from oracle import ref_port as rp
+    g = nx.erdos_renyi_graph(n, p, seed=3)
+    g = nx.convert_node_labels_to_integers(g.subgraph(max(nx.connected_components(g), key=len)).copy())
+    m = g.number_of_nodes()
+    rng = np.random.default_rng(5)
+    pd = rng.random(m * (m - 1) // 2).astype(np.float32)
+    pd[::7] = pd[3]  # ties
+    nb = [set(g.neighbors(u)) for u in range(m)]
+    fp = FastPrecision(g)
+    ref = rp.mean_average_precision(squareform(pd.astype(np.float64)), nb)
+    assert abs(fp.mean_average_precision(torch.from_numpy(pd)) - ref) <= 1e-6
+    assert abs(fp.mean_average_precision(torch.from_numpy(compute_graph_pdists(g)).float()) - 1.0) <= 1e-6

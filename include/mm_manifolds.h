@@ -259,6 +259,11 @@ int mm_product_loss(int dtype, int loss_kind, int nf, const void* const* d2, con
                     const void* const* scale_raw, int64_t npairs, double alpha, double eps, int terms,
                     void* const* g_out, void* loss_out, void* ws, mm_stream_t stream);
 
+/* Targets of a node minibatch: out[pair (a,b), a<b] = dense[idx[a]][idx[b]] in pair-vector order
+ * (GraphDataset.__getitem__, data/dataset.py:19-27).  dense [n,n]; idx int64[bs] (device); out [bs(bs-1)/2]. */
+int mm_pair_gather(int dtype, const void* dense, int64_t n, const int64_t* idx, int64_t bs, void* out,
+                   mm_stream_t stream);
+
 /* ---- graph-reconstruction metric --------------------------------------------- */
 /* Per-node average precision of the embedding's neighbour ranking — what
  * FastPrecision::MeanAveragePrecision (pyx/impl/precision.cpp) and py_mean_average_precision

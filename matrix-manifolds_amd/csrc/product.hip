@@ -103,6 +103,19 @@ int product_loss_t(int loss_kind, int nf, const void* const* d2, const void* tar
   return e == hipSuccess ? MM_OK : int(e);
 }
 
+// Targets of a node minibatch straight from the dense target matrix (GraphDataset.__getitem__,
+// data/dataset.py:19-27; train.py:203-213): out[pair (a, b)] = dense[idx[a]][idx[b]] for a < b in the
+// pair-vector order — one launch instead of two row/column gathers, a triu_indices and a masked gather.
+template <typename T>
+__global__ __launch_bounds__(256) void pair_gather_kernel(const T* __restrict__ dense, int64_t n,
+                                                          const int64_t* __restrict__ idx, int bs, T* __restrict__ out) {
+  const int a = blockIdx.y;
+  const int b = a + 1 + blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= bs) return;
+  const int64_t ia = idx[a], ibb = idx[b];
+  out[int64_t(a) * (2 * int64_t(bs) - a - 1) / 2 + (b - a - 1)] = dense[ia * n + ibb];
+}
+
 }  // namespace mm
 
 using namespace mm;
@@ -128,6 +141,24 @@ int mm_product_loss(int dtype, int loss_kind, int nf, const void* const* d2, con
   if (dtype == MM_F64)
     return product_loss_t<double>(loss_kind, nf, d2, target, scale_raw, npairs, alpha, eps, terms, g_out, loss_out, ws, st);
   return MM_ERR_ARG;
+}
+
+int mm_pair_gather(int dtype, const void* dense, int64_t n, const int64_t* idx, int64_t bs, void* out,
+                   mm_stream_t stream) {
+  if (n < 0 || bs < 0 || bs > (1 << 30) || (bs > 1 && (!dense || !idx || !out))) return MM_ERR_ARG;
+  if (bs < 2) return MM_OK;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const dim3 grid(unsigned((bs - 1 + 255) / 256), unsigned(bs - 1));
+  if (dtype == MM_F32)
+    pair_gather_kernel<float><<<grid, dim3(256), 0, st>>>(static_cast<const float*>(dense), n, idx, int(bs),
+                                                         static_cast<float*>(out));
+  else if (dtype == MM_F64)
+    pair_gather_kernel<double><<<grid, dim3(256), 0, st>>>(static_cast<const double*>(dense), n, idx, int(bs),
+                                                          static_cast<double*>(out));
+  else
+    return MM_ERR_ARG;
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? MM_OK : int(e);
 }
 
 }  // extern "C"

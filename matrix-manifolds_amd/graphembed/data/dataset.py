@@ -37,7 +37,17 @@ class GraphDataset(Dataset):
         if node_indices is None:
             return self.condensed
         idx = node_indices.to(self.device)
-        return squareform1(self.pdists.index_select(0, idx).index_select(1, idx))
+        dense = self.pdists
+        if dense.is_cuda and dense.dtype in (torch.float32, torch.float64):
+            from graphembed import _backend as B   # one gather kernel straight into pair-vector order
+            idx = idx.to(torch.int64).contiguous()
+            bs = idx.numel()
+            with B.on_device(dense.device):
+                out = torch.empty(bs * (bs - 1) // 2, dtype=dense.dtype, device=dense.device)
+                B.lib().call('mm_pair_gather', B.dtype_code(dense), B.ptr(dense), dense.shape[0], B.ptr(idx), bs,
+                             B.ptr(out), B.stream_of(dense))
+            return out
+        return squareform1(dense.index_select(0, idx).index_select(1, idx))
 
     def pairs(self, shard):
         """The slice of the full pair vector owned by a `graphembed.parallel.PairShard`."""

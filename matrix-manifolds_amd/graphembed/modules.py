@@ -10,6 +10,30 @@ def _max_product_factors():
     return B.lib().raw('mm_product_max_factors')()
 
 
+class _TakeRows(torch.autograd.Function):
+    """x[i] for a node minibatch; the backward is a plain index_add into zeros (the generic indexing
+    backward sorts the indices first: two radix-sort kernels per step for nothing)."""
+
+    @staticmethod
+    def forward(ctx, x, i):
+        ctx.save_for_backward(i)
+        ctx.shape = x.shape
+        return x.index_select(0, i)
+
+    @staticmethod
+    def backward(ctx, g):
+        i, = ctx.saved_tensors
+        return torch.zeros(ctx.shape, dtype=g.dtype, device=g.device).index_add_(0, i, g), None
+
+
+def take_rows(x, i):
+    if i is None:
+        return x
+    if i.dtype != torch.int64 or i.device != x.device:
+        i = i.to(device=x.device, dtype=torch.int64)
+    return _TakeRows.apply(x, i)
+
+
 class _ProductLoss(torch.autograd.Function):
     """Objective of a product embedding with the element-wise part in ONE kernel (mm_product_loss):
     per-factor pdist forward kernels -> loss, per-factor upstream gradients and scale gradients ->
@@ -122,7 +146,7 @@ class ManifoldEmbedding(torch.nn.Module):
     def compute_dists(self, i=None):
         """sum_k softplus(s_k) * pdist_k(x_k[i], squared=True) — modules.py:84-88."""
         return sum(
-            softplus(s) * man.pdist(x if i is None else x[i], squared=True)
+            softplus(s) * man.pdist(take_rows(x, i), squared=True)
             for x, s, man in zip(self.xs, self.scales, self.manifolds))
 
     def fused_objective(self, objective_fn, gdists, i=None, rows=None, **kwargs):
@@ -135,11 +159,11 @@ class ManifoldEmbedding(torch.nn.Module):
             return None
         spec = objective_fn.fused_spec(**kwargs)
         if self.n_components == 1 and getattr(self.manifolds[0], 'pdist_loss', None) is not None:
-            x = self.xs[0] if i is None else self.xs[0][i]
+            x = take_rows(self.xs[0], i)
             return self.manifolds[0].pdist_loss(x, self.scales[0], gdists, spec, rows=rows)
         if self.n_components > _max_product_factors():
             return None
-        xs = [x if i is None else x[i] for x in self.xs]
+        xs = [take_rows(x, i) for x in self.xs]
         return _ProductLoss.apply(gdists, spec, rows, tuple(self.manifolds), *xs, *self.scales)
 
     def __len__(self):

@@ -254,3 +254,52 @@ def test_fused_loss_full_size_tall_tiles():
         err = (g[0] - rg[0]).abs().max().item() / rg[0].abs().max().item()
         assert err <= 2e-4, err
         assert abs(g[1].item() - rg[1].item()) <= 2e-3 * abs(rg[1].item())
+
+
+def test_graphed_minibatch_steps_match_eager():
+    """Node-minibatch training (train.py:198-222, batch_size 512 in the paper grid) as a replayed HIP graph:
+    the index buffer is refreshed in place between replays; targets come from mm_pair_gather, the
+    embedding rows through the index_add backward.  Same parameters as the eager loop."""
+    from graphembed import manifolds as M
+    from graphembed.data import GraphDataset
+    from graphembed.graphed import GraphedTrainStep
+    from graphembed.modules import BatchedObjective, ManifoldEmbedding
+    from graphembed.objectives import StressLoss
+    from graphembed.optim import RiemannianSGD
+    n, bs = 900, 256
+    torch.set_default_dtype(torch.float64)
+    try:
+        def build():
+            torch.manual_seed(9)
+            with torch.device('cuda'):
+                emb = ManifoldEmbedding(n, [M.SymmetricPositiveDefinite(3)])
+                ds = GraphDataset(torch.rand(n * (n - 1) // 2) + 0.1)
+            obj = BatchedObjective(StressLoss(), ds, emb)
+            opts = [RiemannianSGD(list(emb.xs), lr=0.01, exact=True, max_grad_norm=20),
+                    RiemannianSGD(list(emb.scales), lr=1e-4, max_grad_norm=500)]
+            return emb, obj, opts
+        torch.manual_seed(3)
+        perm = torch.randperm(n, device='cuda')
+        batches = [perm[k * bs:(k + 1) * bs] for k in range(3)] * 2
+        emb_e, obj_e, opts_e = build()
+        for idx in batches:
+            for o in opts_e:
+                o.zero_grad()
+            obj_e(idx).backward()
+            for o in opts_e:
+                o.step()
+        emb_g, obj_g, opts_g = build()
+        idx_static = batches[0].clone()
+        step = GraphedTrainStep(lambda: obj_g(idx_static), opts_g, warmup=1).capture()  # = batches[0]
+        for idx in batches[1:]:
+            idx_static.copy_(idx)
+            step()
+        np.testing.assert_allclose(emb_g.xs[0].detach().cpu().numpy(), emb_e.xs[0].detach().cpu().numpy(),
+                                   rtol=1e-8, atol=1e-10)
+        assert abs(emb_g.scales[0].item() - emb_e.scales[0].item()) <= 1e-10
+        # the gather kernel against the dense fancy-index of the reference
+        sub = obj_e.dataset.pdists[batches[0]][:, batches[0]]
+        iu = torch.triu_indices(bs, bs, 1, device='cuda')
+        assert torch.equal(obj_e.dataset[batches[0]], sub[iu[0], iu[1]])
+    finally:
+        torch.set_default_dtype(torch.float32)

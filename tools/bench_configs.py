@@ -116,10 +116,56 @@ CASES = {
     'c3_spd3_step_n5000_f32_fused_graph': lambda: step_case([M.SymmetricPositiveDefinite(3)], 5000, torch.float32, fused=True, graph=True),
     'c3_spd3_step_n5000_f32_graph': lambda: step_case([M.SymmetricPositiveDefinite(3)], 5000, torch.float32, graph=True),
     'c5_spd4_step_n2274_f32_fused': lambda: step_case([M.SymmetricPositiveDefinite(4)], 2274, torch.float32, fused=True),
+    'c3_spd3_minibatch512_step_f32': lambda: minibatch_case([M.SymmetricPositiveDefinite(3)], 5000, 512, torch.float32),
+    'c3_spd3_minibatch512_step_f32_graph': lambda: minibatch_case([M.SymmetricPositiveDefinite(3)], 5000, 512, torch.float32, graph=True),
+    'c2_lorentz11_minibatch512_step_f32': lambda: minibatch_case([M.Lorentz(11)], 4039, 512, torch.float32),
     'sphere6_n5000_f32': lambda: pdist_case(M.Sphere(6), 5000, torch.float32),
     'euclidean10_n5000_f32': lambda: pdist_case(M.Euclidean(10), 5000, torch.float32),
     'grassmann52_n2000_f32': lambda: pdist_case(M.Grassmann(5, 2), 2000, torch.float32),
 }
+
+
+def minibatch_case(mans, n, bs, dtype, graph=False):
+    """node-minibatch training step as train.py:198-222 runs it (batch_size=512 in the paper grid): targets of the
+    induced sub-graph from the dense matrix, embedding rows gathered, fused loss, scatter-add backward, RSGD"""
+    from graphembed.data import GraphDataset
+    from graphembed.modules import BatchedObjective
+    torch.manual_seed(0)
+    torch.set_default_dtype(dtype)
+    try:
+        with torch.device('cuda'):
+            emb = ManifoldEmbedding(n, mans)
+            ds = GraphDataset(torch.rand(n * (n - 1) // 2) * 0.99 + 0.01)
+    finally:
+        torch.set_default_dtype(torch.float32)
+    obj = BatchedObjective(StressLoss(), ds, emb)
+    opt = RiemannianSGD(list(emb.xs), lr=1e-3, exact=True, max_grad_norm=20)
+    opt_s = RiemannianSGD(list(emb.scales), lr=1e-4, max_grad_norm=500)
+    perm = torch.randperm(n, device='cuda')
+    state = {'i': 0}
+
+    def step():
+        i = state['i']
+        idx = perm[i:i + bs]
+        state['i'] = (i + bs) % (n - bs)
+        opt.zero_grad()
+        opt_s.zero_grad()
+        obj(idx).backward()
+        opt.step()
+        opt_s.step()
+    if graph:  # static index buffer, refreshed in place before every replay
+        from graphembed.graphed import GraphedTrainStep
+        idx_static = perm[:bs].clone()
+        gstep = GraphedTrainStep(lambda: obj(idx_static), [opt, opt_s]).capture()
+
+        def step():  # noqa: F811
+            i = state['i']
+            idx_static.copy_(perm[i:i + bs])
+            state['i'] = (i + bs) % (n - bs)
+            gstep()
+    t = timeit(step, iters=50)
+    P = bs * (bs - 1) // 2
+    return {'n': n, 'pairs': P, 'dtype': str(dtype).split('.')[-1], 'step_us': t, 'pairs_per_s': P / (t * 1e-6)}
 
 
 def _valu(man):

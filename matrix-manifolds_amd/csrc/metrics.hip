@@ -68,6 +68,82 @@ __global__ __launch_bounds__(kApBlock) void average_precision_kernel(const T* __
   }
 }
 
+// ---- layer-wise F1 scores (precision.cpp:300-429) ---------------------------------------------------
+// For the shortest-path tree rooted at u every other node v gets an F1 score that compares the embedding's
+// ordering around u with the tree's layers:
+//   i(v)  = rank of v by embedding distance to u (1 = closest; ties by node index)
+//   nb(v) = 1 + #{w ranked before v with layer(w) <= layer(v)}          ("before v in BOTH orderings")
+//   precision = nb / i,   recall = nb / (#{layer < layer(v)} + #{w ranked before v on v's layer} + 1)
+// and the scores are averaged per layer over all trees (LayerMeanF1Scores) or first per tree, then over
+// the trees (LayerMeanAverageF1Scores).  The reference walks a sorted list with an ordered multiset; all
+// three counts are rank statistics, so — as for the average precision — they are COUNTED: thread v scans
+// the row of u once (every lane reads the same element: one broadcast transaction per step).
+constexpr int kMaxLayers = 256;
+
+template <typename T>
+__global__ __launch_bounds__(kApBlock) void layer_f1_kernel(const T* __restrict__ dist /* [n][n] */,
+                                                            const int* __restrict__ hops /* [n][n] */, int n,
+                                                            const int* __restrict__ indptr, int min_degree,
+                                                            int max_degree, int per_tree_average, int num_layers,
+                                                            double* __restrict__ m1, double* __restrict__ m2,
+                                                            double* __restrict__ counts) {
+  __shared__ int hist[kMaxLayers], strict_before[kMaxLayers], lcnt[kMaxLayers];
+  __shared__ double lm1[kMaxLayers], lm2[kMaxLayers];
+  const int u = blockIdx.x;
+  const int deg = indptr[u + 1] - indptr[u];
+  if (deg < min_degree || deg > max_degree) return;  // block-uniform
+  const T* drow = dist + size_t(u) * n;
+  const int* hrow = hops + size_t(u) * n;
+  for (int l = threadIdx.x; l < kMaxLayers; l += kApBlock) { hist[l] = 0; lcnt[l] = 0; lm1[l] = 0.0; lm2[l] = 0.0; }
+  __syncthreads();
+  for (int w = threadIdx.x; w < n; w += kApBlock)
+    if (w != u) atomicAdd(&hist[min(hrow[w], kMaxLayers - 1)], 1);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int run = 0;  // nodes on layers 1 .. l-1 (the root's layer 0 is not counted)
+    strict_before[0] = 0;
+    for (int l = 1; l < kMaxLayers; ++l) { strict_before[l] = run; run += hist[l]; }
+  }
+  __syncthreads();
+  for (int v = threadIdx.x; v < n; v += kApBlock) {
+    if (v == u) continue;
+    const T dv = drow[v];
+    const int hv = min(hrow[v], kMaxLayers - 1);
+    int before = 0, before_le = 0, before_eq = 0;
+    for (int w = 0; w < n; ++w) {
+      const T dw = drow[w];
+      const int hw = hrow[w];
+      const bool closer = w != u && w != v && (dw < dv || (dw == dv && w < v));
+      before += closer ? 1 : 0;
+      before_le += (closer && hw <= hv) ? 1 : 0;
+      before_eq += (closer && hw == hv) ? 1 : 0;
+    }
+    const double nb = double(before_le + 1);
+    const double precision = nb / double(before + 1);
+    const double recall = nb / double(strict_before[hv] + before_eq + 1);
+    const double f1 = 2.0 * precision * recall / (precision + recall);
+    if (hv >= 1) {
+      atomicAdd(&lm1[hv - 1], f1);
+      atomicAdd(&lm2[hv - 1], f1 * f1);
+      atomicAdd(&lcnt[hv - 1], 1);
+    }
+  }
+  __syncthreads();
+  for (int l = threadIdx.x; l < num_layers - 1 && l < kMaxLayers; l += kApBlock) {
+    if (lcnt[l] == 0) continue;
+    if (per_tree_average) {
+      const double mean = lm1[l] / double(lcnt[l]);
+      atomicAdd(&m1[l], mean);
+      atomicAdd(&m2[l], mean * mean);
+      atomicAdd(&counts[l], 1.0);
+    } else {
+      atomicAdd(&m1[l], lm1[l]);
+      atomicAdd(&m2[l], lm2[l]);
+      atomicAdd(&counts[l], double(lcnt[l]));
+    }
+  }
+}
+
 }  // namespace mm
 
 using namespace mm;
@@ -83,6 +159,28 @@ extern "C" int mm_graph_average_precision(int dtype, const void* dist, int64_t n
   else if (dtype == MM_F64)
     average_precision_kernel<double><<<dim3(unsigned(n)), dim3(kApBlock), 0, st>>>(
         static_cast<const double*>(dist), int(n), indptr, indices, rank_scratch, static_cast<double*>(ap_out));
+  else
+    return MM_ERR_ARG;
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? MM_OK : int(e);
+}
+
+extern "C" int mm_graph_layer_f1(int dtype, const void* dist, const int* hops, int64_t n, const int* indptr, int min_degree,
+                                 int max_degree, int per_tree_average, int num_layers, double* m1, double* m2,
+                                 double* counts, mm_stream_t stream) {
+  if (n < 0 || n > (1 << 30) || num_layers < 1 || (n > 0 && (!dist || !hops || !indptr || !m1 || !m2 || !counts)))
+    return MM_ERR_ARG;
+  if (num_layers > kMaxLayers) return MM_ERR_UNSUPPORTED;
+  if (n == 0) return MM_OK;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (dtype == MM_F32)
+    layer_f1_kernel<float><<<dim3(unsigned(n)), dim3(kApBlock), 0, st>>>(static_cast<const float*>(dist), hops, int(n),
+                                                                       indptr, min_degree, max_degree,
+                                                                       per_tree_average, num_layers, m1, m2, counts);
+  else if (dtype == MM_F64)
+    layer_f1_kernel<double><<<dim3(unsigned(n)), dim3(kApBlock), 0, st>>>(static_cast<const double*>(dist), hops,
+                                                                        int(n), indptr, min_degree, max_degree,
+                                                                        per_tree_average, num_layers, m1, m2, counts);
   else
     return MM_ERR_ARG;
   hipError_t e = hipGetLastError();

@@ -1,34 +1,77 @@
 """`graphembed.pyx.FastPrecision` — the name under which the reference exposes its native evaluator
-(pyx/precision.pyx:46-60 over pyx/impl/precision.cpp).  Here the CSR adjacency is uploaded once and the
-mean average precision runs on the GPU (csrc/metrics.hip).  The layer-wise F1 curves of the reference's
-class are not part of this path yet."""
+(pyx/precision.pyx:46-110 over pyx/impl/precision.cpp).  Here the graph side (CSR adjacency, hop
+distances = layers of every shortest-path tree) is prepared once and uploaded; the mean average precision
+and the layer-wise F1 curves are rank statistics counted on the GPU (csrc/metrics.hip).  Unweighted graphs."""
 import numpy as np
 import torch
 
+from graphembed import _backend as B
 from graphembed.metrics import graph_csr, node_average_precision
+from graphembed.utils import squareform1
 
 
 class FastPrecision:
 
     def __init__(self, g, device='cuda'):
+        import networkx as nx
+        from scipy.sparse.csgraph import shortest_path
         self.n = g.number_of_nodes()
         self.n_pdists = self.n * (self.n - 1) // 2
         self.device = torch.device(device)
         self.indptr, self.indices = graph_csr(g, self.device)
+        adj = nx.to_scipy_sparse_array(g, nodelist=range(self.n))
+        hops = shortest_path(adj, unweighted=True, directed=g.is_directed())
+        if not np.isfinite(hops).all():
+            raise ValueError('FastPrecision needs a connected graph')
+        hops = hops.astype(np.int32)
+        # layers of the tree rooted at u = hop distances from u (precision.cpp:150-190)
+        self.num_layers = int(hops.max()) + 1
+        self._nodes_per_layer = np.bincount(hops.reshape(-1), minlength=self.num_layers)
+        self.hops = torch.from_numpy(hops).to(self.device).contiguous()
 
+    # -- precision.pyx:58-60
     def mean_average_precision(self, mpdists):
         """Mean over the nodes of the average precision of their neighbour ranking."""
-        if not torch.is_tensor(mpdists):
-            mpdists = torch.from_numpy(np.ascontiguousarray(mpdists))
-        if mpdists.numel() != self.n_pdists:
-            raise ValueError(f'expected {self.n_pdists} pairwise distances, got {mpdists.numel()}')
-        ap = node_average_precision(mpdists.to(self.device), self.indptr, self.indices)
+        ap = node_average_precision(self._pdists(mpdists, 1)[0], self.indptr, self.indices)
         return ap.double().mean().item()
 
-    def _not_yet(self, *args, **kwargs):
-        raise NotImplementedError('layer-wise F1 curves (precision.cpp:300-429) are not on the GPU path yet')
+    def nodes_per_layer(self):
+        """Number of nodes on each layer, summed over all shortest-path trees (layer 0 = the roots)."""
+        return [int(c) for c in self._nodes_per_layer]
 
-    layer_mean_f1_scores = layer_mean_average_f1_scores = nodes_per_layer = _not_yet
+    # -- precision.pyx:62-110
+    def layer_mean_f1_scores(self, mpdists, num_pdists_sets=1, min_degree=1, max_degree=99999):
+        return self._layer_f1(mpdists, num_pdists_sets, min_degree, max_degree, per_tree=False)
+
+    def layer_mean_average_f1_scores(self, mpdists, num_pdists_sets=1):
+        return self._layer_f1(mpdists, num_pdists_sets, 0, 2**31 - 1, per_tree=True)
+
+    # ------------------------------------------------------------------------------------------------
+    def _pdists(self, mpdists, sets):
+        if not torch.is_tensor(mpdists):
+            mpdists = torch.from_numpy(np.ascontiguousarray(mpdists))
+        if mpdists.numel() != self.n_pdists * sets:
+            raise ValueError(f'expected {self.n_pdists * sets} pairwise distances, got {mpdists.numel()}')
+        mpdists = mpdists.to(self.device)
+        if mpdists.dtype not in (torch.float32, torch.float64):
+            mpdists = mpdists.float()
+        return mpdists.reshape(sets, self.n_pdists)
+
+    def _layer_f1(self, mpdists, sets, min_degree, max_degree, per_tree):
+        pd = self._pdists(mpdists, sets)
+        width = self.num_layers - 1
+        with B.on_device(self.device):
+            acc = torch.zeros(3, max(width, 1), dtype=torch.float64, device=self.device)
+            for k in range(sets):
+                dense = squareform1(pd[k]).contiguous()
+                B.lib().call('mm_graph_layer_f1', B.dtype_code(dense), B.ptr(dense), B.ptr(self.hops), self.n,
+                             B.ptr(self.indptr), int(min_degree), int(min(max_degree, 2**31 - 1)), int(per_tree),
+                             self.num_layers, B.ptr(acc[0]), B.ptr(acc[1]), B.ptr(acc[2]), B.stream_of(dense))
+        m1, m2, cnt = acc.cpu().numpy()[:, :width]
+        with np.errstate(invalid='ignore', divide='ignore'):
+            means = m1 / cnt
+            stds = m2 / cnt - means * means   # (the reference returns this variance under the name `stds`)
+        return means, stds
 
 
 PyFastPrecision = FastPrecision

@@ -578,3 +578,44 @@ def mean_average_precision(dense, neighbours):
                     break
         scores.append(psum / len(nb))
     return float(np.mean(scores))
+
+
+# ---------------------------------------------------------------- pyx/impl/precision.cpp:300-429
+def layer_f1_scores(dense, hops, per_tree_average=False, min_degree=1, max_degree=10**9, degrees=None):
+    """LayerMeanF1Scores / LayerMeanAverageF1Scores restated on numpy (unweighted graphs): `dense` the
+    (n, n) embedding distances, `hops` the (n, n) hop distances (= layers of every shortest-path tree).
+    Walks each tree's nodes in embedding order exactly as the C++ does (ordered multiset -> counts)."""
+    import numpy as np
+    n = dense.shape[0]
+    width = int(hops.max())
+    m1, m2, cnt = np.zeros(width), np.zeros(width), np.zeros(width)
+    for u in range(n):
+        if degrees is not None and not (min_degree <= degrees[u] <= max_degree):
+            continue
+        order = [v for v in np.argsort(dense[u], kind='stable') if v != u]
+        layer_sizes = np.bincount(hops[u], minlength=width + 1)
+        strict_before = np.concatenate([[0, 0], np.cumsum(layer_sizes[1:])])  # nodes on layers 1..l-1
+        seen = np.zeros(width + 1, dtype=np.int64)
+        t1, t2, tc = np.zeros(width), np.zeros(width), np.zeros(width)
+        for i, v in enumerate(order, start=1):
+            l = hops[u, v]
+            nodes_before = seen[:l + 1].sum() + 1
+            precision = nodes_before / i
+            recall = nodes_before / (strict_before[l] + seen[l] + 1)
+            f1 = 2 * precision * recall / (precision + recall)
+            seen[l] += 1
+            t1[l - 1] += f1
+            t2[l - 1] += f1 * f1
+            tc[l - 1] += 1
+        if per_tree_average:
+            has = tc > 0
+            mean = np.where(has, t1 / np.maximum(tc, 1), 0.0)
+            m1 += mean
+            m2 += mean * mean
+            cnt += has
+        else:
+            m1 += t1
+            m2 += t2
+            cnt += tc
+    means = m1 / cnt
+    return means, m2 / cnt - means * means

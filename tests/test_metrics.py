@@ -76,3 +76,79 @@ def test_gpu_map_vs_oracle_seeded(n, p):
     ref = rp.mean_average_precision(squareform(pd.astype(np.float64)), nb)
     assert abs(fp.mean_average_precision(torch.from_numpy(pd)) - ref) <= 1e-6
     assert abs(fp.mean_average_precision(torch.from_numpy(compute_graph_pdists(g)).float()) - 1.0) <= 1e-6
+
+
+def _er(n, p, seed):
+    import networkx as nx
+    g = nx.erdos_renyi_graph(n, p, seed=seed)
+    return nx.convert_node_labels_to_integers(g.subgraph(max(nx.connected_components(g), key=len)).copy())
+
+
+def _hops(g):
+    import networkx as nx
+    from scipy.sparse.csgraph import shortest_path
+    return shortest_path(nx.to_scipy_sparse_array(g, nodelist=range(len(g))), unweighted=True).astype(np.int64)
+
+
+@pytest.mark.parametrize('n,p', [(50, 0.1), (120, 0.04)])
+def test_oracle_f1_known_answer(n, p):
+    """The reference's own known-answer test (tests/test_metrics.py:27-35): with the graph distances as the
+    embedding distances every layer scores F1 = 1 — whatever the order inside the tied layers."""
+    from oracle import ref_port as rp
+    g = _er(n, p, 1)
+    hops = _hops(g)
+    for avg in (False, True):
+        means, var = rp.layer_f1_scores(hops.astype(np.float64), hops, per_tree_average=avg)
+        np.testing.assert_allclose(means, np.ones_like(means), atol=1e-12)
+        np.testing.assert_allclose(var, np.zeros_like(var), atol=1e-12)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('n,p', [(50, 0.1), (500, 0.01), (500, 0.1)])
+def test_gpu_f1_trivial(n, p):
+    """test_f1_trivial of the reference (tests/test_metrics.py:27-35) on the GPU evaluator."""
+    from graphembed.data.graph import compute_graph_pdists
+    from graphembed.metrics import area_under_curve
+    from graphembed.pyx import FastPrecision
+    g = _er(n, p, 0)
+    fp = FastPrecision(g)
+    pd = torch.from_numpy(compute_graph_pdists(g)).float()
+    means, _ = fp.layer_mean_f1_scores(pd)
+    np.testing.assert_allclose(means, np.ones(len(means)), atol=1e-6)
+    np.testing.assert_allclose(area_under_curve(means), 1, atol=1e-6)
+    means, _ = fp.layer_mean_average_f1_scores(pd)
+    np.testing.assert_allclose(means, np.ones(len(means)), atol=1e-6)
+    assert fp.nodes_per_layer()[0] == g.number_of_nodes() and sum(fp.nodes_per_layer()) == g.number_of_nodes() ** 2
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('n,p', [(80, 0.08), (300, 0.02)])
+def test_gpu_f1_vs_oracle(n, p):
+    """Random embedding distances (with ties): GPU layer F1 curves vs the numpy restatement of
+    precision.cpp:300-429, both aggregations, the degree filter and two concatenated distance sets."""
+    from scipy.spatial.distance import squareform
+    from graphembed.pyx import FastPrecision
+    from oracle import ref_port as rp
+    g = _er(n, p, 2)
+    m = g.number_of_nodes()
+    hops = _hops(g)
+    rng = np.random.default_rng(4)
+    pd = rng.random(m * (m - 1) // 2)
+    pd[::5] = pd[2]
+    dense = squareform(pd)
+    deg = np.array([g.degree(u) for u in range(m)])
+    fp = FastPrecision(g)
+    for kw, okw in ((dict(), dict(degrees=deg)), (dict(min_degree=2, max_degree=6), dict(degrees=deg, min_degree=2, max_degree=6))):
+        means, var = fp.layer_mean_f1_scores(torch.from_numpy(pd), **kw)
+        rmeans, rvar = rp.layer_f1_scores(dense, hops, **okw)
+        np.testing.assert_allclose(means, rmeans, rtol=1e-10, atol=1e-12)
+        np.testing.assert_allclose(var, rvar, rtol=1e-8, atol=1e-12)
+    means, var = fp.layer_mean_average_f1_scores(torch.from_numpy(pd))
+    rmeans, rvar = rp.layer_f1_scores(dense, hops, per_tree_average=True)
+    np.testing.assert_allclose(means, rmeans, rtol=1e-10, atol=1e-12)
+    np.testing.assert_allclose(var, rvar, rtol=1e-8, atol=1e-12)
+    pd2 = rng.random(pd.shape)
+    means2, _ = fp.layer_mean_f1_scores(torch.from_numpy(np.concatenate([pd, pd2])), num_pdists_sets=2)
+    a, _ = rp.layer_f1_scores(dense, hops)
+    b, _ = rp.layer_f1_scores(squareform(pd2), hops)
+    np.testing.assert_allclose(means2, 0.5 * (a + b), rtol=1e-10)

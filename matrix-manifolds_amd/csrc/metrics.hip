@@ -75,26 +75,28 @@ __global__ __launch_bounds__(kApBlock) void average_precision_kernel(const T* __
 //   nb(v) = 1 + #{w ranked before v with layer(w) <= layer(v)}          ("before v in BOTH orderings")
 //   precision = nb / i,   recall = nb / (#{layer < layer(v)} + #{w ranked before v on v's layer} + 1)
 // and the scores are averaged per layer over all trees (LayerMeanF1Scores) or first per tree, then over
-// the trees (LayerMeanAverageF1Scores).  The reference walks a sorted list with an ordered multiset; all
-// three counts are rank statistics, so — as for the average precision — they are COUNTED: thread v scans
-// the row of u once (every lane reads the same element: one broadcast transaction per step).
+// the trees (LayerMeanAverageF1Scores).  The reference walks each sorted row with an ordered multiset
+// (O(n) per insertion).  Here the rows arrive sorted (`order`: node ids by embedding distance, a stable
+// segmented sort done by the caller) and one workgroup per tree walks its row in chunks of 256 positions:
+// running per-layer counts of the nodes already passed live in LDS, the positions inside a chunk are
+// resolved by a 256 x 256 comparison — O(n L + 256 n) per tree instead of O(n^2).
 constexpr int kMaxLayers = 256;
 
-template <typename T>
-__global__ __launch_bounds__(kApBlock) void layer_f1_kernel(const T* __restrict__ dist /* [n][n] */,
+__global__ __launch_bounds__(kApBlock) void layer_f1_kernel(const int* __restrict__ order /* [n][n] */,
                                                             const int* __restrict__ hops /* [n][n] */, int n,
                                                             const int* __restrict__ indptr, int min_degree,
                                                             int max_degree, int per_tree_average, int num_layers,
                                                             double* __restrict__ m1, double* __restrict__ m2,
                                                             double* __restrict__ counts) {
-  __shared__ int hist[kMaxLayers], strict_before[kMaxLayers], lcnt[kMaxLayers];
+  __shared__ int hist[kMaxLayers], strict_before[kMaxLayers], seen[kMaxLayers], seen_le[kMaxLayers], lcnt[kMaxLayers];
   __shared__ double lm1[kMaxLayers], lm2[kMaxLayers];
+  __shared__ int chunk_layer[kApBlock];
   const int u = blockIdx.x;
   const int deg = indptr[u + 1] - indptr[u];
   if (deg < min_degree || deg > max_degree) return;  // block-uniform
-  const T* drow = dist + size_t(u) * n;
+  const int* orow = order + size_t(u) * n;
   const int* hrow = hops + size_t(u) * n;
-  for (int l = threadIdx.x; l < kMaxLayers; l += kApBlock) { hist[l] = 0; lcnt[l] = 0; lm1[l] = 0.0; lm2[l] = 0.0; }
+  for (int l = threadIdx.x; l < kMaxLayers; l += kApBlock) { hist[l] = 0; seen[l] = 0; lcnt[l] = 0; lm1[l] = 0.0; lm2[l] = 0.0; }
   __syncthreads();
   for (int w = threadIdx.x; w < n; w += kApBlock)
     if (w != u) atomicAdd(&hist[min(hrow[w], kMaxLayers - 1)], 1);
@@ -104,29 +106,42 @@ __global__ __launch_bounds__(kApBlock) void layer_f1_kernel(const T* __restrict_
     strict_before[0] = 0;
     for (int l = 1; l < kMaxLayers; ++l) { strict_before[l] = run; run += hist[l]; }
   }
-  __syncthreads();
-  for (int v = threadIdx.x; v < n; v += kApBlock) {
-    if (v == u) continue;
-    const T dv = drow[v];
-    const int hv = min(hrow[v], kMaxLayers - 1);
-    int before = 0, before_le = 0, before_eq = 0;
-    for (int w = 0; w < n; ++w) {
-      const T dw = drow[w];
-      const int hw = hrow[w];
-      const bool closer = w != u && w != v && (dw < dv || (dw == dv && w < v));
-      before += closer ? 1 : 0;
-      before_le += (closer && hw <= hv) ? 1 : 0;
-      before_eq += (closer && hw == hv) ? 1 : 0;
+  int passed = 0;  // positions of the sorted row already consumed, the root excluded (block-uniform)
+  for (int p0 = 0; p0 < n; p0 += kApBlock) {
+    __syncthreads();
+    if (threadIdx.x == 0) {  // seen_le[l] = nodes already passed on layers <= l
+      int run = 0;
+      for (int l = 0; l < kMaxLayers; ++l) { run += seen[l]; seen_le[l] = run; }
     }
-    const double nb = double(before_le + 1);
-    const double precision = nb / double(before + 1);
-    const double recall = nb / double(strict_before[hv] + before_eq + 1);
-    const double f1 = 2.0 * precision * recall / (precision + recall);
-    if (hv >= 1) {
-      atomicAdd(&lm1[hv - 1], f1);
-      atomicAdd(&lm2[hv - 1], f1 * f1);
-      atomicAdd(&lcnt[hv - 1], 1);
+    const int p = p0 + threadIdx.x;
+    const int v = p < n ? orow[p] : u;
+    const bool live = p < n && v != u;
+    const int hv = live ? min(hrow[v], kMaxLayers - 1) : -1;
+    chunk_layer[threadIdx.x] = hv;
+    __syncthreads();
+    int in_le = 0, in_eq = 0, in_before = 0;  // live positions of this chunk in front of mine
+    for (int t = 0; t < int(threadIdx.x); ++t) {
+      const int ht = chunk_layer[t];
+      in_before += ht >= 0 ? 1 : 0;
+      in_le += (ht >= 0 && ht <= hv) ? 1 : 0;
+      in_eq += ht == hv ? 1 : 0;
     }
+    if (live) {
+      const double nb = double(seen_le[hv] + in_le + 1);
+      const double precision = nb / double(passed + in_before + 1);
+      const double recall = nb / double(strict_before[hv] + seen[hv] + in_eq + 1);
+      const double f1 = 2.0 * precision * recall / (precision + recall);
+      if (hv >= 1) {
+        atomicAdd(&lm1[hv - 1], f1);
+        atomicAdd(&lm2[hv - 1], f1 * f1);
+        atomicAdd(&lcnt[hv - 1], 1);
+      }
+    }
+    __syncthreads();  // everyone has read seen / seen_le
+    if (live) atomicAdd(&seen[hv], 1);
+    int chunk_live = 0;  // block-uniform count of live positions in this chunk
+    for (int t = 0; t < kApBlock; ++t) chunk_live += chunk_layer[t] >= 0 ? 1 : 0;
+    passed += chunk_live;
   }
   __syncthreads();
   for (int l = threadIdx.x; l < num_layers - 1 && l < kMaxLayers; l += kApBlock) {
@@ -165,24 +180,16 @@ extern "C" int mm_graph_average_precision(int dtype, const void* dist, int64_t n
   return e == hipSuccess ? MM_OK : int(e);
 }
 
-extern "C" int mm_graph_layer_f1(int dtype, const void* dist, const int* hops, int64_t n, const int* indptr, int min_degree,
+extern "C" int mm_graph_layer_f1(const int* order, const int* hops, int64_t n, const int* indptr, int min_degree,
                                  int max_degree, int per_tree_average, int num_layers, double* m1, double* m2,
                                  double* counts, mm_stream_t stream) {
-  if (n < 0 || n > (1 << 30) || num_layers < 1 || (n > 0 && (!dist || !hops || !indptr || !m1 || !m2 || !counts)))
+  if (n < 0 || n > (1 << 30) || num_layers < 1 || (n > 0 && (!order || !hops || !indptr || !m1 || !m2 || !counts)))
     return MM_ERR_ARG;
   if (num_layers > kMaxLayers) return MM_ERR_UNSUPPORTED;
   if (n == 0) return MM_OK;
   hipStream_t st = static_cast<hipStream_t>(stream);
-  if (dtype == MM_F32)
-    layer_f1_kernel<float><<<dim3(unsigned(n)), dim3(kApBlock), 0, st>>>(static_cast<const float*>(dist), hops, int(n),
-                                                                       indptr, min_degree, max_degree,
-                                                                       per_tree_average, num_layers, m1, m2, counts);
-  else if (dtype == MM_F64)
-    layer_f1_kernel<double><<<dim3(unsigned(n)), dim3(kApBlock), 0, st>>>(static_cast<const double*>(dist), hops,
-                                                                        int(n), indptr, min_degree, max_degree,
-                                                                        per_tree_average, num_layers, m1, m2, counts);
-  else
-    return MM_ERR_ARG;
+  layer_f1_kernel<<<dim3(unsigned(n)), dim3(kApBlock), 0, st>>>(order, hops, int(n), indptr, min_degree, max_degree,
+                                                              per_tree_average, num_layers, m1, m2, counts);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? MM_OK : int(e);
 }

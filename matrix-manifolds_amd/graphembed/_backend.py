@@ -30,7 +30,7 @@ SIGNATURES = {
     'mm_prof_collect': (_i, [_i, _c.POINTER(_i64), _c.POINTER(_dbl)]),
     'mm_pair_offset': (_i64, [_i64, _i64]),
     'mm_shard_rows': (_i, [_i64, _i, _i, _c.POINTER(_i64), _c.POINTER(_i64)]),
-    'mm_graph_layer_f1': (_i, [_i, _vp, _vp, _i64, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    'mm_graph_layer_f1': (_i, [_vp, _vp, _i64, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     'mm_graph_average_precision': (_i, [_i, _vp, _i64, _vp, _vp, _vp, _vp, _vp]),
     'mm_pair_gather': (_i, [_i, _vp, _i64, _vp, _i64, _vp, _vp]),
     'mm_product_max_factors': (_i, []),

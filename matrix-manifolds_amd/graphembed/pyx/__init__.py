@@ -63,10 +63,12 @@ class FastPrecision:
         with B.on_device(self.device):
             acc = torch.zeros(3, max(width, 1), dtype=torch.float64, device=self.device)
             for k in range(sets):
-                dense = squareform1(pd[k]).contiguous()
-                B.lib().call('mm_graph_layer_f1', B.dtype_code(dense), B.ptr(dense), B.ptr(self.hops), self.n,
-                             B.ptr(self.indptr), int(min_degree), int(min(max_degree, 2**31 - 1)), int(per_tree),
-                             self.num_layers, B.ptr(acc[0]), B.ptr(acc[1]), B.ptr(acc[2]), B.stream_of(dense))
+                # rows sorted by embedding distance (stable: ties by node id) — the library's segmented sort;
+                # the rank statistics themselves are the HIP kernel
+                order = torch.sort(squareform1(pd[k]), dim=1, stable=True).indices.to(torch.int32).contiguous()
+                B.lib().call('mm_graph_layer_f1', B.ptr(order), B.ptr(self.hops), self.n, B.ptr(self.indptr),
+                             int(min_degree), int(min(max_degree, 2**31 - 1)), int(per_tree), self.num_layers,
+                             B.ptr(acc[0]), B.ptr(acc[1]), B.ptr(acc[2]), B.stream_of(order))
         m1, m2, cnt = acc.cpu().numpy()[:, :width]
         with np.errstate(invalid='ignore', divide='ignore'):
             means = m1 / cnt

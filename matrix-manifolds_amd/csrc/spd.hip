@@ -5,18 +5,20 @@
 // linalg/{fast,torch_batch}.py (see include/mm_manifolds.h for the per-entry
 // citations).  Design notes: DESIGN.md §3.
 //
-// Pair kernels: one workgroup = 256 lanes = 256 consecutive columns j of the
-// upper triangle; it walks TI rows i.  Each lane keeps its X_j (packed
-// symmetric) in VGPRs for the whole tile; the row operand L_i^-1 is
-// wave-uniform, so it is fetched with scalar loads into SGPRs (no LDS, no VGPRs)
-// and every `L_i^-1 X_j L_i^-T` FMA takes one scalar and one vector operand.
-// The eigensolve is a cyclic Jacobi entirely in registers (smallmat.hpp).
-// Forward stores d^2 with lanes on consecutive j -> 256-B coalesced segments of
-// the row-major pair vector.  Backward recomputes the decomposition (cheaper
-// than a 28-48 B/pair round trip through HBM), accumulates the column-side
-// gradient per lane in registers, reduces the row-side gradient across the
-// wavefront, and flushes both once per tile with coalesced float atomics into
-// structure-of-arrays accumulators.
+// Pair kernels: lanes own consecutive columns j of the upper triangle and keep the Cholesky factor
+// L_j of their column (packed) in VGPRs for a whole tile; the row operand L_i^-1 is wave-uniform, so
+// it is fetched with scalar loads into SGPRs (no LDS, no VGPRs) and A = (L_i^-1 L_j)(L_i^-1 L_j)^T
+// = L_i^-1 X_j L_i^-T costs 20 FMAs with one scalar operand each (D = 3).
+// log(A) comes, per wavefront, from the cheapest method that holds for all 64 pairs: the
+// Cayley-Hamilton series of log(I + E) for close pairs (fp32), the Cayley-transform logarithm
+// (atanh of (A - mu)(A + mu)^-1) for eigenvalue ratios up to ~16, cyclic Jacobi in registers for the
+// rest (smallmat.hpp).  Forward stores d^2 with lanes on consecutive j -> 256-B coalesced segments
+// of the row-major pair vector.  Backward recomputes log(A) (cheaper than a 28-48 B/pair round trip
+// through HBM), accumulates the column side per lane in registers (64-column tiles shared by the
+// wavefronts of a workgroup, combined in LDS), reduces the row side across the wavefront with a
+// transposing DPP/permlane reduction, and flushes both once per tile with float atomics into
+// self-cleaning structure-of-arrays accumulators; the fused objective (loss.hpp) rides on the same
+// kernel.  spd_stein.hpp: the Stein divergence on the same tiling and workspace.
 #include <hip/hip_runtime.h>
 
 #include "../../include/mm_manifolds.h"

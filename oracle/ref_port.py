@@ -617,5 +617,6 @@ def layer_f1_scores(dense, hops, per_tree_average=False, min_degree=1, max_degre
             m1 += t1
             m2 += t2
             cnt += tc
-    means = m1 / cnt
-    return means, m2 / cnt - means * means
+    with np.errstate(invalid='ignore', divide='ignore'):  # layers nobody contributed to -> nan, as in the C++
+        means = m1 / cnt
+        return means, m2 / cnt - means * means

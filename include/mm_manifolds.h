@@ -70,6 +70,11 @@ size_t mm_spd_pdist_ws_bytes(int dtype, int64_t n, int d);
 /* flags for the pdist calls */
 enum { MM_WS_PREPARED = 1 /* ws already holds the per-node factors of this x */ };
 
+/* Fills ws with the per-node factors of x (Cholesky factor, its inverse, log det; the part of
+ * _lult, manifolds/spd.py:108-111, that depends on one point only) and clears its accumulators and
+ * status word; later pdist calls on the same x may then pass MM_WS_PREPARED. */
+int mm_spd_prepare(int dtype, const void* x, int64_t n, int d, void* ws, mm_stream_t stream);
+
 /* SymmetricPositiveDefinite.pdist — manifolds/spd.py:175-181 (+ _norm_log
  * 163-169, _lult 108-111).  out[k] = sum_m log^2 lambda_m(L_i^-1 X_j L_i^-T)
  * (sqrt of it if !squared), eigenvalues value-clamped to [wmin,wmax], result
@@ -258,6 +263,25 @@ size_t mm_product_loss_ws_bytes(int dtype, int nf);
 int mm_product_loss(int dtype, int loss_kind, int nf, const void* const* d2, const void* target,
                     const void* const* scale_raw, int64_t npairs, double alpha, double eps, int terms,
                     void* const* g_out, void* loss_out, void* ws, mm_stream_t stream);
+
+/* The same objective in ONE pair kernel over all factors (the csphd configuration: Lorentz x sphere x
+ * SPD(2) — one launch computes every factor's squared distance, the weighted sum, the loss term and all
+ * gradients; ManifoldEmbedding.compute_dists modules.py:84-88 + objectives.py:16-45 + their backward).
+ *   kinds[k]   MM_EUCLIDEAN / MM_LORENTZ / MM_SPHERE (xs[k] = [n, dims[k]], dims[k] <= 16) or
+ *              MM_FACTOR_SPD (xs[k] = [n, d, d] with d = dims[k] in {2, 3}; spd_ws[k] = a workspace of
+ *              mm_spd_pdist_ws_bytes that this call prepares; spd_ws[k] is ignored for vector factors)
+ *   grads[k]   Euclidean gradient of the loss w.r.t. xs[k] (same shape), rows [row_begin,row_end) of the
+ *              pair list only — summed over shards it is the full gradient
+ *   loss_out   { loss, dloss/dscale_raw[0..nf-1] }
+ * At most 3 vector factors and one SPD factor; otherwise MM_ERR_UNSUPPORTED (use mm_product_loss around
+ * the per-factor kernels).  kinds, dims, xs, spd_ws, scale_raw, grads are HOST arrays. */
+enum { MM_FACTOR_SPD = 16 };
+size_t mm_product_pairs_ws_bytes(int dtype, int nf, const int* kinds, const int* dims, int64_t n);
+int mm_product_pairs_loss(int dtype, int loss_kind, int nf, const int* kinds, const int* dims,
+                          const void* const* xs, void* const* spd_ws, const void* const* scale_raw,
+                          const void* target, int64_t n, int64_t row_begin, int64_t row_end, double alpha,
+                          double eps, int terms, double wmin, double wmax, void* const* grads,
+                          void* loss_out, void* ws, mm_stream_t stream);
 
 /* Targets of a node minibatch: out[pair (a,b), a<b] = dense[idx[a]][idx[b]] in pair-vector order
  * (GraphDataset.__getitem__, data/dataset.py:19-27).  dense [n,n]; idx int64[bs] (device); out [bs(bs-1)/2]. */

@@ -1,0 +1,468 @@
+// The fused mixed-manifold pair kernel for PRODUCT embeddings (the reference's csphd configuration:
+// Lorentz(6) x Sphere(6) x SPD(2), n ~ 1e3; ManifoldEmbedding.compute_dists, modules.py:84-88, with the
+// objective of objectives.py:16-45 and what loss.backward() computes, train.py:213-217).
+//
+// One launch evaluates, for every pair, the squared distance of EVERY factor, their softplus-weighted sum,
+// the loss term and its derivative, and accumulates the gradients of all factors' points and scales.  At the
+// sizes of these configurations (5e5 pairs) the arithmetic is microseconds; what the reference — and a
+// kernel-per-factor design — pays for is launches (~60 resp. ~15 per step).  So the kernel is written for
+// simplicity, not for the last flop: every ORDERED pair is visited (a lane accumulates only into its own
+// column j: no cross-lane reduction for any factor), the row point of each factor is wave-uniform (scalar
+// loads), SPD factors use the Jacobi path.  Supported per launch: up to 3 vector factors (Euclidean /
+// Lorentz / sphere, m <= 16) and at most one SPD(2) or SPD(3) factor; anything else takes the per-factor
+// kernels around mm_product_loss.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdlib>
+
+#include "../../include/mm_manifolds.h"
+#include "loss.hpp"
+#include "smallmat.hpp"
+#include "spd_ws.hpp"
+#include "vecfn.hpp"
+
+namespace mm {
+
+constexpr int kPMaxVec = 3;
+constexpr int kPMP = 16;   // padded dimension of a vector factor
+constexpr int kPMaxTI = 16;  // most rows per wavefront
+constexpr int kPCols = 64;   // columns per workgroup (n = 1025 wastes 6 % of the lanes; 256 columns would waste 20 %)
+constexpr int kPWaves = 4;   // wavefronts per workgroup: same columns, consecutive row tiles; their column
+                             // sums are combined in LDS before the flush (a quarter of the atomics)
+
+template <typename T> struct PVec {
+  const T* x;          // [n][m]
+  const T* scale_raw;  // device scalar
+  T* acc;              // [(kPMP + 1)][n]: sum_i w x_i, and sum_i w (Euclidean)
+  T* grad;             // [n][m]
+  int m, kind, slot;   // slot = position in the caller's factor list (for loss_out)
+};
+template <typename T> struct PSpd {
+  const T* nodeL;      // packed L_i^-1
+  const T* nodeC;      // packed L_i
+  const T* scale_raw;
+  T* accS;             // [D*D][n]
+  T* grad;             // [n][D][D]
+  T wmin, wmax;
+  int slot;
+};
+template <typename T> struct PArgs {
+  PVec<T> v[kPMaxVec];
+  PSpd<T> s;
+  int nf;
+};
+
+// Pins a loaded value (per-lane / wave-uniform) so that the load is issued where it is written: without
+// it the compiler sinks each load under the condition that masks its result — one basic block and one
+// full memory round trip per element.
+__device__ __forceinline__ void pin_v(float& v) { asm volatile("" : "+v"(v)); }
+__device__ __forceinline__ void pin_v(double& v) { asm volatile("" : "+v"(v)); }
+
+template <typename T> __device__ __forceinline__ T vec_q_rt(int kind, const T (&xi)[kPMP], const T (&xj)[kPMP]) {
+  using N = Num<T>;
+  T q = T(0);
+  if (kind == MM_EUCLIDEAN) {
+#pragma unroll
+    for (int k = 0; k < kPMP; ++k) { const T df = xj[k] - xi[k]; q = N::fma(df, df, q); }
+  } else {
+#pragma unroll
+    for (int k = 1; k < kPMP; ++k) q = N::fma(xi[k], xj[k], q);
+    q = kind == MM_LORENTZ ? N::fma(xi[0], xj[0], -q) : N::fma(xi[0], xj[0], q);
+  }
+  return q;
+}
+template <typename T> __device__ __forceinline__ T vec_value_rt(int kind, T q) {
+  return kind == MM_EUCLIDEAN ? PairFn<T, MM_EUCLIDEAN>::value(q, 1)
+                              : (kind == MM_LORENTZ ? PairFn<T, MM_LORENTZ>::value(q, 1) : PairFn<T, MM_SPHERE>::value(q, 1));
+}
+template <typename T> __device__ __forceinline__ T vec_dq_rt(int kind, T q) {
+  return kind == MM_EUCLIDEAN ? PairFn<T, MM_EUCLIDEAN>::dq(q, 1)
+                              : (kind == MM_LORENTZ ? PairFn<T, MM_LORENTZ>::dq(q, 1) : PairFn<T, MM_SPHERE>::dq(q, 1));
+}
+
+template <typename T, int NV, int SD, int LOSS>
+__global__ __launch_bounds__(kPCols * kPWaves) void product_pair_kernel(PArgs<T> pa, const T* __restrict__ target, int n,
+                                                               int row_begin, int row_end, int ti, LossArgs<T> la) {
+  constexpr int NPS = SD > 0 ? Packed<(SD > 0 ? SD : 2)>::NP : 1;
+  constexpr int DS = SD > 0 ? SD : 2;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int j = blockIdx.x * kPCols + lane;
+  const int i0 = min((blockIdx.y * kPWaves + wave) * ti, n), i1 = min(i0 + ti, n);
+  const bool jin = j < n;
+  const bool jown = jin && j >= row_begin && j < row_end;
+  // per-lane column data
+  T xj[NV > 0 ? NV : 1][kPMP], accv[NV > 0 ? NV : 1][kPMP], wsum[NV > 0 ? NV : 1], spv[NV > 0 ? NV : 1],
+      dsv[NV > 0 ? NV : 1];
+#pragma unroll
+  for (int f = 0; f < NV; ++f) {
+    const PVec<T>& F = pa.v[f];
+    const int jc = jin ? j : n - 1;
+#pragma unroll
+    for (int k = 0; k < kPMP; ++k) xj[f][k] = F.x[size_t(jc) * F.m + min(k, F.m - 1)];  // clamped, masked below
+#pragma unroll
+    for (int k = 0; k < kPMP; ++k) accv[f][k] = T(0);
+    wsum[f] = T(0);
+    dsv[f] = T(0);
+    spv[f] = *F.scale_raw;
+  }
+  T sps = T(1), dss = T(0);
+  if constexpr (SD > 0) sps = *pa.s.scale_raw;
+
+  T yj[NPS], accS[DS][DS];
+  if constexpr (SD > 0) {
+#pragma unroll
+    for (int k = 0; k < NPS; ++k) yj[k] = pa.s.nodeC[size_t(jin ? j : n - 1) * NPS + k];  // lanes past n: masked later
+#pragma unroll
+    for (int r = 0; r < SD; ++r)
+#pragma unroll
+      for (int c = 0; c < SD; ++c) accS[r][c] = T(0);
+  }
+  const int64_t base = int64_t(row_begin) * (2 * int64_t(n) - row_begin - 1) / 2;
+  auto pair_ok = [&](int i) {  // pair (i, j) is stored under row min(i, j)
+    return jin && i != j && (i < j ? (i >= row_begin && i < row_end) : jown);
+  };
+  auto target_at = [&](int i) -> T {  // unconditional load from a clamped address, one row ahead of its use
+    const int lo = i < j ? i : j, hi = i < j ? j : i;
+    return target[pair_ok(i) ? int64_t(lo) * (2 * int64_t(n) - lo - 1) / 2 - base + (hi - lo - 1) : int64_t(0)];
+  };
+  T tnext = target_at(i0);
+  // the row points of the tile, zero-padded to kPMP, staged once (coalesced); a load under `k < m` in the
+  // row loop would sit in its own basic block and serialise 16 memory round trips per factor and row
+  __shared__ T rowpt[NV > 0 ? NV : 1][kPWaves][kPMaxTI][kPMP];
+#pragma unroll
+  for (int f = 0; f < NV; ++f) {
+    const PVec<T>& F = pa.v[f];
+    for (int e = lane; e < ti * kPMP; e += 64) {
+      const int r = e / kPMP, k = e % kPMP;
+      rowpt[f][wave][r][k] = (k < F.m && i0 + r < n) ? F.x[size_t(i0 + r) * F.m + k] : T(0);
+    }
+  }
+  // every load of the preamble is in flight by now; pin them here so that none is sunk below its mask
+#pragma unroll
+  for (int f = 0; f < NV; ++f) {
+    pin_v(spv[f]);
+#pragma unroll
+    for (int k = 0; k < kPMP; ++k) pin_v(xj[f][k]);
+  }
+  pin_v(tnext);
+#pragma unroll
+  for (int f = 0; f < NV; ++f) {
+#pragma unroll
+    for (int k = 0; k < kPMP; ++k) xj[f][k] = (jin && k < pa.v[f].m) ? xj[f][k] : T(0);
+    spv[f] = softplus_of(&spv[f]);
+  }
+  if constexpr (SD > 0) sps = softplus_of(&sps);
+  __syncthreads();
+  T loss_acc = T(0);
+  for (int i = i0; i < i1; ++i) {  // wave-uniform row
+    const bool up = i < j;
+    const bool valid = pair_ok(i);
+    const T tgt = tnext;
+    tnext = target_at(min(i + 1, i1 - 1));
+    // ---- phase 1: every factor's squared distance, the weighted sum
+    T m = T(0), qv[NV > 0 ? NV : 1], d2v[NV > 0 ? NV : 1], xi[NV > 0 ? NV : 1][kPMP];
+#pragma unroll
+    for (int f = 0; f < NV; ++f) {
+      const PVec<T>& F = pa.v[f];
+#pragma unroll
+      for (int k = 0; k < kPMP; ++k) xi[f][k] = rowpt[f][wave][i - i0][k];  // same address in every lane: LDS broadcast
+      qv[f] = vec_q_rt<T>(F.kind, xi[f], xj[f]);
+      d2v[f] = vec_value_rt<T>(F.kind, qv[f]);
+      m = Num<T>::fma(spv[f], d2v[f], m);
+    }
+    T li[NPS], lc[NPS], lw[DS], vv[DS][DS], d2s = T(0);
+    if constexpr (SD > 0) {
+#pragma unroll
+      for (int k = 0; k < NPS; ++k) { li[k] = pa.s.nodeL[size_t(i) * NPS + k]; lc[k] = pa.s.nodeC[size_t(i) * NPS + k]; }
+      T a[NPS];
+      congr_chol<T, SD>(li, yj, a);
+      jacobi_eig<T, SD, true, true>(a, vv, T(64) * Num<T>::eps() * Num<T>::eps());
+      T s = T(0);
+#pragma unroll
+      for (int k = 0; k < SD; ++k) {  // eigenvalue clamp as _norm_log, spd.py:163-169
+        lw[k] = Num<T>::log(Num<T>::min(Num<T>::max(a[pidx(k, k)], pa.s.wmin), pa.s.wmax));
+        s = Num<T>::fma(lw[k], lw[k], s);
+      }
+      d2s = Num<T>::max(s, pa.s.wmin);  // value clamp (gradient-transparent), spd.py:163-169
+      m = Num<T>::fma(sps, d2s, m);
+    }
+    T dldm;
+    const T l = loss_term<T, LOSS>(m, valid ? tgt : T(1), la, dldm);
+    const bool once = valid && up;
+    loss_acc += once ? l : T(0);
+    const T coef = valid ? dldm : T(0);
+    // ---- phase 2: gradients, into this lane's column only
+#pragma unroll
+    for (int f = 0; f < NV; ++f) {
+      dsv[f] += once ? dldm * d2v[f] : T(0);
+      const T w = coef * spv[f] * vec_dq_rt<T>(pa.v[f].kind, qv[f]);
+      wsum[f] += w;
+#pragma unroll
+      for (int k = 0; k < kPMP; ++k) accv[f][k] = Num<T>::fma(w, xi[f][k], accv[f][k]);
+    }
+    if constexpr (SD > 0) {
+      dss += once ? dldm * d2s : T(0);
+      const T gs = coef * sps;
+      T cm[DS], mm_[NPS], cj[DS][DS];
+#pragma unroll
+      for (int k = 0; k < SD; ++k) cm[k] = (gs + gs) * lw[k];
+      vdvt<T, SD>(vv, cm, mm_);
+      lt_m_lt<T, SD>(li, lc, mm_, cj);
+#pragma unroll
+      for (int r = 0; r < SD; ++r)
+#pragma unroll
+        for (int c = 0; c < SD; ++c) accS[r][c] += cj[r][c];
+    }
+  }
+  // ---- flush: the workgroup's wavefronts hold partial sums of the same columns; combine them in LDS, then
+  // one coalesced atomic per accumulator row (float atomics cost ~60 ns of CU time per wave instruction)
+  __shared__ T red[kPWaves][kPMP + 1][64];
+  auto combine_and_add = [&](int rows, auto&& dst_of) {  // red[w][k][lane], k < rows -> atomics on dst_of(k)
+    __syncthreads();
+    for (int k = wave; k < rows; k += kPWaves) {  // wave-uniform k
+      T* dst = dst_of(k);
+      if (!dst) continue;
+      T sum = red[0][k][lane];
+#pragma unroll
+      for (int w = 1; w < kPWaves; ++w) sum += red[w][k][lane];
+      if (jin) atomic_add(dst + j, sum);
+    }
+    __syncthreads();
+  };
+#pragma unroll
+  for (int f = 0; f < NV; ++f) {
+    const PVec<T>& F = pa.v[f];
+#pragma unroll
+    for (int k = 0; k < kPMP; ++k) red[wave][k][lane] = accv[f][k];
+    red[wave][kPMP][lane] = wsum[f];
+    combine_and_add(kPMP + 1, [&](int k) -> T* {
+      return (k < F.m || (k == kPMP && F.kind == MM_EUCLIDEAN)) ? F.acc + size_t(k) * n : nullptr;
+    });
+  }
+  if constexpr (SD > 0) {
+#pragma unroll
+    for (int r = 0; r < SD; ++r)
+#pragma unroll
+      for (int c = 0; c < SD; ++c) red[wave][r * SD + c][lane] = accS[r][c];
+    combine_and_add(SD * SD, [&](int k) -> T* { return pa.s.accS + size_t(k) * n; });
+  }
+  // loss and scale-gradient partials: slots [1 + nf][kLossSlots]
+  const int slot = (blockIdx.x + (blockIdx.y * kPWaves + wave) * gridDim.x) & (kLossSlots - 1);
+  {
+    const T v = wave_sum(loss_acc);
+    if (lane == 0) atomic_add(&la.slots[slot], v);
+  }
+#pragma unroll
+  for (int f = 0; f < NV; ++f) {
+    const T v = wave_sum(dsv[f]);
+    if (lane == 0) atomic_add(&la.slots[size_t(1 + pa.v[f].slot) * kLossSlots + slot], v);
+  }
+  if constexpr (SD > 0) {
+    const T v = wave_sum(dss);
+    if (lane == 0) atomic_add(&la.slots[size_t(1 + pa.s.slot) * kLossSlots + slot], v);
+  }
+}
+
+// Accumulators -> gradients (the manifold-specific map of each factor) and the loss sums.
+// blockIdx.y selects the job: vector factor y (one thread per coordinate), the SPD factor (one thread per
+// node), or the loss / scale-gradient sums (one block per output).
+template <typename T, int NV, int SD>
+__global__ __launch_bounds__(256) void product_pair_finalize_kernel(PArgs<T> pa, int n, T* __restrict__ slots,
+                                                                    T* __restrict__ loss_out) {
+  constexpr int NPS = SD > 0 ? Packed<(SD > 0 ? SD : 2)>::NP : 1;
+  const int job = blockIdx.y;
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (job == NV + (SD > 0 ? 1 : 0)) {
+    const int q = blockIdx.x;  // 0: loss, 1 + k: d loss / d scale_raw of the caller's factor k
+    if (q > pa.nf) return;
+    __shared__ double part[4];
+    static_assert(kLossSlots == 256, "one slot per thread");
+    const double v = wave_sum(double(slots[size_t(q) * kLossSlots + threadIdx.x]));
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const double tot = part[0] + part[1] + part[2] + part[3];
+      const T* raw = nullptr;
+#pragma unroll
+      for (int f = 0; f < NV; ++f)
+        if (pa.v[f].slot == q - 1) raw = pa.v[f].scale_raw;
+      if (SD > 0 && pa.s.slot == q - 1) raw = pa.s.scale_raw;
+      loss_out[q] = q == 0 ? T(tot) : (raw ? T(tot / (1.0 + ::exp(-double(*raw)))) : T(0));  // d softplus = sigmoid
+    }
+    return;
+  }
+  if (job < NV) {
+    PVec<T> F = pa.v[0];
+#pragma unroll
+    for (int f = 1; f < NV; ++f)
+      if (job == f) F = pa.v[f];
+    const int j = t / kPMP, k = t % kPMP;
+    if (j >= n || k >= F.m) return;
+    const T s = F.acc[size_t(k) * n + j];
+    T r = s;
+    if (F.kind == MM_EUCLIDEAN) r = T(2) * (F.acc[size_t(kPMP) * n + j] * F.x[size_t(j) * F.m + k] - s);
+    else if (F.kind == MM_LORENTZ) r = (k == 0) ? s : -s;
+    F.grad[size_t(j) * F.m + k] = r;
+    return;
+  }
+  const int j = t;
+  if (j >= n) return;
+  if constexpr (SD > 0) {
+    T li[NPS], xinv[NPS], sc[SD][SD], gi[NPS];
+#pragma unroll
+    for (int k = 0; k < NPS; ++k) li[k] = pa.s.nodeL[size_t(j) * NPS + k];
+#pragma unroll
+    for (int r = 0; r < SD; ++r)
+#pragma unroll
+      for (int c = 0; c < SD; ++c) sc[r][c] = pa.s.accS[size_t(r * SD + c) * n + j];
+#pragma unroll
+    for (int r = 0; r < SD; ++r)
+#pragma unroll
+      for (int c = 0; c <= r; ++c) {
+        T acc = T(0);  // X^-1 = L^-T L^-1
+#pragma unroll
+        for (int k = r; k < SD; ++k) acc = Num<T>::fma(li[pidx(k, r)], li[pidx(k, c)], acc);
+        xinv[pidx(r, c)] = acc;
+      }
+#pragma unroll
+    for (int r = 0; r < SD; ++r)
+#pragma unroll
+      for (int c = 0; c <= r; ++c) {
+        T a = T(0), b = T(0);
+#pragma unroll
+        for (int k = 0; k < SD; ++k) {
+          a = Num<T>::fma(sc[r][k], xinv[pidx(k, c)], a);
+          b = Num<T>::fma(sc[c][k], xinv[pidx(k, r)], b);
+        }
+        gi[pidx(r, c)] = T(0.5) * (a + b);  // ordered pairs: both roles of a node arrive as "column side"
+      }
+    store_sym_full<T, SD>(pa.s.grad + size_t(j) * SD * SD, gi);
+  }
+}
+
+template <typename T, int NV, int SD>
+int product_pairs_launch(int loss_kind, PArgs<T> pa, const T* target, int64_t n, int64_t rb, int64_t re, LossArgs<T> la,
+                         T* loss_out, hipStream_t st) {
+  if (mm_pair_offset(n, re) > mm_pair_offset(n, rb)) {
+    // rows per wavefront: short enough that the launch has ~2 wavefronts per SIMD (the work of a small
+    // product embedding is latency, not throughput; measured at n = 1025: 2 -> 123, 4 -> 103, 8 -> 94,
+    // 16 -> 97 us per training step), at most 32
+    const int64_t cols = (n + kPCols - 1) / kPCols;
+    static const int ti_env = [] { const char* e = std::getenv("MM_PRODUCT_TI"); return e ? std::atoi(e) : 0; }();
+    const int ti = (ti_env > 0 && ti_env <= kPMaxTI) ? ti_env : int(std::min<int64_t>(kPMaxTI, std::max<int64_t>(4, cols * n / 2048)));
+    const dim3 grid(unsigned(cols), unsigned((n + kPWaves * ti - 1) / (kPWaves * ti)));
+    if (loss_kind == MM_LOSS_STRESS)
+      product_pair_kernel<T, NV, SD, MM_LOSS_STRESS><<<grid, dim3(kPCols * kPWaves), 0, st>>>(pa, target, int(n), int(rb), int(re), ti, la);
+    else
+      product_pair_kernel<T, NV, SD, MM_LOSS_QUOTIENT><<<grid, dim3(kPCols * kPWaves), 0, st>>>(pa, target, int(n), int(rb), int(re), ti, la);
+  }
+  const dim3 fgrid(unsigned(std::max<int64_t>((n * kPMP + 255) / 256, 8)), unsigned(NV + (SD > 0 ? 1 : 0) + 1));
+  product_pair_finalize_kernel<T, NV, SD><<<fgrid, dim3(256), 0, st>>>(pa, int(n), la.slots, loss_out);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? MM_OK : int(e);
+}
+
+template <typename T>
+int product_pairs_t(int loss_kind, int nf, const int* kinds, const int* dims, const void* const* xs,
+                    void* const* spd_ws, const void* const* scale_raw, const void* target, int64_t n, int64_t rb,
+                    int64_t re, double alpha, double eps, int terms, double wmin, double wmax, void* const* grads,
+                    void* loss_out, void* wsp, hipStream_t st) {
+  PArgs<T> pa{};
+  pa.nf = nf;
+  int nv = 0, sd = 0;
+  // workspace: [64 bytes reserved] [slots (1+nf) x 256] [accumulators]
+  char* wsb = static_cast<char*>(wsp);
+  T* slots = reinterpret_cast<T*>(wsb + 64);
+  T* accp = slots + size_t(1 + nf) * kLossSlots;
+  size_t acc_elems = 0;
+  for (int k = 0; k < nf; ++k) {
+    if (kinds[k] == MM_FACTOR_SPD) {
+      if (sd != 0 || (dims[k] != 2 && dims[k] != 3) || !spd_ws[k]) return MM_ERR_UNSUPPORTED;
+      sd = dims[k];
+      const int rc = mm_spd_prepare(std::is_same<T, double>::value ? MM_F64 : MM_F32, xs[k], n, sd, spd_ws[k], st);
+      if (rc != MM_OK) return rc;
+      Ws<T> w(spd_ws[k], n, sd);
+      pa.s.nodeL = w.nodeL;
+      pa.s.nodeC = w.nodeC;
+      pa.s.scale_raw = static_cast<const T*>(scale_raw[k]);
+      pa.s.accS = accp + acc_elems;
+      pa.s.wmin = T(wmin);
+      pa.s.wmax = T(wmax);
+      pa.s.slot = k;
+      pa.s.grad = static_cast<T*>(grads[k]);
+      acc_elems += size_t(sd) * sd * n;
+    } else {
+      if (nv == kPMaxVec || dims[k] < 1 || dims[k] > kPMP || kinds[k] < MM_EUCLIDEAN || kinds[k] > MM_SPHERE)
+        return MM_ERR_UNSUPPORTED;
+      PVec<T>& F = pa.v[nv++];
+      F.x = static_cast<const T*>(xs[k]);
+      F.scale_raw = static_cast<const T*>(scale_raw[k]);
+      F.acc = accp + acc_elems;
+      F.m = dims[k];
+      F.kind = kinds[k];
+      F.slot = k;
+      F.grad = static_cast<T*>(grads[k]);
+      acc_elems += size_t(kPMP + 1) * n;
+    }
+  }
+  hipError_t e = hipMemsetAsync(slots, 0, sizeof(T) * (size_t(1 + nf) * kLossSlots + acc_elems), st);
+  if (e != hipSuccess) return int(e);
+  LossArgs<T> la{nullptr, T(alpha), T(eps), terms, slots};
+  const T* tg = static_cast<const T*>(target);
+  T* lo = static_cast<T*>(loss_out);
+#define MM_PP(NV_, SD_) return product_pairs_launch<T, NV_, SD_>(loss_kind, pa, tg, n, rb, re, la, lo, st)
+  switch (nv * 4 + sd) {
+    case 0 * 4 + 2: MM_PP(0, 2);
+    case 0 * 4 + 3: MM_PP(0, 3);
+    case 1 * 4 + 0: MM_PP(1, 0);
+    case 1 * 4 + 2: MM_PP(1, 2);
+    case 1 * 4 + 3: MM_PP(1, 3);
+    case 2 * 4 + 0: MM_PP(2, 0);
+    case 2 * 4 + 2: MM_PP(2, 2);
+    case 2 * 4 + 3: MM_PP(2, 3);
+    case 3 * 4 + 0: MM_PP(3, 0);
+    case 3 * 4 + 2: MM_PP(3, 2);
+    case 3 * 4 + 3: MM_PP(3, 3);
+    default: return MM_ERR_UNSUPPORTED;
+  }
+#undef MM_PP
+}
+
+}  // namespace mm
+
+using namespace mm;
+
+extern "C" {
+
+size_t mm_product_pairs_ws_bytes(int dtype, int nf, const int* kinds, const int* dims, int64_t n) {
+  const size_t es = dtype == MM_F64 ? 8 : 4;
+  size_t elems = size_t(1 + nf) * kLossSlots;
+  for (int k = 0; k < nf; ++k)
+    elems += kinds[k] == MM_FACTOR_SPD ? size_t(dims[k]) * dims[k] * n : size_t(kPMP + 1) * n;
+  return 64 + es * elems;
+}
+
+int mm_product_pairs_loss(int dtype, int loss_kind, int nf, const int* kinds, const int* dims, const void* const* xs,
+                          void* const* spd_ws, const void* const* scale_raw, const void* target, int64_t n,
+                          int64_t row_begin, int64_t row_end, double alpha, double eps, int terms, double wmin,
+                          double wmax, void* const* grads, void* loss_out, void* ws, mm_stream_t stream) {
+  if (nf < 1 || nf > 4 || !kinds || !dims || !xs || !spd_ws || !scale_raw || !grads || !loss_out || !ws || n < 1 ||
+      n > (1 << 30) || row_begin < 0 || row_end > n || row_begin > row_end)
+    return MM_ERR_ARG;
+  for (int k = 0; k < nf; ++k)
+    if (!xs[k] || !scale_raw[k] || !grads[k]) return MM_ERR_ARG;
+  if (!target && mm_pair_offset(n, row_end) > mm_pair_offset(n, row_begin)) return MM_ERR_ARG;
+  if (loss_kind != MM_LOSS_STRESS && loss_kind != MM_LOSS_QUOTIENT) return MM_ERR_UNSUPPORTED;
+  if (loss_kind == MM_LOSS_QUOTIENT && !(terms & 3)) return MM_ERR_ARG;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (dtype == MM_F32)
+    return product_pairs_t<float>(loss_kind, nf, kinds, dims, xs, spd_ws, scale_raw, target, n, row_begin, row_end, alpha,
+                                  eps, terms, wmin, wmax, grads, loss_out, ws, st);
+  if (dtype == MM_F64)
+    return product_pairs_t<double>(loss_kind, nf, kinds, dims, xs, spd_ws, scale_raw, target, n, row_begin, row_end,
+                                   alpha, eps, terms, wmin, wmax, grads, loss_out, ws, st);
+  return MM_ERR_ARG;
+}
+
+}  // extern "C"

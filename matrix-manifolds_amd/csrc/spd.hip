@@ -836,6 +836,11 @@ int spd_pdist_bwd_t(const T* x, const T* g, int64_t n, int64_t rb, int64_t re, i
 #include "spd_stein.hpp"
 
 // dtype x D dispatch ---------------------------------------------------------
+template <typename T, int D> int spd_prepare_t(const T* x, int64_t n, void* wsp, hipStream_t st) {
+  Ws<T> ws(wsp, n, D);
+  return spd_pdist_prepare<T, D>(x, n, ws, 0, st);
+}
+
 #define MM_DISPATCH_D(T, d, CALL)                \
   switch (d) {                                   \
     case 2: { constexpr int D = 2; return CALL; } \
@@ -882,6 +887,13 @@ int mm_spd_pdist_fwd(int dtype, const void* x, int64_t n, int d, int64_t row_beg
   MM_DISPATCH(dtype, d,
               (spd_pdist_fwd_t<T, D>(static_cast<const T*>(x), n, row_begin, row_end, squared, wmin, wmax,
                                      static_cast<T*>(out), ws, flags, st)));
+}
+
+int mm_spd_prepare(int dtype, const void* x, int64_t n, int d, void* ws, mm_stream_t stream) {
+  if (!x || !ws || n < 0 || n > (1 << 30)) return MM_ERR_ARG;
+  if (n == 0) return MM_OK;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  MM_DISPATCH(dtype, d, (spd_prepare_t<T, D>(static_cast<const T*>(x), n, ws, st)));
 }
 
 int mm_spd_pdist_bwd(int dtype, const void* x, const void* g, int64_t n, int d, int64_t row_begin, int64_t row_end,

@@ -36,8 +36,11 @@ class GraphedTrainStep:
         return [p for o in self.optimizers for g in o.param_groups for p in g['params']]
 
     def _eager_step(self):
+        # gradients are dropped, not zeroed: backward then ASSIGNS them (no fill and no accumulate
+        # kernel per parameter — 2 launches per parameter of a step that has ~20 in total); while
+        # capturing they land in the graph's private pool, where every replay rewrites them in place
         for o in self.optimizers:
-            o.zero_grad(set_to_none=False)
+            o.zero_grad(set_to_none=True)
         loss = self.loss_fn()
         loss.backward()
         for o in self.optimizers:
@@ -51,9 +54,6 @@ class GraphedTrainStep:
         params = self._params()
         if not params or not all(p.is_cuda for p in params):
             raise RuntimeError('GraphedTrainStep needs parameters in GPU memory')
-        for p in params:  # static gradient buffers: zero_grad(set_to_none=False) keeps them
-            if p.grad is None:
-                p.grad = torch.zeros_like(p)
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):

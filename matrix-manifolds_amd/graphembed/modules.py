@@ -80,6 +80,89 @@ class _ProductLoss(torch.autograd.Function):
         return (None, None, None, None) + tuple(grads)
 
 
+def _pair_kernel_factor(man):
+    """(kind, dim) of a factor the single mixed-manifold pair kernel (mm_product_pairs_loss) handles,
+    else None."""
+    from graphembed import _backend as B
+    from graphembed.manifolds.vector import VectorManifold
+    kind = getattr(man, '_kind', None)
+    if isinstance(man, VectorManifold) and kind in (B.EUCLIDEAN, B.LORENTZ, B.SPHERE):
+        m = getattr(man, '_m', None)
+        return (kind, m) if m is not None and m <= 16 else None
+    if hasattr(man, 'wmin') and hasattr(man, 'n') and not getattr(man, 'use_stein_div', False):
+        return (B.FACTOR_SPD, man.n) if man.n in (2, 3) else None
+    return None
+
+
+def _pair_kernel_factors(manifolds):
+    from graphembed import _backend as B
+    fs = [_pair_kernel_factor(m) for m in manifolds]
+    if any(f is None for f in fs) or len(fs) > 4:
+        return None
+    n_spd = sum(1 for k, _ in fs if k == B.FACTOR_SPD)
+    if n_spd > 1 or len(fs) - n_spd > 3:
+        return None
+    return fs
+
+
+class _ProductPairsLoss(torch.autograd.Function):
+    """Objective and all gradients of a product embedding from ONE mixed-manifold pair kernel
+    (mm_product_pairs_loss): every factor's squared distance, their softplus-weighted sum
+    (modules.py:84-88), the loss term (objectives.py:16-45) and the gradients w.r.t. every factor's
+    points and scale, without a pair vector in memory — the csphd configuration's
+    Lorentz x sphere x SPD(2) step in two launches (+ the SPD factor's per-node preparation)."""
+
+    @staticmethod
+    def forward(ctx, target, spec, rows, manifolds, factors, *params):
+        import ctypes
+        from graphembed import _backend as B
+        k = len(manifolds)
+        xs, scales = params[:k], params[k:]
+        B.require_gpu(*xs)
+        lib = B.lib()
+        lkind, alpha, eps, terms = spec
+        dtype, dev = xs[0].dtype, xs[0].device
+        n = xs[0].shape[0]
+        rb, re = (0, n) if rows is None else rows
+        npairs = B.pair_offset(n, re) - B.pair_offset(n, rb)
+        tc = target.detach().to(dtype).contiguous()
+        if tc.numel() != npairs:
+            raise ValueError(f'target has {tc.numel()} entries, the pair range has {npairs}')
+        dt = B.dtype_code(xs[0])
+        kinds = (ctypes.c_int * k)(*[f[0] for f in factors])
+        dims = (ctypes.c_int * k)(*[f[1] for f in factors])
+        wmin, wmax = 0.0, 0.0
+        with B.on_device(dev):
+            xc = [x.detach().to(dtype).contiguous() for x in xs]
+            sc = [s.detach().to(dtype).reshape(1).contiguous() for s in scales]
+            grads = [torch.empty_like(x) for x in xc]
+            spd_ws = (ctypes.c_void_p * k)()
+            keep = []
+            for i, (man, f) in enumerate(zip(manifolds, factors)):
+                if f[0] == B.FACTOR_SPD:
+                    w = torch.empty(lib.raw('mm_spd_pdist_ws_bytes')(dt, n, f[1]), dtype=torch.uint8, device=dev)
+                    keep.append(w)
+                    spd_ws[i] = w.data_ptr()
+                    wmin, wmax = man.wmin, man.wmax
+            out = torch.empty(1 + k, dtype=dtype, device=dev)
+            ws = torch.empty(lib.raw('mm_product_pairs_ws_bytes')(dt, k, kinds, dims, n), dtype=torch.uint8,
+                             device=dev)
+            lib.call('mm_product_pairs_loss', dt, B.LOSS_STRESS if lkind == 'stress' else B.LOSS_QUOTIENT, k,
+                     kinds, dims, B.ptr_array(xc), spd_ws, B.ptr_array(sc), B.ptr(tc), n, rb, re, alpha, eps,
+                     terms, wmin, wmax, B.ptr_array(grads), B.ptr(out), B.ptr(ws), B.stream_of(xs[0]))
+        ctx.grads = [g.reshape(x.shape) for g, x in zip(grads, xs)] + \
+            [out[1 + i].reshape(s.shape).to(s.dtype) for i, s in enumerate(scales)]
+        return out[0]
+
+    @staticmethod
+    def backward(ctx, up):
+        try:
+            grads = list(torch._foreach_mul(ctx.grads, up))
+        except (RuntimeError, TypeError):
+            grads = [g * up for g in ctx.grads]
+        return (None, None, None, None, None) + tuple(grads)
+
+
 class ManifoldParameter(torch.nn.Parameter):
     """A Parameter that knows the manifold it lives on (modules.py:9-23)."""
 
@@ -106,6 +189,7 @@ class ManifoldEmbedding(torch.nn.Module):
         super().__init__()
         self.n = n
         self.n_components = len(manifolds)
+        self.pair_kernel = True  # products: use the single mixed-manifold pair kernel when it applies
         self.manifolds = manifolds
         self.xs = torch.nn.ParameterList(
             [ManifoldParameter(data=man.rand(n), manifold=man) for man in manifolds])
@@ -153,8 +237,11 @@ class ManifoldEmbedding(torch.nn.Module):
         """`objective_fn(gdists, self.compute_dists(i), **kwargs)` evaluated by ONE pair kernel
         that also produces the gradients (no pair vector of distances, no element-wise passes),
         or None when the objective has no fused kernel (a loss without `fused_spec`, CPU tensors).
-        Single factors run the whole pair computation in one kernel; products run one forward and
-        one backward kernel per factor around a single loss kernel (`mm_product_loss`)."""
+        Single factors run the whole pair computation in one kernel; products of up to three
+        vector factors (dimension <= 16) and one SPD(2)/SPD(3) factor likewise (the mixed-manifold
+        pair kernel `mm_product_pairs_loss`; `self.pair_kernel = False` turns it off); other products
+        run one forward and one backward kernel per factor around a single loss kernel
+        (`mm_product_loss`)."""
         if not hasattr(objective_fn, 'fused_spec') or not self.xs[0].is_cuda:
             return None
         spec = objective_fn.fused_spec(**kwargs)
@@ -164,6 +251,10 @@ class ManifoldEmbedding(torch.nn.Module):
         if self.n_components > _max_product_factors():
             return None
         xs = [take_rows(x, i) for x in self.xs]
+        factors = _pair_kernel_factors(self.manifolds) if self.pair_kernel else None
+        if factors is not None:
+            return _ProductPairsLoss.apply(gdists, spec, rows, tuple(self.manifolds), tuple(factors), *xs,
+                                           *self.scales)
         return _ProductLoss.apply(gdists, spec, rows, tuple(self.manifolds), *xs, *self.scales)
 
     def __len__(self):

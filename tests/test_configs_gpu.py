@@ -179,8 +179,9 @@ def test_graphed_train_step_matches_eager(case):
 @pytest.mark.parametrize('dname', ['f32', 'f64'])
 @pytest.mark.parametrize('loss_name', ['stress', 'quotient'])
 def test_product_fused_objective_equals_unfused(dname, loss_name):
-    """csphd-style product (Lorentz x Sphere x SPD(2)) and a Grassmann single factor: the fused
-    objective (per-factor pair kernels around ONE loss kernel, mm_product_loss) gives the loss and all
+    """csphd-style product (Lorentz x Sphere x SPD(2)), other mixes and a Grassmann single factor: the
+    fused objective — the single mixed-manifold pair kernel (mm_product_pairs_loss) where it applies,
+    else per-factor pair kernels around ONE loss kernel (mm_product_loss) — gives the loss and all
     gradients of compute_dists -> objective -> backward; row shards sum to the whole."""
     from graphembed import _backend as B
     from graphembed import manifolds as M
@@ -190,7 +191,15 @@ def test_product_fused_objective_equals_unfused(dname, loss_name):
     n = 300
     fn, kw = (StressLoss(), {}) if loss_name == 'stress' else (QuotientLoss(), dict(epoch=1, alpha=1.2))
     tol = 1e-4 if dname == 'f32' else 1e-10
-    for mans in ([M.Lorentz(6), M.Sphere(6), M.SymmetricPositiveDefinite(2)], [M.Grassmann(5, 2)]):
+    from graphembed.modules import _pair_kernel_factors
+    cases = [([M.Lorentz(6), M.Sphere(6), M.SymmetricPositiveDefinite(2)], True),
+             ([M.Lorentz(6), M.Sphere(6), M.SymmetricPositiveDefinite(2)], False),
+             ([M.Euclidean(5), M.SymmetricPositiveDefinite(3)], True),
+             ([M.Lorentz(3), M.Euclidean(2), M.Sphere(16)], True),
+             ([M.SymmetricPositiveDefinite(2), M.SymmetricPositiveDefinite(3)], True),  # two SPD: per-factor path
+             ([M.Grassmann(5, 2)], True)]
+    assert _pair_kernel_factors(cases[0][0]) is not None and _pair_kernel_factors(cases[4][0]) is None
+    for mans, pair_kernel in cases:
         torch.manual_seed(4)
         torch.set_default_dtype(dt)
         try:
@@ -200,6 +209,7 @@ def test_product_fused_objective_equals_unfused(dname, loss_name):
                     emb.perturb(0.3)
         finally:
             torch.set_default_dtype(torch.float32)
+        emb.pair_kernel = pair_kernel
         params = list(emb.xs) + list(emb.scales)
         md = emb.compute_dists(None).detach()
         gen = torch.Generator(device='cuda').manual_seed(2)
@@ -212,8 +222,16 @@ def test_product_fused_objective_equals_unfused(dname, loss_name):
             assert not near.any()
         ref = fn(target, emb.compute_dists(None), **kw)
         rg = torch.autograd.grad(ref, params)
-        loss = emb.fused_objective(fn, target, None, **kw)
+        lib, calls = B.lib(), []
+        orig = lib.call
+        lib.call = lambda name, *a: (calls.append(name), orig(name, *a))[1]
+        try:
+            loss = emb.fused_objective(fn, target, None, **kw)
+        finally:
+            del lib.call
         assert loss is not None
+        assert ('mm_product_pairs_loss' in calls) == (pair_kernel and _pair_kernel_factors(mans) is not None
+                                                      and len(mans) > 1), calls
         g = torch.autograd.grad(loss * 2.0, params)
         assert abs(loss.item() - ref.item()) <= tol * abs(ref.item())
         for a, b in zip(g, rg):

@@ -45,13 +45,14 @@ def pdist_case(man, n, dtype, **kw):
             'pairs_per_s': P / (tot * 1e-6), 'GBps_8B_per_pair': P * 2 * x.element_size() / (tot * 1e-6) / 1e9}
 
 
-def step_case(mans, n, dtype, fused=False, graph=False):
+def step_case(mans, n, dtype, fused=False, graph=False, pair_kernel=True):
     """full training step: compute_dists + stress loss + backward + fused RSGD (momentum 0)"""
     torch.manual_seed(0)
     torch.set_default_dtype(dtype)
     try:
         with torch.device('cuda'):
             emb = ManifoldEmbedding(n, mans)
+            emb.pair_kernel = pair_kernel  # products: the single mixed-manifold pair kernel
     finally:
         torch.set_default_dtype(torch.float32)
     P = n * (n - 1) // 2
@@ -62,8 +63,8 @@ def step_case(mans, n, dtype, fused=False, graph=False):
     opt_s = RiemannianSGD(list(emb.scales), lr=1e-4, max_grad_norm=500)
 
     def step():
-        opt.zero_grad(set_to_none=False)
-        opt_s.zero_grad(set_to_none=False)
+        opt.zero_grad(set_to_none=True)
+        opt_s.zero_grad(set_to_none=True)
         if fused:
             emb.fused_objective(fn, target, None).backward()
         else:
@@ -71,8 +72,6 @@ def step_case(mans, n, dtype, fused=False, graph=False):
         opt.step()
         opt_s.step()
     if graph:  # whole training step replayed as one hipGraph (static shapes, no host sync inside)
-        for p in list(emb.xs) + list(emb.scales):
-            p.grad = torch.zeros_like(p)
         side = torch.cuda.Stream()
         with torch.cuda.stream(side):
             for _ in range(3):
@@ -107,6 +106,9 @@ CASES = {
     'c4_csphd_product_step_f32': lambda: step_case([M.Lorentz(6), M.Sphere(6), M.SymmetricPositiveDefinite(2)], 1025, torch.float32),
     'c4_csphd_product_step_f32_fused': lambda: step_case([M.Lorentz(6), M.Sphere(6), M.SymmetricPositiveDefinite(2)], 1025, torch.float32, fused=True),
     'c4_csphd_product_step_f32_fused_graph': lambda: step_case([M.Lorentz(6), M.Sphere(6), M.SymmetricPositiveDefinite(2)], 1025, torch.float32, fused=True, graph=True),
+    'c4_csphd_product_step_f32_perfactor': lambda: step_case([M.Lorentz(6), M.Sphere(6), M.SymmetricPositiveDefinite(2)], 1025, torch.float32, fused=True, pair_kernel=False),
+    'c4_csphd_product_step_f32_perfactor_graph': lambda: step_case([M.Lorentz(6), M.Sphere(6), M.SymmetricPositiveDefinite(2)], 1025, torch.float32, fused=True, graph=True, pair_kernel=False),
+    'c4_csphd_product_step_f64_fused_graph': lambda: step_case([M.Lorentz(6), M.Sphere(6), M.SymmetricPositiveDefinite(2)], 1025, torch.float64, fused=True, graph=True),
     'c4_csphd_product_step_f32_graph': lambda: step_case([M.Lorentz(6), M.Sphere(6), M.SymmetricPositiveDefinite(2)], 1025, torch.float32, graph=True),
     'c4_csphd_product_step_f64': lambda: step_case([M.Lorentz(6), M.Sphere(6), M.SymmetricPositiveDefinite(2)], 1025, torch.float64),
     'c5_wormnet_spd4_n2274_f32': lambda: pdist_case(M.SymmetricPositiveDefinite(4), 2274, torch.float32),

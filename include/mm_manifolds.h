@@ -268,20 +268,24 @@ int mm_product_loss(int dtype, int loss_kind, int nf, const void* const* d2, con
  * SPD(2) — one launch computes every factor's squared distance, the weighted sum, the loss term and all
  * gradients; ManifoldEmbedding.compute_dists modules.py:84-88 + objectives.py:16-45 + their backward).
  *   kinds[k]   MM_EUCLIDEAN / MM_LORENTZ / MM_SPHERE (xs[k] = [n, dims[k]], dims[k] <= 16) or
- *              MM_FACTOR_SPD (xs[k] = [n, d, d] with d = dims[k] in {2, 3}; spd_ws[k] = a workspace of
- *              mm_spd_pdist_ws_bytes that this call prepares; spd_ws[k] is ignored for vector factors)
+ *              MM_FACTOR_SPD (xs[k] = [n, d, d] with d = dims[k] in {2, 3}; the Cholesky factors are
+ *              formed inside the pair kernel — no workspace, no preparation launch)
  *   grads[k]   Euclidean gradient of the loss w.r.t. xs[k] (same shape), rows [row_begin,row_end) of the
  *              pair list only — summed over shards it is the full gradient
  *   loss_out   { loss, dloss/dscale_raw[0..nf-1] }
+ *   ws         mm_product_pairs_ws_bytes; every successful call leaves its accumulators zero, so a
+ *              workspace that is reused for the same (dtype, factor list, n) may be passed with
+ *              flags = MM_WS_CLEAN from the second call on (saves the clearing launches)
  * At most 3 vector factors and one SPD factor; otherwise MM_ERR_UNSUPPORTED (use mm_product_loss around
- * the per-factor kernels).  kinds, dims, xs, spd_ws, scale_raw, grads are HOST arrays. */
+ * the per-factor kernels).  kinds, dims, xs, scale_raw, grads are HOST arrays. */
 enum { MM_FACTOR_SPD = 16 };
+enum { MM_WS_CLEAN = 2 /* flag: the workspace's accumulators are already zero */ };
 size_t mm_product_pairs_ws_bytes(int dtype, int nf, const int* kinds, const int* dims, int64_t n);
 int mm_product_pairs_loss(int dtype, int loss_kind, int nf, const int* kinds, const int* dims,
-                          const void* const* xs, void* const* spd_ws, const void* const* scale_raw,
-                          const void* target, int64_t n, int64_t row_begin, int64_t row_end, double alpha,
-                          double eps, int terms, double wmin, double wmax, void* const* grads,
-                          void* loss_out, void* ws, mm_stream_t stream);
+                          const void* const* xs, const void* const* scale_raw, const void* target,
+                          int64_t n, int64_t row_begin, int64_t row_end, double alpha, double eps,
+                          int terms, double wmin, double wmax, void* const* grads, void* loss_out,
+                          void* ws, int flags, mm_stream_t stream);
 
 /* Targets of a node minibatch: out[pair (a,b), a<b] = dense[idx[a]][idx[b]] in pair-vector order
  * (GraphDataset.__getitem__, data/dataset.py:19-27).  dense [n,n]; idx int64[bs] (device); out [bs(bs-1)/2]. */

@@ -19,7 +19,6 @@
 #include "../../include/mm_manifolds.h"
 #include "loss.hpp"
 #include "smallmat.hpp"
-#include "spd_ws.hpp"
 #include "vecfn.hpp"
 
 namespace mm {
@@ -39,8 +38,7 @@ template <typename T> struct PVec {
   int m, kind, slot;   // slot = position in the caller's factor list (for loss_out)
 };
 template <typename T> struct PSpd {
-  const T* nodeL;      // packed L_i^-1
-  const T* nodeC;      // packed L_i
+  const T* x;          // [n][D][D]
   const T* scale_raw;
   T* accS;             // [D*D][n]
   T* grad;             // [n][D][D]
@@ -111,8 +109,12 @@ __global__ __launch_bounds__(kPCols * kPWaves) void product_pair_kernel(PArgs<T>
 
   T yj[NPS], accS[DS][DS];
   if constexpr (SD > 0) {
-#pragma unroll
-    for (int k = 0; k < NPS; ++k) yj[k] = pa.s.nodeC[size_t(jin ? j : n - 1) * NPS + k];  // lanes past n: masked later
+    {  // Cholesky factor of the column point, in registers (no per-node tables, no preparation launch:
+       // the factorisation is ~1 % of a row's arithmetic)
+      T xs[NPS];
+      load_sym_packed<T, SD>(pa.s.x + size_t(jin ? j : n - 1) * SD * SD, xs);  // lanes past n: masked later
+      cholesky<T, SD>(xs, yj);
+    }
 #pragma unroll
     for (int r = 0; r < SD; ++r)
 #pragma unroll
@@ -136,6 +138,17 @@ __global__ __launch_bounds__(kPCols * kPWaves) void product_pair_kernel(PArgs<T>
     for (int e = lane; e < ti * kPMP; e += 64) {
       const int r = e / kPMP, k = e % kPMP;
       rowpt[f][wave][r][k] = (k < F.m && i0 + r < n) ? F.x[size_t(i0 + r) * F.m + k] : T(0);
+    }
+  }
+  __shared__ T rowL[kPWaves][kPMaxTI][2 * NPS];  // L_i^-1 and L_i of the tile's rows
+  if constexpr (SD > 0) {
+    if (lane < ti) {
+      T xs[NPS], l[NPS], li_[NPS];
+      load_sym_packed<T, SD>(pa.s.x + size_t(min(i0 + lane, n - 1)) * SD * SD, xs);
+      cholesky<T, SD>(xs, l);
+      invert_lower<T, SD>(l, li_);
+#pragma unroll
+      for (int k = 0; k < NPS; ++k) { rowL[wave][lane][k] = li_[k]; rowL[wave][lane][NPS + k] = l[k]; }
     }
   }
   // every load of the preamble is in flight by now; pin them here so that none is sunk below its mask
@@ -174,7 +187,7 @@ __global__ __launch_bounds__(kPCols * kPWaves) void product_pair_kernel(PArgs<T>
     T li[NPS], lc[NPS], lw[DS], vv[DS][DS], d2s = T(0);
     if constexpr (SD > 0) {
 #pragma unroll
-      for (int k = 0; k < NPS; ++k) { li[k] = pa.s.nodeL[size_t(i) * NPS + k]; lc[k] = pa.s.nodeC[size_t(i) * NPS + k]; }
+      for (int k = 0; k < NPS; ++k) { li[k] = rowL[wave][i - i0][k]; lc[k] = rowL[wave][i - i0][NPS + k]; }
       T a[NPS];
       congr_chol<T, SD>(li, yj, a);
       jacobi_eig<T, SD, true, true>(a, vv, T(64) * Num<T>::eps() * Num<T>::eps());
@@ -279,6 +292,7 @@ __global__ __launch_bounds__(256) void product_pair_finalize_kernel(PArgs<T> pa,
     __shared__ double part[4];
     static_assert(kLossSlots == 256, "one slot per thread");
     const double v = wave_sum(double(slots[size_t(q) * kLossSlots + threadIdx.x]));
+    slots[size_t(q) * kLossSlots + threadIdx.x] = T(0);  // every accumulator is left clean (MM_WS_CLEAN)
     if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = v;
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -300,9 +314,16 @@ __global__ __launch_bounds__(256) void product_pair_finalize_kernel(PArgs<T> pa,
     const int j = t / kPMP, k = t % kPMP;
     if (j >= n || k >= F.m) return;
     const T s = F.acc[size_t(k) * n + j];
+    F.acc[size_t(k) * n + j] = T(0);
     T r = s;
-    if (F.kind == MM_EUCLIDEAN) r = T(2) * (F.acc[size_t(kPMP) * n + j] * F.x[size_t(j) * F.m + k] - s);
-    else if (F.kind == MM_LORENTZ) r = (k == 0) ? s : -s;
+    if (F.kind == MM_EUCLIDEAN) {
+      const T ws = F.acc[size_t(kPMP) * n + j];
+      r = T(2) * (ws * F.x[size_t(j) * F.m + k] - s);
+      // the 16 threads of a node share a wavefront (64 % kPMP == 0): all of them have read ws by now
+      if (k == 0) F.acc[size_t(kPMP) * n + j] = T(0);
+    } else if (F.kind == MM_LORENTZ) {
+      r = (k == 0) ? s : -s;
+    }
     F.grad[size_t(j) * F.m + k] = r;
     return;
   }
@@ -310,12 +331,19 @@ __global__ __launch_bounds__(256) void product_pair_finalize_kernel(PArgs<T> pa,
   if (j >= n) return;
   if constexpr (SD > 0) {
     T li[NPS], xinv[NPS], sc[SD][SD], gi[NPS];
-#pragma unroll
-    for (int k = 0; k < NPS; ++k) li[k] = pa.s.nodeL[size_t(j) * NPS + k];
+    {
+      T xs[NPS], l[NPS];
+      load_sym_packed<T, SD>(pa.s.x + size_t(j) * SD * SD, xs);
+      cholesky<T, SD>(xs, l);
+      invert_lower<T, SD>(l, li);
+    }
 #pragma unroll
     for (int r = 0; r < SD; ++r)
 #pragma unroll
-      for (int c = 0; c < SD; ++c) sc[r][c] = pa.s.accS[size_t(r * SD + c) * n + j];
+      for (int c = 0; c < SD; ++c) {
+        sc[r][c] = pa.s.accS[size_t(r * SD + c) * n + j];
+        pa.s.accS[size_t(r * SD + c) * n + j] = T(0);
+      }
 #pragma unroll
     for (int r = 0; r < SD; ++r)
 #pragma unroll
@@ -365,9 +393,9 @@ int product_pairs_launch(int loss_kind, PArgs<T> pa, const T* target, int64_t n,
 
 template <typename T>
 int product_pairs_t(int loss_kind, int nf, const int* kinds, const int* dims, const void* const* xs,
-                    void* const* spd_ws, const void* const* scale_raw, const void* target, int64_t n, int64_t rb,
-                    int64_t re, double alpha, double eps, int terms, double wmin, double wmax, void* const* grads,
-                    void* loss_out, void* wsp, hipStream_t st) {
+                    const void* const* scale_raw, const void* target, int64_t n, int64_t rb, int64_t re, double alpha,
+                    double eps, int terms, double wmin, double wmax, void* const* grads, void* loss_out, void* wsp,
+                    int flags, hipStream_t st) {
   PArgs<T> pa{};
   pa.nf = nf;
   int nv = 0, sd = 0;
@@ -378,13 +406,9 @@ int product_pairs_t(int loss_kind, int nf, const int* kinds, const int* dims, co
   size_t acc_elems = 0;
   for (int k = 0; k < nf; ++k) {
     if (kinds[k] == MM_FACTOR_SPD) {
-      if (sd != 0 || (dims[k] != 2 && dims[k] != 3) || !spd_ws[k]) return MM_ERR_UNSUPPORTED;
+      if (sd != 0 || (dims[k] != 2 && dims[k] != 3)) return MM_ERR_UNSUPPORTED;
       sd = dims[k];
-      const int rc = mm_spd_prepare(std::is_same<T, double>::value ? MM_F64 : MM_F32, xs[k], n, sd, spd_ws[k], st);
-      if (rc != MM_OK) return rc;
-      Ws<T> w(spd_ws[k], n, sd);
-      pa.s.nodeL = w.nodeL;
-      pa.s.nodeC = w.nodeC;
+      pa.s.x = static_cast<const T*>(xs[k]);
       pa.s.scale_raw = static_cast<const T*>(scale_raw[k]);
       pa.s.accS = accp + acc_elems;
       pa.s.wmin = T(wmin);
@@ -406,8 +430,10 @@ int product_pairs_t(int loss_kind, int nf, const int* kinds, const int* dims, co
       acc_elems += size_t(kPMP + 1) * n;
     }
   }
-  hipError_t e = hipMemsetAsync(slots, 0, sizeof(T) * (size_t(1 + nf) * kLossSlots + acc_elems), st);
-  if (e != hipSuccess) return int(e);
+  if (!(flags & MM_WS_CLEAN)) {
+    hipError_t e = hipMemsetAsync(slots, 0, sizeof(T) * (size_t(1 + nf) * kLossSlots + acc_elems), st);
+    if (e != hipSuccess) return int(e);
+  }
   LossArgs<T> la{nullptr, T(alpha), T(eps), terms, slots};
   const T* tg = static_cast<const T*>(target);
   T* lo = static_cast<T*>(loss_out);
@@ -444,10 +470,10 @@ size_t mm_product_pairs_ws_bytes(int dtype, int nf, const int* kinds, const int*
 }
 
 int mm_product_pairs_loss(int dtype, int loss_kind, int nf, const int* kinds, const int* dims, const void* const* xs,
-                          void* const* spd_ws, const void* const* scale_raw, const void* target, int64_t n,
-                          int64_t row_begin, int64_t row_end, double alpha, double eps, int terms, double wmin,
-                          double wmax, void* const* grads, void* loss_out, void* ws, mm_stream_t stream) {
-  if (nf < 1 || nf > 4 || !kinds || !dims || !xs || !spd_ws || !scale_raw || !grads || !loss_out || !ws || n < 1 ||
+                          const void* const* scale_raw, const void* target, int64_t n, int64_t row_begin,
+                          int64_t row_end, double alpha, double eps, int terms, double wmin, double wmax,
+                          void* const* grads, void* loss_out, void* ws, int flags, mm_stream_t stream) {
+  if (nf < 1 || nf > 4 || !kinds || !dims || !xs || !scale_raw || !grads || !loss_out || !ws || n < 1 ||
       n > (1 << 30) || row_begin < 0 || row_end > n || row_begin > row_end)
     return MM_ERR_ARG;
   for (int k = 0; k < nf; ++k)
@@ -457,11 +483,11 @@ int mm_product_pairs_loss(int dtype, int loss_kind, int nf, const int* kinds, co
   if (loss_kind == MM_LOSS_QUOTIENT && !(terms & 3)) return MM_ERR_ARG;
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (dtype == MM_F32)
-    return product_pairs_t<float>(loss_kind, nf, kinds, dims, xs, spd_ws, scale_raw, target, n, row_begin, row_end, alpha,
-                                  eps, terms, wmin, wmax, grads, loss_out, ws, st);
+    return product_pairs_t<float>(loss_kind, nf, kinds, dims, xs, scale_raw, target, n, row_begin, row_end, alpha, eps,
+                                  terms, wmin, wmax, grads, loss_out, ws, flags, st);
   if (dtype == MM_F64)
-    return product_pairs_t<double>(loss_kind, nf, kinds, dims, xs, spd_ws, scale_raw, target, n, row_begin, row_end,
-                                   alpha, eps, terms, wmin, wmax, grads, loss_out, ws, st);
+    return product_pairs_t<double>(loss_kind, nf, kinds, dims, xs, scale_raw, target, n, row_begin, row_end, alpha, eps,
+                                   terms, wmin, wmax, grads, loss_out, ws, flags, st);
   return MM_ERR_ARG;
 }
 

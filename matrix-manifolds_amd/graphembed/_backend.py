@@ -18,6 +18,7 @@ MM_WS_PREPARED = 1
 LOSS_STRESS, LOSS_QUOTIENT = 1, 2
 EUCLIDEAN, LORENTZ, SPHERE = 0, 1, 2
 FACTOR_SPD = 16  # MM_FACTOR_SPD: factor kind of mm_product_pairs_loss
+WS_CLEAN = 2     # MM_WS_CLEAN
 SPD_EGRAD2RGRAD, SPD_EXP, SPD_RETR, SPD_LOG, SPD_PROJX, SPD_PROJU = range(6)
 
 _c = ctypes
@@ -40,8 +41,8 @@ SIGNATURES = {
                               _c.POINTER(_vp), _vp, _vp, _vp]),
     'mm_product_pairs_ws_bytes': (_sz, [_i, _i, _c.POINTER(_i), _c.POINTER(_i), _i64]),
     'mm_product_pairs_loss': (_i, [_i, _i, _i, _c.POINTER(_i), _c.POINTER(_i), _c.POINTER(_vp), _c.POINTER(_vp),
-                                    _c.POINTER(_vp), _vp, _i64, _i64, _i64, _dbl, _dbl, _i, _dbl, _dbl,
-                                    _c.POINTER(_vp), _vp, _vp, _vp]),
+                                    _vp, _i64, _i64, _i64, _dbl, _dbl, _i, _dbl, _dbl, _c.POINTER(_vp), _vp, _vp,
+                                    _i, _vp]),
     'mm_spd_prepare': (_i, [_i, _vp, _i64, _i, _vp, _vp]),
     'mm_spd_max_dim': (_i, []),
     'mm_spd_pdist_ws_bytes': (_sz, [_i, _i64, _i]),

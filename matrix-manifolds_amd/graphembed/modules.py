@@ -110,10 +110,10 @@ class _ProductPairsLoss(torch.autograd.Function):
     (mm_product_pairs_loss): every factor's squared distance, their softplus-weighted sum
     (modules.py:84-88), the loss term (objectives.py:16-45) and the gradients w.r.t. every factor's
     points and scale, without a pair vector in memory — the csphd configuration's
-    Lorentz x sphere x SPD(2) step in two launches (+ the SPD factor's per-node preparation)."""
+    Lorentz x sphere x SPD(2) step in two launches."""
 
     @staticmethod
-    def forward(ctx, target, spec, rows, manifolds, factors, *params):
+    def forward(ctx, target, spec, rows, manifolds, factors, cache, *params):
         import ctypes
         from graphembed import _backend as B
         k = len(manifolds)
@@ -132,24 +132,30 @@ class _ProductPairsLoss(torch.autograd.Function):
         kinds = (ctypes.c_int * k)(*[f[0] for f in factors])
         dims = (ctypes.c_int * k)(*[f[1] for f in factors])
         wmin, wmax = 0.0, 0.0
+        for man, f in zip(manifolds, factors):
+            if f[0] == B.FACTOR_SPD:
+                wmin, wmax = man.wmin, man.wmax
         with B.on_device(dev):
             xc = [x.detach().to(dtype).contiguous() for x in xs]
             sc = [s.detach().to(dtype).reshape(1).contiguous() for s in scales]
             grads = [torch.empty_like(x) for x in xc]
-            spd_ws = (ctypes.c_void_p * k)()
-            keep = []
-            for i, (man, f) in enumerate(zip(manifolds, factors)):
-                if f[0] == B.FACTOR_SPD:
-                    w = torch.empty(lib.raw('mm_spd_pdist_ws_bytes')(dt, n, f[1]), dtype=torch.uint8, device=dev)
-                    keep.append(w)
-                    spd_ws[i] = w.data_ptr()
-                    wmin, wmax = man.wmin, man.wmax
             out = torch.empty(1 + k, dtype=dtype, device=dev)
-            ws = torch.empty(lib.raw('mm_product_pairs_ws_bytes')(dt, k, kinds, dims, n), dtype=torch.uint8,
-                             device=dev)
+            # the kernels leave the workspace's accumulators zero: kept across steps, it is cleared once
+            key = (dtype, dev, n, factors)
+            entry = cache.get(key) if cache is not None else None
+            if entry is None:
+                entry = [torch.empty(lib.raw('mm_product_pairs_ws_bytes')(dt, k, kinds, dims, n),
+                                     dtype=torch.uint8, device=dev), False]
+                if cache is not None:
+                    cache.clear()  # one shape at a time (a minibatch loop has one; the full batch another)
+                    cache[key] = entry
+            ws, clean = entry
+            entry[1] = False  # until the call has been enqueued completely
             lib.call('mm_product_pairs_loss', dt, B.LOSS_STRESS if lkind == 'stress' else B.LOSS_QUOTIENT, k,
-                     kinds, dims, B.ptr_array(xc), spd_ws, B.ptr_array(sc), B.ptr(tc), n, rb, re, alpha, eps,
-                     terms, wmin, wmax, B.ptr_array(grads), B.ptr(out), B.ptr(ws), B.stream_of(xs[0]))
+                     kinds, dims, B.ptr_array(xc), B.ptr_array(sc), B.ptr(tc), n, rb, re, alpha, eps,
+                     terms, wmin, wmax, B.ptr_array(grads), B.ptr(out), B.ptr(ws), B.WS_CLEAN if clean else 0,
+                     B.stream_of(xs[0]))
+            entry[1] = True
         ctx.grads = [g.reshape(x.shape) for g, x in zip(grads, xs)] + \
             [out[1 + i].reshape(s.shape).to(s.dtype) for i, s in enumerate(scales)]
         return out[0]
@@ -160,7 +166,7 @@ class _ProductPairsLoss(torch.autograd.Function):
             grads = list(torch._foreach_mul(ctx.grads, up))
         except (RuntimeError, TypeError):
             grads = [g * up for g in ctx.grads]
-        return (None, None, None, None, None) + tuple(grads)
+        return (None, None, None, None, None, None) + tuple(grads)
 
 
 class ManifoldParameter(torch.nn.Parameter):
@@ -190,6 +196,8 @@ class ManifoldEmbedding(torch.nn.Module):
         self.n = n
         self.n_components = len(manifolds)
         self.pair_kernel = True  # products: use the single mixed-manifold pair kernel when it applies
+        # its workspace, kept clean by the kernels themselves (one stream at a time may step an embedding)
+        self._pair_ws = {}
         self.manifolds = manifolds
         self.xs = torch.nn.ParameterList(
             [ManifoldParameter(data=man.rand(n), manifold=man) for man in manifolds])
@@ -253,8 +261,8 @@ class ManifoldEmbedding(torch.nn.Module):
         xs = [take_rows(x, i) for x in self.xs]
         factors = _pair_kernel_factors(self.manifolds) if self.pair_kernel else None
         if factors is not None:
-            return _ProductPairsLoss.apply(gdists, spec, rows, tuple(self.manifolds), tuple(factors), *xs,
-                                           *self.scales)
+            return _ProductPairsLoss.apply(gdists, spec, rows, tuple(self.manifolds), tuple(factors),
+                                           self._pair_ws, *xs, *self.scales)
         return _ProductLoss.apply(gdists, spec, rows, tuple(self.manifolds), *xs, *self.scales)
 
     def __len__(self):

@@ -222,6 +222,13 @@ int mm_vec_norm(int dtype, int kind, const void* u, int64_t cnt, int m, int squa
 /* Fused momentum-free RiemannianSGD update (rsgd.py:63-68,82). */
 int mm_vec_rsgd_step(int dtype, int kind, const void* x, const void* egrad, int64_t cnt, int m,
                      double lr, double max_grad_norm, int exact, void* x_new, mm_stream_t stream);
+/* The same update for `count` (<= mm_vec_rsgd_multi_max()) parameters of one optimizer group in one
+ * launch — the loop over group['params'] of rsgd.py:52-82 for parameters that share lr / max_grad_norm /
+ * exact.  kinds, xs, egrads, cnts, ms, x_new are HOST arrays; x_new[t] may equal xs[t]. */
+int mm_vec_rsgd_multi_max(void);
+int mm_vec_rsgd_step_multi(int dtype, int count, const int* kinds, const void* const* xs,
+                           const void* const* egrads, const int64_t* cnts, const int* ms, double lr,
+                           double max_grad_norm, int exact, void* const* x_new, mm_stream_t stream);
 
 /* ---- Grassmann Gr(N,p) / Stiefel St(N,p): points are [cnt,N,p], N <= 9, p <= 4 ---- */
 enum { MM_GRASSMANN = 0, MM_STIEFEL = 1 };

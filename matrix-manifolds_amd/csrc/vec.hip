@@ -338,12 +338,10 @@ __global__ void vec_norm_kernel(const T* __restrict__ u, int64_t cnt, int m, int
 }
 
 // fused momentum-free RSGD update (rsgd.py:63-68,82)
-template <typename T, int KIND>
 // (x and xnew are deliberately not __restrict__: the update may be done in place, xnew == x)
-__global__ void vec_rsgd_step_kernel(const T* x, const T* __restrict__ eg, int64_t cnt, int m, T lr,
-                                     T max_grad_norm, int exact, T* xnew) {
-  const int64_t p = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
-  if (p >= cnt) return;
+template <typename T, int KIND>
+__device__ __forceinline__ void vec_rsgd_point(const T* x, const T* __restrict__ eg, int64_t p, int m, T lr,
+                                               T max_grad_norm, int exact, T* xnew) {
   T r[kVecMaxDim], o[kVecMaxDim];
   vec_egrad2rgrad<T, KIND>(x + p * m, eg + p * m, m, r);
   T scale = -lr;
@@ -351,6 +349,37 @@ __global__ void vec_rsgd_step_kernel(const T* x, const T* __restrict__ eg, int64
   for (int k = 0; k < m; ++k) r[k] *= scale;
   vec_exp_or_retr<T, KIND>(x + p * m, r, m, exact, o);
   for (int k = 0; k < m; ++k) xnew[p * m + k] = o[k];
+}
+
+template <typename T, int KIND>
+// (x and xnew are deliberately not __restrict__: the update may be done in place, xnew == x)
+__global__ void vec_rsgd_step_kernel(const T* x, const T* __restrict__ eg, int64_t cnt, int m, T lr,
+                                     T max_grad_norm, int exact, T* xnew) {
+  const int64_t p = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (p >= cnt) return;
+  vec_rsgd_point<T, KIND>(x, eg, p, m, lr, max_grad_norm, exact, xnew);
+}
+
+// The same update for several parameters of one optimizer group in ONE launch (blockIdx.y = parameter):
+// the points of the vector factors of a product embedding, or its scale parameters — updates that are a
+// microsecond of work behind ~3 us of launch each.
+constexpr int kRsgdMultiMax = 8;
+template <typename T> struct RsgdMulti {
+  const T* x[kRsgdMultiMax];
+  const T* eg[kRsgdMultiMax];
+  T* xnew[kRsgdMultiMax];
+  int64_t cnt[kRsgdMultiMax];
+  int m[kRsgdMultiMax], kind[kRsgdMultiMax];
+};
+template <typename T>
+__global__ void vec_rsgd_multi_kernel(RsgdMulti<T> a, T lr, T max_grad_norm, int exact) {
+  const int t = blockIdx.y;
+  const int64_t p = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (p >= a.cnt[t]) return;
+  const int kind = a.kind[t];
+  if (kind == MM_EUCLIDEAN) vec_rsgd_point<T, MM_EUCLIDEAN>(a.x[t], a.eg[t], p, a.m[t], lr, max_grad_norm, exact, a.xnew[t]);
+  else if (kind == MM_LORENTZ) vec_rsgd_point<T, MM_LORENTZ>(a.x[t], a.eg[t], p, a.m[t], lr, max_grad_norm, exact, a.xnew[t]);
+  else vec_rsgd_point<T, MM_SPHERE>(a.x[t], a.eg[t], p, a.m[t], lr, max_grad_norm, exact, a.xnew[t]);
 }
 
 // ------------------------------------------------------------------ launchers
@@ -438,6 +467,28 @@ bool vec_gram_supports(int dtype, int kind, int64_t n, int m);
 int vec_gram_loss(int dtype, int kind, int loss_kind, const void* x, const void* target, const void* scale_raw, int64_t n,
                   int m, int64_t row_begin, int64_t row_end, double alpha, double eps, int terms, void* loss_out,
                   void* grad, void* slots, hipStream_t st);
+
+template <typename T>
+int vec_rsgd_multi_t(int count, const int* kinds, const void* const* xs, const void* const* egrads,
+                            const int64_t* cnts, const int* ms, double lr, double max_grad_norm, int exact,
+                            void* const* x_new, hipStream_t st) {
+  RsgdMulti<T> a{};
+  int64_t most = 0;
+  for (int t = 0; t < count; ++t) {
+    a.x[t] = static_cast<const T*>(xs[t]);
+    a.eg[t] = static_cast<const T*>(egrads[t]);
+    a.xnew[t] = static_cast<T*>(x_new[t]);
+    a.cnt[t] = cnts[t];
+    a.m[t] = ms[t];
+    a.kind[t] = kinds[t];
+    most = cnts[t] > most ? cnts[t] : most;
+  }
+  if (most == 0) return MM_OK;
+  vec_rsgd_multi_kernel<T><<<dim3(unsigned((most + 127) / 128), unsigned(count)), dim3(128), 0, st>>>(
+      a, T(lr), T(max_grad_norm), exact);
+  MMV_CHECK();
+  return MM_OK;
+}
 
 }  // namespace mm
 
@@ -544,6 +595,26 @@ int mm_vec_rsgd_step(int dtype, int kind, const void* x, const void* egrad, int6
     vec_rsgd_step_kernel<T, KIND><<<dim3(nb), dim3(128), 0, st>>>(static_cast<const T*>(x),
         static_cast<const T*>(egrad), cnt, m, T(lr), T(max_grad_norm), exact, static_cast<T*>(x_new));
     MMV_CHECK(); return MM_OK; }))
+}
+
+int mm_vec_rsgd_multi_max(void) { return kRsgdMultiMax; }
+
+int mm_vec_rsgd_step_multi(int dtype, int count, const int* kinds, const void* const* xs, const void* const* egrads,
+                           const int64_t* cnts, const int* ms, double lr, double max_grad_norm, int exact,
+                           void* const* x_new, mm_stream_t stream) {
+  if (count < 1 || !kinds || !xs || !egrads || !cnts || !ms || !x_new) return MM_ERR_ARG;
+  if (count > kRsgdMultiMax) return MM_ERR_UNSUPPORTED;
+  for (int t = 0; t < count; ++t) {
+    if (cnts[t] < 0 || ms[t] < 1 || (cnts[t] > 0 && (!xs[t] || !egrads[t] || !x_new[t]))) return MM_ERR_ARG;
+    if (kinds[t] < MM_EUCLIDEAN || kinds[t] > MM_SPHERE) return MM_ERR_ARG;
+    if (ms[t] > kVecMaxDim) return MM_ERR_UNSUPPORTED;
+  }
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (dtype == MM_F32)
+    return vec_rsgd_multi_t<float>(count, kinds, xs, egrads, cnts, ms, lr, max_grad_norm, exact, x_new, st);
+  if (dtype == MM_F64)
+    return vec_rsgd_multi_t<double>(count, kinds, xs, egrads, cnts, ms, lr, max_grad_norm, exact, x_new, st);
+  return MM_ERR_ARG;
 }
 
 }  // extern "C"

@@ -9,5 +9,6 @@ from . import objectives
 from . import optim
 from . import data
 from . import parallel
+from ._backend import unit_seed  # loss.backward(unit_seed(loss)): a backward without the `ones * grad` launches
 
 __version__ = '0.1.0'

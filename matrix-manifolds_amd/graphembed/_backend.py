@@ -44,6 +44,9 @@ SIGNATURES = {
                                     _vp, _i64, _i64, _i64, _dbl, _dbl, _i, _dbl, _dbl, _c.POINTER(_vp), _vp, _vp,
                                     _i, _vp]),
     'mm_spd_prepare': (_i, [_i, _vp, _i64, _i, _vp, _vp]),
+    'mm_vec_rsgd_multi_max': (_i, []),
+    'mm_vec_rsgd_step_multi': (_i, [_i, _i, _c.POINTER(_i), _c.POINTER(_vp), _c.POINTER(_vp), _c.POINTER(_i64),
+                                     _c.POINTER(_i), _dbl, _dbl, _i, _c.POINTER(_vp), _vp]),
     'mm_spd_max_dim': (_i, []),
     'mm_spd_pdist_ws_bytes': (_sz, [_i, _i64, _i]),
     'mm_spd_pdist_fwd': (_i, [_i, _vp, _i64, _i, _i64, _i64, _i, _dbl, _dbl, _vp, _vp, _i, _vp]),
@@ -211,3 +214,61 @@ def ptr_array(tensors):
     for k, t in enumerate(tensors):
         arr[k] = t.data_ptr()
     return arr
+
+
+# ---- the seed of a backward pass -------------------------------------------------------------------
+# `loss.backward()` materialises ones_like(loss) and the fused objective Functions then multiply every
+# stored gradient by it: two launches of a step that is ~10 launches long.  `unit_seed(loss)` is a cached,
+# read-only tensor holding 1; a backward seeded with it (`loss.backward(unit_seed(loss))`, what
+# GraphedTrainStep does) is recognised by its storage address and the multiplication is skipped.
+_unit_seeds = {}
+
+
+def unit_seed(like):
+    """The cached 0-dim tensor 1 of `like`'s dtype and device.  Never write to it."""
+    import torch
+    key = (like.dtype, like.device)
+    t = _unit_seeds.get(key)
+    if t is None:
+        t = torch.ones((), dtype=like.dtype, device=like.device)
+        _unit_seeds[key] = t
+    return t
+
+
+def is_unit_seed(up):
+    seed = _unit_seeds.get((up.dtype, up.device))
+    return seed is not None and up.numel() == 1 and up.data_ptr() == seed.data_ptr()
+
+
+def take_grads(ctx, up, *names):
+    """The gradients a fused objective Function stored on `ctx` under `names`, times `up`.  Seeded
+    with a unit seed they are handed over as they are AND released from `ctx`, so that autograd can
+    adopt them as `.grad` without a copy (it clones gradients somebody else still references); such
+    a backward can therefore run once."""
+    vals = []
+    for name in names:
+        v = getattr(ctx, name)
+        vals.extend(v) if isinstance(v, (list, tuple)) else vals.append(v)
+    if is_unit_seed(up):
+        if getattr(ctx, '_taken', False):
+            raise RuntimeError('the gradients of this fused objective were handed over by an earlier '
+                               'backward seeded with unit_seed(); seed with a plain tensor to backward twice')
+        ctx._taken = True
+        for name in names:
+            setattr(ctx, name, None)
+        return vals
+    if getattr(ctx, '_taken', False):
+        raise RuntimeError('the gradients of this fused objective were handed over by an earlier backward')
+    return scale_grads(vals, up)
+
+
+def scale_grads(grads, up):
+    """[g * up for g in grads] (None entries kept)."""
+    import torch
+    live = [g for g in grads if g is not None]
+    try:  # one multi-tensor launch
+        scaled = list(torch._foreach_mul(live, up))
+    except (RuntimeError, TypeError):
+        scaled = [g * up for g in live]
+    it = iter(scaled)
+    return [None if g is None else next(it) for g in grads]

@@ -17,6 +17,8 @@ learning-rate tensors); Python scalars are frozen at capture time — re-capture
 when they change (e.g. the quotient loss's `epoch`)."""
 import torch
 
+from graphembed._backend import unit_seed
+
 
 class GraphedTrainStep:
 
@@ -42,7 +44,7 @@ class GraphedTrainStep:
         for o in self.optimizers:
             o.zero_grad(set_to_none=True)
         loss = self.loss_fn()
-        loss.backward()
+        loss.backward(unit_seed(loss))  # no ones_like fill; the fused objectives skip their `* 1`
         for o in self.optimizers:
             o.step()
         return loss.detach()

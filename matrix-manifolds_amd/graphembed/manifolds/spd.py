@@ -109,8 +109,8 @@ class _SpdPdistLoss(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, up):
-        gs = None if ctx.grad_s is None else ctx.grad_s * up
-        return ctx.grad_x * up, gs, None, None, None, None, None, None, None
+        gx, gs = B.take_grads(ctx, up, 'grad_x', 'grad_s')
+        return gx, gs, None, None, None, None, None, None, None
 
 
 class _SpdDist(torch.autograd.Function):

@@ -73,11 +73,8 @@ class _ProductLoss(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, up):
-        try:  # one multi-tensor launch for all 2K gradients
-            grads = list(torch._foreach_mul(ctx.grads, up))
-        except (RuntimeError, TypeError):
-            grads = [g * up for g in ctx.grads]
-        return (None, None, None, None) + tuple(grads)
+        from graphembed import _backend as B
+        return (None, None, None, None) + tuple(B.take_grads(ctx, up, 'grads'))
 
 
 def _pair_kernel_factor(man):
@@ -162,11 +159,8 @@ class _ProductPairsLoss(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, up):
-        try:
-            grads = list(torch._foreach_mul(ctx.grads, up))
-        except (RuntimeError, TypeError):
-            grads = [g * up for g in ctx.grads]
-        return (None, None, None, None, None, None) + tuple(grads)
+        from graphembed import _backend as B
+        return (None, None, None, None, None, None) + tuple(B.take_grads(ctx, up, 'grads'))
 
 
 class ManifoldParameter(torch.nn.Parameter):

@@ -80,10 +80,14 @@ class ManifoldOptimizer(torch.optim.Optimizer):
         loss = closure() if closure is not None else None
         with torch.no_grad():
             for group in self.param_groups:
-                for p in group['params']:
-                    if p.grad is not None:
-                        self._update(group, p, self.state[p], self.manifold_of(p))
+                for p in self._params_of(group):
+                    self._update(group, p, self.state[p], self.manifold_of(p))
         return loss
+
+    def _params_of(self, group):
+        """The parameters of `group` that `_update` has to visit (subclasses may serve some of them
+        with a batched launch first)."""
+        return [p for p in group['params'] if p.grad is not None]
 
     # torch.optim.Optimizer wraps `step` of every subclass in a profiler range plus pre/post hook
     # dispatch (~25 us of host time per call) unless it is marked as hooked already; the updates

@@ -19,6 +19,15 @@ class RiemannianSGD(ManifoldOptimizer):
         super().__init__(params, dict(lr=lr, momentum=momentum, dampening=dampening,
                                       max_grad_norm=max_grad_norm, exact=exact))
 
+    def _params_of(self, group):
+        """Momentum-free groups first update every parameter that lives in a vector space (Euclidean /
+        Lorentz / sphere points, flat scales) with ONE launch per dtype; what is left goes through
+        `_update` one by one."""
+        params = [p for p in group['params'] if p.grad is not None]
+        if group['momentum'] != 0 or len(params) < 2:
+            return params
+        return _multi_vector_step(params, self.manifold_of, group)
+
     def _update(self, group, p, state, manifold):
         lr, momentum, clip = group['lr'], group['momentum'], group['max_grad_norm']
         if momentum == 0:
@@ -47,3 +56,58 @@ class RiemannianSGD(ManifoldOptimizer):
         carried = manifold.transp(p, new_p, buf)
         assign(p, new_p)
         assign(buf, carried)
+
+
+def _vector_layout(p, manifold):
+    """(kind, m) when `p` can be stepped by mm_vec_rsgd_step_multi, else None."""
+    import torch
+    from graphembed import _backend as B
+    from graphembed.manifolds.vector import VectorManifold
+    if not p.is_cuda or p.dtype not in (torch.float32, torch.float64) or not p.is_contiguous():
+        return None
+    if p.grad.dtype != p.dtype or not p.grad.is_contiguous() or p.numel() == 0:
+        return None
+    if manifold is FLAT:
+        kind, m = B.EUCLIDEAN, (p.shape[-1] if p.ndim else 1)
+    elif isinstance(manifold, VectorManifold) and type(manifold).rsgd_step is VectorManifold.rsgd_step:
+        kind, m = manifold._kind, manifold._m
+    else:
+        return None
+    return (kind, m) if 1 <= m <= 32 else None
+
+
+def _multi_vector_step(params, manifold_of, group):
+    import ctypes
+    import torch
+    from graphembed import _backend as B
+    layouts = [_vector_layout(p, manifold_of(p)) for p in params]
+    rest = [p for p, lay in zip(params, layouts) if lay is None]
+    by_dtype = {}
+    for p, lay in zip(params, layouts):
+        if lay is not None:
+            by_dtype.setdefault((p.dtype, p.device), []).append((p, lay))
+    lib = B.lib()
+    most = lib.raw('mm_vec_rsgd_multi_max')()
+    clip = group['max_grad_norm']
+    for (dtype, dev), items in by_dtype.items():
+        if len(items) < 2:
+            rest.extend(p for p, _ in items)
+            continue
+        for lo in range(0, len(items), most):
+            chunk = items[lo:lo + most]
+            k = len(chunk)
+            inplace = capturing(chunk[0][0])
+            with B.on_device(dev):
+                xs = [p.detach() for p, _ in chunk]
+                outs = xs if inplace else [torch.empty_like(x) for x in xs]
+                lib.call('mm_vec_rsgd_step_multi', B.dtype_code(xs[0]), k,
+                         (ctypes.c_int * k)(*[lay[0] for _, lay in chunk]), B.ptr_array(xs),
+                         B.ptr_array([p.grad for p, _ in chunk]),
+                         (ctypes.c_int64 * k)(*[x.numel() // lay[1] for x, (_, lay) in zip(xs, chunk)]),
+                         (ctypes.c_int * k)(*[lay[1] for _, lay in chunk]), float(group['lr']),
+                         -1.0 if clip is None else float(clip), int(bool(group['exact'])),
+                         B.ptr_array(outs), B.stream_of(xs[0]))
+            if not inplace:
+                for (p, _), new in zip(chunk, outs):
+                    assign(p, new)
+    return rest

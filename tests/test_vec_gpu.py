@@ -416,3 +416,39 @@ def test_tree40_training_trace_fused(case, loss_name):
     check_rel(np.array(losses), G[f'{base}/losses'], 1e-7, 'loss trace')
     check_rel(emb.xs[0].data, G[f'{base}/x20_0'], 1e-6, 'x20')
     check_rel(np.array([s.item() for s in emb.scales]), G[f'{base}/scales20'], 1e-6, 'scales')
+
+
+@pytest.mark.parametrize('dname', ['f32', 'f64'])
+@pytest.mark.parametrize('exact,clip', [(False, None), (True, 0.05)])
+def test_rsgd_multi_parameter_launch_equals_single_steps(dname, exact, clip):
+    """RiemannianSGD steps all vector-space parameters of a momentum-free group with one launch
+    (mm_vec_rsgd_step_multi): bit-identical to the one-kernel-per-parameter updates (rsgd.py:52-82)."""
+    from graphembed import _backend as B
+    from graphembed import manifolds as M
+    from graphembed.modules import ManifoldParameter
+    from graphembed.optim import RiemannianSGD
+    from graphembed.optim._common import FLAT
+    dt = {'f32': torch.float32, 'f64': torch.float64}[dname]
+    torch.manual_seed(11)
+    mans = [M.Euclidean(5), M.Lorentz(6), M.Sphere(4), M.SymmetricPositiveDefinite(2)]
+    pts = [man.rand(37 + 5 * k, out=torch.empty(0, dtype=dt, device='cuda')) for k, man in enumerate(mans)]
+    grads = [torch.randn_like(x) for x in pts]
+    scal = [torch.randn((), dtype=dt, device='cuda') for _ in range(3)] + [torch.randn(4, 3, dtype=dt, device='cuda')]
+    sgrads = [torch.randn_like(s) for s in scal]
+    want = [man.rsgd_step(x.clone(), g, lr=0.1, max_grad_norm=clip, exact=exact) for man, x, g in zip(mans, pts, grads)]
+    want += [FLAT.rsgd_step(s.clone(), g, lr=0.1, max_grad_norm=clip, exact=exact) for s, g in zip(scal, sgrads)]
+    params = [ManifoldParameter(x.clone(), manifold=man) for man, x in zip(mans, pts)]
+    params += [torch.nn.Parameter(s.clone()) for s in scal]
+    for p, g in zip(params, grads + sgrads):
+        p.grad = g.clone()
+    lib, calls = B.lib(), []
+    orig = lib.call
+    lib.call = lambda name, *a: (calls.append(name), orig(name, *a))[1]
+    try:
+        RiemannianSGD(params, lr=0.1, exact=exact, max_grad_norm=clip).step()
+    finally:
+        del lib.call
+    assert calls.count('mm_vec_rsgd_step_multi') == 1 and calls.count('mm_vec_rsgd_step') == 0, calls
+    assert calls.count('mm_spd_rsgd_step') == 1
+    for p, w in zip(params, want):
+        assert torch.equal(p.detach(), w)

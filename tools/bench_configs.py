@@ -12,6 +12,7 @@ for p in (ROOT, os.path.join(ROOT, 'matrix-manifolds_amd')):
     sys.path.insert(0, p)
 import torch  # noqa: E402
 from graphembed import manifolds as M  # noqa: E402
+from graphembed._backend import unit_seed  # noqa: E402
 from graphembed.modules import ManifoldEmbedding  # noqa: E402
 from graphembed.objectives import StressLoss  # noqa: E402
 from graphembed.optim import RiemannianSGD  # noqa: E402
@@ -65,10 +66,8 @@ def step_case(mans, n, dtype, fused=False, graph=False, pair_kernel=True):
     def step():
         opt.zero_grad(set_to_none=True)
         opt_s.zero_grad(set_to_none=True)
-        if fused:
-            emb.fused_objective(fn, target, None).backward()
-        else:
-            fn(target, emb.compute_dists(None)).backward()
+        loss = emb.fused_objective(fn, target, None) if fused else fn(target, emb.compute_dists(None))
+        loss.backward(unit_seed(loss))
         opt.step()
         opt_s.step()
     if graph:  # whole training step replayed as one hipGraph (static shapes, no host sync inside)

@@ -108,6 +108,10 @@ CASES = {
     'c4_csphd_product_step_f32_perfactor': lambda: step_case([M.Lorentz(6), M.Sphere(6), M.SymmetricPositiveDefinite(2)], 1025, torch.float32, fused=True, pair_kernel=False),
     'c4_csphd_product_step_f32_perfactor_graph': lambda: step_case([M.Lorentz(6), M.Sphere(6), M.SymmetricPositiveDefinite(2)], 1025, torch.float32, fused=True, graph=True, pair_kernel=False),
     'c4_csphd_product_step_f64_fused_graph': lambda: step_case([M.Lorentz(6), M.Sphere(6), M.SymmetricPositiveDefinite(2)], 1025, torch.float64, fused=True, graph=True),
+    'c4_product_n5000_step_f32_fused_graph': lambda: step_case([M.Lorentz(6), M.Sphere(6), M.SymmetricPositiveDefinite(2)], 5000, torch.float32, fused=True, graph=True),
+    'c4_product_n5000_step_f32_perfactor_graph': lambda: step_case([M.Lorentz(6), M.Sphere(6), M.SymmetricPositiveDefinite(2)], 5000, torch.float32, fused=True, graph=True, pair_kernel=False),
+    'c4_product_n2500_step_f32_fused_graph': lambda: step_case([M.Lorentz(6), M.Sphere(6), M.SymmetricPositiveDefinite(2)], 2500, torch.float32, fused=True, graph=True),
+    'c4_product_n2500_step_f32_perfactor_graph': lambda: step_case([M.Lorentz(6), M.Sphere(6), M.SymmetricPositiveDefinite(2)], 2500, torch.float32, fused=True, graph=True, pair_kernel=False),
     'c4_csphd_product_step_f32_graph': lambda: step_case([M.Lorentz(6), M.Sphere(6), M.SymmetricPositiveDefinite(2)], 1025, torch.float32, graph=True),
     'c4_csphd_product_step_f64': lambda: step_case([M.Lorentz(6), M.Sphere(6), M.SymmetricPositiveDefinite(2)], 1025, torch.float64),
     'c5_wormnet_spd4_n2274_f32': lambda: pdist_case(M.SymmetricPositiveDefinite(4), 2274, torch.float32),

@@ -230,6 +230,22 @@ int mm_vec_rsgd_step_multi(int dtype, int count, const int* kinds, const void* c
                            const void* const* egrads, const int64_t* cnts, const int* ms, double lr,
                            double max_grad_norm, int exact, void* const* x_new, mm_stream_t stream);
 
+/* One fused RiemannianAdam update (radam.py:62-98): Riemannian gradient, second moment from its norm
+ * BEFORE clipping (one scalar per point, stored broadcast over the point as the reference does), clipping,
+ * first moment, step size lr sqrt(1-beta2^t)/(1-beta1^t) (nc != 0: beta2 = 1 - 1/t), exp (exact) or
+ * retr, transport of the first moment to the new point.  exp_avg / exp_avg_sq are updated in place;
+ * x_new may equal x.  `step` is state['step'] as a DEVICE fp64 scalar (>= 1), advanced by the kernel;
+ * `ticket` is a device uint32 that is zero between calls (the last block to finish advances `step`), so a
+ * captured graph of a training step keeps counting when replayed. */
+int mm_vec_radam_step(int dtype, int kind, const void* x, const void* egrad, void* exp_avg,
+                      void* exp_avg_sq, double* step, unsigned* ticket, int64_t cnt, int m, double lr,
+                      double beta1, double beta2, int nc, double eps, double max_grad_norm, int exact,
+                      void* x_new, mm_stream_t stream);
+int mm_spd_radam_step(int dtype, const void* x, const void* egrad, void* exp_avg, void* exp_avg_sq,
+                      double* step, unsigned* ticket, int64_t m, int d, double lr, double beta1,
+                      double beta2, int nc, double eps, double max_grad_norm, int exact, void* x_new,
+                      mm_stream_t stream);
+
 /* ---- Grassmann Gr(N,p) / Stiefel St(N,p): points are [cnt,N,p], N <= 9, p <= 4 ---- */
 enum { MM_GRASSMANN = 0, MM_STIEFEL = 1 };
 enum {

@@ -28,6 +28,7 @@
 
 #include "smallmat.hpp"
 #include "loss.hpp"
+#include "adam.hpp"
 
 #include "spd_ws.hpp"
 
@@ -713,6 +714,58 @@ __global__ void spd_rsgd_step_kernel(const T* x, const T* __restrict__ eg, int64
   if (in) store_sym_full<T, D>(xnew + k * D * D, o);
 }
 
+// fused Riemannian Adam update (radam.py:62-98) — see vec_radam_step_kernel; the SPD transport is the identity
+// (spd.py:196-199), exp_avg is kept symmetric.
+template <typename T, int D>
+__global__ void spd_radam_step_kernel(const T* x, const T* __restrict__ eg, T* exp_avg, T* exp_avg_sq, int64_t m,
+                                      AdamArgs<T> a, T* xnew) {
+  constexpr int NP = Packed<D>::NP;
+  const int64_t k0 = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  const bool in = k0 < m;
+  const int64_t k = in ? k0 : 0;
+  T beta2, alpha;
+  adam_coeffs(a, beta2, alpha);
+  T xs[NP], gs[NP], r[NP], l[NP], li[NP], o[NP], mo[NP];
+  load_sym_packed<T, D>(x + k * D * D, xs);
+  load_sym_packed<T, D>(eg + k * D * D, gs);
+  load_sym_packed<T, D>(exp_avg + k * D * D, mo);
+  T xf[D * D];
+#pragma unroll
+  for (int p = 0; p < D; ++p)
+#pragma unroll
+    for (int c = 0; c < D; ++c) xf[p * D + c] = xs[pidx(p, c)];
+  congr_full<T, D>(xf, gs, r);  // Riemannian gradient X sym(G) X
+  cholesky<T, D>(xs, l);
+  invert_lower<T, D>(l, li);
+  T nn = T(0);  // ||r||_X^2 = ||L^-1 r L^-T||_F^2 (spd.py:113-117; no floor, unlike Manifold.norm)
+  {
+    T w[NP];
+    congr_lower<T, D>(li, r, w);
+#pragma unroll
+    for (int p = 0; p < D; ++p)
+#pragma unroll
+      for (int c = 0; c <= p; ++c) nn += (p == c ? T(1) : T(2)) * w[pidx(p, c)] * w[pidx(p, c)];
+  }
+  const T nrm = Num<T>::sqrt(nn);
+  const T clip = a.max_grad_norm > T(0) ? Num<T>::min(a.max_grad_norm / nrm, T(1)) : T(1);
+  const T v = Num<T>::fma(beta2, exp_avg_sq[k * D * D], (T(1) - beta2) * nrm * nrm);
+  const T f = -alpha / (Num<T>::sqrt(v) + a.eps);
+#pragma unroll
+  for (int q = 0; q < NP; ++q) {
+    mo[q] = Num<T>::fma(a.beta1, mo[q], (T(1) - a.beta1) * (r[q] * clip));
+    r[q] = mo[q] * f;
+  }
+  if (a.exact) spd_explog<T, D, false>(l, li, r, o);
+  else spd_retr<T, D>(xs, li, r, o);
+  if (in) {
+    store_sym_full<T, D>(xnew + k * D * D, o);
+    store_sym_full<T, D>(exp_avg + k * D * D, mo);
+#pragma unroll
+    for (int q = 0; q < D * D; ++q) exp_avg_sq[k * D * D + q] = v;
+  }
+  adam_tick(a.step, a.ticket);
+}
+
 // ------------------------------------------------------------------ launchers
 #define MM_CHECK_LAUNCH()                         \
   do {                                            \
@@ -988,6 +1041,20 @@ int mm_spd_rsgd_step(int dtype, const void* x, const void* egrad, int64_t m, int
   MM_DISPATCH(dtype, d,
               (launch_pointwise<T, D>(spd_rsgd_step_kernel<T, D>, m, st, static_cast<const T*>(x),
                                       static_cast<const T*>(egrad), m, T(lr), T(max_grad_norm), exact,
+                                      static_cast<T*>(x_new))));
+}
+
+int mm_spd_radam_step(int dtype, const void* x, const void* egrad, void* exp_avg, void* exp_avg_sq, double* step,
+                      unsigned* ticket, int64_t m, int d, double lr, double beta1, double beta2, int nc, double eps,
+                      double max_grad_norm, int exact, void* x_new, mm_stream_t stream) {
+  if (m < 0 || !step || !ticket || (m > 0 && (!x || !egrad || !exp_avg || !exp_avg_sq || !x_new))) return MM_ERR_ARG;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  MM_DISPATCH(dtype, d,
+              (launch_pointwise<T, D>(spd_radam_step_kernel<T, D>, m, st, static_cast<const T*>(x),
+                                      static_cast<const T*>(egrad), static_cast<T*>(exp_avg),
+                                      static_cast<T*>(exp_avg_sq), m,
+                                      AdamArgs<T>{T(lr), T(beta1), T(beta2), T(eps), T(max_grad_norm), nc, exact, step,
+                                                  ticket},
                                       static_cast<T*>(x_new))));
 }
 

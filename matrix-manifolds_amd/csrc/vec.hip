@@ -21,6 +21,7 @@
 #include "smallmat.hpp"
 #include "loss.hpp"
 #include "vecfn.hpp"
+#include "adam.hpp"
 
 namespace mm {
 
@@ -360,6 +361,47 @@ __global__ void vec_rsgd_step_kernel(const T* x, const T* __restrict__ eg, int64
   vec_rsgd_point<T, KIND>(x, eg, p, m, lr, max_grad_norm, exact, xnew);
 }
 
+// fused Riemannian Adam update (radam.py:62-98): Riemannian gradient, its norm (second moment: ONE scalar per
+// point, before clipping), clipping, both moments, the bias-corrected step, exp / retr, and the transport of
+// the first moment to the new point — one launch instead of ~25.  exp_avg / exp_avg_sq are updated in place.
+template <typename T, int KIND>
+__global__ void vec_radam_step_kernel(const T* x, const T* __restrict__ eg, T* exp_avg, T* exp_avg_sq, int64_t cnt,
+                                      int m, AdamArgs<T> a, T* xnew) {
+  using N = Num<T>;
+  const int64_t p = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  T beta2, alpha;
+  adam_coeffs(a, beta2, alpha);
+  if (p < cnt) {
+    T xp[kVecMaxDim], r[kVecMaxDim], mo[kVecMaxDim], o[kVecMaxDim];
+    for (int k = 0; k < m; ++k) xp[k] = x[p * m + k];
+    vec_egrad2rgrad<T, KIND>(xp, eg + p * m, m, r);
+    const T nrm = vec_norm<T, KIND>(r, m);
+    const T clip = a.max_grad_norm > T(0) ? N::min(a.max_grad_norm / nrm, T(1)) : T(1);
+    const T v = N::fma(beta2, exp_avg_sq[p * m], (T(1) - beta2) * nrm * nrm);
+    const T f = -alpha / (N::sqrt(v) + a.eps);
+    for (int k = 0; k < m; ++k) {
+      mo[k] = N::fma(a.beta1, exp_avg[p * m + k], (T(1) - a.beta1) * (r[k] * clip));
+      r[k] = mo[k] * f;  // the step direction
+    }
+    vec_exp_or_retr<T, KIND>(xp, r, m, a.exact, o);
+    // transport of the first moment from x to the new point
+    if (KIND == MM_LORENTZ) {  // lorentz.py:79-82
+      const T xy = ldot(xp, o, m), uy = ldot(mo, o, m);
+      const T g = uy / (T(1) - xy);
+      for (int k = 0; k < m; ++k) mo[k] = N::fma(g, xp[k] + o[k], mo[k]);
+    } else if (KIND == MM_SPHERE) {  // base.py:65-66: proju(y, u)
+      const T d = edot(o, mo, m);
+      for (int k = 0; k < m; ++k) mo[k] = N::fma(-d, o[k], mo[k]);
+    }
+    for (int k = 0; k < m; ++k) {
+      xnew[p * m + k] = o[k];
+      exp_avg[p * m + k] = mo[k];
+      exp_avg_sq[p * m + k] = v;
+    }
+  }
+  adam_tick(a.step, a.ticket);
+}
+
 // The same update for several parameters of one optimizer group in ONE launch (blockIdx.y = parameter):
 // the points of the vector factors of a product embedding, or its scale parameters — updates that are a
 // microsecond of work behind ~3 us of launch each.
@@ -594,6 +636,23 @@ int mm_vec_rsgd_step(int dtype, int kind, const void* x, const void* egrad, int6
   MMV_DISPATCH_T(dtype, MMV_DISPATCH_KIND(kind, {
     vec_rsgd_step_kernel<T, KIND><<<dim3(nb), dim3(128), 0, st>>>(static_cast<const T*>(x),
         static_cast<const T*>(egrad), cnt, m, T(lr), T(max_grad_norm), exact, static_cast<T*>(x_new));
+    MMV_CHECK(); return MM_OK; }))
+}
+
+int mm_vec_radam_step(int dtype, int kind, const void* x, const void* egrad, void* exp_avg, void* exp_avg_sq,
+                      double* step, unsigned* ticket, int64_t cnt, int m, double lr, double beta1, double beta2, int nc,
+                      double eps, double max_grad_norm, int exact, void* x_new, mm_stream_t stream) {
+  if (cnt < 0 || m < 1 || !step || !ticket || (cnt > 0 && (!x || !egrad || !exp_avg || !exp_avg_sq || !x_new)))
+    return MM_ERR_ARG;
+  if (m > kVecMaxDim) return MM_ERR_UNSUPPORTED;
+  if (cnt == 0) return MM_OK;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const unsigned nb = unsigned((cnt + 127) / 128);
+  MMV_DISPATCH_T(dtype, MMV_DISPATCH_KIND(kind, {
+    AdamArgs<T> a{T(lr), T(beta1), T(beta2), T(eps), T(max_grad_norm), nc, exact, step, ticket};
+    vec_radam_step_kernel<T, KIND><<<dim3(nb), dim3(128), 0, st>>>(static_cast<const T*>(x),
+        static_cast<const T*>(egrad), static_cast<T*>(exp_avg), static_cast<T*>(exp_avg_sq), cnt, m, a,
+        static_cast<T*>(x_new));
     MMV_CHECK(); return MM_OK; }))
 }
 

@@ -301,6 +301,30 @@ class SymmetricPositiveDefinite(Manifold):
         x.set_(x_new)
         return x
 
+    def radam_step(self, x, egrad, exp_avg, exp_avg_sq, step, ticket, *, lr, betas, nc, eps, max_grad_norm=None,
+                   exact=False, inplace=False):
+        """Fused RiemannianAdam update (optim/radam.py:62-98) in one launch — see
+        VectorManifold.radam_step; None when the tensors are not eligible."""
+        d = self.n
+        ok = (x.is_cuda and x.dtype in (torch.float32, torch.float64) and x.numel() > 0
+              and d <= B.lib().raw('mm_spd_max_dim')() and exp_avg.is_contiguous() and exp_avg_sq.is_contiguous()
+              and exp_avg.dtype == x.dtype and exp_avg_sq.dtype == x.dtype and exp_avg.shape == x.shape
+              and exp_avg_sq.shape == x.shape)
+        if not ok:
+            return None
+        xd = x.detach()
+        inplace = inplace and xd.is_contiguous()
+        xc = xd.reshape(-1, d, d).contiguous()
+        gc = egrad.detach().reshape(-1, d, d).to(xc.dtype).contiguous()
+        with B.on_device(xc.device):
+            out = xc if inplace else torch.empty_like(xc)
+            B.lib().call('mm_spd_radam_step', B.dtype_code(xc), B.ptr(xc), B.ptr(gc), B.ptr(exp_avg),
+                         B.ptr(exp_avg_sq), B.ptr(step), B.ptr(ticket), xc.shape[0], d, float(lr), float(betas[0]),
+                         float(betas[1] if betas[1] is not None else 0.0), int(bool(nc)), float(eps),
+                         -1.0 if max_grad_norm is None else float(max_grad_norm), int(bool(exact)), B.ptr(out),
+                         B.stream_of(xc))
+        return x if inplace else out.reshape(x.shape)
+
     def egrad2rgrad(self, x, u):  # spd.py:134-135
         return self._map(B.SPD_EGRAD2RGRAD, x, u)
 

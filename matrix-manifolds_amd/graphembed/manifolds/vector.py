@@ -212,6 +212,14 @@ class VectorManifold(Manifold):
                          B.ptr(out), B.stream_of(xc))
         return x if inplace else out.reshape(x.shape)
 
+    def radam_step(self, x, egrad, exp_avg, exp_avg_sq, step, ticket, *, lr, betas, nc, eps, max_grad_norm=None,
+                   exact=False, inplace=False):
+        """Fused RiemannianAdam update (optim/radam.py:62-98) in one launch: moments updated in place,
+        `step` (device fp64 scalar) advanced by the kernel; returns the new points (`x` itself when
+        `inplace`), or None when the tensors are not eligible."""
+        return _vec_radam(self._kind, self._m, x, egrad, exp_avg, exp_avg_sq, step, ticket, lr, betas, nc, eps,
+                          max_grad_norm, exact, inplace)
+
     # -- distances -------------------------------------------------------------
     def dist(self, x, y, squared=False, keepdim=False):
         shape = torch.broadcast_shapes(x.shape, y.shape)
@@ -232,3 +240,24 @@ class VectorManifold(Manifold):
         assert x.ndim == self.ndim + 1
         rb, re = (0, x.shape[0]) if rows is None else rows
         return _VecPdistLoss.apply(x, scale, target, self._kind, self._m, spec, rb, re)
+
+
+def _vec_radam(kind, m, x, egrad, exp_avg, exp_avg_sq, step, ticket, lr, betas, nc, eps, max_grad_norm, exact,
+               inplace):
+    ok = (x.is_cuda and x.dtype in (torch.float32, torch.float64) and 1 <= m <= 32 and x.numel() > 0
+          and exp_avg.is_contiguous() and exp_avg_sq.is_contiguous() and exp_avg.dtype == x.dtype
+          and exp_avg_sq.dtype == x.dtype and exp_avg.shape == x.shape and exp_avg_sq.shape == x.shape)
+    if not ok:
+        return None
+    xd = x.detach()
+    inplace = inplace and xd.is_contiguous()
+    xc = xd.reshape(-1, m).contiguous()
+    gc = egrad.detach().reshape(-1, m).to(xc.dtype).contiguous()
+    with B.on_device(xc.device):
+        out = xc if inplace else torch.empty_like(xc)
+        B.lib().call('mm_vec_radam_step', B.dtype_code(xc), kind, B.ptr(xc), B.ptr(gc), B.ptr(exp_avg),
+                     B.ptr(exp_avg_sq), B.ptr(step), B.ptr(ticket), xc.shape[0], m, float(lr), float(betas[0]),
+                     float(betas[1] if betas[1] is not None else 0.0), int(bool(nc)), float(eps),
+                     -1.0 if max_grad_norm is None else float(max_grad_norm), int(bool(exact)), B.ptr(out),
+                     B.stream_of(xc))
+    return x if inplace else out.reshape(x.shape)

@@ -57,6 +57,19 @@ class FlatRule:
         return x if inplace else out.reshape(x.shape)
 
 
+    @staticmethod
+    def radam_step(x, egrad, exp_avg, exp_avg_sq, step, ticket, *, lr, betas, nc, eps, max_grad_norm=None,
+                   exact=False, inplace=False):
+        """The fused Adam update of the Euclidean kernel for flat parameters (None when not eligible)."""
+        if not x.is_cuda:
+            return None
+        from graphembed import _backend as B
+        from graphembed.manifolds.vector import _vec_radam
+        width = x.shape[-1] if x.ndim else 1
+        return _vec_radam(B.EUCLIDEAN, width, x, egrad, exp_avg, exp_avg_sq, step, ticket, lr, betas, nc, eps,
+                          max_grad_norm, exact, inplace)
+
+
 FLAT = FlatRule()
 
 

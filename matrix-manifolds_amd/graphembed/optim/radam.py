@@ -5,13 +5,15 @@ order), built on the shared scaffold of `_common.py`.
 Unlike the reference, the step counter lives in device memory and the bias corrections are computed
 there, so a captured HIP graph of a training step replays correctly (`graph_safe`)."""
 import logging
+import os
 
 import torch
 
-from graphembed.optim._common import ManifoldOptimizer, assign
+from graphembed.optim._common import ManifoldOptimizer, assign, capturing
 from graphembed.utils import EPS
 
 logger = logging.getLogger(__name__)
+_UNFUSED = bool(os.environ.get('MM_RADAM_UNFUSED'))  # measurement knob: compose the update from Manifold calls
 
 
 class RiemannianAdam(ManifoldOptimizer):
@@ -21,6 +23,11 @@ class RiemannianAdam(ManifoldOptimizer):
         if nc and betas[1] is not None:
             logger.warning('beta1=%.5f will be ignored because `nc` is True', betas[1])
         super().__init__(params, dict(lr=lr, betas=betas, nc=nc, max_grad_norm=max_grad_norm, exact=exact))
+        self._tickets = {}  # per parameter: the device counter the fused kernel uses to advance state['step']
+
+    def __setstate__(self, state):
+        super().__setstate__(state)
+        self._tickets = {}
 
     @staticmethod
     def _counter(state, like):
@@ -38,6 +45,20 @@ class RiemannianAdam(ManifoldOptimizer):
         t = self._counter(state, p)
         m, v = state['exp_avg'], state['exp_avg_sq']
         beta1, beta2 = group['betas']
+        fused = getattr(manifold, 'radam_step', None) if p.is_cuda and not _UNFUSED else None
+        if fused is not None:
+            # one launch: moments in place, the kernel advances the step counter (optim/radam.py:62-98)
+            ticket = self._tickets.get(p)
+            if ticket is None or ticket.device != p.device:
+                ticket = torch.zeros(1, dtype=torch.int32, device=p.device)
+                self._tickets[p] = ticket
+            new_p = fused(p, p.grad, m, v, t, ticket, lr=group['lr'], betas=group['betas'], nc=group['nc'],
+                          eps=EPS[p.dtype], max_grad_norm=group['max_grad_norm'], exact=group['exact'],
+                          inplace=capturing(p))
+            if new_p is not None:
+                if new_p is not p:
+                    assign(p, new_p)
+                return
         if group['nc']:
             beta2 = 1.0 - 1.0 / t                        # AdamNc: the varying second-moment decay (radam.py:81-82)
 

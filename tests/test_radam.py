@@ -29,6 +29,10 @@ def run_trace(man, G, base, dname, to, tol):
             ref = G[f'{tag}/x{k + 1}']
             err = np.abs(p.data.double().cpu().numpy() - ref).max() / np.abs(ref).max()
             assert err <= tol, f'{tag}/x{k + 1}: {err:.2e}'
+        assert float(opt.state[p]['step']) == 4.0  # advanced once per step (by the fused kernel on the GPU)
+        ref = G[f'{tag}/exp_avg_sq']
+        err = np.abs(opt.state[p]['exp_avg_sq'].double().cpu().numpy() - ref).max() / max(np.abs(ref).max(), 1e-30)
+        assert err <= tol * 10, f'{tag}/exp_avg_sq: {err:.2e}'
         ref = G[f'{tag}/exp_avg']
         err = np.abs(opt.state[p]['exp_avg'].double().cpu().numpy() - ref).max() / max(np.abs(ref).max(), 1e-30)
         assert err <= tol * 10, f'{tag}/exp_avg: {err:.2e}'
@@ -53,3 +57,43 @@ def test_radam_gpu(key, dname):
            'grassmann': M.Grassmann, 'stiefel': M.Stiefel}[kind[0]](*kind[1:])
     run_trace(man, G, f'{key}/{dname}', dname, lambda a: torch.from_numpy(np.array(a)).cuda(),
               2e-4 if dname == 'f32' else 1e-7)
+
+
+@pytest.mark.gpu
+def test_radam_fused_kernel_is_used_and_flat_parameters():
+    """Vector / SPD / flat parameters take the one-launch Adam kernels (mm_vec_radam_step, mm_spd_radam_step);
+    a flat parameter's update equals torch's arithmetic of radam.py:62-98 with the Euclidean(1) fallback."""
+    from graphembed import _backend as B
+    from graphembed import manifolds as M
+    from graphembed.modules import ManifoldParameter
+    from graphembed.optim import RiemannianAdam
+    torch.manual_seed(3)
+    xs = [ManifoldParameter(M.Lorentz(6).rand(20, out=torch.empty(0, device='cuda')), manifold=M.Lorentz(6)),
+          ManifoldParameter(M.SymmetricPositiveDefinite(3).rand(20, out=torch.empty(0, device='cuda')),
+                            manifold=M.SymmetricPositiveDefinite(3)),
+          torch.nn.Parameter(torch.randn(5, 3, device='cuda', dtype=torch.float64))]
+    w0 = xs[2].detach().clone()
+    opt = RiemannianAdam(xs, lr=0.01, betas=(0.9, 0.99), max_grad_norm=0.5)
+    lib, calls = B.lib(), []
+    orig = lib.call
+    lib.call = lambda name, *a: (calls.append(name), orig(name, *a))[1]
+    gs = []
+    try:
+        for _ in range(3):
+            for p in xs:
+                p.grad = torch.randn_like(p)
+            gs.append(xs[2].grad.clone())
+            opt.step()
+    finally:
+        del lib.call
+    assert calls.count('mm_vec_radam_step') == 6 and calls.count('mm_spd_radam_step') == 3
+    assert not any(c.endswith('_map') or c.endswith('_norm') for c in calls), calls
+    w, m, v = w0.clone(), torch.zeros_like(w0), torch.zeros_like(w0)
+    for t, g in enumerate(gs, start=1):
+        nrm = (g * g).sum(-1, keepdim=True).clamp(min=1e-8).sqrt()
+        gc = g * torch.clamp(0.5 / nrm, max=1.0)
+        m = 0.9 * m + 0.1 * gc
+        v = 0.99 * v + 0.01 * nrm**2
+        alpha = 0.01 * (1 - 0.99**t)**0.5 / (1 - 0.9**t)
+        w = w - alpha * m / (v.sqrt() + 1e-8)
+    assert (xs[2].detach() - w).abs().max().item() <= 1e-12

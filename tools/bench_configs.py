@@ -15,7 +15,7 @@ from graphembed import manifolds as M  # noqa: E402
 from graphembed._backend import unit_seed  # noqa: E402
 from graphembed.modules import ManifoldEmbedding  # noqa: E402
 from graphembed.objectives import StressLoss  # noqa: E402
-from graphembed.optim import RiemannianSGD  # noqa: E402
+from graphembed.optim import RiemannianAdam, RiemannianSGD  # noqa: E402
 
 
 def timeit(fn, iters=20, warm=5):
@@ -46,7 +46,7 @@ def pdist_case(man, n, dtype, **kw):
             'pairs_per_s': P / (tot * 1e-6), 'GBps_8B_per_pair': P * 2 * x.element_size() / (tot * 1e-6) / 1e9}
 
 
-def step_case(mans, n, dtype, fused=False, graph=False, pair_kernel=True):
+def step_case(mans, n, dtype, fused=False, graph=False, pair_kernel=True, adam=False):
     """full training step: compute_dists + stress loss + backward + fused RSGD (momentum 0)"""
     torch.manual_seed(0)
     torch.set_default_dtype(dtype)
@@ -58,10 +58,13 @@ def step_case(mans, n, dtype, fused=False, graph=False, pair_kernel=True):
         torch.set_default_dtype(torch.float32)
     P = n * (n - 1) // 2
     target = torch.rand(P, dtype=dtype, device='cuda') * 0.99 + 0.01
-    opt = RiemannianSGD(list(emb.xs), lr=1e-3, exact=True, max_grad_norm=20)
     fn = StressLoss()
-
-    opt_s = RiemannianSGD(list(emb.scales), lr=1e-4, max_grad_norm=500)
+    if adam:  # the optimizer of the paper grid (experiments/run_grid.py:24-36)
+        opt = RiemannianAdam(list(emb.xs), lr=1e-3, exact=True, max_grad_norm=20)
+        opt_s = RiemannianAdam(list(emb.scales), lr=1e-4, max_grad_norm=500)
+    else:
+        opt = RiemannianSGD(list(emb.xs), lr=1e-3, exact=True, max_grad_norm=20)
+        opt_s = RiemannianSGD(list(emb.scales), lr=1e-4, max_grad_norm=500)
 
     def step():
         opt.zero_grad(set_to_none=True)
@@ -112,6 +115,9 @@ CASES = {
     'c4_product_n5000_step_f32_perfactor_graph': lambda: step_case([M.Lorentz(6), M.Sphere(6), M.SymmetricPositiveDefinite(2)], 5000, torch.float32, fused=True, graph=True, pair_kernel=False),
     'c4_product_n2500_step_f32_fused_graph': lambda: step_case([M.Lorentz(6), M.Sphere(6), M.SymmetricPositiveDefinite(2)], 2500, torch.float32, fused=True, graph=True),
     'c4_product_n2500_step_f32_perfactor_graph': lambda: step_case([M.Lorentz(6), M.Sphere(6), M.SymmetricPositiveDefinite(2)], 2500, torch.float32, fused=True, graph=True, pair_kernel=False),
+    'c4_csphd_product_step_f32_fused_radam_graph': lambda: step_case([M.Lorentz(6), M.Sphere(6), M.SymmetricPositiveDefinite(2)], 1025, torch.float32, fused=True, graph=True, adam=True),
+    'c3_spd3_step_n5000_f32_fused_radam_graph': lambda: step_case([M.SymmetricPositiveDefinite(3)], 5000, torch.float32, fused=True, graph=True, adam=True),
+    'c3_spd3_step_n5000_f32_fused_radam': lambda: step_case([M.SymmetricPositiveDefinite(3)], 5000, torch.float32, fused=True, adam=True),
     'c4_csphd_product_step_f32_graph': lambda: step_case([M.Lorentz(6), M.Sphere(6), M.SymmetricPositiveDefinite(2)], 1025, torch.float32, graph=True),
     'c4_csphd_product_step_f64': lambda: step_case([M.Lorentz(6), M.Sphere(6), M.SymmetricPositiveDefinite(2)], 1025, torch.float64),
     'c5_wormnet_spd4_n2274_f32': lambda: pdist_case(M.SymmetricPositiveDefinite(4), 2274, torch.float32),

@@ -241,6 +241,13 @@ int mm_vec_radam_step(int dtype, int kind, const void* x, const void* egrad, voi
                       void* exp_avg_sq, double* step, unsigned* ticket, int64_t cnt, int m, double lr,
                       double beta1, double beta2, int nc, double eps, double max_grad_norm, int exact,
                       void* x_new, mm_stream_t stream);
+/* ... for `count` (<= mm_vec_rsgd_multi_max()) vector-space parameters of one group in one launch; every
+ * parameter has its own moments, step counter and ticket (HOST arrays of device pointers; cnts[t] >= 1). */
+int mm_vec_radam_step_multi(int dtype, int count, const int* kinds, const void* const* xs,
+                            const void* const* egrads, void* const* exp_avg, void* const* exp_avg_sq,
+                            double* const* steps, unsigned* const* tickets, const int64_t* cnts,
+                            const int* ms, double lr, double beta1, double beta2, int nc, double eps,
+                            double max_grad_norm, int exact, void* const* x_new, mm_stream_t stream);
 int mm_spd_radam_step(int dtype, const void* x, const void* egrad, void* exp_avg, void* exp_avg_sq,
                       double* step, unsigned* ticket, int64_t m, int d, double lr, double beta1,
                       double beta2, int nc, double eps, double max_grad_norm, int exact, void* x_new,

@@ -23,11 +23,11 @@ template <typename T> __device__ __forceinline__ void adam_coeffs(const AdamArgs
 // Called by every block as its last action: the block that arrives last — every other block has read the
 // counter by then — advances it and re-arms the ticket.  (No separate `step += 1` launch, and replaying a
 // captured graph keeps counting.)
-__device__ __forceinline__ void adam_tick(double* step, unsigned* ticket) {
+// `total` = number of blocks that work on this parameter (and call this).
+__device__ __forceinline__ void adam_tick(double* step, unsigned* ticket, unsigned total) {
   __syncthreads();
   if (threadIdx.x == 0) {
     __threadfence();
-    const unsigned total = gridDim.x * gridDim.y;
     if (atomicAdd(ticket, 1u) == total - 1) {
       *ticket = 0;
       *step += 1.0;

@@ -763,7 +763,7 @@ __global__ void spd_radam_step_kernel(const T* x, const T* __restrict__ eg, T* e
 #pragma unroll
     for (int q = 0; q < D * D; ++q) exp_avg_sq[k * D * D + q] = v;
   }
-  adam_tick(a.step, a.ticket);
+  adam_tick(a.step, a.ticket, gridDim.x);
 }
 
 // ------------------------------------------------------------------ launchers

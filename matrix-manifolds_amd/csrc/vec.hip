@@ -365,41 +365,45 @@ __global__ void vec_rsgd_step_kernel(const T* x, const T* __restrict__ eg, int64
 // point, before clipping), clipping, both moments, the bias-corrected step, exp / retr, and the transport of
 // the first moment to the new point — one launch instead of ~25.  exp_avg / exp_avg_sq are updated in place.
 template <typename T, int KIND>
+__device__ __forceinline__ void vec_radam_point(const T* x, const T* __restrict__ eg, T* exp_avg, T* exp_avg_sq,
+                                                int64_t p, int m, const AdamArgs<T>& a, T beta2, T alpha, T* xnew) {
+  using N = Num<T>;
+  T xp[kVecMaxDim], r[kVecMaxDim], mo[kVecMaxDim], o[kVecMaxDim];
+  for (int k = 0; k < m; ++k) xp[k] = x[p * m + k];
+  vec_egrad2rgrad<T, KIND>(xp, eg + p * m, m, r);
+  const T nrm = vec_norm<T, KIND>(r, m);
+  const T clip = a.max_grad_norm > T(0) ? N::min(a.max_grad_norm / nrm, T(1)) : T(1);
+  const T v = N::fma(beta2, exp_avg_sq[p * m], (T(1) - beta2) * nrm * nrm);
+  const T f = -alpha / (N::sqrt(v) + a.eps);
+  for (int k = 0; k < m; ++k) {
+    mo[k] = N::fma(a.beta1, exp_avg[p * m + k], (T(1) - a.beta1) * (r[k] * clip));
+    r[k] = mo[k] * f;  // the step direction
+  }
+  vec_exp_or_retr<T, KIND>(xp, r, m, a.exact, o);
+  // transport of the first moment from x to the new point
+  if (KIND == MM_LORENTZ) {  // lorentz.py:79-82
+    const T xy = ldot(xp, o, m), uy = ldot(mo, o, m);
+    const T g = uy / (T(1) - xy);
+    for (int k = 0; k < m; ++k) mo[k] = N::fma(g, xp[k] + o[k], mo[k]);
+  } else if (KIND == MM_SPHERE) {  // base.py:65-66: proju(y, u)
+    const T d = edot(o, mo, m);
+    for (int k = 0; k < m; ++k) mo[k] = N::fma(-d, o[k], mo[k]);
+  }
+  for (int k = 0; k < m; ++k) {
+    xnew[p * m + k] = o[k];
+    exp_avg[p * m + k] = mo[k];
+    exp_avg_sq[p * m + k] = v;
+  }
+}
+
+template <typename T, int KIND>
 __global__ void vec_radam_step_kernel(const T* x, const T* __restrict__ eg, T* exp_avg, T* exp_avg_sq, int64_t cnt,
                                       int m, AdamArgs<T> a, T* xnew) {
-  using N = Num<T>;
   const int64_t p = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
   T beta2, alpha;
   adam_coeffs(a, beta2, alpha);
-  if (p < cnt) {
-    T xp[kVecMaxDim], r[kVecMaxDim], mo[kVecMaxDim], o[kVecMaxDim];
-    for (int k = 0; k < m; ++k) xp[k] = x[p * m + k];
-    vec_egrad2rgrad<T, KIND>(xp, eg + p * m, m, r);
-    const T nrm = vec_norm<T, KIND>(r, m);
-    const T clip = a.max_grad_norm > T(0) ? N::min(a.max_grad_norm / nrm, T(1)) : T(1);
-    const T v = N::fma(beta2, exp_avg_sq[p * m], (T(1) - beta2) * nrm * nrm);
-    const T f = -alpha / (N::sqrt(v) + a.eps);
-    for (int k = 0; k < m; ++k) {
-      mo[k] = N::fma(a.beta1, exp_avg[p * m + k], (T(1) - a.beta1) * (r[k] * clip));
-      r[k] = mo[k] * f;  // the step direction
-    }
-    vec_exp_or_retr<T, KIND>(xp, r, m, a.exact, o);
-    // transport of the first moment from x to the new point
-    if (KIND == MM_LORENTZ) {  // lorentz.py:79-82
-      const T xy = ldot(xp, o, m), uy = ldot(mo, o, m);
-      const T g = uy / (T(1) - xy);
-      for (int k = 0; k < m; ++k) mo[k] = N::fma(g, xp[k] + o[k], mo[k]);
-    } else if (KIND == MM_SPHERE) {  // base.py:65-66: proju(y, u)
-      const T d = edot(o, mo, m);
-      for (int k = 0; k < m; ++k) mo[k] = N::fma(-d, o[k], mo[k]);
-    }
-    for (int k = 0; k < m; ++k) {
-      xnew[p * m + k] = o[k];
-      exp_avg[p * m + k] = mo[k];
-      exp_avg_sq[p * m + k] = v;
-    }
-  }
-  adam_tick(a.step, a.ticket);
+  if (p < cnt) vec_radam_point<T, KIND>(x, eg, exp_avg, exp_avg_sq, p, m, a, beta2, alpha, xnew);
+  adam_tick(a.step, a.ticket, gridDim.x);
 }
 
 // The same update for several parameters of one optimizer group in ONE launch (blockIdx.y = parameter):
@@ -422,6 +426,34 @@ __global__ void vec_rsgd_multi_kernel(RsgdMulti<T> a, T lr, T max_grad_norm, int
   if (kind == MM_EUCLIDEAN) vec_rsgd_point<T, MM_EUCLIDEAN>(a.x[t], a.eg[t], p, a.m[t], lr, max_grad_norm, exact, a.xnew[t]);
   else if (kind == MM_LORENTZ) vec_rsgd_point<T, MM_LORENTZ>(a.x[t], a.eg[t], p, a.m[t], lr, max_grad_norm, exact, a.xnew[t]);
   else vec_rsgd_point<T, MM_SPHERE>(a.x[t], a.eg[t], p, a.m[t], lr, max_grad_norm, exact, a.xnew[t]);
+}
+
+// ... and the Adam update of several parameters (each with its own moments, step counter and ticket)
+template <typename T> struct RadamMulti {
+  RsgdMulti<T> p;
+  T* exp_avg[kRsgdMultiMax];
+  T* exp_avg_sq[kRsgdMultiMax];
+  double* step[kRsgdMultiMax];
+  unsigned* ticket[kRsgdMultiMax];
+};
+template <typename T>
+__global__ void vec_radam_multi_kernel(RadamMulti<T> s, AdamArgs<T> a) {
+  const int t = blockIdx.y;
+  const int64_t p = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  a.step = s.step[t];
+  a.ticket = s.ticket[t];
+  T beta2, alpha;
+  adam_coeffs(a, beta2, alpha);
+  if (p < s.p.cnt[t]) {
+    const int kind = s.p.kind[t], m = s.p.m[t];
+    if (kind == MM_EUCLIDEAN)
+      vec_radam_point<T, MM_EUCLIDEAN>(s.p.x[t], s.p.eg[t], s.exp_avg[t], s.exp_avg_sq[t], p, m, a, beta2, alpha, s.p.xnew[t]);
+    else if (kind == MM_LORENTZ)
+      vec_radam_point<T, MM_LORENTZ>(s.p.x[t], s.p.eg[t], s.exp_avg[t], s.exp_avg_sq[t], p, m, a, beta2, alpha, s.p.xnew[t]);
+    else
+      vec_radam_point<T, MM_SPHERE>(s.p.x[t], s.p.eg[t], s.exp_avg[t], s.exp_avg_sq[t], p, m, a, beta2, alpha, s.p.xnew[t]);
+  }
+  adam_tick(a.step, a.ticket, gridDim.x);
 }
 
 // ------------------------------------------------------------------ launchers
@@ -509,6 +541,33 @@ bool vec_gram_supports(int dtype, int kind, int64_t n, int m);
 int vec_gram_loss(int dtype, int kind, int loss_kind, const void* x, const void* target, const void* scale_raw, int64_t n,
                   int m, int64_t row_begin, int64_t row_end, double alpha, double eps, int terms, void* loss_out,
                   void* grad, void* slots, hipStream_t st);
+
+template <typename T>
+int vec_radam_multi_t(int count, const int* kinds, const void* const* xs, const void* const* egrads,
+                      void* const* exp_avg, void* const* exp_avg_sq, double* const* steps, unsigned* const* tickets,
+                      const int64_t* cnts, const int* ms, double lr, double beta1, double beta2, int nc, double eps,
+                      double max_grad_norm, int exact, void* const* x_new, hipStream_t st) {
+  RadamMulti<T> s{};
+  int64_t most = 0;
+  for (int t = 0; t < count; ++t) {
+    s.p.x[t] = static_cast<const T*>(xs[t]);
+    s.p.eg[t] = static_cast<const T*>(egrads[t]);
+    s.p.xnew[t] = static_cast<T*>(x_new[t]);
+    s.p.cnt[t] = cnts[t];
+    s.p.m[t] = ms[t];
+    s.p.kind[t] = kinds[t];
+    s.exp_avg[t] = static_cast<T*>(exp_avg[t]);
+    s.exp_avg_sq[t] = static_cast<T*>(exp_avg_sq[t]);
+    s.step[t] = steps[t];
+    s.ticket[t] = tickets[t];
+    most = cnts[t] > most ? cnts[t] : most;
+  }
+  if (most == 0) return MM_OK;
+  AdamArgs<T> a{T(lr), T(beta1), T(beta2), T(eps), T(max_grad_norm), nc, exact, nullptr, nullptr};
+  vec_radam_multi_kernel<T><<<dim3(unsigned((most + 127) / 128), unsigned(count)), dim3(128), 0, st>>>(s, a);
+  MMV_CHECK();
+  return MM_OK;
+}
 
 template <typename T>
 int vec_rsgd_multi_t(int count, const int* kinds, const void* const* xs, const void* const* egrads,
@@ -654,6 +713,30 @@ int mm_vec_radam_step(int dtype, int kind, const void* x, const void* egrad, voi
         static_cast<const T*>(egrad), static_cast<T*>(exp_avg), static_cast<T*>(exp_avg_sq), cnt, m, a,
         static_cast<T*>(x_new));
     MMV_CHECK(); return MM_OK; }))
+}
+
+int mm_vec_radam_step_multi(int dtype, int count, const int* kinds, const void* const* xs, const void* const* egrads,
+                            void* const* exp_avg, void* const* exp_avg_sq, double* const* steps,
+                            unsigned* const* tickets, const int64_t* cnts, const int* ms, double lr, double beta1,
+                            double beta2, int nc, double eps, double max_grad_norm, int exact, void* const* x_new,
+                            mm_stream_t stream) {
+  if (count < 1 || !kinds || !xs || !egrads || !exp_avg || !exp_avg_sq || !steps || !tickets || !cnts || !ms || !x_new)
+    return MM_ERR_ARG;
+  if (count > kRsgdMultiMax) return MM_ERR_UNSUPPORTED;
+  for (int t = 0; t < count; ++t) {
+    if (cnts[t] < 1 || ms[t] < 1 || !xs[t] || !egrads[t] || !exp_avg[t] || !exp_avg_sq[t] || !steps[t] || !tickets[t] ||
+        !x_new[t] || kinds[t] < MM_EUCLIDEAN || kinds[t] > MM_SPHERE)
+      return MM_ERR_ARG;
+    if (ms[t] > kVecMaxDim) return MM_ERR_UNSUPPORTED;
+  }
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (dtype == MM_F32)
+    return vec_radam_multi_t<float>(count, kinds, xs, egrads, exp_avg, exp_avg_sq, steps, tickets, cnts, ms, lr, beta1,
+                                    beta2, nc, eps, max_grad_norm, exact, x_new, st);
+  if (dtype == MM_F64)
+    return vec_radam_multi_t<double>(count, kinds, xs, egrads, exp_avg, exp_avg_sq, steps, tickets, cnts, ms, lr,
+                                     beta1, beta2, nc, eps, max_grad_norm, exact, x_new, st);
+  return MM_ERR_ARG;
 }
 
 int mm_vec_rsgd_multi_max(void) { return kRsgdMultiMax; }

@@ -87,6 +87,26 @@ def assign(t, new):
         t.set_(new)
 
 
+def vector_layout(p, manifold):
+    """(kind, m) when `p` can be stepped by the multi-parameter vector kernels
+    (mm_vec_rsgd_step_multi, mm_vec_radam_step_multi), else None."""
+    import torch
+    from graphembed import _backend as B
+    from graphembed.manifolds.vector import VectorManifold
+    if not p.is_cuda or p.dtype not in (torch.float32, torch.float64) or not p.is_contiguous():
+        return None
+    if p.grad.dtype != p.dtype or not p.grad.is_contiguous() or p.numel() == 0:
+        return None
+    if manifold is FLAT:
+        kind, m = B.EUCLIDEAN, (p.shape[-1] if p.ndim else 1)
+    elif isinstance(manifold, VectorManifold) and type(manifold).rsgd_step is VectorManifold.rsgd_step \
+            and type(manifold).radam_step is VectorManifold.radam_step:
+        kind, m = manifold._kind, manifold._m
+    else:
+        return None
+    return (kind, m) if 1 <= m <= 32 else None
+
+
 class ManifoldOptimizer(torch.optim.Optimizer):
 
     def step(self, closure=None):

@@ -9,7 +9,7 @@ import os
 
 import torch
 
-from graphembed.optim._common import ManifoldOptimizer, assign, capturing
+from graphembed.optim._common import ManifoldOptimizer, assign, capturing, vector_layout
 from graphembed.utils import EPS
 
 logger = logging.getLogger(__name__)
@@ -36,22 +36,80 @@ class RiemannianAdam(ManifoldOptimizer):
         if not torch.is_tensor(t):
             t = torch.tensor(float(t), dtype=torch.float64, device=like.device)
             state['step'] = t
+        elif t.device != like.device or t.dtype != torch.float64:  # e.g. restored by load_state_dict
+            t = t.detach().to(device=like.device, dtype=torch.float64).reshape(())
+            state['step'] = t
         return t
 
-    def _update(self, group, p, state, manifold):
+    def _moments(self, p):
+        state = self.state[p]
         if 'exp_avg' not in state:
             state['exp_avg'] = torch.zeros_like(p)      # first moment, a tangent vector at p
             state['exp_avg_sq'] = torch.zeros_like(p)   # ONE scalar per point, broadcast over it (radam.py:60)
-        t = self._counter(state, p)
-        m, v = state['exp_avg'], state['exp_avg_sq']
+        return state['exp_avg'], state['exp_avg_sq'], self._counter(state, p)
+
+    def _ticket(self, p):
+        ticket = self._tickets.get(p)
+        if ticket is None or ticket.device != p.device:
+            ticket = torch.zeros(1, dtype=torch.int32, device=p.device)
+            self._tickets[p] = ticket
+        return ticket
+
+    def _params_of(self, group):
+        """All vector-space parameters of the group (Euclidean / Lorentz / sphere points, flat scales) take
+        ONE launch per dtype (mm_vec_radam_step_multi); the rest goes through `_update`."""
+        params = [p for p in group['params'] if p.grad is not None]
+        if _UNFUSED or len(params) < 2:
+            return params
+        import ctypes
+        from graphembed import _backend as B
+        layouts = [vector_layout(p, self.manifold_of(p)) for p in params]
+        rest = [p for p, lay in zip(params, layouts) if lay is None]
+        by_dtype = {}
+        for p, lay in zip(params, layouts):
+            if lay is not None:
+                by_dtype.setdefault((p.dtype, p.device), []).append((p, lay))
+        lib = B.lib()
+        most = lib.raw('mm_vec_rsgd_multi_max')()
+        clip, betas = group['max_grad_norm'], group['betas']
+        for (dtype, dev), items in by_dtype.items():
+            if len(items) < 2:
+                rest.extend(p for p, _ in items)
+                continue
+            for lo in range(0, len(items), most):
+                chunk = items[lo:lo + most]
+                k = len(chunk)
+                moments = [self._moments(p) for p, _ in chunk]
+                if not all(m.is_contiguous() and v.is_contiguous() and m.dtype == dtype and v.dtype == dtype
+                           for m, v, _ in moments):
+                    rest.extend(p for p, _ in chunk)
+                    continue
+                inplace = capturing(chunk[0][0])
+                with B.on_device(dev):
+                    xs = [p.detach() for p, _ in chunk]
+                    outs = xs if inplace else [torch.empty_like(x) for x in xs]
+                    lib.call('mm_vec_radam_step_multi', B.dtype_code(xs[0]), k,
+                             (ctypes.c_int * k)(*[lay[0] for _, lay in chunk]), B.ptr_array(xs),
+                             B.ptr_array([p.grad for p, _ in chunk]), B.ptr_array([m for m, _, _ in moments]),
+                             B.ptr_array([v for _, v, _ in moments]), B.ptr_array([t for _, _, t in moments]),
+                             B.ptr_array([self._ticket(p) for p, _ in chunk]),
+                             (ctypes.c_int64 * k)(*[x.numel() // lay[1] for x, (_, lay) in zip(xs, chunk)]),
+                             (ctypes.c_int * k)(*[lay[1] for _, lay in chunk]), float(group['lr']), float(betas[0]),
+                             float(betas[1] if betas[1] is not None else 0.0), int(bool(group['nc'])),
+                             float(EPS[dtype]), -1.0 if clip is None else float(clip), int(bool(group['exact'])),
+                             B.ptr_array(outs), B.stream_of(xs[0]))
+                if not inplace:
+                    for (p, _), new in zip(chunk, outs):
+                        assign(p, new)
+        return rest
+
+    def _update(self, group, p, state, manifold):
+        m, v, t = self._moments(p)
         beta1, beta2 = group['betas']
         fused = getattr(manifold, 'radam_step', None) if p.is_cuda and not _UNFUSED else None
         if fused is not None:
             # one launch: moments in place, the kernel advances the step counter (optim/radam.py:62-98)
-            ticket = self._tickets.get(p)
-            if ticket is None or ticket.device != p.device:
-                ticket = torch.zeros(1, dtype=torch.int32, device=p.device)
-                self._tickets[p] = ticket
+            ticket = self._ticket(p)
             new_p = fused(p, p.grad, m, v, t, ticket, lr=group['lr'], betas=group['betas'], nc=group['nc'],
                           eps=EPS[p.dtype], max_grad_norm=group['max_grad_norm'], exact=group['exact'],
                           inplace=capturing(p))

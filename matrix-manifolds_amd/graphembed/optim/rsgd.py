@@ -3,7 +3,7 @@ graphembed/graphembed/optim/rsgd.py:10-82: same constructor and param-group keys
 order (egrad2rgrad -> per-point norm clip -> momentum with transport | plain exp/retr step)."""
 from torch.optim.optimizer import required
 
-from graphembed.optim._common import FLAT, ManifoldOptimizer, assign, capturing
+from graphembed.optim._common import FLAT, ManifoldOptimizer, assign, capturing, vector_layout
 
 _default_manifold = FLAT  # (kept under the reference's name for callers that import it)
 _assign = assign
@@ -58,29 +58,11 @@ class RiemannianSGD(ManifoldOptimizer):
         assign(buf, carried)
 
 
-def _vector_layout(p, manifold):
-    """(kind, m) when `p` can be stepped by mm_vec_rsgd_step_multi, else None."""
-    import torch
-    from graphembed import _backend as B
-    from graphembed.manifolds.vector import VectorManifold
-    if not p.is_cuda or p.dtype not in (torch.float32, torch.float64) or not p.is_contiguous():
-        return None
-    if p.grad.dtype != p.dtype or not p.grad.is_contiguous() or p.numel() == 0:
-        return None
-    if manifold is FLAT:
-        kind, m = B.EUCLIDEAN, (p.shape[-1] if p.ndim else 1)
-    elif isinstance(manifold, VectorManifold) and type(manifold).rsgd_step is VectorManifold.rsgd_step:
-        kind, m = manifold._kind, manifold._m
-    else:
-        return None
-    return (kind, m) if 1 <= m <= 32 else None
-
-
 def _multi_vector_step(params, manifold_of, group):
     import ctypes
     import torch
     from graphembed import _backend as B
-    layouts = [_vector_layout(p, manifold_of(p)) for p in params]
+    layouts = [vector_layout(p, manifold_of(p)) for p in params]
     rest = [p for p, lay in zip(params, layouts) if lay is None]
     by_dtype = {}
     for p, lay in zip(params, layouts):

@@ -97,3 +97,46 @@ def test_radam_fused_kernel_is_used_and_flat_parameters():
         alpha = 0.01 * (1 - 0.99**t)**0.5 / (1 - 0.9**t)
         w = w - alpha * m / (v.sqrt() + 1e-8)
     assert (xs[2].detach() - w).abs().max().item() <= 1e-12
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('dname', ['f32', 'f64'])
+def test_radam_multi_parameter_launch_equals_single_steps(dname):
+    """All vector-space parameters of a group in one launch (mm_vec_radam_step_multi): bit-identical points,
+    moments and step counters to one fused launch per parameter, over 3 steps (incl. AdamNc)."""
+    from graphembed import _backend as B
+    from graphembed import manifolds as M
+    from graphembed.modules import ManifoldParameter
+    from graphembed.optim import RiemannianAdam
+    dt = {'f32': torch.float32, 'f64': torch.float64}[dname]
+    for nc in (False, True):
+        torch.manual_seed(5)
+        mans = [M.Euclidean(5), M.Lorentz(6), M.Sphere(4)]
+        pts = [man.rand(33 + 7 * k, out=torch.empty(0, dtype=dt, device='cuda')) for k, man in enumerate(mans)]
+        scal = [torch.randn((), dtype=dt, device='cuda') for _ in range(2)]
+
+        def build():
+            ps = [ManifoldParameter(x.clone(), manifold=man) for man, x in zip(mans, pts)]
+            return ps + [torch.nn.Parameter(s.clone()) for s in scal]
+        pa, pb = build(), build()
+        oa = RiemannianAdam(pa, lr=0.05, betas=(0.9, 0.99), nc=nc, max_grad_norm=1.0, exact=True)
+        obs = [RiemannianAdam([p], lr=0.05, betas=(0.9, 0.99), nc=nc, max_grad_norm=1.0, exact=True) for p in pb]
+        lib, calls = B.lib(), []
+        orig = lib.call
+        lib.call = lambda name, *a: (calls.append(name), orig(name, *a))[1]
+        try:
+            for _ in range(3):
+                gs = [torch.randn_like(p) for p in pa]
+                for p, q, g in zip(pa, pb, gs):
+                    p.grad, q.grad = g.clone(), g.clone()
+                oa.step()
+                for o in obs:
+                    o.step()
+        finally:
+            del lib.call
+        assert calls.count('mm_vec_radam_step_multi') == 3 and calls.count('mm_vec_radam_step') == 3 * len(pb)
+        for p, q, o in zip(pa, pb, obs):
+            assert torch.equal(p.detach(), q.detach())
+            for key in ('exp_avg', 'exp_avg_sq', 'step'):
+                assert torch.equal(oa.state[p][key], o.state[q][key]), key
+            assert float(oa.state[p]['step']) == 4.0

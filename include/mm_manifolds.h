@@ -317,6 +317,19 @@ int mm_product_pairs_loss(int dtype, int loss_kind, int nf, const int* kinds, co
                           int terms, double wmin, double wmax, void* const* grads, void* loss_out,
                           void* ws, int flags, mm_stream_t stream);
 
+/* The same for a node minibatch (train.py:198-222, batch_size = 512 in the paper grid) without any gather or
+ * scatter launch around it: the `bs` points of the step are rows idx[0..bs) (device int64) of the factors'
+ * FULL tables xs[k] = [n_total, ...]; the target of pair (a, b) is dense[idx[a]][idx[b]] (the dense
+ * n_total x n_total matrix of GraphDataset, data/dataset.py:19-27); gradients are written to rows idx[.] of
+ * the full-size grads[k] — the other rows are NOT touched: pass zero-filled buffers.  row_begin/row_end
+ * shard the pair list of the batch; ws as mm_product_pairs_ws_bytes(..., n = bs). */
+int mm_product_pairs_loss_subset(int dtype, int loss_kind, int nf, const int* kinds, const int* dims,
+                                 const void* const* xs, const void* const* scale_raw, const void* dense,
+                                 int64_t n_total, const int64_t* idx, int64_t bs, int64_t row_begin,
+                                 int64_t row_end, double alpha, double eps, int terms, double wmin,
+                                 double wmax, void* const* grads, void* loss_out, void* ws, int flags,
+                                 mm_stream_t stream);
+
 /* Targets of a node minibatch: out[pair (a,b), a<b] = dense[idx[a]][idx[b]] in pair-vector order
  * (GraphDataset.__getitem__, data/dataset.py:19-27).  dense [n,n]; idx int64[bs] (device); out [bs(bs-1)/2]. */
 int mm_pair_gather(int dtype, const void* dense, int64_t n, const int64_t* idx, int64_t bs, void* out,

@@ -49,7 +49,15 @@ template <typename T> struct PArgs {
   PVec<T> v[kPMaxVec];
   PSpd<T> s;
   int nf;
+  // node minibatch (train.py:198-222): the n points of this call are rows idx[0..n) of the factors' full
+  // tables, targets come from the dense matrix, gradients go to rows idx[.] of full-size buffers
+  const int64_t* idx;  // null: all nodes, in order
+  const T* dense;      // [dense_n][dense_n] targets (with idx); null: `target` is the pair vector
+  int64_t dense_n;
 };
+template <typename T> __device__ __forceinline__ int64_t node_of(const PArgs<T>& pa, int j) {
+  return pa.idx ? pa.idx[j] : int64_t(j);
+}
 
 // Pins a loaded value (per-lane / wave-uniform) so that the load is issued where it is written: without
 // it the compiler sinks each load under the condition that masks its result — one basic block and one
@@ -89,15 +97,15 @@ __global__ __launch_bounds__(kPCols * kPWaves) void product_pair_kernel(PArgs<T>
   const int i0 = min((blockIdx.y * kPWaves + wave) * ti, n), i1 = min(i0 + ti, n);
   const bool jin = j < n;
   const bool jown = jin && j >= row_begin && j < row_end;
+  const int64_t jnode = node_of(pa, jin ? j : n - 1);  // lanes past n: clamped, masked later
   // per-lane column data
   T xj[NV > 0 ? NV : 1][kPMP], accv[NV > 0 ? NV : 1][kPMP], wsum[NV > 0 ? NV : 1], spv[NV > 0 ? NV : 1],
       dsv[NV > 0 ? NV : 1];
 #pragma unroll
   for (int f = 0; f < NV; ++f) {
     const PVec<T>& F = pa.v[f];
-    const int jc = jin ? j : n - 1;
 #pragma unroll
-    for (int k = 0; k < kPMP; ++k) xj[f][k] = F.x[size_t(jc) * F.m + min(k, F.m - 1)];  // clamped, masked below
+    for (int k = 0; k < kPMP; ++k) xj[f][k] = F.x[size_t(jnode) * F.m + min(k, F.m - 1)];  // clamped, masked below
 #pragma unroll
     for (int k = 0; k < kPMP; ++k) accv[f][k] = T(0);
     wsum[f] = T(0);
@@ -112,7 +120,7 @@ __global__ __launch_bounds__(kPCols * kPWaves) void product_pair_kernel(PArgs<T>
     {  // Cholesky factor of the column point, in registers (no per-node tables, no preparation launch:
        // the factorisation is ~1 % of a row's arithmetic)
       T xs[NPS];
-      load_sym_packed<T, SD>(pa.s.x + size_t(jin ? j : n - 1) * SD * SD, xs);  // lanes past n: masked later
+      load_sym_packed<T, SD>(pa.s.x + size_t(jnode) * SD * SD, xs);
       cholesky<T, SD>(xs, yj);
     }
 #pragma unroll
@@ -125,26 +133,32 @@ __global__ __launch_bounds__(kPCols * kPWaves) void product_pair_kernel(PArgs<T>
     return jin && i != j && (i < j ? (i >= row_begin && i < row_end) : jown);
   };
   auto target_at = [&](int i) -> T {  // unconditional load from a clamped address, one row ahead of its use
+    if (pa.dense) return pa.dense[node_of(pa, min(i, n - 1)) * pa.dense_n + jnode];
     const int lo = i < j ? i : j, hi = i < j ? j : i;
     return target[pair_ok(i) ? int64_t(lo) * (2 * int64_t(n) - lo - 1) / 2 - base + (hi - lo - 1) : int64_t(0)];
   };
-  T tnext = target_at(i0);
+  T tnext = target_at(min(i0, n - 1));
   // the row points of the tile, zero-padded to kPMP, staged once (coalesced); a load under `k < m` in the
   // row loop would sit in its own basic block and serialise 16 memory round trips per factor and row
   __shared__ T rowpt[NV > 0 ? NV : 1][kPWaves][kPMaxTI][kPMP];
+  __shared__ int rownode[kPWaves][kPMaxTI];
+  if (lane < ti) rownode[wave][lane] = int(node_of(pa, min(i0 + lane, n - 1)));
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #pragma unroll
   for (int f = 0; f < NV; ++f) {
     const PVec<T>& F = pa.v[f];
     for (int e = lane; e < ti * kPMP; e += 64) {
       const int r = e / kPMP, k = e % kPMP;
-      rowpt[f][wave][r][k] = (k < F.m && i0 + r < n) ? F.x[size_t(i0 + r) * F.m + k] : T(0);
+      rowpt[f][wave][r][k] = (k < F.m && i0 + r < n) ? F.x[size_t(rownode[wave][r]) * F.m + k] : T(0);
     }
   }
   __shared__ T rowL[kPWaves][kPMaxTI][2 * NPS];  // L_i^-1 and L_i of the tile's rows
   if constexpr (SD > 0) {
     if (lane < ti) {
       T xs[NPS], l[NPS], li_[NPS];
-      load_sym_packed<T, SD>(pa.s.x + size_t(min(i0 + lane, n - 1)) * SD * SD, xs);
+      load_sym_packed<T, SD>(pa.s.x + size_t(rownode[wave][lane]) * SD * SD, xs);
       cholesky<T, SD>(xs, l);
       invert_lower<T, SD>(l, li_);
 #pragma unroll
@@ -313,18 +327,19 @@ __global__ __launch_bounds__(256) void product_pair_finalize_kernel(PArgs<T> pa,
       if (job == f) F = pa.v[f];
     const int j = t / kPMP, k = t % kPMP;
     if (j >= n || k >= F.m) return;
+    const int64_t jn = node_of(pa, j);
     const T s = F.acc[size_t(k) * n + j];
     F.acc[size_t(k) * n + j] = T(0);
     T r = s;
     if (F.kind == MM_EUCLIDEAN) {
       const T ws = F.acc[size_t(kPMP) * n + j];
-      r = T(2) * (ws * F.x[size_t(j) * F.m + k] - s);
+      r = T(2) * (ws * F.x[size_t(jn) * F.m + k] - s);
       // the 16 threads of a node share a wavefront (64 % kPMP == 0): all of them have read ws by now
       if (k == 0) F.acc[size_t(kPMP) * n + j] = T(0);
     } else if (F.kind == MM_LORENTZ) {
       r = (k == 0) ? s : -s;
     }
-    F.grad[size_t(j) * F.m + k] = r;
+    F.grad[size_t(jn) * F.m + k] = r;
     return;
   }
   const int j = t;
@@ -333,7 +348,7 @@ __global__ __launch_bounds__(256) void product_pair_finalize_kernel(PArgs<T> pa,
     T li[NPS], xinv[NPS], sc[SD][SD], gi[NPS];
     {
       T xs[NPS], l[NPS];
-      load_sym_packed<T, SD>(pa.s.x + size_t(j) * SD * SD, xs);
+      load_sym_packed<T, SD>(pa.s.x + size_t(node_of(pa, j)) * SD * SD, xs);
       cholesky<T, SD>(xs, l);
       invert_lower<T, SD>(l, li);
     }
@@ -365,7 +380,7 @@ __global__ __launch_bounds__(256) void product_pair_finalize_kernel(PArgs<T> pa,
         }
         gi[pidx(r, c)] = T(0.5) * (a + b);  // ordered pairs: both roles of a node arrive as "column side"
       }
-    store_sym_full<T, SD>(pa.s.grad + size_t(j) * SD * SD, gi);
+    store_sym_full<T, SD>(pa.s.grad + size_t(node_of(pa, j)) * SD * SD, gi);
   }
 }
 
@@ -395,9 +410,13 @@ template <typename T>
 int product_pairs_t(int loss_kind, int nf, const int* kinds, const int* dims, const void* const* xs,
                     const void* const* scale_raw, const void* target, int64_t n, int64_t rb, int64_t re, double alpha,
                     double eps, int terms, double wmin, double wmax, void* const* grads, void* loss_out, void* wsp,
-                    int flags, hipStream_t st) {
+                    int flags, hipStream_t st, const int64_t* idx = nullptr, const void* dense = nullptr,
+                    int64_t dense_n = 0) {
   PArgs<T> pa{};
   pa.nf = nf;
+  pa.idx = idx;
+  pa.dense = static_cast<const T*>(dense);
+  pa.dense_n = dense_n;
   int nv = 0, sd = 0;
   // workspace: [64 bytes reserved] [slots (1+nf) x 256] [accumulators]
   char* wsb = static_cast<char*>(wsp);
@@ -488,6 +507,28 @@ int mm_product_pairs_loss(int dtype, int loss_kind, int nf, const int* kinds, co
   if (dtype == MM_F64)
     return product_pairs_t<double>(loss_kind, nf, kinds, dims, xs, scale_raw, target, n, row_begin, row_end, alpha, eps,
                                    terms, wmin, wmax, grads, loss_out, ws, flags, st);
+  return MM_ERR_ARG;
+}
+
+int mm_product_pairs_loss_subset(int dtype, int loss_kind, int nf, const int* kinds, const int* dims,
+                                 const void* const* xs, const void* const* scale_raw, const void* dense,
+                                 int64_t n_total, const int64_t* idx, int64_t bs, int64_t row_begin, int64_t row_end,
+                                 double alpha, double eps, int terms, double wmin, double wmax, void* const* grads,
+                                 void* loss_out, void* ws, int flags, mm_stream_t stream) {
+  if (nf < 1 || nf > 4 || !kinds || !dims || !xs || !scale_raw || !grads || !loss_out || !ws || !idx || !dense ||
+      bs < 1 || bs > n_total || n_total >= (int64_t(1) << 31) || row_begin < 0 || row_end > bs || row_begin > row_end)
+    return MM_ERR_ARG;
+  for (int k = 0; k < nf; ++k)
+    if (!xs[k] || !scale_raw[k] || !grads[k]) return MM_ERR_ARG;
+  if (loss_kind != MM_LOSS_STRESS && loss_kind != MM_LOSS_QUOTIENT) return MM_ERR_UNSUPPORTED;
+  if (loss_kind == MM_LOSS_QUOTIENT && !(terms & 3)) return MM_ERR_ARG;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (dtype == MM_F32)
+    return product_pairs_t<float>(loss_kind, nf, kinds, dims, xs, scale_raw, nullptr, bs, row_begin, row_end, alpha, eps,
+                                  terms, wmin, wmax, grads, loss_out, ws, flags, st, idx, dense, n_total);
+  if (dtype == MM_F64)
+    return product_pairs_t<double>(loss_kind, nf, kinds, dims, xs, scale_raw, nullptr, bs, row_begin, row_end, alpha,
+                                   eps, terms, wmin, wmax, grads, loss_out, ws, flags, st, idx, dense, n_total);
   return MM_ERR_ARG;
 }
 

@@ -110,7 +110,9 @@ class _ProductPairsLoss(torch.autograd.Function):
     Lorentz x sphere x SPD(2) step in two launches."""
 
     @staticmethod
-    def forward(ctx, target, spec, rows, manifolds, factors, cache, *params):
+    def forward(ctx, target, spec, rows, manifolds, factors, cache, subset, *params):
+        """`subset` = None, or (idx, dense) for a node minibatch handled inside the kernels: `params` are
+        then the FULL tables, targets are read from the dense matrix, gradients come back full-size."""
         import ctypes
         from graphembed import _backend as B
         k = len(manifolds)
@@ -119,12 +121,9 @@ class _ProductPairsLoss(torch.autograd.Function):
         lib = B.lib()
         lkind, alpha, eps, terms = spec
         dtype, dev = xs[0].dtype, xs[0].device
-        n = xs[0].shape[0]
+        n_total = xs[0].shape[0]
+        n = n_total if subset is None else subset[0].numel()
         rb, re = (0, n) if rows is None else rows
-        npairs = B.pair_offset(n, re) - B.pair_offset(n, rb)
-        tc = target.detach().to(dtype).contiguous()
-        if tc.numel() != npairs:
-            raise ValueError(f'target has {tc.numel()} entries, the pair range has {npairs}')
         dt = B.dtype_code(xs[0])
         kinds = (ctypes.c_int * k)(*[f[0] for f in factors])
         dims = (ctypes.c_int * k)(*[f[1] for f in factors])
@@ -132,10 +131,10 @@ class _ProductPairsLoss(torch.autograd.Function):
         for man, f in zip(manifolds, factors):
             if f[0] == B.FACTOR_SPD:
                 wmin, wmax = man.wmin, man.wmax
+        loss_code = B.LOSS_STRESS if lkind == 'stress' else B.LOSS_QUOTIENT
         with B.on_device(dev):
             xc = [x.detach().to(dtype).contiguous() for x in xs]
             sc = [s.detach().to(dtype).reshape(1).contiguous() for s in scales]
-            grads = [torch.empty_like(x) for x in xc]
             out = torch.empty(1 + k, dtype=dtype, device=dev)
             # the kernels leave the workspace's accumulators zero: kept across steps, it is cleared once
             key = (dtype, dev, n, factors)
@@ -148,10 +147,28 @@ class _ProductPairsLoss(torch.autograd.Function):
                     cache[key] = entry
             ws, clean = entry
             entry[1] = False  # until the call has been enqueued completely
-            lib.call('mm_product_pairs_loss', dt, B.LOSS_STRESS if lkind == 'stress' else B.LOSS_QUOTIENT, k,
-                     kinds, dims, B.ptr_array(xc), B.ptr_array(sc), B.ptr(tc), n, rb, re, alpha, eps,
-                     terms, wmin, wmax, B.ptr_array(grads), B.ptr(out), B.ptr(ws), B.WS_CLEAN if clean else 0,
-                     B.stream_of(xs[0]))
+            flags = B.WS_CLEAN if clean else 0
+            if subset is None:
+                tc = target.detach().to(dtype).contiguous()
+                npairs = B.pair_offset(n, re) - B.pair_offset(n, rb)
+                if tc.numel() != npairs:
+                    raise ValueError(f'target has {tc.numel()} entries, the pair range has {npairs}')
+                grads = [torch.empty_like(x) for x in xc]
+                lib.call('mm_product_pairs_loss', dt, loss_code, k, kinds, dims, B.ptr_array(xc), B.ptr_array(sc),
+                         B.ptr(tc), n, rb, re, alpha, eps, terms, wmin, wmax, B.ptr_array(grads), B.ptr(out),
+                         B.ptr(ws), flags, B.stream_of(xs[0]))
+            else:
+                idx, dense = subset
+                if dense.dtype != dtype or not dense.is_contiguous() or dense.shape != (n_total, n_total):
+                    raise ValueError('dense targets must be a contiguous [n, n] matrix of the embedding\'s dtype')
+                idx = idx.to(device=dev, dtype=torch.int64).contiguous()
+                # rows outside the batch get zero gradients: ONE fill for all factors
+                sizes = [x.numel() for x in xc]
+                flat = torch.zeros(sum(sizes), dtype=dtype, device=dev)
+                grads = [g.view(x.shape) for g, x in zip(flat.split(sizes), xc)]
+                lib.call('mm_product_pairs_loss_subset', dt, loss_code, k, kinds, dims, B.ptr_array(xc),
+                         B.ptr_array(sc), B.ptr(dense), n_total, B.ptr(idx), n, rb, re, alpha, eps, terms, wmin,
+                         wmax, B.ptr_array(grads), B.ptr(out), B.ptr(ws), flags, B.stream_of(xs[0]))
             entry[1] = True
         ctx.grads = [g.reshape(x.shape) for g, x in zip(grads, xs)] + \
             [out[1 + i].reshape(s.shape).to(s.dtype) for i, s in enumerate(scales)]
@@ -160,7 +177,7 @@ class _ProductPairsLoss(torch.autograd.Function):
     @staticmethod
     def backward(ctx, up):
         from graphembed import _backend as B
-        return (None, None, None, None, None, None) + tuple(B.take_grads(ctx, up, 'grads'))
+        return (None, None, None, None, None, None, None) + tuple(B.take_grads(ctx, up, 'grads'))
 
 
 class ManifoldParameter(torch.nn.Parameter):
@@ -235,7 +252,7 @@ class ManifoldEmbedding(torch.nn.Module):
             softplus(s) * man.pdist(take_rows(x, i), squared=True)
             for x, s, man in zip(self.xs, self.scales, self.manifolds))
 
-    def fused_objective(self, objective_fn, gdists, i=None, rows=None, **kwargs):
+    def fused_objective(self, objective_fn, gdists, i=None, rows=None, dense=None, **kwargs):
         """`objective_fn(gdists, self.compute_dists(i), **kwargs)` evaluated by ONE pair kernel
         that also produces the gradients (no pair vector of distances, no element-wise passes),
         or None when the objective has no fused kernel (a loss without `fused_spec`, CPU tensors).
@@ -243,20 +260,32 @@ class ManifoldEmbedding(torch.nn.Module):
         vector factors (dimension <= 16) and one SPD(2)/SPD(3) factor likewise (the mixed-manifold
         pair kernel `mm_product_pairs_loss`; `self.pair_kernel = False` turns it off); other products
         run one forward and one backward kernel per factor around a single loss kernel
-        (`mm_product_loss`)."""
+        (`mm_product_loss`).  With a node minibatch `i` and the dataset's dense target matrix `dense`
+        (then `gdists` may be None) the pair kernel reads rows `i` of the full tables and the targets
+        `dense[i[a], i[b]]` itself and writes full-size gradients — no gather / scatter launches (the
+        indices of a batch must be distinct, as slices of a `randperm` are: train.py:206-209)."""
         if not hasattr(objective_fn, 'fused_spec') or not self.xs[0].is_cuda:
             return None
         spec = objective_fn.fused_spec(**kwargs)
         if self.n_components == 1 and getattr(self.manifolds[0], 'pdist_loss', None) is not None:
+            if gdists is None:
+                return None
             x = take_rows(self.xs[0], i)
             return self.manifolds[0].pdist_loss(x, self.scales[0], gdists, spec, rows=rows)
         if self.n_components > _max_product_factors():
             return None
-        xs = [take_rows(x, i) for x in self.xs]
         factors = _pair_kernel_factors(self.manifolds) if self.pair_kernel else None
+        if factors is not None and i is not None and dense is not None and dense.is_cuda \
+                and dense.dtype == self.xs[0].dtype:
+            # node minibatch entirely inside the pair kernel: no row gathers, no target gather, no scatter-adds
+            return _ProductPairsLoss.apply(None, spec, rows, tuple(self.manifolds), tuple(factors),
+                                           self._pair_ws, (i, dense), *self.xs, *self.scales)
+        if gdists is None:
+            return None
+        xs = [take_rows(x, i) for x in self.xs]
         if factors is not None:
             return _ProductPairsLoss.apply(gdists, spec, rows, tuple(self.manifolds), tuple(factors),
-                                           self._pair_ws, *xs, *self.scales)
+                                           self._pair_ws, None, *xs, *self.scales)
         return _ProductLoss.apply(gdists, spec, rows, tuple(self.manifolds), *xs, *self.scales)
 
     def __len__(self):
@@ -274,6 +303,14 @@ class BatchedObjective(torch.nn.Module):
         self.fused = fused  # use the one-pass loss+gradient kernel when the configuration has one
 
     def forward(self, indices, *args, **kwargs):
+        emb = self.embedding
+        if self.fused and not args and indices is not None and emb.n_components > 1 and emb.xs[0].is_cuda \
+                and hasattr(self.objective_fn, 'fused_spec') and hasattr(self.dataset, 'pdists'):
+            dense = self.dataset.pdists   # products: the pair kernel gathers rows and targets itself
+            if dense.is_cuda and dense.dtype == emb.xs[0].dtype:
+                loss = emb.fused_objective(self.objective_fn, None, indices, dense=dense, **kwargs)
+                if loss is not None:
+                    return loss
         gdists = self.dataset[indices].to(self.embedding.device)
         if self.fused and not args:
             loss = self.embedding.fused_objective(self.objective_fn, gdists, indices, **kwargs)

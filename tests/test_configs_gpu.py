@@ -321,3 +321,99 @@ def test_graphed_minibatch_steps_match_eager():
         assert torch.equal(obj_e.dataset[batches[0]], sub[iu[0], iu[1]])
     finally:
         torch.set_default_dtype(torch.float32)
+
+
+@pytest.mark.parametrize('dname', ['f32', 'f64'])
+@pytest.mark.parametrize('loss_name', ['stress', 'quotient'])
+def test_product_minibatch_inside_pair_kernel(dname, loss_name):
+    """Node minibatch of a product embedding handled entirely by the mixed-manifold pair kernel
+    (mm_product_pairs_loss_subset: rows, targets and gradient rows addressed through the index vector)
+    == gather rows -> compute_dists -> objective(dataset[idx]) -> autograd (modules.py:84-105,
+    data/dataset.py:19-27), full-size gradients incl. the zero rows; shards of the batch's pair list sum up;
+    and as a replayed graph with the index buffer refreshed in place it tracks the eager loop."""
+    from graphembed import _backend as B
+    from graphembed import manifolds as M
+    from graphembed.data import GraphDataset
+    from graphembed.graphed import GraphedTrainStep
+    from graphembed.modules import BatchedObjective, ManifoldEmbedding
+    from graphembed.objectives import QuotientLoss, StressLoss
+    from graphembed.optim import RiemannianSGD
+    dt = {'f32': torch.float32, 'f64': torch.float64}[dname]
+    n, bs = 700, 200
+    fn, kw = (StressLoss(), {}) if loss_name == 'stress' else (QuotientLoss(), dict(epoch=1, alpha=1.2))
+    tol = 2e-4 if dname == 'f32' else 1e-10
+    torch.set_default_dtype(dt)
+    try:
+        def build():
+            torch.manual_seed(4)
+            with torch.device('cuda'):
+                emb = ManifoldEmbedding(n, [M.Lorentz(6), M.Euclidean(3), M.Sphere(6), M.SymmetricPositiveDefinite(2)])
+                with torch.no_grad():
+                    emb.perturb(0.3)
+                ds = GraphDataset(torch.rand(n * (n - 1) // 2) * 3 + 0.5)
+            return emb, ds
+        emb, ds = build()
+        params = list(emb.xs) + list(emb.scales)
+        idx = torch.randperm(n, device='cuda')[:bs]
+        # reference-shaped path
+        ref = fn(ds[idx], emb.compute_dists(idx), **kw)
+        rg = torch.autograd.grad(ref, params)
+        lib, calls = B.lib(), []
+        orig = lib.call
+        lib.call = lambda name, *a: (calls.append(name), orig(name, *a))[1]
+        try:
+            loss = BatchedObjective(fn, ds, emb)(idx, **kw)
+        finally:
+            del lib.call
+        assert calls == ['mm_product_pairs_loss_subset'], calls
+        g = torch.autograd.grad(loss, params)
+        assert abs(loss.item() - ref.item()) <= tol * abs(ref.item())
+        for a, b in zip(g, rg):
+            assert a.shape == b.shape
+            err = (a - b).abs().max().item() / max(b.abs().max().item(), 1e-30)
+            assert err <= 50 * tol, err
+        rest = torch.ones(n, dtype=torch.bool, device='cuda')
+        rest[idx] = False
+        for a in g[:4]:
+            assert not a[rest].any()          # rows outside the batch: exactly zero
+        tot, gsum = 0.0, [torch.zeros_like(p) for p in params]
+        for r in range(3):
+            rows = B.shard_rows(bs, 3, r)
+            part = emb.fused_objective(fn, None, idx, rows=rows, dense=ds.pdists, **kw)
+            pg = torch.autograd.grad(part, params)
+            tot += part.item()
+            gsum = [s_ + p for s_, p in zip(gsum, pg)]
+        assert abs(tot - ref.item()) <= tol * abs(ref.item())
+        for a, b in zip(gsum, rg):
+            err = (a - b).abs().max().item() / max(b.abs().max().item(), 1e-30)
+            assert err <= 50 * tol, err
+        if loss_name != 'stress':
+            return
+        # graph replay over several batches == eager loop
+        perm = torch.randperm(n, device='cuda')
+        batches = [perm[k * bs:(k + 1) * bs] for k in range(3)] * 2
+
+        def trainer():
+            emb_, ds_ = build()
+            obj = BatchedObjective(fn, ds_, emb_)
+            opts = [RiemannianSGD(list(emb_.xs), lr=0.01, exact=True, max_grad_norm=20),
+                    RiemannianSGD(list(emb_.scales), lr=1e-4, max_grad_norm=500)]
+            return emb_, obj, opts
+        emb_e, obj_e, opts_e = trainer()
+        for b in batches:
+            for o in opts_e:
+                o.zero_grad()
+            obj_e(b).backward()
+            for o in opts_e:
+                o.step()
+        emb_g, obj_g, opts_g = trainer()
+        idx_static = batches[0].clone()
+        step = GraphedTrainStep(lambda: obj_g(idx_static), opts_g, warmup=1).capture()
+        for b in batches[1:]:
+            idx_static.copy_(b)
+            step()
+        for a, b in zip(emb_g.xs, emb_e.xs):
+            np.testing.assert_allclose(a.detach().cpu().numpy(), b.detach().cpu().numpy(),
+                                       rtol=1e-3 if dname == 'f32' else 1e-8, atol=1e-5 if dname == 'f32' else 1e-10)
+    finally:
+        torch.set_default_dtype(torch.float32)

@@ -129,6 +129,8 @@ CASES = {
     'c5_spd4_step_n2274_f32_fused': lambda: step_case([M.SymmetricPositiveDefinite(4)], 2274, torch.float32, fused=True),
     'c3_spd3_minibatch512_step_f32': lambda: minibatch_case([M.SymmetricPositiveDefinite(3)], 5000, 512, torch.float32),
     'c3_spd3_minibatch512_step_f32_graph': lambda: minibatch_case([M.SymmetricPositiveDefinite(3)], 5000, 512, torch.float32, graph=True),
+    'c4_csphd_minibatch512_step_f32_graph': lambda: minibatch_case([M.Lorentz(6), M.Sphere(6), M.SymmetricPositiveDefinite(2)], 1025, 512, torch.float32, graph=True),
+    'c4_csphd_minibatch512_step_f32': lambda: minibatch_case([M.Lorentz(6), M.Sphere(6), M.SymmetricPositiveDefinite(2)], 1025, 512, torch.float32),
     'c2_lorentz11_minibatch512_step_f32': lambda: minibatch_case([M.Lorentz(11)], 4039, 512, torch.float32),
     'sphere6_n5000_f32': lambda: pdist_case(M.Sphere(6), 5000, torch.float32),
     'euclidean10_n5000_f32': lambda: pdist_case(M.Euclidean(10), 5000, torch.float32),

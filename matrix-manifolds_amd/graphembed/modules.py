@@ -77,6 +77,11 @@ class _ProductLoss(torch.autograd.Function):
         return (None, None, None, None) + tuple(B.take_grads(ctx, up, 'grads'))
 
 
+# Largest node minibatch that is handled inside the mixed-manifold pair kernel (beyond it the step is
+# arithmetic again and single factors are better served by their specialised kernels).
+_SUBSET_MAX_NODES = 2048
+
+
 def _pair_kernel_factor(man):
     """(kind, dim) of a factor the single mixed-manifold pair kernel (mm_product_pairs_loss) handles,
     else None."""
@@ -267,6 +272,15 @@ class ManifoldEmbedding(torch.nn.Module):
         if not hasattr(objective_fn, 'fused_spec') or not self.xs[0].is_cuda:
             return None
         spec = objective_fn.fused_spec(**kwargs)
+        in_kernel_batch = (i is not None and dense is not None and dense.is_cuda and self.pair_kernel
+                           and dense.dtype == self.xs[0].dtype and i.numel() <= _SUBSET_MAX_NODES)
+        if in_kernel_batch:
+            # node minibatch entirely inside the pair kernel: no row gathers, no target gather, no scatter-adds
+            # (single factors too: at minibatch sizes a step is launches, not arithmetic)
+            factors = _pair_kernel_factors(self.manifolds)
+            if factors is not None:
+                return _ProductPairsLoss.apply(None, spec, rows, tuple(self.manifolds), tuple(factors),
+                                               self._pair_ws, (i, dense), *self.xs, *self.scales)
         if self.n_components == 1 and getattr(self.manifolds[0], 'pdist_loss', None) is not None:
             if gdists is None:
                 return None
@@ -275,11 +289,6 @@ class ManifoldEmbedding(torch.nn.Module):
         if self.n_components > _max_product_factors():
             return None
         factors = _pair_kernel_factors(self.manifolds) if self.pair_kernel else None
-        if factors is not None and i is not None and dense is not None and dense.is_cuda \
-                and dense.dtype == self.xs[0].dtype:
-            # node minibatch entirely inside the pair kernel: no row gathers, no target gather, no scatter-adds
-            return _ProductPairsLoss.apply(None, spec, rows, tuple(self.manifolds), tuple(factors),
-                                           self._pair_ws, (i, dense), *self.xs, *self.scales)
         if gdists is None:
             return None
         xs = [take_rows(x, i) for x in self.xs]
@@ -304,9 +313,9 @@ class BatchedObjective(torch.nn.Module):
 
     def forward(self, indices, *args, **kwargs):
         emb = self.embedding
-        if self.fused and not args and indices is not None and emb.n_components > 1 and emb.xs[0].is_cuda \
+        if self.fused and not args and indices is not None and emb.xs[0].is_cuda \
                 and hasattr(self.objective_fn, 'fused_spec') and hasattr(self.dataset, 'pdists'):
-            dense = self.dataset.pdists   # products: the pair kernel gathers rows and targets itself
+            dense = self.dataset.pdists   # the pair kernel gathers rows and targets itself
             if dense.is_cuda and dense.dtype == emb.xs[0].dtype:
                 loss = emb.fused_objective(self.objective_fn, None, indices, dense=dense, **kwargs)
                 if loss is not None:

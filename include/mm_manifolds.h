@@ -104,12 +104,15 @@ int mm_spd_pdist_bwd(int dtype, const void* x, const void* g, int64_t n, int d,
  *                                                                            objectives.py:16-36
  *   target     pair vector (layout of mm_spd_pdist_fwd's `out`) of squared graph distances
  *   scale_raw  device scalar (the raw scale parameter) or NULL for scale 1
+ *   loss_params  NULL, or a device fp64 array {alpha, eps} that overrides the two by-value arguments
+ *              (quotient loss): a captured graph of a step then follows eps = 1/(epoch+1) across epochs
+ *              by updating that array, without being re-recorded.  Same argument in every *_loss entry.
  *   loss_out   device [2]: { loss of this shard, d loss / d scale_raw of this shard }
  *   grad_x     [n,d,d], OVERWRITTEN with this shard's partial d loss / d x. */
 enum { MM_LOSS_NONE = 0, MM_LOSS_STRESS = 1, MM_LOSS_QUOTIENT = 2 };
 int mm_spd_pdist_loss(int dtype, int loss_kind, const void* x, const void* target,
                       const void* scale_raw, int64_t n, int d, int64_t row_begin, int64_t row_end,
-                      double alpha, double eps, int terms, double wmin, double wmax,
+                      double alpha, double eps, int terms, const double* loss_params, double wmin, double wmax,
                       void* loss_out, void* grad_x, void* ws, int flags, mm_stream_t stream);
 
 /* Stein divergence S(X,Y) = log det((X+Y)/2) - (log det X + log det Y)/2 — the second SPD "distance" of the
@@ -197,7 +200,7 @@ int mm_vec_pdist_bwd_gram(int dtype, int kind, const void* x, const void* g, int
  * mm_spd_pdist_loss (same loss kinds, arguments and outputs; squared distances). */
 int mm_vec_pdist_loss(int dtype, int kind, int loss_kind, const void* x, const void* target,
                       const void* scale_raw, int64_t n, int m, int64_t row_begin, int64_t row_end,
-                      double alpha, double eps, int terms, void* loss_out, void* grad_x, void* ws,
+                      double alpha, double eps, int terms, const double* loss_params, void* loss_out, void* grad_x, void* ws,
                       mm_stream_t stream);
 /* Element-wise dist over cnt pairs (x[k],y[k]).  out may be NULL (backward only);
  * grad_x/grad_y may both be NULL (forward only), else g [cnt] is required. */
@@ -291,7 +294,7 @@ int mm_grass_pdist_bwd(int dtype, const void* x, const void* g, int64_t n, int N
 int mm_product_max_factors(void);
 size_t mm_product_loss_ws_bytes(int dtype, int nf);
 int mm_product_loss(int dtype, int loss_kind, int nf, const void* const* d2, const void* target,
-                    const void* const* scale_raw, int64_t npairs, double alpha, double eps, int terms,
+                    const void* const* scale_raw, int64_t npairs, double alpha, double eps, int terms, const double* loss_params,
                     void* const* g_out, void* loss_out, void* ws, mm_stream_t stream);
 
 /* The same objective in ONE pair kernel over all factors (the csphd configuration: Lorentz x sphere x
@@ -314,7 +317,7 @@ size_t mm_product_pairs_ws_bytes(int dtype, int nf, const int* kinds, const int*
 int mm_product_pairs_loss(int dtype, int loss_kind, int nf, const int* kinds, const int* dims,
                           const void* const* xs, const void* const* scale_raw, const void* target,
                           int64_t n, int64_t row_begin, int64_t row_end, double alpha, double eps,
-                          int terms, double wmin, double wmax, void* const* grads, void* loss_out,
+                          int terms, const double* loss_params, double wmin, double wmax, void* const* grads, void* loss_out,
                           void* ws, int flags, mm_stream_t stream);
 
 /* The same for a node minibatch (train.py:198-222, batch_size = 512 in the paper grid) without any gather or
@@ -326,7 +329,7 @@ int mm_product_pairs_loss(int dtype, int loss_kind, int nf, const int* kinds, co
 int mm_product_pairs_loss_subset(int dtype, int loss_kind, int nf, const int* kinds, const int* dims,
                                  const void* const* xs, const void* const* scale_raw, const void* dense,
                                  int64_t n_total, const int64_t* idx, int64_t bs, int64_t row_begin,
-                                 int64_t row_end, double alpha, double eps, int terms, double wmin,
+                                 int64_t row_end, double alpha, double eps, int terms, const double* loss_params, double wmin,
                                  double wmax, void* const* grads, void* loss_out, void* ws, int flags,
                                  mm_stream_t stream);
 

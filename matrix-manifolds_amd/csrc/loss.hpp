@@ -18,7 +18,15 @@ template <typename T> struct LossArgs {
   T alpha, eps;        // quotient loss: target * alpha, 1 / (epoch + 1)
   int terms;           // quotient loss: bit 0 = |m/(a g) - 1|, bit 1 = |a g/(m + eps) - 1|
   T* slots;            // [2][kLossSlots]
+  // optional device array {alpha, eps}: when set it overrides the two values above, so that a captured graph
+  // of a training step follows the quotient loss's per-epoch eps = 1/(epoch+1) without being re-recorded
+  const double* dyn;
 };
+template <typename T, int LOSS> __device__ __forceinline__ void loss_resolve(LossArgs<T>& la) {
+  if constexpr (LOSS == MM_LOSS_QUOTIENT) {
+    if (la.dyn) { la.alpha = T(la.dyn[0]); la.eps = T(la.dyn[1]); }
+  }
+}
 template <typename T> __device__ __forceinline__ T softplus_of(const T* raw) {
   if (!raw) return T(1);
   const T v = *raw;  // torch.nn.functional.softplus: beta = 1, threshold = 20

@@ -27,6 +27,7 @@ template <typename T, int LOSS>
 __global__ __launch_bounds__(256) void product_loss_kernel(ProductArgs<T> pa, const T* __restrict__ target,
                                                            int64_t npairs, LossArgs<T> la) {
   T sp[kMaxFactors], ds[kMaxFactors];
+  loss_resolve<T, LOSS>(la);
 #pragma unroll
   for (int k = 0; k < kMaxFactors; ++k) { sp[k] = k < pa.nf ? softplus_of(pa.scale_raw[k]) : T(0); ds[k] = T(0); }
   T loss = T(0);
@@ -78,7 +79,7 @@ __global__ void product_loss_finalize_kernel(ProductArgs<T> pa, T* __restrict__ 
 
 template <typename T>
 int product_loss_t(int loss_kind, int nf, const void* const* d2, const void* target, const void* const* scale_raw,
-                   int64_t npairs, double alpha, double eps, int terms, void* const* g_out, void* loss_out, void* ws,
+                   int64_t npairs, double alpha, double eps, int terms, const double* loss_params, void* const* g_out, void* loss_out, void* ws,
                    hipStream_t st) {
   ProductArgs<T> pa;
   pa.nf = nf;
@@ -90,7 +91,7 @@ int product_loss_t(int loss_kind, int nf, const void* const* d2, const void* tar
   T* slots = static_cast<T*>(ws);
   hipError_t e = hipMemsetAsync(slots, 0, sizeof(T) * size_t(1 + nf) * kLossSlots, st);
   if (e != hipSuccess) return int(e);
-  LossArgs<T> la{nullptr, T(alpha), T(eps), terms, slots};
+  LossArgs<T> la{nullptr, T(alpha), T(eps), terms, slots, loss_params};
   if (npairs > 0) {
     const int blocks = int(npairs / 1024 < 1 ? 1 : (npairs / 1024 > 2048 ? 2048 : npairs / 1024));
     if (loss_kind == MM_LOSS_STRESS)
@@ -127,7 +128,7 @@ int mm_product_max_factors(void) { return kMaxFactors; }
 size_t mm_product_loss_ws_bytes(int dtype, int nf) { return (dtype == MM_F64 ? 8 : 4) * size_t(1 + nf) * kLossSlots; }
 
 int mm_product_loss(int dtype, int loss_kind, int nf, const void* const* d2, const void* target,
-                    const void* const* scale_raw, int64_t npairs, double alpha, double eps, int terms,
+                    const void* const* scale_raw, int64_t npairs, double alpha, double eps, int terms, const double* loss_params,
                     void* const* g_out, void* loss_out, void* ws, mm_stream_t stream) {
   if (nf < 1 || nf > kMaxFactors || !d2 || !scale_raw || !g_out || !loss_out || !ws || npairs < 0 || (npairs > 0 && !target))
     return MM_ERR_ARG;
@@ -137,9 +138,9 @@ int mm_product_loss(int dtype, int loss_kind, int nf, const void* const* d2, con
   if (loss_kind == MM_LOSS_QUOTIENT && !(terms & 3)) return MM_ERR_ARG;
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (dtype == MM_F32)
-    return product_loss_t<float>(loss_kind, nf, d2, target, scale_raw, npairs, alpha, eps, terms, g_out, loss_out, ws, st);
+    return product_loss_t<float>(loss_kind, nf, d2, target, scale_raw, npairs, alpha, eps, terms, loss_params, g_out, loss_out, ws, st);
   if (dtype == MM_F64)
-    return product_loss_t<double>(loss_kind, nf, d2, target, scale_raw, npairs, alpha, eps, terms, g_out, loss_out, ws, st);
+    return product_loss_t<double>(loss_kind, nf, d2, target, scale_raw, npairs, alpha, eps, terms, loss_params, g_out, loss_out, ws, st);
   return MM_ERR_ARG;
 }
 

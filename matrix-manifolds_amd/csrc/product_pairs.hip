@@ -92,6 +92,7 @@ __global__ __launch_bounds__(kPCols * kPWaves) void product_pair_kernel(PArgs<T>
                                                                int row_begin, int row_end, int ti, LossArgs<T> la) {
   constexpr int NPS = SD > 0 ? Packed<(SD > 0 ? SD : 2)>::NP : 1;
   constexpr int DS = SD > 0 ? SD : 2;
+  loss_resolve<T, LOSS>(la);
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int j = blockIdx.x * kPCols + lane;
   const int i0 = min((blockIdx.y * kPWaves + wave) * ti, n), i1 = min(i0 + ti, n);
@@ -409,7 +410,7 @@ int product_pairs_launch(int loss_kind, PArgs<T> pa, const T* target, int64_t n,
 template <typename T>
 int product_pairs_t(int loss_kind, int nf, const int* kinds, const int* dims, const void* const* xs,
                     const void* const* scale_raw, const void* target, int64_t n, int64_t rb, int64_t re, double alpha,
-                    double eps, int terms, double wmin, double wmax, void* const* grads, void* loss_out, void* wsp,
+                    double eps, int terms, const double* loss_params, double wmin, double wmax, void* const* grads, void* loss_out, void* wsp,
                     int flags, hipStream_t st, const int64_t* idx = nullptr, const void* dense = nullptr,
                     int64_t dense_n = 0) {
   PArgs<T> pa{};
@@ -453,7 +454,7 @@ int product_pairs_t(int loss_kind, int nf, const int* kinds, const int* dims, co
     hipError_t e = hipMemsetAsync(slots, 0, sizeof(T) * (size_t(1 + nf) * kLossSlots + acc_elems), st);
     if (e != hipSuccess) return int(e);
   }
-  LossArgs<T> la{nullptr, T(alpha), T(eps), terms, slots};
+  LossArgs<T> la{nullptr, T(alpha), T(eps), terms, slots, loss_params};
   const T* tg = static_cast<const T*>(target);
   T* lo = static_cast<T*>(loss_out);
 #define MM_PP(NV_, SD_) return product_pairs_launch<T, NV_, SD_>(loss_kind, pa, tg, n, rb, re, la, lo, st)
@@ -490,7 +491,7 @@ size_t mm_product_pairs_ws_bytes(int dtype, int nf, const int* kinds, const int*
 
 int mm_product_pairs_loss(int dtype, int loss_kind, int nf, const int* kinds, const int* dims, const void* const* xs,
                           const void* const* scale_raw, const void* target, int64_t n, int64_t row_begin,
-                          int64_t row_end, double alpha, double eps, int terms, double wmin, double wmax,
+                          int64_t row_end, double alpha, double eps, int terms, const double* loss_params, double wmin, double wmax,
                           void* const* grads, void* loss_out, void* ws, int flags, mm_stream_t stream) {
   if (nf < 1 || nf > 4 || !kinds || !dims || !xs || !scale_raw || !grads || !loss_out || !ws || n < 1 ||
       n > (1 << 30) || row_begin < 0 || row_end > n || row_begin > row_end)
@@ -503,17 +504,17 @@ int mm_product_pairs_loss(int dtype, int loss_kind, int nf, const int* kinds, co
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (dtype == MM_F32)
     return product_pairs_t<float>(loss_kind, nf, kinds, dims, xs, scale_raw, target, n, row_begin, row_end, alpha, eps,
-                                  terms, wmin, wmax, grads, loss_out, ws, flags, st);
+                                  terms, loss_params, wmin, wmax, grads, loss_out, ws, flags, st);
   if (dtype == MM_F64)
     return product_pairs_t<double>(loss_kind, nf, kinds, dims, xs, scale_raw, target, n, row_begin, row_end, alpha, eps,
-                                   terms, wmin, wmax, grads, loss_out, ws, flags, st);
+                                   terms, loss_params, wmin, wmax, grads, loss_out, ws, flags, st);
   return MM_ERR_ARG;
 }
 
 int mm_product_pairs_loss_subset(int dtype, int loss_kind, int nf, const int* kinds, const int* dims,
                                  const void* const* xs, const void* const* scale_raw, const void* dense,
                                  int64_t n_total, const int64_t* idx, int64_t bs, int64_t row_begin, int64_t row_end,
-                                 double alpha, double eps, int terms, double wmin, double wmax, void* const* grads,
+                                 double alpha, double eps, int terms, const double* loss_params, double wmin, double wmax, void* const* grads,
                                  void* loss_out, void* ws, int flags, mm_stream_t stream) {
   if (nf < 1 || nf > 4 || !kinds || !dims || !xs || !scale_raw || !grads || !loss_out || !ws || !idx || !dense ||
       bs < 1 || bs > n_total || n_total >= (int64_t(1) << 31) || row_begin < 0 || row_end > bs || row_begin > row_end)
@@ -525,10 +526,10 @@ int mm_product_pairs_loss_subset(int dtype, int loss_kind, int nf, const int* ki
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (dtype == MM_F32)
     return product_pairs_t<float>(loss_kind, nf, kinds, dims, xs, scale_raw, nullptr, bs, row_begin, row_end, alpha, eps,
-                                  terms, wmin, wmax, grads, loss_out, ws, flags, st, idx, dense, n_total);
+                                  terms, loss_params, wmin, wmax, grads, loss_out, ws, flags, st, idx, dense, n_total);
   if (dtype == MM_F64)
     return product_pairs_t<double>(loss_kind, nf, kinds, dims, xs, scale_raw, nullptr, bs, row_begin, row_end, alpha,
-                                   eps, terms, wmin, wmax, grads, loss_out, ws, flags, st, idx, dense, n_total);
+                                   eps, terms, loss_params, wmin, wmax, grads, loss_out, ws, flags, st, idx, dense, n_total);
   return MM_ERR_ARG;
 }
 

@@ -279,6 +279,7 @@ __global__ __launch_bounds__((64 * bwd_waves<T, D>())) void spd_pdist_bwd_kernel
   // LOSS != 0: `g` holds the TARGET (graph) squared distances; the upstream gradient of each pair is
   // derived in registers from the loss, and the loss / scale-gradient sums leave through la.slots.
   T sp = T(1), loss_acc = T(0), ds_acc = T(0);
+  loss_resolve<T, LOSS>(la);
   if constexpr (LOSS != MM_LOSS_NONE) sp = softplus_of(la.scale_raw);
   // Workgroup tile: 64 columns x (NW waves x TI rows).  The wavefronts share the columns, so
   // their column-side partial sums are combined through LDS and flushed with ONE set of atomics:
@@ -842,13 +843,13 @@ int spd_pdist_bwd_ti(Ws<T>& ws, const T* g, int64_t n, int64_t rb, int64_t re, i
 // loss + gradients in one pass over the pairs (no pair vector of distances is ever written)
 template <typename T, int D>
 int spd_pdist_loss_t(int kind, const T* x, const T* target, const T* scale_raw, int64_t n, int64_t rb, int64_t re,
-                     double alpha, double eps, int terms, double wmin, double wmax, T* loss_out, T* grad, void* wsp,
+                     double alpha, double eps, int terms, const double* loss_params, double wmin, double wmax, T* loss_out, T* grad, void* wsp,
                      int flags, hipStream_t st) {
   Ws<T> ws(wsp, n, D);
   int rc = spd_pdist_prepare<T, D>(x, n, ws, flags, st);
   if (rc) return rc;
   if (re > rb && pair_off(n, re) > pair_off(n, rb)) {
-    LossArgs<T> la{scale_raw, T(alpha), T(eps), terms, ws.loss};
+    LossArgs<T> la{scale_raw, T(alpha), T(eps), terms, ws.loss, loss_params};
     const bool tall = bwd_tile_rows(pair_off(n, re) - pair_off(n, rb)) >= 16;
     if (kind == MM_LOSS_STRESS)
       rc = tall ? spd_pdist_bwd_ti<T, D, 16, MM_LOSS_STRESS>(ws, target, n, rb, re, 1, wmin, wmax, st, la)
@@ -962,7 +963,7 @@ int mm_spd_pdist_bwd(int dtype, const void* x, const void* g, int64_t n, int d, 
 }
 
 int mm_spd_pdist_loss(int dtype, int loss_kind, const void* x, const void* target, const void* scale_raw, int64_t n,
-                      int d, int64_t row_begin, int64_t row_end, double alpha, double eps, int terms, double wmin,
+                      int d, int64_t row_begin, int64_t row_end, double alpha, double eps, int terms, const double* loss_params, double wmin,
                       double wmax, void* loss_out, void* grad_x, void* ws, int flags, mm_stream_t stream) {
   if (!x || !ws || !grad_x || !loss_out || n < 0 || row_begin < 0 || row_end > n || row_begin > row_end ||
       n > (1 << 30))
@@ -978,7 +979,7 @@ int mm_spd_pdist_loss(int dtype, int loss_kind, const void* x, const void* targe
   }
   MM_DISPATCH(dtype, d,
               (spd_pdist_loss_t<T, D>(loss_kind, static_cast<const T*>(x), static_cast<const T*>(target),
-                                      static_cast<const T*>(scale_raw), n, row_begin, row_end, alpha, eps, terms, wmin,
+                                      static_cast<const T*>(scale_raw), n, row_begin, row_end, alpha, eps, terms, loss_params, wmin,
                                       wmax, static_cast<T*>(loss_out), static_cast<T*>(grad_x), ws, flags, st)));
 }
 

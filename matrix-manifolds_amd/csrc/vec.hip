@@ -95,6 +95,7 @@ __global__ __launch_bounds__(kVBlock) void vec_pdist_bwd_kernel(const T* __restr
 #pragma unroll
   for (int k = 0; k < MP; ++k) a[k] = T(0);
   T wsum = T(0), sp = T(1), loss_acc = T(0), ds_acc = T(0);
+  loss_resolve<T, LOSS>(la);
   if constexpr (LOSS != MM_LOSS_NONE) sp = softplus_of(la.scale_raw);
   const int64_t base = vpair_off(n, row_begin);
   // The per-pair arithmetic (~45 VALU ops) is far too short to hide the latency of the load
@@ -504,8 +505,8 @@ int vec_bwd_t(const T* x, const T* g, int64_t n, int m, int64_t rb, int64_t re, 
 
 template <typename T, int KIND, int MP>
 int vec_loss_t(int loss_kind, const T* x, const T* target, const T* scale_raw, int64_t n, int m, int64_t rb, int64_t re,
-               double alpha, double eps, int terms, T* loss_out, T* grad, void* ws, hipStream_t st) {
-  LossArgs<T> la{scale_raw, T(alpha), T(eps), terms, nullptr};
+               double alpha, double eps, int terms, const double* loss_params, T* loss_out, T* grad, void* ws, hipStream_t st) {
+  LossArgs<T> la{scale_raw, T(alpha), T(eps), terms, nullptr, loss_params};
   if (loss_kind == MM_LOSS_STRESS)
     return vec_bwd_t<T, KIND, MP, MM_LOSS_STRESS>(x, target, n, m, rb, re, 1, grad, ws, st, la, loss_out);
   return vec_bwd_t<T, KIND, MP, MM_LOSS_QUOTIENT>(x, target, n, m, rb, re, 1, grad, ws, st, la, loss_out);
@@ -539,7 +540,7 @@ constexpr int pad_dim(int m) { return m <= 4 ? 4 : m <= 8 ? 8 : m <= 12 ? 12 : m
 // matrix-core path of the fused objective (vec_gram.hip)
 bool vec_gram_supports(int dtype, int kind, int64_t n, int m);
 int vec_gram_loss(int dtype, int kind, int loss_kind, const void* x, const void* target, const void* scale_raw, int64_t n,
-                  int m, int64_t row_begin, int64_t row_end, double alpha, double eps, int terms, void* loss_out,
+                  int m, int64_t row_begin, int64_t row_end, double alpha, double eps, int terms, const double* loss_params, void* loss_out,
                   void* grad, void* slots, hipStream_t st);
 
 template <typename T>
@@ -626,7 +627,7 @@ int mm_vec_pdist_bwd(int dtype, int kind, const void* x, const void* g, int64_t 
 }
 
 int mm_vec_pdist_loss(int dtype, int kind, int loss_kind, const void* x, const void* target, const void* scale_raw,
-                      int64_t n, int m, int64_t row_begin, int64_t row_end, double alpha, double eps, int terms,
+                      int64_t n, int m, int64_t row_begin, int64_t row_end, double alpha, double eps, int terms, const double* loss_params,
                       void* loss_out, void* grad_x, void* ws, mm_stream_t stream) {
   if (!x || !grad_x || !ws || !loss_out || n < 1 || m < 1 || row_begin < 0 || row_end > n || row_begin > row_end ||
       n > (1 << 30))
@@ -637,11 +638,11 @@ int mm_vec_pdist_loss(int dtype, int kind, int loss_kind, const void* x, const v
   if (!target && mm_pair_offset(n, row_end) > mm_pair_offset(n, row_begin)) return MM_ERR_ARG;
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (vec_gram_supports(dtype, kind, n, m) && !std::getenv("MM_VEC_LOSS_VALU"))  // inner-product manifolds: MFMA
-    return vec_gram_loss(dtype, kind, loss_kind, x, target, scale_raw, n, m, row_begin, row_end, alpha, eps, terms,
+    return vec_gram_loss(dtype, kind, loss_kind, x, target, scale_raw, n, m, row_begin, row_end, alpha, eps, terms, loss_params,
                          loss_out, grad_x, ws, st);
   MMV_DISPATCH_T(dtype, MMV_DISPATCH_KIND(kind, MMV_DISPATCH_MP(m, (vec_loss_t<T, KIND, MP>(
       loss_kind, static_cast<const T*>(x), static_cast<const T*>(target), static_cast<const T*>(scale_raw), n, m,
-      row_begin, row_end, alpha, eps, terms, static_cast<T*>(loss_out), static_cast<T*>(grad_x), ws, st)))))
+      row_begin, row_end, alpha, eps, terms, loss_params, static_cast<T*>(loss_out), static_cast<T*>(grad_x), ws, st)))))
 }
 
 int mm_vec_dist(int dtype, int kind, const void* x, const void* y, const void* g, int64_t cnt, int m, int squared,

@@ -202,6 +202,7 @@ void vec_gram_bwd_f32_kernel(const float* __restrict__ x, const float* __restric
 #pragma unroll
   for (int q = 0; q < 16; ++q) accJ[q] = 0.f;
   float sp = 1.f, loss_acc = 0.f, ds_acc = 0.f;
+  loss_resolve<float, LOSS>(la);
   if constexpr (LOSS != MM_LOSS_NONE) sp = softplus_of(la.scale_raw);
   const float kInvalid = LOSS != MM_LOSS_NONE ? __builtin_nanf("") : 0.f;
   const u32 base = u32(gpair_off(n, row_begin));
@@ -533,11 +534,11 @@ bool vec_gram_bwd_supports(int dtype, int kind, int64_t n, int m, int squared) {
 }
 template <typename T>
 int vec_gram_loss_t(int kind, int loss_kind, const T* x, const T* target, const T* scale_raw, int64_t n, int m,
-                    int64_t row_begin, int64_t row_end, double alpha, double eps, int terms, T* loss_out, T* grad,
+                    int64_t row_begin, int64_t row_end, double alpha, double eps, int terms, const double* loss_params, T* loss_out, T* grad,
                     T* slots, hipStream_t st) {
   hipError_t e = hipMemsetAsync(slots, 0, sizeof(T) * 2 * kLossSlots, st);
   if (e != hipSuccess) return int(e);
-  LossArgs<T> la{scale_raw, T(alpha), T(eps), terms, slots};
+  LossArgs<T> la{scale_raw, T(alpha), T(eps), terms, slots, loss_params};
   const int rc = vec_gram_bwd_launch(kind, loss_kind, x, target, n, m, row_begin, row_end, 1, grad, la, st);
   if (rc) return rc;
   gram_loss_finalize_kernel<T><<<dim3(1), dim3(64), 0, st>>>(slots, scale_raw, loss_out);
@@ -546,14 +547,14 @@ int vec_gram_loss_t(int kind, int loss_kind, const T* x, const T* target, const 
 }
 // mm_vec_pdist_loss on the matrix cores (called from vec.hip when the configuration qualifies)
 int vec_gram_loss(int dtype, int kind, int loss_kind, const void* x, const void* target, const void* scale_raw, int64_t n,
-                  int m, int64_t row_begin, int64_t row_end, double alpha, double eps, int terms, void* loss_out,
+                  int m, int64_t row_begin, int64_t row_end, double alpha, double eps, int terms, const double* loss_params, void* loss_out,
                   void* grad, void* slots, hipStream_t st) {
   if (dtype == MM_F32)
     return vec_gram_loss_t<float>(kind, loss_kind, static_cast<const float*>(x), static_cast<const float*>(target),
-                                  static_cast<const float*>(scale_raw), n, m, row_begin, row_end, alpha, eps, terms,
+                                  static_cast<const float*>(scale_raw), n, m, row_begin, row_end, alpha, eps, terms, loss_params,
                                   static_cast<float*>(loss_out), static_cast<float*>(grad), static_cast<float*>(slots), st);
   return vec_gram_loss_t<double>(kind, loss_kind, static_cast<const double*>(x), static_cast<const double*>(target),
-                                 static_cast<const double*>(scale_raw), n, m, row_begin, row_end, alpha, eps, terms,
+                                 static_cast<const double*>(scale_raw), n, m, row_begin, row_end, alpha, eps, terms, loss_params,
                                  static_cast<double*>(loss_out), static_cast<double*>(grad), static_cast<double*>(slots),
                                  st);
 }

@@ -33,6 +33,7 @@ __global__ __launch_bounds__(64 * kGramBwdWaves) void vec_gram_bwd_f64_kernel(co
   }
   f64x4 accJ = {0.0, 0.0, 0.0, 0.0};
   double sp = 1.0, loss_acc = 0.0, ds_acc = 0.0;
+  loss_resolve<double, LOSS>(la);
   if constexpr (LOSS != MM_LOSS_NONE) sp = softplus_of(la.scale_raw);
   const double kInvalid = LOSS != MM_LOSS_NONE ? __builtin_nan("") : 0.0;
   const u32 base = u32(gpair_off(n, row_begin));

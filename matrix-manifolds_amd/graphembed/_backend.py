@@ -37,11 +37,11 @@ SIGNATURES = {
     'mm_pair_gather': (_i, [_i, _vp, _i64, _vp, _i64, _vp, _vp]),
     'mm_product_max_factors': (_i, []),
     'mm_product_loss_ws_bytes': (_sz, [_i, _i]),
-    'mm_product_loss': (_i, [_i, _i, _i, _c.POINTER(_vp), _vp, _c.POINTER(_vp), _i64, _dbl, _dbl, _i,
+    'mm_product_loss': (_i, [_i, _i, _i, _c.POINTER(_vp), _vp, _c.POINTER(_vp), _i64, _dbl, _dbl, _i, _vp,
                               _c.POINTER(_vp), _vp, _vp, _vp]),
     'mm_product_pairs_ws_bytes': (_sz, [_i, _i, _c.POINTER(_i), _c.POINTER(_i), _i64]),
     'mm_product_pairs_loss': (_i, [_i, _i, _i, _c.POINTER(_i), _c.POINTER(_i), _c.POINTER(_vp), _c.POINTER(_vp),
-                                    _vp, _i64, _i64, _i64, _dbl, _dbl, _i, _dbl, _dbl, _c.POINTER(_vp), _vp, _vp,
+                                    _vp, _i64, _i64, _i64, _dbl, _dbl, _i, _vp, _dbl, _dbl, _c.POINTER(_vp), _vp, _vp,
                                     _i, _vp]),
     'mm_spd_prepare': (_i, [_i, _vp, _i64, _i, _vp, _vp]),
     'mm_vec_rsgd_multi_max': (_i, []),
@@ -55,13 +55,13 @@ SIGNATURES = {
                                       _c.POINTER(_vp), _c.POINTER(_vp), _c.POINTER(_vp), _c.POINTER(_i64),
                                       _c.POINTER(_i), _dbl, _dbl, _dbl, _i, _dbl, _dbl, _i, _c.POINTER(_vp), _vp]),
     'mm_product_pairs_loss_subset': (_i, [_i, _i, _i, _c.POINTER(_i), _c.POINTER(_i), _c.POINTER(_vp),
-                                           _c.POINTER(_vp), _vp, _i64, _vp, _i64, _i64, _i64, _dbl, _dbl, _i, _dbl,
+                                           _c.POINTER(_vp), _vp, _i64, _vp, _i64, _i64, _i64, _dbl, _dbl, _i, _vp, _dbl,
                                            _dbl, _c.POINTER(_vp), _vp, _vp, _i, _vp]),
     'mm_spd_max_dim': (_i, []),
     'mm_spd_pdist_ws_bytes': (_sz, [_i, _i64, _i]),
     'mm_spd_pdist_fwd': (_i, [_i, _vp, _i64, _i, _i64, _i64, _i, _dbl, _dbl, _vp, _vp, _i, _vp]),
     'mm_spd_pdist_bwd': (_i, [_i, _vp, _vp, _i64, _i, _i64, _i64, _i, _dbl, _dbl, _vp, _vp, _i, _vp]),
-    'mm_spd_pdist_loss': (_i, [_i, _i, _vp, _vp, _vp, _i64, _i, _i64, _i64, _dbl, _dbl, _i, _dbl, _dbl, _vp, _vp,
+    'mm_spd_pdist_loss': (_i, [_i, _i, _vp, _vp, _vp, _i64, _i, _i64, _i64, _dbl, _dbl, _i, _vp, _dbl, _dbl, _vp, _vp,
                                 _vp, _i, _vp]),
     'mm_spd_stein_pdiv_fwd': (_i, [_i, _vp, _i64, _i, _i64, _i64, _i, _dbl, _vp, _vp, _i, _vp]),
     'mm_spd_stein_pdiv_bwd': (_i, [_i, _vp, _vp, _i64, _i, _i64, _i64, _i, _dbl, _vp, _vp, _i, _vp]),
@@ -78,7 +78,7 @@ SIGNATURES = {
     'mm_vec_pdist_fwd_gram': (_i, [_i, _i, _vp, _i64, _i, _i64, _i64, _i, _vp, _vp]),
     'mm_vec_pdist_bwd': (_i, [_i, _i, _vp, _vp, _i64, _i, _i64, _i64, _i, _vp, _vp, _vp]),
     'mm_vec_pdist_bwd_gram': (_i, [_i, _i, _vp, _vp, _i64, _i, _i64, _i64, _i, _vp, _vp]),
-    'mm_vec_pdist_loss': (_i, [_i, _i, _i, _vp, _vp, _vp, _i64, _i, _i64, _i64, _dbl, _dbl, _i, _vp, _vp, _vp, _vp]),
+    'mm_vec_pdist_loss': (_i, [_i, _i, _i, _vp, _vp, _vp, _i64, _i, _i64, _i64, _dbl, _dbl, _i, _vp, _vp, _vp, _vp, _vp]),
     'mm_vec_dist': (_i, [_i, _i, _vp, _vp, _vp, _i64, _i, _i, _vp, _vp, _vp, _vp]),
     'mm_vec_map': (_i, [_i, _i, _i, _vp, _vp, _vp, _i64, _i, _vp, _vp]),
     'mm_vec_norm': (_i, [_i, _i, _vp, _i64, _i, _i, _vp, _vp]),

@@ -89,7 +89,8 @@ class _SpdPdistLoss(torch.autograd.Function):
         xc = x.detach().contiguous()
         n = xc.shape[0]
         dt = B.dtype_code(xc)
-        kind, alpha, eps, terms = spec
+        kind, alpha, eps, terms = spec[:4]
+        dyn = spec[4] if len(spec) > 4 else None  # device {alpha, eps} (QuotientLoss.on_device)
         tc = target.detach().to(xc.dtype).contiguous()
         npairs = B.pair_offset(n, row_end) - B.pair_offset(n, row_begin)
         if tc.numel() != npairs:
@@ -101,7 +102,7 @@ class _SpdPdistLoss(torch.autograd.Function):
             out = torch.empty(2, dtype=xc.dtype, device=xc.device)
             grad = torch.empty_like(xc)
             lib.call('mm_spd_pdist_loss', dt, B.LOSS_STRESS if kind == 'stress' else B.LOSS_QUOTIENT,
-                     B.ptr(xc), B.ptr(tc), B.ptr(sc), n, n_mat, row_begin, row_end, alpha, eps, terms,
+                     B.ptr(xc), B.ptr(tc), B.ptr(sc), n, n_mat, row_begin, row_end, alpha, eps, terms, B.ptr(dyn),
                      wmin, wmax, B.ptr(out), B.ptr(grad), B.ptr(ws), 0, B.stream_of(xc))
         ctx.grad_x = grad
         ctx.grad_s = None if scale is None else out[1].reshape(scale.shape).to(scale.dtype)

@@ -68,7 +68,8 @@ class _VecPdistLoss(torch.autograd.Function):
         n = x.shape[0]
         xc = x.detach().reshape(n, m).contiguous()
         dt = B.dtype_code(xc)
-        lkind, alpha, eps, terms = spec
+        lkind, alpha, eps, terms = spec[:4]
+        dyn = spec[4] if len(spec) > 4 else None  # device {alpha, eps} (QuotientLoss.on_device)
         tc = target.detach().to(xc.dtype).contiguous()
         npairs = B.pair_offset(n, row_end) - B.pair_offset(n, row_begin)
         if tc.numel() != npairs:
@@ -80,7 +81,7 @@ class _VecPdistLoss(torch.autograd.Function):
             out = torch.empty(2, dtype=xc.dtype, device=xc.device)
             grad = torch.empty_like(xc)
             lib.call('mm_vec_pdist_loss', dt, kind, B.LOSS_STRESS if lkind == 'stress' else B.LOSS_QUOTIENT,
-                     B.ptr(xc), B.ptr(tc), B.ptr(sc), n, m, row_begin, row_end, alpha, eps, terms,
+                     B.ptr(xc), B.ptr(tc), B.ptr(sc), n, m, row_begin, row_end, alpha, eps, terms, B.ptr(dyn),
                      B.ptr(out), B.ptr(grad), B.ptr(ws), B.stream_of(xc))
         ctx.grad_x = grad.reshape(x.shape)
         ctx.grad_s = None if scale is None else out[1].reshape(scale.shape).to(scale.dtype)

@@ -47,7 +47,8 @@ class _ProductLoss(torch.autograd.Function):
         xs, scales = params[:k], params[k:]
         B.require_gpu(*xs)
         lib = B.lib()
-        kind, alpha, eps, terms = spec
+        kind, alpha, eps, terms = spec[:4]
+        dyn = spec[4] if len(spec) > 4 else None
         dtype = xs[0].dtype
         with torch.enable_grad():
             leaves = [x.detach().requires_grad_() for x in xs]
@@ -66,7 +67,7 @@ class _ProductLoss(torch.autograd.Function):
             ws = torch.empty(lib.raw('mm_product_loss_ws_bytes')(dt, k), dtype=torch.uint8, device=dev)
             lib.call('mm_product_loss', dt, B.LOSS_STRESS if kind == 'stress' else B.LOSS_QUOTIENT, k,
                      B.ptr_array([d.detach() for d in d2]), B.ptr(tc), B.ptr_array(sc), npairs, alpha, eps,
-                     terms, B.ptr_array(gs), B.ptr(out), B.ptr(ws), B.stream_of(xs[0]))
+                     terms, B.ptr(dyn), B.ptr_array(gs), B.ptr(out), B.ptr(ws), B.stream_of(xs[0]))
             grads = [torch.autograd.grad(d, x, g)[0] for d, x, g in zip(d2, leaves, gs)]
         ctx.grads = grads + [out[1 + i].reshape(s.shape).to(s.dtype) for i, s in enumerate(scales)]
         return out[0]
@@ -124,7 +125,8 @@ class _ProductPairsLoss(torch.autograd.Function):
         xs, scales = params[:k], params[k:]
         B.require_gpu(*xs)
         lib = B.lib()
-        lkind, alpha, eps, terms = spec
+        lkind, alpha, eps, terms = spec[:4]
+        dyn = spec[4] if len(spec) > 4 else None
         dtype, dev = xs[0].dtype, xs[0].device
         n_total = xs[0].shape[0]
         n = n_total if subset is None else subset[0].numel()
@@ -160,7 +162,7 @@ class _ProductPairsLoss(torch.autograd.Function):
                     raise ValueError(f'target has {tc.numel()} entries, the pair range has {npairs}')
                 grads = [torch.empty_like(x) for x in xc]
                 lib.call('mm_product_pairs_loss', dt, loss_code, k, kinds, dims, B.ptr_array(xc), B.ptr_array(sc),
-                         B.ptr(tc), n, rb, re, alpha, eps, terms, wmin, wmax, B.ptr_array(grads), B.ptr(out),
+                         B.ptr(tc), n, rb, re, alpha, eps, terms, B.ptr(dyn), wmin, wmax, B.ptr_array(grads), B.ptr(out),
                          B.ptr(ws), flags, B.stream_of(xs[0]))
             else:
                 idx, dense = subset
@@ -172,8 +174,8 @@ class _ProductPairsLoss(torch.autograd.Function):
                 flat = torch.zeros(sum(sizes), dtype=dtype, device=dev)
                 grads = [g.view(x.shape) for g, x in zip(flat.split(sizes), xc)]
                 lib.call('mm_product_pairs_loss_subset', dt, loss_code, k, kinds, dims, B.ptr_array(xc),
-                         B.ptr_array(sc), B.ptr(dense), n_total, B.ptr(idx), n, rb, re, alpha, eps, terms, wmin,
-                         wmax, B.ptr_array(grads), B.ptr(out), B.ptr(ws), flags, B.stream_of(xs[0]))
+                         B.ptr_array(sc), B.ptr(dense), n_total, B.ptr(idx), n, rb, re, alpha, eps, terms,
+                         B.ptr(dyn), wmin, wmax, B.ptr_array(grads), B.ptr(out), B.ptr(ws), flags, B.stream_of(xs[0]))
             entry[1] = True
         ctx.grads = [g.reshape(x.shape) for g, x in zip(grads, xs)] + \
             [out[1 + i].reshape(s.shape).to(s.dtype) for i, s in enumerate(scales)]

@@ -31,9 +31,32 @@ class QuotientLoss(ObjectiveFunction):
             loss = loss + (gdists / (mdists + 1.0 / (epoch + 1)) - 1.0).abs().sum()
         return loss
 
+    _dyn = None
+
+    def on_device(self, device):
+        """Keep {alpha, eps = 1/(epoch+1)} in device memory from now on: the fused kernels then read them
+        there, so a captured HIP graph of a training step (graphembed.graphed) follows the loss's per-epoch
+        schedule — call `set_epoch(epoch, alpha)` before each replay — instead of being re-recorded.
+        Returns the fp64 tensor [alpha, eps]."""
+        if self._dyn is None or self._dyn.device != torch.device(device):
+            self._dyn = torch.tensor([1.0, 1.0], dtype=torch.float64, device=device)
+        return self._dyn
+
+    def set_epoch(self, epoch, alpha):
+        """Writes the schedule of `epoch` into the device-resident parameters (after `on_device`)."""
+        self._dyn.copy_(torch.tensor([float(alpha), 1.0 / (epoch + 1)], dtype=torch.float64), non_blocking=False)
+
     def fused_spec(self, *, epoch, alpha):
-        """(kind, alpha, eps, terms) for the fused loss+gradient kernels (mm_*_pdist_loss)."""
-        return ('quotient', float(alpha), 1.0 / (epoch + 1), int(self.inc_l1) | (int(self.inc_l2) << 1))
+        """(kind, alpha, eps, terms[, device {alpha, eps}]) for the fused loss+gradient kernels
+        (mm_*_pdist_loss).  After `on_device` the values of this call are also written to the device
+        copy — except while a graph is being recorded, where the device copy is what counts."""
+        eps = 1.0 / (epoch + 1)
+        terms = int(self.inc_l1) | (int(self.inc_l2) << 1)
+        if self._dyn is None:
+            return ('quotient', float(alpha), eps, terms)
+        if not (self._dyn.is_cuda and torch.cuda.is_current_stream_capturing()):
+            self.set_epoch(epoch, alpha)
+        return ('quotient', float(alpha), eps, terms, self._dyn)
 
     def __str__(self):
         return 'quotient_loss'

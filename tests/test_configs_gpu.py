@@ -417,3 +417,62 @@ def test_product_minibatch_inside_pair_kernel(dname, loss_name):
                                        rtol=1e-3 if dname == 'f32' else 1e-8, atol=1e-5 if dname == 'f32' else 1e-10)
     finally:
         torch.set_default_dtype(torch.float32)
+
+
+@pytest.mark.parametrize('case', ['spd3', 'lorentz', 'product', 'product_perfactor'])
+def test_quotient_loss_schedule_in_device_memory(case):
+    """QuotientLoss.on_device(): {alpha, eps = 1/(epoch+1)} are read from device memory by every fused loss
+    kernel, so ONE captured graph follows the per-epoch schedule (objectives.py:16-36, train.py:170-178):
+    replayed with set_epoch() it tracks the eager loop that passes epoch/alpha by value."""
+    from graphembed import manifolds as M
+    from graphembed.graphed import GraphedTrainStep
+    from graphembed.modules import ManifoldEmbedding
+    from graphembed.objectives import QuotientLoss
+    from graphembed.optim import RiemannianSGD
+    n = 150
+    mans = {'spd3': lambda: [M.SymmetricPositiveDefinite(3)], 'lorentz': lambda: [M.Lorentz(5)],
+            'product': lambda: [M.Lorentz(6), M.Sphere(6), M.SymmetricPositiveDefinite(2)],
+            'product_perfactor': lambda: [M.Lorentz(6), M.Sphere(6), M.SymmetricPositiveDefinite(2)]}[case]
+    torch.set_default_dtype(torch.float64)
+    try:
+        def build():
+            torch.manual_seed(5)
+            with torch.device('cuda'):
+                emb = ManifoldEmbedding(n, mans())
+                with torch.no_grad():
+                    emb.perturb(0.2)
+            emb.pair_kernel = case != 'product_perfactor'
+            opts = [RiemannianSGD(list(emb.xs), lr=1e-4, exact=True, max_grad_norm=20),
+                    RiemannianSGD(list(emb.scales), lr=1e-5, max_grad_norm=500)]
+            return emb, opts
+        torch.manual_seed(1)
+        target = torch.rand(n * (n - 1) // 2, device='cuda') * 0.9 + 0.1
+        alphas = [1.0, 1.0, 1.3, 1.3, 0.8, 0.8]
+        emb_e, opts_e = build()
+        fn_e = QuotientLoss()
+        losses_e = []
+        for epoch, alpha in enumerate(alphas):
+            for o in opts_e:
+                o.zero_grad()
+            loss = emb_e.fused_objective(fn_e, target, None, epoch=epoch, alpha=alpha)
+            loss.backward()
+            for o in opts_e:
+                o.step()
+            losses_e.append(loss.item())
+        emb_g, opts_g = build()
+        fn_g = QuotientLoss()
+        fn_g.on_device('cuda')
+        fn_g.set_epoch(0, alphas[0])
+        # the by-value epoch/alpha of the recorded call are deliberately wrong: the device copy counts
+        step = GraphedTrainStep(lambda: emb_g.fused_objective(fn_g, target, None, epoch=0, alpha=alphas[0]),
+                                opts_g, warmup=1).capture()
+        losses_g = [step.warmup_losses[0].item()]
+        for epoch in range(1, len(alphas)):
+            fn_g.set_epoch(epoch, alphas[epoch])
+            losses_g.append(step().item())
+        np.testing.assert_allclose(losses_g, losses_e, rtol=1e-9)
+        assert len(set(np.round(losses_e, 6))) == len(losses_e)   # the schedule does change the loss
+        for a, b in zip(emb_g.xs, emb_e.xs):
+            np.testing.assert_allclose(a.detach().cpu().numpy(), b.detach().cpu().numpy(), rtol=1e-8, atol=1e-10)
+    finally:
+        torch.set_default_dtype(torch.float32)

@@ -1,4 +1,5 @@
-"""Host-side cost of one eager training step (fused loss + RSGD): cProfile over 300 steps."""
+"""Host-side cost of one eager training step (fused loss + RSGD): cProfile over 300 steps.
+Usage: python tools/host_profile.py [product]"""
 import cProfile
 import os
 import pstats
@@ -12,10 +13,14 @@ from graphembed.modules import ManifoldEmbedding  # noqa: E402
 from graphembed.objectives import StressLoss  # noqa: E402
 from graphembed.optim import RiemannianSGD  # noqa: E402
 
-n = 2000
+from graphembed import unit_seed  # noqa: E402
+
+PRODUCT = len(sys.argv) > 1 and sys.argv[1] == 'product'
+n = 1025 if PRODUCT else 2000
 torch.manual_seed(0)
 with torch.device('cuda'):
-    emb = ManifoldEmbedding(n, [M.SymmetricPositiveDefinite(3)])
+    emb = ManifoldEmbedding(n, [M.Lorentz(6), M.Sphere(6), M.SymmetricPositiveDefinite(2)] if PRODUCT
+                            else [M.SymmetricPositiveDefinite(3)])
 target = torch.rand(n * (n - 1) // 2, device='cuda') * 0.99 + 0.01
 opt = RiemannianSGD(list(emb.xs), lr=1e-3, exact=True, max_grad_norm=20)
 opt_s = RiemannianSGD(list(emb.scales), lr=1e-4, max_grad_norm=500)
@@ -23,9 +28,10 @@ fn = StressLoss()
 
 
 def step():
-    opt.zero_grad(set_to_none=False)
-    opt_s.zero_grad(set_to_none=False)
-    emb.fused_objective(fn, target, None).backward()
+    opt.zero_grad()
+    opt_s.zero_grad()
+    loss = emb.fused_objective(fn, target, None)
+    loss.backward(unit_seed(loss))
     opt.step()
     opt_s.step()
 

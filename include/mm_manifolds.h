@@ -233,6 +233,16 @@ int mm_vec_rsgd_step_multi(int dtype, int count, const int* kinds, const void* c
                            const void* const* egrads, const int64_t* cnts, const int* ms, double lr,
                            double max_grad_norm, int exact, void* const* x_new, mm_stream_t stream);
 
+/* The heavy-ball variant of the RSGD update (rsgd.py:70-80): momentum_buffer = momentum * momentum_buffer +
+ * (1 - dampening) * rgrad (clipped), x_new = exp/retr(x, -lr * momentum_buffer), and the buffer is transported
+ * to x_new — updated IN PLACE (SPD: identity transport, the buffer is kept symmetric).  x_new may equal x. */
+int mm_vec_rsgd_momentum_step(int dtype, int kind, const void* x, const void* egrad, void* momentum_buffer,
+                              int64_t cnt, int m, double lr, double momentum, double dampening,
+                              double max_grad_norm, int exact, void* x_new, mm_stream_t stream);
+int mm_spd_rsgd_momentum_step(int dtype, const void* x, const void* egrad, void* momentum_buffer, int64_t m,
+                              int d, double lr, double momentum, double dampening, double max_grad_norm,
+                              int exact, void* x_new, mm_stream_t stream);
+
 /* One fused RiemannianAdam update (radam.py:62-98): Riemannian gradient, second moment from its norm
  * BEFORE clipping (one scalar per point, stored broadcast over the point as the reference does), clipping,
  * first moment, step size lr sqrt(1-beta2^t)/(1-beta1^t) (nc != 0: beta2 = 1 - 1/t), exp (exact) or

@@ -715,6 +715,51 @@ __global__ void spd_rsgd_step_kernel(const T* x, const T* __restrict__ eg, int64
   if (in) store_sym_full<T, D>(xnew + k * D * D, o);
 }
 
+// heavy-ball variant (rsgd.py:70-80): buf = momentum buf + (1 - dampening) rgrad, x' = exp/retr(x, -lr buf); the
+// SPD transport is the identity (spd.py:196-199); buf is kept symmetric and updated in place.
+template <typename T, int D>
+__global__ void spd_rsgd_momentum_kernel(const T* x, const T* __restrict__ eg, T* buf, int64_t m, T lr, T momentum,
+                                         T dampening, T max_grad_norm, int exact, T* xnew) {
+  constexpr int NP = Packed<D>::NP;
+  const int64_t k0 = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  const bool in = k0 < m;
+  const int64_t k = in ? k0 : 0;
+  T xs[NP], gs[NP], r[NP], l[NP], li[NP], o[NP], b[NP];
+  load_sym_packed<T, D>(x + k * D * D, xs);
+  load_sym_packed<T, D>(eg + k * D * D, gs);
+  load_sym_packed<T, D>(buf + k * D * D, b);
+  T xf[D * D];
+#pragma unroll
+  for (int p = 0; p < D; ++p)
+#pragma unroll
+    for (int c = 0; c < D; ++c) xf[p * D + c] = xs[pidx(p, c)];
+  congr_full<T, D>(xf, gs, r);
+  cholesky<T, D>(xs, l);
+  invert_lower<T, D>(l, li);
+  T clip = T(1);
+  if (max_grad_norm > T(0)) {
+    T w[NP];
+    congr_lower<T, D>(li, r, w);
+    T nn = T(0);
+#pragma unroll
+    for (int p = 0; p < D; ++p)
+#pragma unroll
+      for (int c = 0; c <= p; ++c) nn += (p == c ? T(1) : T(2)) * w[pidx(p, c)] * w[pidx(p, c)];
+    clip = Num<T>::min(max_grad_norm / Num<T>::sqrt(nn), T(1));
+  }
+#pragma unroll
+  for (int q = 0; q < NP; ++q) {
+    b[q] = Num<T>::fma(momentum, b[q], (T(1) - dampening) * (r[q] * clip));
+    r[q] = -lr * b[q];
+  }
+  if (exact) spd_explog<T, D, false>(l, li, r, o);
+  else spd_retr<T, D>(xs, li, r, o);
+  if (in) {
+    store_sym_full<T, D>(xnew + k * D * D, o);
+    store_sym_full<T, D>(buf + k * D * D, b);
+  }
+}
+
 // fused Riemannian Adam update (radam.py:62-98) — see vec_radam_step_kernel; the SPD transport is the identity
 // (spd.py:196-199), exp_avg is kept symmetric.
 template <typename T, int D>
@@ -1043,6 +1088,17 @@ int mm_spd_rsgd_step(int dtype, const void* x, const void* egrad, int64_t m, int
               (launch_pointwise<T, D>(spd_rsgd_step_kernel<T, D>, m, st, static_cast<const T*>(x),
                                       static_cast<const T*>(egrad), m, T(lr), T(max_grad_norm), exact,
                                       static_cast<T*>(x_new))));
+}
+
+int mm_spd_rsgd_momentum_step(int dtype, const void* x, const void* egrad, void* momentum_buffer, int64_t m, int d,
+                              double lr, double momentum, double dampening, double max_grad_norm, int exact, void* x_new,
+                              mm_stream_t stream) {
+  if (m < 0 || (m > 0 && (!x || !egrad || !momentum_buffer || !x_new))) return MM_ERR_ARG;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  MM_DISPATCH(dtype, d,
+              (launch_pointwise<T, D>(spd_rsgd_momentum_kernel<T, D>, m, st, static_cast<const T*>(x),
+                                      static_cast<const T*>(egrad), static_cast<T*>(momentum_buffer), m, T(lr),
+                                      T(momentum), T(dampening), T(max_grad_norm), exact, static_cast<T*>(x_new))));
 }
 
 int mm_spd_radam_step(int dtype, const void* x, const void* egrad, void* exp_avg, void* exp_avg_sq, double* step,

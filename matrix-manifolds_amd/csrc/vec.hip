@@ -353,6 +353,37 @@ __device__ __forceinline__ void vec_rsgd_point(const T* x, const T* __restrict__
   for (int k = 0; k < m; ++k) xnew[p * m + k] = o[k];
 }
 
+// heavy-ball variant (rsgd.py:70-80): buf = momentum buf + (1 - dampening) rgrad; x' = exp/retr(x, -lr buf);
+// buf is transported to x' and updated in place.
+template <typename T, int KIND>
+__global__ void vec_rsgd_momentum_kernel(const T* x, const T* __restrict__ eg, T* buf, int64_t cnt, int m, T lr,
+                                         T momentum, T dampening, T max_grad_norm, int exact, T* xnew) {
+  using N = Num<T>;
+  const int64_t p = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (p >= cnt) return;
+  T xp[kVecMaxDim], r[kVecMaxDim], b[kVecMaxDim], o[kVecMaxDim];
+  for (int k = 0; k < m; ++k) xp[k] = x[p * m + k];
+  vec_egrad2rgrad<T, KIND>(xp, eg + p * m, m, r);
+  const T clip = max_grad_norm > T(0) ? N::min(max_grad_norm / vec_norm<T, KIND>(r, m), T(1)) : T(1);
+  for (int k = 0; k < m; ++k) {
+    b[k] = N::fma(momentum, buf[p * m + k], (T(1) - dampening) * (r[k] * clip));
+    r[k] = -lr * b[k];
+  }
+  vec_exp_or_retr<T, KIND>(xp, r, m, exact, o);
+  if (KIND == MM_LORENTZ) {  // lorentz.py:79-82
+    const T xy = ldot(xp, o, m), uy = ldot(b, o, m);
+    const T g = uy / (T(1) - xy);
+    for (int k = 0; k < m; ++k) b[k] = N::fma(g, xp[k] + o[k], b[k]);
+  } else if (KIND == MM_SPHERE) {  // base.py:65-66: proju(y, u)
+    const T d = edot(o, b, m);
+    for (int k = 0; k < m; ++k) b[k] = N::fma(-d, o[k], b[k]);
+  }
+  for (int k = 0; k < m; ++k) {
+    xnew[p * m + k] = o[k];
+    buf[p * m + k] = b[k];
+  }
+}
+
 template <typename T, int KIND>
 // (x and xnew are deliberately not __restrict__: the update may be done in place, xnew == x)
 __global__ void vec_rsgd_step_kernel(const T* x, const T* __restrict__ eg, int64_t cnt, int m, T lr,
@@ -696,6 +727,21 @@ int mm_vec_rsgd_step(int dtype, int kind, const void* x, const void* egrad, int6
   MMV_DISPATCH_T(dtype, MMV_DISPATCH_KIND(kind, {
     vec_rsgd_step_kernel<T, KIND><<<dim3(nb), dim3(128), 0, st>>>(static_cast<const T*>(x),
         static_cast<const T*>(egrad), cnt, m, T(lr), T(max_grad_norm), exact, static_cast<T*>(x_new));
+    MMV_CHECK(); return MM_OK; }))
+}
+
+int mm_vec_rsgd_momentum_step(int dtype, int kind, const void* x, const void* egrad, void* momentum_buffer, int64_t cnt,
+                              int m, double lr, double momentum, double dampening, double max_grad_norm, int exact,
+                              void* x_new, mm_stream_t stream) {
+  if (cnt < 0 || m < 1 || (cnt > 0 && (!x || !egrad || !momentum_buffer || !x_new))) return MM_ERR_ARG;
+  if (m > kVecMaxDim) return MM_ERR_UNSUPPORTED;
+  if (cnt == 0) return MM_OK;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const unsigned nb = unsigned((cnt + 127) / 128);
+  MMV_DISPATCH_T(dtype, MMV_DISPATCH_KIND(kind, {
+    vec_rsgd_momentum_kernel<T, KIND><<<dim3(nb), dim3(128), 0, st>>>(static_cast<const T*>(x),
+        static_cast<const T*>(egrad), static_cast<T*>(momentum_buffer), cnt, m, T(lr), T(momentum), T(dampening),
+        T(max_grad_norm), exact, static_cast<T*>(x_new));
     MMV_CHECK(); return MM_OK; }))
 }
 

@@ -57,6 +57,8 @@ SIGNATURES = {
     'mm_product_pairs_loss_subset': (_i, [_i, _i, _i, _c.POINTER(_i), _c.POINTER(_i), _c.POINTER(_vp),
                                            _c.POINTER(_vp), _vp, _i64, _vp, _i64, _i64, _i64, _dbl, _dbl, _i, _vp, _dbl,
                                            _dbl, _c.POINTER(_vp), _vp, _vp, _i, _vp]),
+    'mm_vec_rsgd_momentum_step': (_i, [_i, _i, _vp, _vp, _vp, _i64, _i, _dbl, _dbl, _dbl, _dbl, _i, _vp, _vp]),
+    'mm_spd_rsgd_momentum_step': (_i, [_i, _vp, _vp, _vp, _i64, _i, _dbl, _dbl, _dbl, _dbl, _i, _vp, _vp]),
     'mm_spd_max_dim': (_i, []),
     'mm_spd_pdist_ws_bytes': (_sz, [_i, _i64, _i]),
     'mm_spd_pdist_fwd': (_i, [_i, _vp, _i64, _i, _i64, _i64, _i, _dbl, _dbl, _vp, _vp, _i, _vp]),

@@ -302,6 +302,28 @@ class SymmetricPositiveDefinite(Manifold):
         x.set_(x_new)
         return x
 
+    def rsgd_momentum_step(self, x, egrad, buf, *, lr, momentum, dampening, max_grad_norm=None, exact=False,
+                           inplace=False):
+        """Fused heavy-ball RiemannianSGD update (optim/rsgd.py:70-80; identity transport): `buf` is
+        updated in place (kept symmetric); returns the new points, or None when not eligible."""
+        d = self.n
+        ok = (x.is_cuda and x.dtype in (torch.float32, torch.float64) and x.numel() > 0
+              and d <= B.lib().raw('mm_spd_max_dim')() and buf.is_contiguous() and buf.dtype == x.dtype
+              and buf.shape == x.shape)
+        if not ok:
+            return None
+        xd = x.detach()
+        inplace = inplace and xd.is_contiguous()
+        xc = xd.reshape(-1, d, d).contiguous()
+        gc = egrad.detach().reshape(-1, d, d).to(xc.dtype).contiguous()
+        with B.on_device(xc.device):
+            out = xc if inplace else torch.empty_like(xc)
+            B.lib().call('mm_spd_rsgd_momentum_step', B.dtype_code(xc), B.ptr(xc), B.ptr(gc), B.ptr(buf),
+                         xc.shape[0], d, float(lr), float(momentum), float(dampening),
+                         -1.0 if max_grad_norm is None else float(max_grad_norm), int(bool(exact)), B.ptr(out),
+                         B.stream_of(xc))
+        return x if inplace else out.reshape(x.shape)
+
     def radam_step(self, x, egrad, exp_avg, exp_avg_sq, step, ticket, *, lr, betas, nc, eps, max_grad_norm=None,
                    exact=False, inplace=False):
         """Fused RiemannianAdam update (optim/radam.py:62-98) in one launch — see

@@ -213,6 +213,13 @@ class VectorManifold(Manifold):
                          B.ptr(out), B.stream_of(xc))
         return x if inplace else out.reshape(x.shape)
 
+    def rsgd_momentum_step(self, x, egrad, buf, *, lr, momentum, dampening, max_grad_norm=None, exact=False,
+                           inplace=False):
+        """Fused heavy-ball RiemannianSGD update (optim/rsgd.py:70-80): `buf` (the momentum buffer) is
+        updated and transported in place; returns the new points, or None when not eligible."""
+        return _vec_momentum(self._kind, self._m, x, egrad, buf, lr, momentum, dampening, max_grad_norm, exact,
+                             inplace)
+
     def radam_step(self, x, egrad, exp_avg, exp_avg_sq, step, ticket, *, lr, betas, nc, eps, max_grad_norm=None,
                    exact=False, inplace=False):
         """Fused RiemannianAdam update (optim/radam.py:62-98) in one launch: moments updated in place,
@@ -259,6 +266,24 @@ def _vec_radam(kind, m, x, egrad, exp_avg, exp_avg_sq, step, ticket, lr, betas, 
         B.lib().call('mm_vec_radam_step', B.dtype_code(xc), kind, B.ptr(xc), B.ptr(gc), B.ptr(exp_avg),
                      B.ptr(exp_avg_sq), B.ptr(step), B.ptr(ticket), xc.shape[0], m, float(lr), float(betas[0]),
                      float(betas[1] if betas[1] is not None else 0.0), int(bool(nc)), float(eps),
+                     -1.0 if max_grad_norm is None else float(max_grad_norm), int(bool(exact)), B.ptr(out),
+                     B.stream_of(xc))
+    return x if inplace else out.reshape(x.shape)
+
+
+def _vec_momentum(kind, m, x, egrad, buf, lr, momentum, dampening, max_grad_norm, exact, inplace):
+    ok = (x.is_cuda and x.dtype in (torch.float32, torch.float64) and 1 <= m <= 32 and x.numel() > 0
+          and buf.is_contiguous() and buf.dtype == x.dtype and buf.shape == x.shape)
+    if not ok:
+        return None
+    xd = x.detach()
+    inplace = inplace and xd.is_contiguous()
+    xc = xd.reshape(-1, m).contiguous()
+    gc = egrad.detach().reshape(-1, m).to(xc.dtype).contiguous()
+    with B.on_device(xc.device):
+        out = xc if inplace else torch.empty_like(xc)
+        B.lib().call('mm_vec_rsgd_momentum_step', B.dtype_code(xc), kind, B.ptr(xc), B.ptr(gc), B.ptr(buf),
+                     xc.shape[0], m, float(lr), float(momentum), float(dampening),
                      -1.0 if max_grad_norm is None else float(max_grad_norm), int(bool(exact)), B.ptr(out),
                      B.stream_of(xc))
     return x if inplace else out.reshape(x.shape)

@@ -58,6 +58,18 @@ class FlatRule:
 
 
     @staticmethod
+    def rsgd_momentum_step(x, egrad, buf, *, lr, momentum, dampening, max_grad_norm=None, exact=False,
+                           inplace=False):
+        """The fused heavy-ball update of the Euclidean kernel for flat parameters (None when not eligible)."""
+        if not x.is_cuda:
+            return None
+        from graphembed import _backend as B
+        from graphembed.manifolds.vector import _vec_momentum
+        width = x.shape[-1] if x.ndim else 1
+        return _vec_momentum(B.EUCLIDEAN, width, x, egrad, buf, lr, momentum, dampening, max_grad_norm, exact,
+                             inplace)
+
+    @staticmethod
     def radam_step(x, egrad, exp_avg, exp_avg_sq, step, ticket, *, lr, betas, nc, eps, max_grad_norm=None,
                    exact=False, inplace=False):
         """The fused Adam update of the Euclidean kernel for flat parameters (None when not eligible)."""

@@ -48,6 +48,15 @@ class RiemannianSGD(ManifoldOptimizer):
         # heavy-ball momentum, transported to the new point (rsgd.py:70-80)
         if 'momentum_buffer' not in state:
             state['momentum_buffer'] = p.grad.clone()
+        fused = getattr(manifold, 'rsgd_momentum_step', None) if p.is_cuda else None
+        if fused is not None:  # one launch: the buffer is updated and transported in place
+            new_p = fused(p, p.grad, state['momentum_buffer'], lr=lr, momentum=momentum,
+                          dampening=group['dampening'], max_grad_norm=clip, exact=group['exact'],
+                          inplace=capturing(p))
+            if new_p is not None:
+                if new_p is not p:
+                    assign(p, new_p)
+                return
         rgrad, _ = self.riemannian_gradient(manifold, p, clip)
         buf = state['momentum_buffer']
         buf.mul_(momentum).add_(rgrad, alpha=1 - group['dampening'])

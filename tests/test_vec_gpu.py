@@ -452,3 +452,32 @@ def test_rsgd_multi_parameter_launch_equals_single_steps(dname, exact, clip):
     assert calls.count('mm_spd_rsgd_step') == 1
     for p, w in zip(params, want):
         assert torch.equal(p.detach(), w)
+
+
+def test_rsgd_momentum_uses_fused_kernels():
+    """momentum > 0: one launch per parameter (mm_*_rsgd_momentum_step), no per-map kernels; the golden traces
+    of test_rsgd_vs_reference_golden / test_spd_gpu pin the values."""
+    from graphembed import _backend as B
+    from graphembed import manifolds as M
+    from graphembed.modules import ManifoldParameter
+    from graphembed.optim import RiemannianSGD
+    torch.manual_seed(2)
+    mans = [M.Lorentz(6), M.Sphere(5), M.SymmetricPositiveDefinite(3)]
+    ps = [ManifoldParameter(man.rand(30, out=torch.empty(0, device='cuda')), manifold=man) for man in mans]
+    ps.append(torch.nn.Parameter(torch.randn(3, device='cuda')))
+    opt = RiemannianSGD(ps, lr=0.05, momentum=0.9, dampening=0.1, max_grad_norm=2.0, exact=True)
+    lib, calls = B.lib(), []
+    orig = lib.call
+    lib.call = lambda name, *a: (calls.append(name), orig(name, *a))[1]
+    try:
+        for _ in range(2):
+            for p in ps:
+                g = torch.randn_like(p)
+                p.grad = g + g.transpose(-2, -1) if p.ndim == 3 else g
+            opt.step()
+    finally:
+        del lib.call
+    assert calls.count('mm_vec_rsgd_momentum_step') == 6 and calls.count('mm_spd_rsgd_momentum_step') == 2, calls
+    assert len(calls) == 8
+    for p in ps:
+        assert bool(torch.isfinite(p).all()) and bool(torch.isfinite(opt.state[p]['momentum_buffer']).all())

@@ -259,7 +259,7 @@ class ManifoldEmbedding(torch.nn.Module):
             softplus(s) * man.pdist(take_rows(x, i), squared=True)
             for x, s, man in zip(self.xs, self.scales, self.manifolds))
 
-    def fused_objective(self, objective_fn, gdists, i=None, rows=None, dense=None, **kwargs):
+    def fused_objective(self, objective_fn, gdists, i=None, rows=None, dense=None, params=None, **kwargs):
         """`objective_fn(gdists, self.compute_dists(i), **kwargs)` evaluated by ONE pair kernel
         that also produces the gradients (no pair vector of distances, no element-wise passes),
         or None when the objective has no fused kernel (a loss without `fused_spec`, CPU tensors).
@@ -273,31 +273,34 @@ class ManifoldEmbedding(torch.nn.Module):
         indices of a batch must be distinct, as slices of a `randperm` are: train.py:206-209)."""
         if not hasattr(objective_fn, 'fused_spec') or not self.xs[0].is_cuda:
             return None
+        # `params` = (points, scales) to differentiate instead of self.xs / self.scales — views of them whose
+        # backward all-reduces the gradients (graphembed.parallel.sharded_fused_objective)
+        pts, scales = (list(self.xs), list(self.scales)) if params is None else params
         spec = objective_fn.fused_spec(**kwargs)
         in_kernel_batch = (i is not None and dense is not None and dense.is_cuda and self.pair_kernel
-                           and dense.dtype == self.xs[0].dtype and i.numel() <= _SUBSET_MAX_NODES)
+                           and dense.dtype == pts[0].dtype and i.numel() <= _SUBSET_MAX_NODES)
         if in_kernel_batch:
             # node minibatch entirely inside the pair kernel: no row gathers, no target gather, no scatter-adds
             # (single factors too: at minibatch sizes a step is launches, not arithmetic)
             factors = _pair_kernel_factors(self.manifolds)
             if factors is not None:
                 return _ProductPairsLoss.apply(None, spec, rows, tuple(self.manifolds), tuple(factors),
-                                               self._pair_ws, (i, dense), *self.xs, *self.scales)
+                                               self._pair_ws, (i, dense), *pts, *scales)
         if self.n_components == 1 and getattr(self.manifolds[0], 'pdist_loss', None) is not None:
             if gdists is None:
                 return None
-            x = take_rows(self.xs[0], i)
-            return self.manifolds[0].pdist_loss(x, self.scales[0], gdists, spec, rows=rows)
+            x = take_rows(pts[0], i)
+            return self.manifolds[0].pdist_loss(x, scales[0], gdists, spec, rows=rows)
         if self.n_components > _max_product_factors():
             return None
         factors = _pair_kernel_factors(self.manifolds) if self.pair_kernel else None
         if gdists is None:
             return None
-        xs = [take_rows(x, i) for x in self.xs]
+        xs = [take_rows(x, i) for x in pts]
         if factors is not None:
             return _ProductPairsLoss.apply(gdists, spec, rows, tuple(self.manifolds), tuple(factors),
-                                           self._pair_ws, None, *xs, *self.scales)
-        return _ProductLoss.apply(gdists, spec, rows, tuple(self.manifolds), *xs, *self.scales)
+                                           self._pair_ws, None, *xs, *scales)
+        return _ProductLoss.apply(gdists, spec, rows, tuple(self.manifolds), *xs, *scales)
 
     def __len__(self):
         return self.n

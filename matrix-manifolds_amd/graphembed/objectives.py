@@ -38,7 +38,10 @@ class QuotientLoss(ObjectiveFunction):
         there, so a captured HIP graph of a training step (graphembed.graphed) follows the loss's per-epoch
         schedule — call `set_epoch(epoch, alpha)` before each replay — instead of being re-recorded.
         Returns the fp64 tensor [alpha, eps]."""
-        if self._dyn is None or self._dyn.device != torch.device(device):
+        device = torch.device(device)
+        if device.type == 'cuda' and device.index is None:
+            device = torch.device('cuda', torch.cuda.current_device())
+        if self._dyn is None or self._dyn.device != device:
             self._dyn = torch.tensor([1.0, 1.0], dtype=torch.float64, device=device)
         return self._dyn
 

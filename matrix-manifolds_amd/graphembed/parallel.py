@@ -92,3 +92,18 @@ def sharded_compute_dists(embedding, shard):
     return sum(
         softplus(s) * man.pdist(x, squared=True, rows=shard.rows)
         for x, s, man in zip(synced[:k], synced[k:], embedding.manifolds))
+
+
+def sharded_fused_objective(embedding, objective_fn, targets, shard, **kwargs):
+    """`objective_fn(targets, embedding.compute_dists())` of this rank's pair slice through the fused
+    loss+gradient kernels (ManifoldEmbedding.fused_objective: one pass, no pair vector), or None when the
+    configuration has no fused kernel.  `targets` is the full pair vector (sliced here) or already this
+    rank's slice.  Backward leaves the all-reduced (i.e. full) gradients in `x.grad` / `scale.grad` on every
+    rank — one collective; the returned loss is the LOCAL part (sum over ranks = the loss)."""
+    if targets.numel() != shard.num_pairs:
+        targets = shard.slice(targets)
+    params = list(embedding.xs) + list(embedding.scales)
+    synced = sync_grads(*params, group=shard.group)
+    k = len(embedding.xs)
+    return embedding.fused_objective(objective_fn, targets, None, rows=shard.rows,
+                                     params=(list(synced[:k]), list(synced[k:])), **kwargs)

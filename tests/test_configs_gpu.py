@@ -476,3 +476,40 @@ def test_quotient_loss_schedule_in_device_memory(case):
             np.testing.assert_allclose(a.detach().cpu().numpy(), b.detach().cpu().numpy(), rtol=1e-8, atol=1e-10)
     finally:
         torch.set_default_dtype(torch.float32)
+
+
+@pytest.mark.parametrize('mix', ['spd3', 'product'])
+def test_sharded_fused_objective_sums_to_full(mix):
+    """graphembed.parallel.sharded_fused_objective: each rank's fused loss+gradient pass over its pair rows
+    (here the 3 ranks of a world are played one after the other; the all-reduce is the sum) gives the full
+    loss and the full gradients of compute_dists -> objective -> backward."""
+    from graphembed import manifolds as M
+    from graphembed.modules import ManifoldEmbedding
+    from graphembed.objectives import QuotientLoss
+    from graphembed.parallel import PairShard, sharded_fused_objective
+    n = 260
+    torch.manual_seed(8)
+    torch.set_default_dtype(torch.float64)
+    try:
+        with torch.device('cuda'):
+            emb = ManifoldEmbedding(n, [M.SymmetricPositiveDefinite(3)] if mix == 'spd3'
+                                    else [M.Lorentz(6), M.Sphere(6), M.SymmetricPositiveDefinite(2)])
+            with torch.no_grad():
+                emb.perturb(0.3)
+            target = torch.rand(n * (n - 1) // 2) * 2 + 0.2
+    finally:
+        torch.set_default_dtype(torch.float32)
+    fn, kw = QuotientLoss(), dict(epoch=2, alpha=1.1)
+    params = list(emb.xs) + list(emb.scales)
+    ref = fn(target, emb.compute_dists(None), **kw)
+    rg = torch.autograd.grad(ref, params)
+    tot, gsum = 0.0, [torch.zeros_like(p) for p in params]
+    for r in range(3):
+        shard = PairShard(n, world=3, rank=r)
+        part = sharded_fused_objective(emb, fn, target, shard, **kw)
+        pg = torch.autograd.grad(part, params)
+        tot += part.item()
+        gsum = [s_ + p for s_, p in zip(gsum, pg)]
+    assert abs(tot - ref.item()) <= 1e-9 * abs(ref.item())
+    for a, b in zip(gsum, rg):
+        assert (a - b).abs().max().item() <= 1e-8 * max(b.abs().max().item(), 1e-30)

@@ -249,3 +249,19 @@ def test_pair_sharding_over_gloo_matches_single_process(tmp_path):
     ref_grads = [p.grad for p in list(emb.xs) + list(emb.scales)]
     for a, b in zip(r0['grads'], ref_grads):
         np.testing.assert_allclose(a.numpy(), b.numpy(), rtol=1e-9, atol=1e-12)
+
+
+def test_sharded_fused_objective_declines_on_cpu():
+    """No CPU fallback behind the fused path: on CPU tensors it answers None and the caller composes the
+    step from sharded_compute_dists (which then fails loudly in pdist without the HIP library / a GPU)."""
+    import torch
+    from graphembed.objectives import StressLoss
+    from graphembed.parallel import PairShard, sharded_fused_objective
+
+    class Emb:
+        xs = [torch.zeros(6, 3, requires_grad=True)]
+        scales = [torch.zeros((), requires_grad=True)]
+
+        def fused_objective(self, *a, **k):
+            return None if not self.xs[0].is_cuda else 1
+    assert sharded_fused_objective(Emb(), StressLoss(), torch.zeros(15), PairShard(6, world=2, rank=0)) is None

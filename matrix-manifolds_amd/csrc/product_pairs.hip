@@ -5,12 +5,20 @@
 // One launch evaluates, for every pair, the squared distance of EVERY factor, their softplus-weighted sum,
 // the loss term and its derivative, and accumulates the gradients of all factors' points and scales.  At the
 // sizes of these configurations (5e5 pairs) the arithmetic is microseconds; what the reference — and a
-// kernel-per-factor design — pays for is launches (~60 resp. ~15 per step).  So the kernel is written for
-// simplicity, not for the last flop: every ORDERED pair is visited (a lane accumulates only into its own
-// column j: no cross-lane reduction for any factor), the row point of each factor is wave-uniform (scalar
-// loads), SPD factors use the Jacobi path.  Supported per launch: up to 3 vector factors (Euclidean /
-// Lorentz / sphere, m <= 16) and at most one SPD(2) or SPD(3) factor; anything else takes the per-factor
-// kernels around mm_product_loss.
+// kernel-per-factor design — pays for is launches (~95 resp. ~15 per step) and serialised memory round
+// trips.  So the kernel is organised around latency, not the last flop:
+//  * every ORDERED pair is visited: a lane (= column j) accumulates only into its own column, no factor needs
+//    a cross-lane reduction; the row point i is wave-uniform and read from LDS, where each wavefront stages
+//    its rows once, zero-padded to 16 coordinates (no load sits under a `k < m` branch);
+//  * the SPD factor's Cholesky factors are formed in the kernel (no per-node tables / preparation launch),
+//    its eigen-decomposition is the Jacobi path;
+//  * 4 wavefronts per workgroup share 64 columns and combine their column sums in LDS before the atomics;
+//  * the finalize kernel leaves all accumulators zero (MM_WS_CLEAN: the workspace is cleared once, ever);
+//  * node minibatches are addressed through an index vector inside the kernels (rows, dense targets, gradient
+//    rows): no gather / scatter launches around it.
+// Supported per launch: up to 3 vector factors (Euclidean / Lorentz / sphere, m <= 16, kinds chosen at run
+// time) and at most one SPD(2) or SPD(3) factor; anything else takes the per-factor kernels around
+// mm_product_loss.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>

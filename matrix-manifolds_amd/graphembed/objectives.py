@@ -1,6 +1,7 @@
 """Losses on vectors of *squared* distances used by the path's configs —
 counterparts of graphembed/graphembed/objectives.py:16-45 (Stress, Quotient).
-The KL / curvature losses are outside the accelerated path."""
+PearsonRLoss runs on the differentiable pdist path; the KL / curvature losses (inference models, graph
+sampling) are outside the accelerated path."""
 import abc
 
 import torch
@@ -76,6 +77,18 @@ class StressLoss(ObjectiveFunction):
 
     def __str__(self):
         return 'stress_loss'
+
+
+class PearsonRLoss(ObjectiveFunction):
+    """Negative Pearson correlation of the two pair vectors (objectives.py:109-117).  No fused kernel: it
+    runs on the differentiable pdist path (`compute_dists`)."""
+
+    def __call__(self, x, y, **kwargs):
+        dx, dy = x - x.mean(), y - y.mean()
+        return -(dx * dy).sum() / (dx.norm() * dy.norm())
+
+    def __str__(self):
+        return 'pearson_r_loss'
 
 
 class Sum(ObjectiveFunction):

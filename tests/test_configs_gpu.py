@@ -196,9 +196,10 @@ def test_product_fused_objective_equals_unfused(dname, loss_name):
              ([M.Lorentz(6), M.Sphere(6), M.SymmetricPositiveDefinite(2)], False),
              ([M.Euclidean(5), M.SymmetricPositiveDefinite(3)], True),
              ([M.Lorentz(3), M.Euclidean(2), M.Sphere(16)], True),
+             ([M.Sphere(3), M.Lorentz(16), M.Euclidean(7), M.SymmetricPositiveDefinite(3)], True),  # largest launch
              ([M.SymmetricPositiveDefinite(2), M.SymmetricPositiveDefinite(3)], True),  # two SPD: per-factor path
              ([M.Grassmann(5, 2)], True)]
-    assert _pair_kernel_factors(cases[0][0]) is not None and _pair_kernel_factors(cases[4][0]) is None
+    assert _pair_kernel_factors(cases[0][0]) is not None and _pair_kernel_factors(cases[5][0]) is None
     for mans, pair_kernel in cases:
         torch.manual_seed(4)
         torch.set_default_dtype(dt)

@@ -380,41 +380,65 @@ def test_fused_loss_equals_unfused_path(case, dname, loss_name):
     check_rel(gsum, rgx.double().cpu().numpy(), tol * 4, 'sum of fused shard grads')
 
 
-@pytest.mark.parametrize('case', ['euclidean10', 'lorentz11'])
+@pytest.mark.parametrize('case', ['euclidean10', 'lorentz11', 'product', 'product_graph'])
 @pytest.mark.parametrize('loss_name', ['stress', 'quotient'])
 def test_tree40_training_trace_fused(case, loss_name):
-    """The reference's 20-epoch tree40 loss traces (golden) driven through the fused kernel."""
+    """The reference's 20-epoch tree40 loss traces (golden, recorded from the real reference) driven through
+    the fused kernels: single factors (mm_vec_pdist_loss), the H^5 x S^5 x SPD(2) product through the
+    mixed-manifold pair kernel + the multi-parameter RSGD launch — and, `product_graph`, the same as
+    ONE captured HIP graph replayed for 19 epochs with the quotient schedule in device memory."""
     from graphembed import manifolds as M
+    from graphembed import unit_seed
+    from graphembed.graphed import GraphedTrainStep
     from graphembed.modules import ManifoldEmbedding
     from graphembed.objectives import QuotientLoss, StressLoss
     from graphembed.optim import RiemannianSGD
     G = load_golden('callers')
-    mk = {'euclidean10': lambda: [M.Euclidean(10)], 'lorentz11': lambda: [M.Lorentz(11)]}[case]
-    base = f'tree40/{case}/{loss_name}'
+    graphed = case == 'product_graph'
+    gcase = 'product' if graphed else case
+    mk = {'euclidean10': lambda: [M.Euclidean(10)], 'lorentz11': lambda: [M.Lorentz(11)],
+          'product': lambda: [M.Lorentz(6), M.Sphere(6), M.SymmetricPositiveDefinite(2)]}[gcase]
+    base = f'tree40/{gcase}/{loss_name}'
     torch.set_default_dtype(torch.float64)
     try:
         with torch.device('cuda'):
             emb = ManifoldEmbedding(40, mk())
         with torch.no_grad():
-            emb.xs[0].copy_(dev(G[f'{base}/x0_0']))
+            for k, x in enumerate(emb.xs):
+                x.copy_(dev(G[f'{base}/x0_{k}']))
         target = dev(G['tree40/target'])
         opt = RiemannianSGD(list(emb.xs), lr=0.01, exact=True, max_grad_norm=20)
         opt_s = RiemannianSGD(list(emb.scales), lr=1e-4, max_grad_norm=500)
         fn = StressLoss() if loss_name == 'stress' else QuotientLoss()
         losses = []
-        for epoch in range(20):
-            loss = emb.fused_objective(fn, target, None, epoch=epoch, alpha=1.0)
-            assert loss is not None
-            opt.zero_grad()
-            opt_s.zero_grad()
-            loss.backward()
-            opt.step()
-            opt_s.step()
-            losses.append(loss.item())
+        if graphed:
+            if loss_name == 'quotient':
+                fn.on_device('cuda')
+                fn.set_epoch(0, 1.0)
+            step = GraphedTrainStep(lambda: emb.fused_objective(fn, target, None, epoch=0, alpha=1.0),
+                                    [opt, opt_s], warmup=1).capture()
+            losses.append(step.warmup_losses[0].item())
+            for epoch in range(1, 20):
+                if loss_name == 'quotient':
+                    fn.set_epoch(epoch, 1.0)
+                losses.append(step().item())
+        else:
+            for epoch in range(20):
+                loss = emb.fused_objective(fn, target, None, epoch=epoch, alpha=1.0)
+                assert loss is not None
+                opt.zero_grad()
+                opt_s.zero_grad()
+                loss.backward(unit_seed(loss) if epoch % 2 else None)   # both seeds
+                opt.step()
+                opt_s.step()
+                losses.append(loss.item())
     finally:
         torch.set_default_dtype(torch.float32)
-    check_rel(np.array(losses), G[f'{base}/losses'], 1e-7, 'loss trace')
-    check_rel(emb.xs[0].data, G[f'{base}/x20_0'], 1e-6, 'x20')
+    # SPD factors differ from the reference by its eps-fudged closed forms (~1e-7, DESIGN.md §5)
+    tol = 1e-7 if gcase in ('euclidean10', 'lorentz11') else 2e-5
+    check_rel(np.array(losses), G[f'{base}/losses'], tol, 'loss trace')
+    for k, x in enumerate(emb.xs):
+        check_rel(x.data, G[f'{base}/x20_{k}'], max(tol, 1e-8) * 10, f'x20_{k}')
     check_rel(np.array([s.item() for s in emb.scales]), G[f'{base}/scales20'], 1e-6, 'scales')
 
 

@@ -12,9 +12,10 @@ all per-step state (momentum, moments, the Adam step counter) in device memory.
     for epoch in range(3, n_epochs):
         loss = step()            # one hipGraphLaunch; `loss` is a device scalar (no sync)
 
-Anything that changes between steps must live in device memory that the closure reads (targets,
-learning-rate tensors); Python scalars are frozen at capture time — re-capture (`step.capture()`)
-when they change (e.g. the quotient loss's `epoch`)."""
+Anything that changes between steps must live in device memory that the closure reads (index buffers,
+targets; the quotient loss's {alpha, eps}: `QuotientLoss.on_device`).  Optimizer hyper-parameters are
+by-value kernel arguments: when one changes (a learning-rate scheduler) the next call notices, runs that
+step eagerly and records the graph again."""
 import torch
 
 from graphembed._backend import unit_seed
@@ -49,7 +50,13 @@ class GraphedTrainStep:
             o.step()
         return loss.detach()
 
-    def capture(self):
+    def _hyper(self):
+        """The by-value hyper-parameters a recorded step has baked in (learning rates, betas, clip norms ...)."""
+        return tuple(tuple(sorted((k, v) for k, v in g.items()
+                                  if k != 'params' and isinstance(v, (int, float, bool, tuple, type(None)))))
+                     for o in self.optimizers for g in o.param_groups)
+
+    def capture(self, warmup=None):
         """Runs `warmup` ordinary (eager) training steps — they COUNT as training steps: optimizer
         state is created and advanced by them, and their losses are kept in `warmup_losses` — then
         records the next step without executing it."""
@@ -59,15 +66,21 @@ class GraphedTrainStep:
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
-            self.warmup_losses = [self._eager_step() for _ in range(max(1, self.warmup))]
+            self.warmup_losses = [self._eager_step() for _ in range(max(1, self.warmup if warmup is None else warmup))]
         torch.cuda.current_stream().wait_stream(side)
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
             self.loss = self._eager_step()
+        self._recorded = self._hyper()
         return self
 
     def __call__(self):
         if self.graph is None:
             self.capture()
+        elif self._recorded != self._hyper():
+            # a scheduler changed a learning rate (ReduceLROnPlateau, train.py:174): this step runs eagerly
+            # with the new values and the graph is recorded again for the following ones
+            self.capture(warmup=1)
+            return self.warmup_losses[-1]
         self.graph.replay()
         return self.loss

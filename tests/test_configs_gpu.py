@@ -514,3 +514,52 @@ def test_sharded_fused_objective_sums_to_full(mix):
     assert abs(tot - ref.item()) <= 1e-9 * abs(ref.item())
     for a, b in zip(gsum, rg):
         assert (a - b).abs().max().item() <= 1e-8 * max(b.abs().max().item(), 1e-30)
+
+
+def test_graphed_step_follows_a_learning_rate_schedule():
+    """A scheduler lowers the learning rate (ReduceLROnPlateau, train.py:174): GraphedTrainStep notices the
+    changed by-value hyper-parameter, runs that step eagerly and re-records — same trajectory as the eager
+    loop with the same schedule."""
+    from graphembed import manifolds as M
+    from graphembed.graphed import GraphedTrainStep
+    from graphembed.modules import ManifoldEmbedding
+    from graphembed.objectives import StressLoss
+    from graphembed.optim import RiemannianSGD
+    n = 120
+    torch.set_default_dtype(torch.float64)
+    try:
+        def build():
+            torch.manual_seed(6)
+            with torch.device('cuda'):
+                emb = ManifoldEmbedding(n, [M.Lorentz(4), M.SymmetricPositiveDefinite(2)])
+            return emb, [RiemannianSGD(list(emb.xs), lr=0.02, exact=True, max_grad_norm=20),
+                         RiemannianSGD(list(emb.scales), lr=1e-3, max_grad_norm=500)]
+        torch.manual_seed(2)
+        target = torch.rand(n * (n - 1) // 2, device='cuda') * 0.9 + 0.1
+        fn = StressLoss()
+        lrs = [0.02, 0.02, 0.02, 0.002, 0.002, 0.0002, 0.0002]
+        emb_e, opts_e = build()
+        losses_e = []
+        for lr in lrs:
+            opts_e[0].param_groups[0]['lr'] = lr
+            for o in opts_e:
+                o.zero_grad()
+            loss = emb_e.fused_objective(fn, target, None)
+            loss.backward()
+            for o in opts_e:
+                o.step()
+            losses_e.append(loss.item())
+        emb_g, opts_g = build()
+        step = GraphedTrainStep(lambda: emb_g.fused_objective(fn, target, None), opts_g, warmup=1).capture()
+        losses_g = [step.warmup_losses[0].item()]
+        graphs = {id(step.graph)}
+        for lr in lrs[1:]:
+            opts_g[0].param_groups[0]['lr'] = lr
+            losses_g.append(step().item())
+            graphs.add(id(step.graph))
+        np.testing.assert_allclose(losses_g, losses_e, rtol=1e-9)
+        assert len(graphs) == 3                     # recorded once per learning rate
+        for a, b in zip(emb_g.xs, emb_e.xs):
+            np.testing.assert_allclose(a.detach().cpu().numpy(), b.detach().cpu().numpy(), rtol=1e-8, atol=1e-10)
+    finally:
+        torch.set_default_dtype(torch.float32)

@@ -18,7 +18,7 @@ import torch
 
 from graphembed import _backend as B
 from graphembed.manifolds.base import Manifold, _like
-from graphembed.utils import squareform0
+from graphembed.utils import _to_square, nnp1d2_to_n, squareform0
 
 
 def _flat(t, n):
@@ -233,7 +233,9 @@ class SymmetricPositiveDefinite(Manifold):
 
     @staticmethod
     def from_vec(x_vec):
-        x = squareform0(x_vec / math.sqrt(2))
+        # (always vector -> matrix: the reference's direction-guessing squareform0 mistakes a batch of
+        # d(d+1)/2 vectors for ONE square matrix when the batch size equals d(d+1)/2 — SPD(2).rand(3) raises there)
+        x = _to_square(x_vec / math.sqrt(2), nnp1d2_to_n(x_vec.shape[-1]), 0)
         x.diagonal(dim1=-2, dim2=-1).mul_(math.sqrt(2))
         return x
 

@@ -265,3 +265,17 @@ def test_sharded_fused_objective_declines_on_cpu():
         def fused_objective(self, *a, **k):
             return None if not self.xs[0].is_cuda else 1
     assert sharded_fused_objective(Emb(), StressLoss(), torch.zeros(15), PairShard(6, world=2, rank=0)) is None
+
+
+def test_spd_from_vec_batch_equal_to_vector_length():
+    """from_vec of a batch of d(d+1)/2-vectors whose batch size is d(d+1)/2 (looks like one square matrix to
+    the reference's squareform0, utils.py:68-87 — SPD(2).rand(3) raises there): always vector -> matrix."""
+    import torch
+    from graphembed.manifolds import SymmetricPositiveDefinite as SPD
+    for d in (2, 3, 4):
+        k = d * (d + 1) // 2
+        v = torch.arange(1.0, k * k + 1).reshape(k, k)
+        x = SPD.from_vec(v)
+        assert x.shape == (k, d, d) and torch.equal(x, x.transpose(1, 2))
+        back = SPD.to_vec(x)
+        assert back.shape == (k, k) and torch.allclose(back, v)

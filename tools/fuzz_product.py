@@ -1,0 +1,98 @@
+#!/usr/bin/env python3
+"""Randomised cross-check of the mixed-manifold pair kernel (mm_product_pairs_loss[_subset]) against the
+differentiable per-factor path (compute_dists -> objective -> autograd): random sizes (incl. n = 2, tile
+edges), factor mixes and dimensions, row shards, node subsets, both losses, fp32/fp64.
+Usage: python tools/fuzz_product.py [cases] [seed]"""
+import os
+import random
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, 'matrix-manifolds_amd'))
+import torch  # noqa: E402
+from graphembed import _backend as B  # noqa: E402
+from graphembed import manifolds as M  # noqa: E402
+from graphembed.modules import ManifoldEmbedding, _pair_kernel_factors  # noqa: E402
+from graphembed.objectives import QuotientLoss, StressLoss  # noqa: E402
+
+
+def squareform(v, n):
+    d = torch.zeros(n, n, dtype=v.dtype, device=v.device)
+    iu = torch.triu_indices(n, n, 1, device=v.device)
+    d[iu[0], iu[1]] = v
+    return d + d.t()
+
+
+def main():
+    cases = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+    rng = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+    worst = {torch.float32: 0.0, torch.float64: 0.0}
+    for c in range(cases):
+        dt = rng.choice([torch.float32, torch.float64])
+        n = rng.choice([2, 3, 5, 17, 63, 64, 65, 127, 129, 200, 257, rng.randint(2, 400)])
+        nv = rng.randint(0, 3)
+        mans = []
+        for _ in range(nv):
+            kind = rng.choice(['e', 'l', 's'])
+            m = rng.randint(2, 16)
+            mans.append({'e': M.Euclidean, 'l': M.Lorentz, 's': M.Sphere}[kind](m))
+        if rng.random() < 0.7 or not mans:
+            mans.append(M.SymmetricPositiveDefinite(rng.choice([2, 3])))
+        rng.shuffle(mans)
+        if len(mans) < 2:
+            mans.append(M.Euclidean(rng.randint(1, 16)))
+        assert _pair_kernel_factors(mans) is not None
+        torch.manual_seed(c)
+        torch.set_default_dtype(dt)
+        try:
+            with torch.device('cuda'):
+                emb = ManifoldEmbedding(n, mans)
+                with torch.no_grad():
+                    emb.perturb(rng.choice([0.05, 0.3, 0.8]))
+                    for s in emb.scales:
+                        s.fill_(rng.uniform(-1.0, 2.0))
+        finally:
+            torch.set_default_dtype(torch.float32)
+        params = list(emb.xs) + list(emb.scales)
+        md = emb.compute_dists(None).detach()
+        P = md.numel()
+        target = md * (0.4 + 1.2 * torch.rand(P, dtype=dt, device='cuda')) + 0.05
+        fn, kw = (StressLoss(), {}) if rng.random() < 0.5 else (QuotientLoss(), dict(epoch=rng.randint(0, 5), alpha=rng.uniform(0.7, 1.4)))
+        subset = n >= 4 and rng.random() < 0.5
+        if subset:
+            bs = rng.randint(2, n)
+            idx = torch.randperm(n, device='cuda')[:bs]
+            dense = squareform(target, n)
+            iu = torch.triu_indices(bs, bs, 1, device='cuda')
+            tsub = dense[idx][:, idx][iu[0], iu[1]]
+            ref = fn(tsub, emb.compute_dists(idx), **kw)
+            world = rng.randint(1, 3)
+            parts = [emb.fused_objective(fn, None, idx, rows=B.shard_rows(bs, world, r), dense=dense, **kw)
+                     for r in range(world)]
+        else:
+            ref = fn(target, emb.compute_dists(None), **kw)
+            world = rng.randint(1, 3)
+            parts = []
+            for r in range(world):
+                rows = B.shard_rows(n, world, r)
+                lo, hi = B.pair_offset(n, rows[0]), B.pair_offset(n, rows[1])
+                parts.append(emb.fused_objective(fn, target[lo:hi], None, rows=rows, **kw))
+        rg = torch.autograd.grad(ref, params)
+        tot = sum(p.item() for p in parts)
+        gs = [sum(g) for g in zip(*[torch.autograd.grad(p, params) for p in parts])]
+        tol = 3e-4 if dt == torch.float32 else 1e-9
+        # the quotient loss has kinks: a pair that sits within rounding of one flips a +-1 — compare with slack
+        kink = isinstance(fn, QuotientLoss)
+        le = abs(tot - ref.item()) / max(abs(ref.item()), 1e-30)
+        ge = max(((a - b).abs().max() / b.abs().max().clamp(min=1e-30)).item() for a, b in zip(gs, rg))
+        worst[dt] = max(worst[dt], le, 0.0 if kink else ge)
+        ok = le <= tol and (ge <= (50 * tol if not kink else 0.2))
+        if not ok or not all(bool(torch.isfinite(g).all()) for g in gs):
+            print(f'FAIL case {c}: n={n} mans={[str(m) for m in mans]} dt={dt} subset={subset} world={world} '
+                  f'loss={type(fn).__name__} le={le:.2e} ge={ge:.2e}')
+            sys.exit(1)
+    print(f'{cases} cases ok; worst rel err fp32 {worst[torch.float32]:.2e}, fp64 {worst[torch.float64]:.2e}')
+
+
+if __name__ == '__main__':
+    main()

@@ -25,7 +25,11 @@ class _VecPdist(torch.autograd.Function):
             return xc.new_empty(0)
         with B.on_device(xc.device):
             out = torch.empty(npairs, dtype=xc.dtype, device=xc.device)
-            name = 'mm_vec_pdist_fwd_gram' if use_gram else 'mm_vec_pdist_fwd'
+            # the matrix-core Gram kernel serves the inner-product manifolds up to m = 32 (fp32) / 16 (fp64)
+            # and n = 32768; anything else takes the VALU kernel
+            gram = (use_gram and kind in (B.LORENTZ, B.SPHERE) and n <= 32768
+                    and m <= (32 if xc.dtype == torch.float32 else 16))
+            name = 'mm_vec_pdist_fwd_gram' if gram else 'mm_vec_pdist_fwd'
             lib.call(name, B.dtype_code(xc), kind, B.ptr(xc), n, m, row_begin, row_end, int(squared),
                      B.ptr(out), B.stream_of(xc))
         return out
@@ -43,7 +47,7 @@ class _VecPdist(torch.autograd.Function):
         with B.on_device(xc.device):
             grad = torch.empty_like(xc)
             f32 = xc.dtype == torch.float32
-            mfma = n <= 32768 and ((ctx.use_gram and (f32 or m <= 16)) or
+            mfma = n <= 32768 and ((ctx.use_gram and kind in (B.LORENTZ, B.SPHERE) and (f32 or m <= 16)) or
                                    (f32 and kind == B.EUCLIDEAN and squared and m <= 31))
             if mfma:
                 # matrix-core backward (inner-product manifolds, fp32): W^T X, no workspace

@@ -505,3 +505,22 @@ def test_rsgd_momentum_uses_fused_kernels():
     assert len(calls) == 8
     for p in ps:
         assert bool(torch.isfinite(p).all()) and bool(torch.isfinite(opt.state[p]['momentum_buffer']).all())
+
+
+def test_gram_default_falls_back_outside_its_range():
+    """Lorentz / Sphere route pdist through the matrix-core Gram kernels by default; dimensions those do not
+    serve (fp64 beyond m = 16) take the VALU kernels instead of failing (found by tests/fuzz_pdist.py)."""
+    from graphembed import manifolds as M
+    from oracle import exact
+    torch.manual_seed(0)
+    for man, kind in ((M.Lorentz(20), 'lorentz'), (M.Sphere(24), 'sphere')):
+        x = man.rand(50, out=torch.empty(0, dtype=torch.float64, device='cuda'), ir=0.3) if kind == 'lorentz' \
+            else torch.nn.functional.normalize(torch.randn(50, 24, dtype=torch.float64, device='cuda'), dim=-1)
+        x.requires_grad_()
+        g = torch.randn(50 * 49 // 2, dtype=torch.float64, device='cuda')
+        d2 = man.pdist(x, squared=True)
+        gr, = torch.autograd.grad(d2, x, g)
+        ref = exact.vec_pdist(kind, x.detach().cpu().numpy())
+        rg = exact.vec_pdist_grad(kind, x.detach().cpu().numpy(), g.cpu().numpy())
+        assert np.abs(d2.detach().cpu().numpy() - ref).max() <= 1e-11
+        assert np.abs(gr.cpu().numpy() - rg).max() <= 1e-8 * np.abs(rg).max()

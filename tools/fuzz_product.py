@@ -2,7 +2,7 @@
 """Randomised cross-check of the mixed-manifold pair kernel (mm_product_pairs_loss[_subset]) against the
 differentiable per-factor path (compute_dists -> objective -> autograd): random sizes (incl. n = 2, tile
 edges), factor mixes and dimensions, row shards, node subsets, both losses, fp32/fp64.
-Usage: python tools/fuzz_product.py [cases] [seed]"""
+Usage: python tools/fuzz_product.py [cases] [seed] [--single]   (--single: one factor, the specialised fused kernels)"""
 import os
 import random
 import sys
@@ -24,24 +24,36 @@ def squareform(v, n):
 
 
 def main():
-    cases = int(sys.argv[1]) if len(sys.argv) > 1 else 200
-    rng = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+    args = [a for a in sys.argv[1:] if not a.startswith('--')]
+    cases = int(args[0]) if args else 200
+    rng = random.Random(int(args[1]) if len(args) > 1 else 0)
     worst = {torch.float32: 0.0, torch.float64: 0.0}
     for c in range(cases):
         dt = rng.choice([torch.float32, torch.float64])
         n = rng.choice([2, 3, 5, 17, 63, 64, 65, 127, 129, 200, 257, rng.randint(2, 400)])
+        single = '--single' in sys.argv
         nv = rng.randint(0, 3)
         mans = []
+        if single:   # one factor: the specialised fused kernels (mm_spd_pdist_loss, mm_vec_pdist_loss / Gram loss)
+            fam = rng.choice(['spd', 'e', 'l', 's'])
+            if fam == 'spd':
+                mans = [M.SymmetricPositiveDefinite(rng.choice([2, 3, 3, 4, 5]))]
+            else:
+                man = {'e': M.Euclidean, 'l': M.Lorentz, 's': M.Sphere}[fam](rng.randint(2, 32))
+                man.use_gram = fam != 'e' and rng.random() < 0.5
+                mans = [man]
+            nv = -1
         for _ in range(nv):
             kind = rng.choice(['e', 'l', 's'])
             m = rng.randint(2, 16)
             mans.append({'e': M.Euclidean, 'l': M.Lorentz, 's': M.Sphere}[kind](m))
-        if rng.random() < 0.7 or not mans:
-            mans.append(M.SymmetricPositiveDefinite(rng.choice([2, 3])))
-        rng.shuffle(mans)
-        if len(mans) < 2:
-            mans.append(M.Euclidean(rng.randint(1, 16)))
-        assert _pair_kernel_factors(mans) is not None
+        if not single:
+            if rng.random() < 0.7 or not mans:
+                mans.append(M.SymmetricPositiveDefinite(rng.choice([2, 3])))
+            rng.shuffle(mans)
+            if len(mans) < 2:
+                mans.append(M.Euclidean(rng.randint(1, 16)))
+            assert _pair_kernel_factors(mans) is not None
         torch.manual_seed(c)
         torch.set_default_dtype(dt)
         try:
@@ -58,7 +70,7 @@ def main():
         P = md.numel()
         target = md * (0.4 + 1.2 * torch.rand(P, dtype=dt, device='cuda')) + 0.05
         fn, kw = (StressLoss(), {}) if rng.random() < 0.5 else (QuotientLoss(), dict(epoch=rng.randint(0, 5), alpha=rng.uniform(0.7, 1.4)))
-        subset = n >= 4 and rng.random() < 0.5
+        subset = n >= 4 and rng.random() < 0.5 and _pair_kernel_factors(mans) is not None
         if subset:
             bs = rng.randint(2, n)
             idx = torch.randperm(n, device='cuda')[:bs]

@@ -258,18 +258,37 @@ __device__ __forceinline__ T grass_pair(const T (&g)[P][P], T (&dg)[P][P]) {
       const T sc = N::min(sg, T(1 - 1e-16));  // value clamp (grassmann.py:94)
       const T th = acos_<T>(sc);
       val = N::fma(th, th, val);
-      if (WANT_GRAD) f[k] = dacos2<T>(sc, th) / N::max(sg, T(1e-30));
+      if (WANT_GRAD) f[k] = dacos2<T>(sc, th);
     }
-    if (WANT_GRAD) {  // dG = U diag(f') V^T = G V diag(f'/s) V^T
-      T m[P][P];
-      vfvt<T, P>(v, f, m);
+    if (WANT_GRAD) {
+      // dG = U diag(f') V^T with the left vectors u_k = (G v_k) / ||G v_k||.  Normalising by the ACTUAL norm
+      // keeps every term bounded: dividing by sqrt(w_k) instead blows up when a principal angle is ~pi/2
+      // (sigma_k ~ 0: w_k is then rounding noise of G^T G, possibly <= 0, while G v_k is not) — found by
+      // tests/fuzz_misc.py as 1e25-sized gradients in fp32.
+      T b[P][P];
+#pragma unroll
+      for (int i = 0; i < P; ++i)
+#pragma unroll
+        for (int k = 0; k < P; ++k) {
+          T acc = T(0);
+#pragma unroll
+          for (int j = 0; j < P; ++j) acc = N::fma(g[i][j], v[j][k], acc);
+          b[i][k] = acc;
+        }
+#pragma unroll
+      for (int k = 0; k < P; ++k) {
+        T nn = T(0);
+#pragma unroll
+        for (int i = 0; i < P; ++i) nn = N::fma(b[i][k], b[i][k], nn);
+        f[k] = f[k] * N::rsqrt(N::max(nn, T(1e-30)));
+      }
 #pragma unroll
       for (int i = 0; i < P; ++i)
 #pragma unroll
         for (int j = 0; j < P; ++j) {
           T acc = T(0);
 #pragma unroll
-          for (int k = 0; k < P; ++k) acc = N::fma(g[i][k], m[k][j], acc);
+          for (int k = 0; k < P; ++k) acc = N::fma(b[i][k] * f[k], v[j][k], acc);
           dg[i][j] = acc;
         }
     }

@@ -164,3 +164,31 @@ def test_pdist_sizes_and_sharding():
         gsum += gp
     assert torch.equal(torch.cat(parts), full.detach())
     np.testing.assert_allclose(gsum.cpu(), gfull.cpu(), rtol=1e-10, atol=1e-12)
+
+
+@pytest.mark.parametrize('dname', ['f32', 'f64'])
+def test_grassmann_gradient_bounded_at_orthogonal_directions(dname):
+    """A principal angle of ~pi/2 (singular value ~0 of x^T y): the gradient of sum acos^2(sigma) is
+    -pi u v^T there — finite.  Forming u as (G v)/sigma with sigma from the eigenvalues of G^T G blew up to 1e25
+    in fp32 (found by tests/fuzz_misc.py); the kernels normalise G v by its own norm."""
+    from graphembed import manifolds as M
+    from oracle import ref_port as rp
+    dt = {'f32': torch.float32, 'f64': torch.float64}[dname]
+    N, p = 9, 4
+    eye = torch.eye(N, dtype=torch.float64)
+    x = eye[:, :4]
+    for t in (0.0, 1e-7, 1e-4):          # sigma_min = sin(t)
+        c5 = torch.cos(torch.tensor(t, dtype=torch.float64)) * eye[:, 4] + torch.sin(torch.tensor(t, dtype=torch.float64)) * eye[:, 0]
+        rot = torch.linalg.qr(torch.randn(4, 4, dtype=torch.float64, generator=torch.Generator().manual_seed(1)))[0]
+        y = torch.stack([c5, eye[:, 1], eye[:, 2], 0.6 * eye[:, 3] + 0.8 * eye[:, 5]], dim=1) @ rot
+        pts = torch.stack([x, y, torch.linalg.qr(torch.randn(N, p, dtype=torch.float64,
+                                                             generator=torch.Generator().manual_seed(2)))[0]])
+        for squared in (True, False):
+            xg = pts.to(dt).cuda().requires_grad_()
+            d = M.Grassmann(N, p).pdist(xg, squared=squared)
+            g, = torch.autograd.grad(d.sum(), xg)
+            assert bool(torch.isfinite(g).all()) and g.abs().max().item() < 50, (t, squared, g.abs().max().item())
+            if dname == 'f64' and t == 1e-4:   # away from the kink: the reference's autograd value
+                xr = pts.clone().requires_grad_()
+                gr, = torch.autograd.grad(rp.make('grassmann', N, p).pdist(xr, squared=squared).sum(), xr)
+                assert (g.cpu() - gr).abs().max().item() <= 1e-6 * gr.abs().max().item()

@@ -364,7 +364,7 @@ int mm_graph_average_precision(int dtype, const void* dist, int64_t n, const int
  * FastPrecision::LayerMeanF1Scores / LayerMeanAverageF1Scores (pyx/impl/precision.cpp:300-429), unweighted
  * graphs.  order [n,n] int32: row u = all nodes sorted by embedding distance to u (stable: ties by node id);
  * hops [n,n] int32 hop distances; indptr CSR row pointers (degrees, for the min/max filter);
- * num_layers = diameter + 1 (<= 256).  ACCUMULATES into the device arrays m1, m2, counts (double[num_layers-1],
+ * num_layers = diameter + 1 (<= 2048).  ACCUMULATES into the device arrays m1, m2, counts (double[num_layers-1],
  * zeroed by the caller): per layer the sum of F1, of F1^2 and the number of terms (per_tree_average = 0), or
  * the same over per-tree layer means (per_tree_average = 1). */
 int mm_graph_layer_f1(const int* order, const int* hops, int64_t n, const int* indptr, int min_degree,

@@ -80,8 +80,8 @@ __global__ __launch_bounds__(kApBlock) void average_precision_kernel(const T* __
 // segmented sort done by the caller) and one workgroup per tree walks its row in chunks of 256 positions:
 // running per-layer counts of the nodes already passed live in LDS, the positions inside a chunk are
 // resolved by a 256 x 256 comparison — O(n L + 256 n) per tree instead of O(n^2).
-constexpr int kMaxLayers = 256;
-
+// (kMaxLayers = layer capacity of the instantiation: 256 for real graphs, 2048 for long paths / rings)
+template <int kMaxLayers>
 __global__ __launch_bounds__(kApBlock) void layer_f1_kernel(const int* __restrict__ order /* [n][n] */,
                                                             const int* __restrict__ hops /* [n][n] */, int n,
                                                             const int* __restrict__ indptr, int min_degree,
@@ -185,11 +185,15 @@ extern "C" int mm_graph_layer_f1(const int* order, const int* hops, int64_t n, c
                                  double* counts, mm_stream_t stream) {
   if (n < 0 || n > (1 << 30) || num_layers < 1 || (n > 0 && (!order || !hops || !indptr || !m1 || !m2 || !counts)))
     return MM_ERR_ARG;
-  if (num_layers > kMaxLayers) return MM_ERR_UNSUPPORTED;
+  if (num_layers > 2048) return MM_ERR_UNSUPPORTED;  // graph diameter >= 2048
   if (n == 0) return MM_OK;
   hipStream_t st = static_cast<hipStream_t>(stream);
-  layer_f1_kernel<<<dim3(unsigned(n)), dim3(kApBlock), 0, st>>>(order, hops, int(n), indptr, min_degree, max_degree,
-                                                              per_tree_average, num_layers, m1, m2, counts);
+  if (num_layers <= 256)
+    layer_f1_kernel<256><<<dim3(unsigned(n)), dim3(kApBlock), 0, st>>>(order, hops, int(n), indptr, min_degree,
+                                                                   max_degree, per_tree_average, num_layers, m1, m2, counts);
+  else
+    layer_f1_kernel<2048><<<dim3(unsigned(n)), dim3(kApBlock), 0, st>>>(order, hops, int(n), indptr, min_degree,
+                                                                    max_degree, per_tree_average, num_layers, m1, m2, counts);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? MM_OK : int(e);
 }

@@ -152,3 +152,23 @@ def test_gpu_f1_vs_oracle(n, p):
     a, _ = rp.layer_f1_scores(dense, hops)
     b, _ = rp.layer_f1_scores(squareform(pd2), hops)
     np.testing.assert_allclose(means2, 0.5 * (a + b), rtol=1e-10)
+
+
+@pytest.mark.gpu
+def test_gpu_f1_long_paths():
+    """Graphs with more than 256 layers (a path, a ring: diameter >= 256) take the large-capacity instantiation
+    of the layer-F1 kernel — found by tests/fuzz_metrics.py as an `unsupported` error."""
+    import networkx as nx
+    from scipy.spatial.distance import squareform
+    from graphembed.pyx import FastPrecision
+    from oracle import ref_port as rp
+    for g in (nx.path_graph(300), nx.cycle_graph(700)):
+        m = g.number_of_nodes()
+        hops = _hops(g)
+        rng = np.random.default_rng(1)
+        pd = rng.random(m * (m - 1) // 2)
+        fp = FastPrecision(g)
+        means, var = fp.layer_mean_f1_scores(torch.from_numpy(pd))
+        rmeans, rvar = rp.layer_f1_scores(squareform(pd), hops, degrees=np.array([g.degree(u) for u in range(m)]))
+        np.testing.assert_allclose(means, rmeans, rtol=1e-10, atol=1e-12)
+        np.testing.assert_allclose(var, rvar, rtol=1e-8, atol=1e-12)

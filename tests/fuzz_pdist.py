@@ -2,7 +2,7 @@
 """Randomised cross-check of the op-level pair kernels (pdist forward + backward, all manifolds of the path)
 against the plain-C fp64 checker oracle/exact.c: random sizes (n = 1, 2, tile edges, ragged), dimensions,
 dtypes, spreads (close-pair series / Cayley / Jacobi regimes), squared or not, row shards.
-Not collected by pytest (run by hand on a GPU box): python tests/fuzz_pdist.py [cases] [seed]"""
+Not collected by pytest (run by hand on a GPU box): python tests/fuzz_pdist.py [cases] [seed] [--big]"""
 import os
 import random
 import sys
@@ -19,13 +19,17 @@ from oracle import exact  # noqa: E402
 
 
 def main():
-    cases = int(sys.argv[1]) if len(sys.argv) > 1 else 200
-    rng = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+    args = [a for a in sys.argv[1:] if not a.startswith('--')]
+    big = '--big' in sys.argv
+    cases = int(args[0]) if args else 200
+    rng = random.Random(int(args[1]) if len(args) > 1 else 0)
     worst = {}
     for c in range(cases):
         dt = rng.choice([torch.float32, torch.float64])
         fam = rng.choice(['spd', 'spd', 'euclidean', 'lorentz', 'sphere'])
         n = rng.choice([1, 2, 3, 8, 9, 63, 64, 65, 255, 256, 257, 511, rng.randint(1, 700)])
+        if big:   # tile-height switch (16-row backward tiles from 8.4 M pairs), many column blocks, ragged edges
+            n = rng.choice([2047, 2049, 3001, 4095, 4097, 4160, 5003])
         torch.manual_seed(c)
         if fam == 'spd':
             d = rng.choice([2, 3, 3, 4, 5])

@@ -109,6 +109,9 @@ def main():
                 break
             if not all(bool(torch.isfinite(r).all()) and r.abs().max() < 1e6 for r in rx):
                 break   # the draw diverged in the reference arithmetic itself (huge unclipped steps)
+            if any(isinstance(m_, M.SymmetricPositiveDefinite) and float(torch.linalg.cond(r).max()) > 1e5
+                   for m_, r in zip(mans, rx)):
+                break   # ... or walked into ill-conditioned SPD points (errors ~ cond * eps from there on)
             for p, r in zip(params, rx):
                 err = ((p.detach().cpu() - r).abs().max() / r.abs().max().clamp(min=1e-30)).item()
                 worst = max(worst, err)

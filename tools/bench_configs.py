@@ -130,6 +130,8 @@ CASES = {
     'c3_spd3_minibatch512_step_f32': lambda: minibatch_case([M.SymmetricPositiveDefinite(3)], 5000, 512, torch.float32),
     'c3_spd3_minibatch512_step_f32_graph': lambda: minibatch_case([M.SymmetricPositiveDefinite(3)], 5000, 512, torch.float32, graph=True),
     'c4_csphd_minibatch512_step_f32_graph': lambda: minibatch_case([M.Lorentz(6), M.Sphere(6), M.SymmetricPositiveDefinite(2)], 1025, 512, torch.float32, graph=True),
+    'c4_csphd_minibatch512_step_f32_radam_graph': lambda: minibatch_case([M.Lorentz(6), M.Sphere(6), M.SymmetricPositiveDefinite(2)], 1025, 512, torch.float32, graph=True, adam=True),
+    'c3_spd3_minibatch512_step_f32_radam_graph': lambda: minibatch_case([M.SymmetricPositiveDefinite(3)], 5000, 512, torch.float32, graph=True, adam=True),
     'c4_csphd_minibatch512_step_f32': lambda: minibatch_case([M.Lorentz(6), M.Sphere(6), M.SymmetricPositiveDefinite(2)], 1025, 512, torch.float32),
     'c2_lorentz11_minibatch512_step_f32': lambda: minibatch_case([M.Lorentz(11)], 4039, 512, torch.float32),
     'sphere6_n5000_f32': lambda: pdist_case(M.Sphere(6), 5000, torch.float32),
@@ -138,7 +140,7 @@ CASES = {
 }
 
 
-def minibatch_case(mans, n, bs, dtype, graph=False):
+def minibatch_case(mans, n, bs, dtype, graph=False, adam=False):
     """node-minibatch training step as train.py:198-222 runs it (batch_size=512 in the paper grid): targets of the
     induced sub-graph from the dense matrix, embedding rows gathered, fused loss, scatter-add backward, RSGD"""
     from graphembed.data import GraphDataset
@@ -152,8 +154,12 @@ def minibatch_case(mans, n, bs, dtype, graph=False):
     finally:
         torch.set_default_dtype(torch.float32)
     obj = BatchedObjective(StressLoss(), ds, emb)
-    opt = RiemannianSGD(list(emb.xs), lr=1e-3, exact=True, max_grad_norm=20)
-    opt_s = RiemannianSGD(list(emb.scales), lr=1e-4, max_grad_norm=500)
+    if adam:
+        opt = RiemannianAdam(list(emb.xs), lr=1e-3, exact=True, max_grad_norm=20)
+        opt_s = RiemannianAdam(list(emb.scales), lr=1e-4, max_grad_norm=500)
+    else:
+        opt = RiemannianSGD(list(emb.xs), lr=1e-3, exact=True, max_grad_norm=20)
+        opt_s = RiemannianSGD(list(emb.scales), lr=1e-4, max_grad_norm=500)
     perm = torch.randperm(n, device='cuda')
     state = {'i': 0}
 

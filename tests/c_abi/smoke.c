@@ -1,0 +1,97 @@
+/* A torch-free C client of the C ABI: plain C (gcc), hipMalloc'ed buffers, the HIP stream API — what a cgo / JNI /
+ * ctypes binding of the reference's Manifold plugin would do.  SPD(3): the pair distances of the
+ * points X_k = diag(e^{a_k}, e^{2 a_k}, e^{-a_k}) have the closed form d^2_ij = 6 (a_i - a_j)^2, and the gradient of
+ * sum_ij d^2_ij w.r.t. X_i is diagonal with entries 2 c_m s_i / x_m, s_i = sum_j (a_i - a_j), c = (1, 2, -1).
+ * Also a vector manifold (Euclidean) and the fused RSGD step.  Exit code 0 = all checks passed. */
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+
+#include <hip/hip_runtime_api.h>
+
+#include "mm_manifolds.h"
+
+#define CHECK_HIP(e) do { hipError_t r_ = (e); if (r_ != hipSuccess) { fprintf(stderr, "hip error %d line %d\n", (int)r_, __LINE__); return 2; } } while (0)
+#define CHECK_MM(e) do { int r_ = (e); if (r_ != MM_OK) { fprintf(stderr, "mm error %d line %d\n", r_, __LINE__); return 3; } } while (0)
+
+int main(void) {
+  const int64_t n = 37;
+  const int d = 3;
+  const int64_t P = n * (n - 1) / 2;
+  if (mm_abi_version() < 1) return 4;
+  if (mm_pair_offset(n, n) != P) return 4;
+  double* a = malloc(sizeof(double) * n);
+  double* x = calloc((size_t)n * d * d, sizeof(double));
+  for (int64_t k = 0; k < n; ++k) {
+    a[k] = 0.02 * (double)k - 0.3;
+    x[k * 9 + 0] = exp(a[k]);
+    x[k * 9 + 4] = exp(2 * a[k]);
+    x[k * 9 + 8] = exp(-a[k]);
+  }
+  hipStream_t st;
+  CHECK_HIP(hipStreamCreate(&st));
+  void *dx, *dout, *dg, *dgrad, *ws;
+  const size_t wsb = mm_spd_pdist_ws_bytes(MM_F64, n, d);
+  CHECK_HIP(hipMalloc(&dx, sizeof(double) * n * 9));
+  CHECK_HIP(hipMalloc(&dout, sizeof(double) * P));
+  CHECK_HIP(hipMalloc(&dg, sizeof(double) * P));
+  CHECK_HIP(hipMalloc(&dgrad, sizeof(double) * n * 9));
+  CHECK_HIP(hipMalloc(&ws, wsb));
+  CHECK_HIP(hipMemcpyAsync(dx, x, sizeof(double) * n * 9, hipMemcpyHostToDevice, st));
+  CHECK_MM(mm_spd_pdist_fwd(MM_F64, dx, n, d, 0, n, 1, 1e-8, 1e8, dout, ws, 0, st));
+  double* out = malloc(sizeof(double) * P);
+  double* ones = malloc(sizeof(double) * P);
+  for (int64_t k = 0; k < P; ++k) ones[k] = 1.0;
+  CHECK_HIP(hipMemcpyAsync(dg, ones, sizeof(double) * P, hipMemcpyHostToDevice, st));
+  CHECK_MM(mm_spd_pdist_bwd(MM_F64, dx, dg, n, d, 0, n, 1, 1e-8, 1e8, dgrad, ws, MM_WS_PREPARED, st));
+  double* grad = malloc(sizeof(double) * n * 9);
+  CHECK_HIP(hipMemcpyAsync(out, dout, sizeof(double) * P, hipMemcpyDeviceToHost, st));
+  CHECK_HIP(hipMemcpyAsync(grad, dgrad, sizeof(double) * n * 9, hipMemcpyDeviceToHost, st));
+  CHECK_HIP(hipStreamSynchronize(st));
+  int status = -1;
+  CHECK_MM(mm_spd_status(ws, n, &status, st));
+  if (status != 0) { fprintf(stderr, "status %d\n", status); return 5; }
+  double worst = 0.0, worst_g = 0.0;
+  int64_t k = 0;
+  for (int64_t i = 0; i < n; ++i)
+    for (int64_t j = i + 1; j < n; ++j, ++k) {
+      const double want = fmax(6.0 * (a[i] - a[j]) * (a[i] - a[j]), 1e-8);
+      worst = fmax(worst, fabs(out[k] - want));
+    }
+  const double c[3] = {1.0, 2.0, -1.0};  /* log x_m = c_m a */
+  for (int64_t i = 0; i < n; ++i) {
+    double s = 0.0;
+    for (int64_t j = 0; j < n; ++j) s += a[i] - a[j];
+    for (int r = 0; r < 3; ++r)
+      for (int q = 0; q < 3; ++q) {
+        const double want = r == q ? 2.0 * c[r] * s / x[i * 9 + r * 4] : 0.0;
+        worst_g = fmax(worst_g, fabs(grad[i * 9 + r * 3 + q] - want));
+      }
+  }
+  printf("spd(3) n=%ld: max |d2 - closed form| = %.3e, max |grad - closed form| = %.3e\n", (long)n, worst, worst_g);
+  if (!(worst < 1e-10 && worst_g < 1e-8)) return 6;
+
+  /* Euclidean(4): d2 = |y - x|^2; one RSGD step x' = x - lr g */
+  const int m = 4;
+  float xe[3 * 4] = {0, 0, 0, 0, 1, 2, 2, 0, -1, 0, 0, 1}, ge[3 * 4], oute[3], xn[3 * 4];
+  for (int t = 0; t < 12; ++t) ge[t] = 0.5f * (float)(t % 3);
+  void *dxe, *doute, *dge, *dxn;
+  CHECK_HIP(hipMalloc(&dxe, sizeof xe)); CHECK_HIP(hipMalloc(&doute, sizeof oute));
+  CHECK_HIP(hipMalloc(&dge, sizeof ge)); CHECK_HIP(hipMalloc(&dxn, sizeof xn));
+  CHECK_HIP(hipMemcpyAsync(dxe, xe, sizeof xe, hipMemcpyHostToDevice, st));
+  CHECK_HIP(hipMemcpyAsync(dge, ge, sizeof ge, hipMemcpyHostToDevice, st));
+  CHECK_MM(mm_vec_pdist_fwd(MM_F32, MM_EUCLIDEAN, dxe, 3, m, 0, 3, 1, doute, st));
+  CHECK_MM(mm_vec_rsgd_step(MM_F32, MM_EUCLIDEAN, dxe, dge, 3, m, 0.1, -1.0, 0, dxn, st));
+  CHECK_HIP(hipMemcpyAsync(oute, doute, sizeof oute, hipMemcpyDeviceToHost, st));
+  CHECK_HIP(hipMemcpyAsync(xn, dxn, sizeof xn, hipMemcpyDeviceToHost, st));
+  CHECK_HIP(hipStreamSynchronize(st));
+  if (fabsf(oute[0] - 9.f) > 1e-5f || fabsf(oute[1] - 2.f) > 1e-5f || fabsf(oute[2] - 13.f) > 1e-5f) return 7;
+  for (int t = 0; t < 12; ++t)
+    if (fabsf(xn[t] - (xe[t] - 0.1f * ge[t])) > 1e-6f) return 8;
+  printf("euclidean(4): pdist and RSGD step ok\n");
+  /* argument errors are return codes, never exceptions */
+  if (mm_spd_pdist_fwd(MM_F64, NULL, n, d, 0, n, 1, 1e-8, 1e8, dout, ws, 0, st) != MM_ERR_ARG) return 9;
+  if (mm_spd_pdist_fwd(MM_F64, dx, n, 9, 0, n, 1, 1e-8, 1e8, dout, ws, 0, st) != MM_ERR_UNSUPPORTED) return 9;
+  printf("C ABI smoke: ok\n");
+  return 0;
+}

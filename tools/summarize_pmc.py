@@ -8,5 +8,5 @@ for path in sys.argv[1:]:
             acc[r['Kernel_Name'][:60]][r['Counter_Name']].append(float(r['Counter_Value']))
         print('#', f)
         for k, cs in acc.items():
-            if 'spd_pdist' not in k and 'vec_' not in k: continue
+            if not any(t in k for t in ('spd_pdist', 'vec_', 'product_pair')): continue
             print(k, {c: (sum(v) / len(v)) for c, v in cs.items()}, 'dispatches', len(next(iter(cs.values()))))

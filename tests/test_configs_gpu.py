@@ -552,11 +552,12 @@ def test_graphed_step_follows_a_learning_rate_schedule():
         emb_g, opts_g = build()
         step = GraphedTrainStep(lambda: emb_g.fused_objective(fn, target, None), opts_g, warmup=1).capture()
         losses_g = [step.warmup_losses[0].item()]
-        graphs = {id(step.graph)}
+        graphs = [step.graph]          # (kept alive: ids of freed graph objects get reused)
         for lr in lrs[1:]:
             opts_g[0].param_groups[0]['lr'] = lr
             losses_g.append(step().item())
-            graphs.add(id(step.graph))
+            if step.graph is not graphs[-1]:
+                graphs.append(step.graph)
         np.testing.assert_allclose(losses_g, losses_e, rtol=1e-9)
         assert len(graphs) == 3                     # recorded once per learning rate
         for a, b in zip(emb_g.xs, emb_e.xs):

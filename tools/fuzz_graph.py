@@ -1,0 +1,121 @@
+#!/usr/bin/env python3
+"""Randomised check that a training step replayed as ONE captured HIP graph (graphembed.graphed.GraphedTrainStep)
+advances parameters and optimizer state exactly like the eager loop: random factor mixes (single factors, products,
+with / without a pair-kernel route), full batch or node minibatches refreshed in place, RSGD with / without momentum
+or Riemannian Adam (incl. AdamNc), stress or quotient loss with its schedule in device memory, fp32 / fp64.
+Usage: python tools/fuzz_graph.py [cases] [seed]"""
+import os
+import random
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, 'matrix-manifolds_amd'))
+import torch  # noqa: E402
+from graphembed import manifolds as M  # noqa: E402
+from graphembed.data import GraphDataset  # noqa: E402
+from graphembed.graphed import GraphedTrainStep  # noqa: E402
+from graphembed.modules import BatchedObjective, ManifoldEmbedding  # noqa: E402
+from graphembed.objectives import QuotientLoss, StressLoss  # noqa: E402
+from graphembed.optim import RiemannianAdam, RiemannianSGD  # noqa: E402
+
+
+def main():
+    cases = int(sys.argv[1]) if len(sys.argv) > 1 else 60
+    rng = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+    worst = 0.0
+    for c in range(cases):
+        dt = rng.choice([torch.float32, torch.float64])
+        n = rng.choice([9, 40, 65, 130, rng.randint(5, 200)])
+        pool = [lambda: M.Euclidean(rng.randint(1, 12)), lambda: M.Lorentz(rng.randint(2, 12)),
+                lambda: M.Sphere(rng.randint(2, 12)), lambda: M.SymmetricPositiveDefinite(rng.choice([2, 3])),
+                lambda: M.SymmetricPositiveDefinite(4), lambda: M.Grassmann(4, 2)]
+        k = rng.choice([1, 1, 2, 3])
+        mk = [rng.choice(pool) for _ in range(k)]
+        seeds = rng.randint(0, 10**6)
+        optk = rng.choice(['rsgd', 'rsgd_mom', 'adam', 'adam_nc'])
+        quot = rng.random() < 0.5
+        bs = rng.choice([None, None, max(4, n // 2)])
+        steps = 5
+
+        def build():
+            st = random.Random(seeds)
+            torch.manual_seed(seeds)
+            torch.set_default_dtype(dt)
+            try:
+                with torch.device('cuda'):
+                    rr = random.Random(seeds)
+                    state = rng.getstate()
+                    rng.setstate(rng_state)
+                    mans = [f() for f in mk]
+                    rng.setstate(state)
+                    emb = ManifoldEmbedding(n, mans)
+                    with torch.no_grad():
+                        emb.perturb(0.2)
+                    ds = GraphDataset(torch.rand(n * (n - 1) // 2) + 0.3)
+            finally:
+                torch.set_default_dtype(torch.float32)
+            fn = QuotientLoss() if quot else StressLoss()
+            obj = BatchedObjective(fn, ds, emb)
+            kw = dict(lr=1e-3, exact=st.random() < 0.5, max_grad_norm=st.choice([None, 5.0]))
+            if optk.startswith('rsgd'):
+                mom = dict(momentum=0.9, dampening=0.1) if optk == 'rsgd_mom' else {}
+                opts = [RiemannianSGD(list(emb.xs), **kw, **mom), RiemannianSGD(list(emb.scales), lr=1e-4, **mom)]
+            else:
+                nc = optk == 'adam_nc'
+                opts = [RiemannianAdam(list(emb.xs), betas=(0.9, 0.99), nc=nc, **kw),
+                        RiemannianAdam(list(emb.scales), lr=1e-4, betas=(0.9, 0.99), nc=nc)]
+            return emb, fn, obj, opts
+        rng_state = rng.getstate()
+        torch.manual_seed(c)
+        perm = torch.randperm(n, device='cuda')
+        batches = [None if bs is None else perm[(t * 3) % max(1, n - bs):][:bs] for t in range(steps)]
+        emb_e, fn_e, obj_e, opts_e = build()
+        trace_e, trace_g = [], []
+        for t in range(steps):
+            for o in opts_e:
+                o.zero_grad()
+            le = obj_e(batches[t], epoch=t, alpha=1.0 + 0.1 * t)
+            le.backward()
+            trace_e.append(le.item())
+            for o in opts_e:
+                o.step()
+        emb_g, fn_g, obj_g, opts_g = build()
+        if quot:
+            fn_g.on_device('cuda')
+            fn_g.set_epoch(0, 1.0)
+        idx_static = None if bs is None else batches[0].clone()
+        step = GraphedTrainStep(lambda: obj_g(idx_static, epoch=0, alpha=1.0), opts_g, warmup=1).capture()
+        trace_g.append(step.warmup_losses[0].item())
+        for t in range(1, steps):
+            if quot:
+                fn_g.set_epoch(t, 1.0 + 0.1 * t)
+            if bs is not None:
+                idx_static.copy_(batches[t])
+            trace_g.append(step().item())
+        # fp32: float atomics make two runs differ in the last bits; a pair within rounding of one of the quotient
+        # loss's |.| kinks then flips a sign — compare loosely there (the logic is pinned by the fp64 cases)
+        tol = (5e-2 if quot else 2e-3) if dt == torch.float32 else 1e-8
+        if any(b_ > 1.5 * a_ for a_, b_ in zip(trace_e, trace_e[1:])):
+            continue   # unstable dynamics (unclipped steps: the loss jumps) amplify rounding-level differences
+        if not all(bool(torch.isfinite(p).all()) for p in list(emb_e.xs) + list(emb_e.scales)):
+            continue   # the draw diverges in the eager loop itself (unclipped quotient gradients with momentum)
+        if any(isinstance(m_, M.SymmetricPositiveDefinite) and float(torch.linalg.cond(x_.detach().double()).max()) > 1e6
+               for m_, x_ in zip(emb_e.manifolds, emb_e.xs)):
+            continue   # ... or walks into near-singular SPD points, where rounding-level differences are amplified
+        for a, b in zip(list(emb_g.xs) + list(emb_g.scales), list(emb_e.xs) + list(emb_e.scales)):
+            err = float((a.detach() - b.detach()).abs().max() / b.detach().abs().max().clamp(min=1e-30))
+            worst = max(worst, err) if dt == torch.float64 else worst
+            if not err <= tol:
+                for k_, (a_, b_) in enumerate(zip(list(emb_g.xs) + list(emb_g.scales), list(emb_e.xs) + list(emb_e.scales))):
+                    print('   param', k_, tuple(b_.shape), 'max|eager|', float(b_.detach().abs().max()), 'max|diff|', float((a_.detach() - b_.detach()).abs().max()))
+                print('  eager losses', trace_e)
+                print('  graph losses', trace_g)
+                print('  nan in eager/graph:', [bool(torch.isnan(p).any()) for p in list(emb_e.xs) + list(emb_e.scales)],
+                      [bool(torch.isnan(p).any()) for p in list(emb_g.xs) + list(emb_g.scales)])
+                print(f'FAIL case {c}: mans={[str(m) for m in emb_e.manifolds]} n={n} {dt} opt={optk} quot={quot} bs={bs} err={err:.2e}')
+                sys.exit(1)
+    print(f'{cases} cases ok; worst fp64 rel err {worst:.2e}')
+
+
+if __name__ == '__main__':
+    main()

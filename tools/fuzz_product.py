@@ -2,7 +2,7 @@
 """Randomised cross-check of the mixed-manifold pair kernel (mm_product_pairs_loss[_subset]) against the
 differentiable per-factor path (compute_dists -> objective -> autograd): random sizes (incl. n = 2, tile
 edges), factor mixes and dimensions, row shards, node subsets, both losses, fp32/fp64.
-Usage: python tools/fuzz_product.py [cases] [seed] [--single]   (--single: one factor, the specialised fused kernels)"""
+Usage: python tools/fuzz_product.py [cases] [seed] [--single] [--big]   (--single: one factor, the specialised fused kernels)"""
 import os
 import random
 import sys
@@ -31,6 +31,8 @@ def main():
     for c in range(cases):
         dt = rng.choice([torch.float32, torch.float64])
         n = rng.choice([2, 3, 5, 17, 63, 64, 65, 127, 129, 200, 257, rng.randint(2, 400)])
+        if '--big' in sys.argv:   # more rows per wavefront (the kernel sizes them by n), many workgroups
+            n = rng.choice([600, 777, 1025, 1500, 2100, 3001])
         single = '--single' in sys.argv
         nv = rng.randint(0, 3)
         mans = []
@@ -72,7 +74,7 @@ def main():
         fn, kw = (StressLoss(), {}) if rng.random() < 0.5 else (QuotientLoss(), dict(epoch=rng.randint(0, 5), alpha=rng.uniform(0.7, 1.4)))
         subset = n >= 4 and rng.random() < 0.5 and _pair_kernel_factors(mans) is not None
         if subset:
-            bs = rng.randint(2, n)
+            bs = rng.randint(2, min(n, 2048))   # (larger batches are not handled inside the kernel: fused_objective -> None)
             idx = torch.randperm(n, device='cuda')[:bs]
             dense = squareform(target, n)
             iu = torch.triu_indices(bs, bs, 1, device='cuda')

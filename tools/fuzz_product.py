@@ -32,7 +32,7 @@ def main():
         dt = rng.choice([torch.float32, torch.float64])
         n = rng.choice([2, 3, 5, 17, 63, 64, 65, 127, 129, 200, 257, rng.randint(2, 400)])
         if '--big' in sys.argv:   # more rows per wavefront (the kernel sizes them by n), many workgroups
-            n = rng.choice([600, 777, 1025, 1500, 2100, 3001])
+            n = rng.choice([600, 777, 1025, 1500, 2100, 3001] + ([4200, 5003] if '--single' in sys.argv else []))
         single = '--single' in sys.argv
         nv = rng.randint(0, 3)
         mans = []

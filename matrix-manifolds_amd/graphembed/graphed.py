@@ -23,7 +23,7 @@ from graphembed._backend import unit_seed
 
 class GraphedTrainStep:
 
-    def __init__(self, loss_fn, optimizers, warmup=3):
+    def __init__(self, loss_fn, optimizers, warmup=3, unroll=1):
         self.loss_fn = loss_fn
         self.optimizers = list(optimizers)
         for o in self.optimizers:
@@ -31,6 +31,11 @@ class GraphedTrainStep:
                 raise TypeError(f'{type(o).__name__} keeps host-side step state and cannot be replayed '
                                 'from a captured graph (RiemannianSGD and RiemannianAdam of this package can)')
         self.warmup = warmup
+        # `unroll` consecutive steps per recorded graph: one hipGraphLaunch (and its ~8 us of launch latency)
+        # per `unroll` steps — for steps that are a few tens of microseconds long and need nothing from the host
+        # in between (full batch, fixed targets); `__call__` then advances `unroll` steps and returns the last loss
+        self.unroll = max(1, int(unroll))
+        self.losses = []
         self.graph = None
         self.loss = None
         self.warmup_losses = []
@@ -70,7 +75,8 @@ class GraphedTrainStep:
         torch.cuda.current_stream().wait_stream(side)
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
-            self.loss = self._eager_step()
+            self.losses = [self._eager_step() for _ in range(self.unroll)]
+            self.loss = self.losses[-1]
         self._recorded = self._hyper()
         return self
 

@@ -564,3 +564,47 @@ def test_graphed_step_follows_a_learning_rate_schedule():
             np.testing.assert_allclose(a.detach().cpu().numpy(), b.detach().cpu().numpy(), rtol=1e-8, atol=1e-10)
     finally:
         torch.set_default_dtype(torch.float32)
+
+
+def test_graphed_step_unrolled():
+    """GraphedTrainStep(unroll=3): three consecutive steps per recorded graph — same trajectory as the eager loop,
+    all three losses available after a replay."""
+    from graphembed import manifolds as M
+    from graphembed.graphed import GraphedTrainStep
+    from graphembed.modules import ManifoldEmbedding
+    from graphembed.objectives import StressLoss
+    from graphembed.optim import RiemannianAdam, RiemannianSGD
+    n = 90
+    torch.set_default_dtype(torch.float64)
+    try:
+        def build():
+            torch.manual_seed(7)
+            with torch.device('cuda'):
+                emb = ManifoldEmbedding(n, [M.Lorentz(5), M.Sphere(4), M.SymmetricPositiveDefinite(2)])
+            return emb, [RiemannianSGD(list(emb.xs), lr=0.01, exact=True, max_grad_norm=20),
+                         RiemannianAdam(list(emb.scales), lr=1e-3)]
+        torch.manual_seed(3)
+        target = torch.rand(n * (n - 1) // 2, device='cuda') * 0.9 + 0.1
+        fn = StressLoss()
+        emb_e, opts_e = build()
+        losses_e = []
+        for _ in range(7):
+            for o in opts_e:
+                o.zero_grad()
+            loss = emb_e.fused_objective(fn, target, None)
+            loss.backward()
+            for o in opts_e:
+                o.step()
+            losses_e.append(loss.item())
+        emb_g, opts_g = build()
+        step = GraphedTrainStep(lambda: emb_g.fused_objective(fn, target, None), opts_g, warmup=1, unroll=3).capture()
+        losses_g = [step.warmup_losses[0].item()]
+        for _ in range(2):
+            last = step()
+            losses_g += [l.item() for l in step.losses]
+            assert last is step.losses[-1]
+        np.testing.assert_allclose(losses_g, losses_e, rtol=1e-9)
+        for a, b in zip(emb_g.xs, emb_e.xs):
+            np.testing.assert_allclose(a.detach().cpu().numpy(), b.detach().cpu().numpy(), rtol=1e-8, atol=1e-10)
+    finally:
+        torch.set_default_dtype(torch.float32)

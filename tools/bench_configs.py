@@ -108,6 +108,8 @@ CASES = {
     'c4_csphd_product_step_f32': lambda: step_case([M.Lorentz(6), M.Sphere(6), M.SymmetricPositiveDefinite(2)], 1025, torch.float32),
     'c4_csphd_product_step_f32_fused': lambda: step_case([M.Lorentz(6), M.Sphere(6), M.SymmetricPositiveDefinite(2)], 1025, torch.float32, fused=True),
     'c4_csphd_product_step_f32_fused_graph': lambda: step_case([M.Lorentz(6), M.Sphere(6), M.SymmetricPositiveDefinite(2)], 1025, torch.float32, fused=True, graph=True),
+    'c4_csphd_product_step_f32_fused_graph_unroll4': lambda: unrolled_case([M.Lorentz(6), M.Sphere(6), M.SymmetricPositiveDefinite(2)], 1025, torch.float32, 4),
+    'c2_facebook_lorentz11_step_f32_fused_graph_unroll4': lambda: unrolled_case([M.Lorentz(11)], 4039, torch.float32, 4),
     'c4_csphd_product_step_f32_perfactor': lambda: step_case([M.Lorentz(6), M.Sphere(6), M.SymmetricPositiveDefinite(2)], 1025, torch.float32, fused=True, pair_kernel=False),
     'c4_csphd_product_step_f32_perfactor_graph': lambda: step_case([M.Lorentz(6), M.Sphere(6), M.SymmetricPositiveDefinite(2)], 1025, torch.float32, fused=True, graph=True, pair_kernel=False),
     'c4_csphd_product_step_f64_fused_graph': lambda: step_case([M.Lorentz(6), M.Sphere(6), M.SymmetricPositiveDefinite(2)], 1025, torch.float64, fused=True, graph=True),
@@ -138,6 +140,26 @@ CASES = {
     'euclidean10_n5000_f32': lambda: pdist_case(M.Euclidean(10), 5000, torch.float32),
     'grassmann52_n2000_f32': lambda: pdist_case(M.Grassmann(5, 2), 2000, torch.float32),
 }
+
+
+def unrolled_case(mans, n, dtype, unroll):
+    """full-batch fused training step, `unroll` steps per recorded graph (GraphedTrainStep(unroll=)); time per STEP"""
+    from graphembed.graphed import GraphedTrainStep
+    torch.manual_seed(0)
+    torch.set_default_dtype(dtype)
+    try:
+        with torch.device('cuda'):
+            emb = ManifoldEmbedding(n, mans)
+    finally:
+        torch.set_default_dtype(torch.float32)
+    P = n * (n - 1) // 2
+    target = torch.rand(P, dtype=dtype, device='cuda') * 0.99 + 0.01
+    fn = StressLoss()
+    opts = [RiemannianSGD(list(emb.xs), lr=1e-3, exact=True, max_grad_norm=20),
+            RiemannianSGD(list(emb.scales), lr=1e-4, max_grad_norm=500)]
+    step = GraphedTrainStep(lambda: emb.fused_objective(fn, target, None), opts, warmup=2, unroll=unroll).capture()
+    t = timeit(step) / unroll
+    return {'n': n, 'pairs': P, 'dtype': str(dtype).split('.')[-1], 'step_us': t, 'pairs_per_s': P / (t * 1e-6)}
 
 
 def minibatch_case(mans, n, bs, dtype, graph=False, adam=False):

@@ -197,6 +197,15 @@ class ManifoldParameter(torch.nn.Parameter):
         instance.manifold = manifold
         return instance
 
+    def __deepcopy__(self, memo):
+        # (torch's Parameter.__deepcopy__ calls type(self)(data, requires_grad): the flag would land in `manifold`;
+        # the training engine deep-copies the best embedding, train.py:116-121)
+        if id(self) in memo:
+            return memo[id(self)]
+        result = type(self)(self.data.clone(memory_format=torch.preserve_format), self.manifold, self.requires_grad)
+        memo[id(self)] = result
+        return result
+
     def proj_(self):
         self.manifold.projx(self, inplace=True)
 

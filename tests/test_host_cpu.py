@@ -279,3 +279,22 @@ def test_spd_from_vec_batch_equal_to_vector_length():
         assert x.shape == (k, d, d) and torch.equal(x, x.transpose(1, 2))
         back = SPD.to_vec(x)
         assert back.shape == (k, k) and torch.allclose(back, v)
+
+
+def test_embedding_deepcopy_keeps_manifolds():
+    """copy.deepcopy(embedding) (the training engine snapshots the best embedding, train.py:116-121): the copies of
+    the ManifoldParameters keep their manifold and their values, and are independent tensors."""
+    import copy
+    import torch
+    from graphembed.modules import ManifoldParameter
+
+    class Man:
+        pass
+    man = Man()
+    p = ManifoldParameter(torch.arange(6.0).reshape(2, 3), manifold=man)
+    holder = torch.nn.ParameterList([p])
+    dup = copy.deepcopy(holder)
+    assert isinstance(dup[0], ManifoldParameter) and dup[0].manifold is man and dup[0].requires_grad
+    assert torch.equal(dup[0].data, p.data) and dup[0].data_ptr() != p.data_ptr()
+    q = ManifoldParameter(torch.zeros(2), manifold=man, requires_grad=False)
+    assert copy.deepcopy(q).requires_grad is False and copy.deepcopy(q).manifold is man

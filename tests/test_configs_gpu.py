@@ -608,3 +608,88 @@ def test_graphed_step_unrolled():
             np.testing.assert_allclose(a.detach().cpu().numpy(), b.detach().cpu().numpy(), rtol=1e-8, atol=1e-10)
     finally:
         torch.set_default_dtype(torch.float32)
+
+
+@pytest.mark.parametrize('opt_name', ['rsgd', 'radam'])
+def test_training_engine_flow(opt_name):
+    """The sequence of calls the reference's TrainingEngine makes (train.py:104-222, experiments/run_grid.py:24-36) —
+    burn-in with frozen scales, CPU randperm minibatches with `drop_last_n`, zero_grad / backward / step on two
+    optimizers, ReduceLROnPlateau, deepcopy of the best embedding, perturb, stabilize, validation on compute_dists,
+    state_dict round trip — runs on this package's classes unchanged and trains."""
+    import copy
+    from graphembed import manifolds as M
+    from graphembed.data import GraphDataset
+    from graphembed.metrics import pearsonr
+    from graphembed.modules import BatchedObjective, ManifoldEmbedding
+    from graphembed.objectives import QuotientLoss
+    from graphembed.optim import RiemannianAdam, RiemannianSGD
+    torch.manual_seed(0)
+    n, bs, drop_last_n = 70, 32, 5
+    torch.set_default_dtype(torch.float64)
+    try:
+        with torch.device('cuda'):
+            emb = ManifoldEmbedding(n, [M.Lorentz(4), M.Sphere(3), M.SymmetricPositiveDefinite(2)])
+            pts = torch.randn(n, 3)
+            ds = GraphDataset(torch.pdist(pts))          # targets: squared, max-normalised (dataset.py:9-13)
+        Opt = RiemannianSGD if opt_name == 'rsgd' else RiemannianAdam
+        opts = [Opt(list(emb.xs), lr=0.05, exact=True, max_grad_norm=20),
+                Opt(list(emb.curvature_params), lr=1e-3, max_grad_norm=500)]
+        sched = torch.optim.lr_scheduler.ReduceLROnPlateau(opts[0], factor=0.1, patience=2, threshold=1e-4, min_lr=1e-5)
+        obj = BatchedObjective(QuotientLoss(), ds, emb)
+
+        def train(alpha, epoch):
+            perm = torch.randperm(n)                       # CPU indices, as the reference draws them
+            total = 0.0
+            for i in range(0, n, bs):
+                idx = perm[i:i + bs]
+                if len(idx) < drop_last_n:
+                    break
+                loss = obj(idx, alpha=alpha, epoch=epoch).sum()
+                for o in opts:
+                    o.zero_grad()
+                loss.backward()
+                for o in opts:
+                    o.step()
+                total += loss.item()
+            return total
+        with torch.no_grad():
+            r0 = pearsonr(emb.compute_dists(None), ds[None]).item()
+        emb.burnin(True)                                   # scales frozen during burn-in (train.py:140-168)
+        s0 = [s.item() for s in emb.scales]
+        for epoch in range(1, 3):
+            train(0.5, epoch)
+        assert [s.item() for s in emb.scales] == s0
+        emb.burnin(False)
+        best = dict(loss=1e30, embedding=copy.deepcopy(emb))
+        losses = []
+        for epoch in range(1, 21):
+            loss = train(1.0, epoch)
+            sched.step(loss)
+            losses.append(loss)
+            if loss < best['loss']:
+                best = dict(loss=loss, embedding=copy.deepcopy(emb))
+            if epoch % 5 == 0:
+                with torch.no_grad():
+                    emb.perturb(0.05 / epoch)
+            if epoch % 4 == 0:
+                with torch.no_grad():
+                    emb.stabilize()
+        assert all(np.isfinite(losses))   # (the quotient loss is not comparable across epochs: eps = 1/(epoch+1))
+        with torch.no_grad():
+            r = pearsonr(emb.compute_dists(None), ds[None]).item()
+        assert r > max(0.5, r0 + 0.2), (r0, r)
+        # the snapshot is an independent, fully functional embedding (manifold tags kept)
+        snap = best['embedding']
+        assert all(a.manifold is not None and a.data_ptr() != b.data_ptr() for a, b in zip(snap.xs, emb.xs))
+        assert torch.isfinite(snap.compute_dists(None)).all()
+        # state_dict round trip into a fresh embedding (keys xs.k / scales.k)
+        with torch.device('cuda'):
+            fresh = ManifoldEmbedding(n, [M.Lorentz(4), M.Sphere(3), M.SymmetricPositiveDefinite(2)])
+        fresh.load_state_dict(emb.state_dict())
+        assert sorted(emb.state_dict()) == ['scales.0', 'scales.1', 'scales.2', 'xs.0', 'xs.1', 'xs.2']
+        assert torch.equal(fresh.compute_dists(None), emb.compute_dists(None))
+        osd = opts[0].state_dict()
+        opts[0].load_state_dict(osd)
+        train(1.0, 21)
+    finally:
+        torch.set_default_dtype(torch.float32)

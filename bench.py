@@ -8,14 +8,24 @@ with the pair list sharded by rows across the ranks and, for N > 1, ONE RCCL
 all-reduce(sum) of the embedding gradient inside the timed region.
 
     python bench.py [--gpus N] [--steps K] [--warmup W]
-N > 1 is launched by torch.distributed.run (one rank per GPU).  Rank 0 prints one
-JSON line.  Inputs are resident in HBM before the timed region starts.
+
+N > 1: `python bench.py --gpus N` starts its N ranks itself (a child `torch.distributed.run`,
+started before this process touches a GPU; the child's exit code is passed on, a run that
+exceeds --launch-timeout is killed and exits 124).  Started BY `torch.distributed.run` (RANK in
+the environment) it is one rank.  Rank 0 prints ONE JSON line.  Inputs are resident in HBM
+before the timed region starts.  The reference gets its multi-GPU from one `python run.py`
+(graphembed/graphembed/train.py:107-109, torch.nn.DataParallel).
 """
 import argparse
 import ctypes
+import hashlib
 import json
 import os
+import signal
+import socket
+import subprocess
 import sys
+import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -23,61 +33,12 @@ for p in (ROOT, os.path.join(ROOT, 'matrix-manifolds_amd')):
     if p not in sys.path:
         sys.path.insert(0, p)
 
-import torch  # noqa: E402
-
 N_NODES = 5000
 DIM = 3
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
-def synthetic_spd(n, d, seed, device):
-    """SPD.rand (spd.py:201-208): X = expm(U), ||vec U|| = 0.1 — the reference's init."""
-    gen = torch.Generator().manual_seed(seed)
-    m = d * (d + 1) // 2
-    u = torch.randn(n, m, generator=gen, dtype=torch.float64)
-    u = u / u.norm(dim=-1, keepdim=True) * 0.1
-    iu = torch.triu_indices(d, d)
-    U = torch.zeros(n, d, d, dtype=torch.float64)
-    U[:, iu[0], iu[1]] = u / 2 ** 0.5
-    U[:, iu[1], iu[0]] = u / 2 ** 0.5
-    k = torch.arange(d)
-    U[:, k, k] *= 2 ** 0.5
-    X = torch.linalg.matrix_exp(U)
-    P = n * (n - 1) // 2
-    g = torch.randn(P, generator=gen, dtype=torch.float32)
-    return X.float().to(device), g.to(device)
-
-
-def cpu_baseline(seed):
-    """The oracle port (reference-faithful op sequence) on this host's cores, on a
-    bounded sample: n=2500 nodes (3.1 M pairs) of the same workload, best of 3."""
-    from oracle import ref_port
-    ncpu = os.cpu_count() or 1
-    n = 2500
-    x, g = synthetic_spd(n, DIM, seed, 'cpu')
-    man = ref_port.SPD(DIM)
-    P = n * (n - 1) // 2
-    best, best_threads = float('inf'), 1
-    # torch's intra-op pool does not scale to hundreds of threads on these element-wise ops:
-    # time a few pool sizes and report the fastest (the fairest baseline for this host)
-    for threads in sorted({min(8, ncpu), min(32, ncpu), min(64, ncpu), ncpu}):
-        torch.set_num_threads(threads)
-        for it in range(3):
-            xr = x.clone().requires_grad_()
-            t0 = time.perf_counter()
-            d2 = man.pdist(xr, squared=True)
-            d2.backward(g)
-            dt = time.perf_counter() - t0
-            if it and dt < best:
-                best, best_threads = dt, threads
-    return {'value': P / best, 'unit': 'pairs/s', 'cores': best_threads, 'kind': 'port',
-            'host_cpus': ncpu,
-            'sample': f'SPD(3) fp32 reference-init, n={n} ({P} pairs), fwd+bwd, best of 2 per pool size '
-                      f'(8/32/64/all threads), fastest pool reported; oracle/ref_port.py '
-                      f'(torch CPU, reference op sequence)'}
-
-
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=50)
@@ -85,134 +46,424 @@ def main():
     ap.add_argument('--n', type=int, default=N_NODES)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-prof', action='store_true', help='no HIP-event bracketing of the kernels')
+    ap.add_argument('--no-extra', action='store_true', help='headline only (no secondary workloads)')
     ap.add_argument('--graph', choices=['auto', 'on', 'off'], default='auto',
                     help='replay the step from a captured hipGraph (auto = on; falls back to eager launches '
                          'if capture is unavailable)')
-    args = ap.parse_args()
+    ap.add_argument('--launch-timeout', type=float, default=900.0,
+                    help='N > 1 self-launch: seconds before the child job is killed (exit 124)')
+    ap.add_argument('--rank-timeout', type=float, default=600.0,
+                    help='a rank that is still running after this many seconds exits with code 3')
+    return ap.parse_args(argv)
 
+
+# ---------------------------------------------------------------------------------------------
+# launcher: `python bench.py --gpus N` without torch.distributed.run around it
+# ---------------------------------------------------------------------------------------------
+def free_port():
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(('127.0.0.1', 0))
+        return s.getsockname()[1]
+
+
+def launch(args, argv):
+    """Spawn the N ranks as ONE child job and wait for it.  This process never initialises a GPU and
+    never execs: it starts a child, waits (bounded) and exits with the child's code."""
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')   # dmabuf IPC (RCCL / cross-process device memory)
+    env['MM_BENCH_LAUNCHED'] = '1'
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={args.gpus}',
+           '--master-addr', '127.0.0.1', '--master-port', str(free_port()), os.path.abspath(__file__)] + argv
+    proc = subprocess.Popen(cmd, env=env, start_new_session=True)   # own process group: killable as a whole
+    try:
+        rc = proc.wait(timeout=args.launch_timeout)
+    except subprocess.TimeoutExpired:
+        print(f'[bench] the {args.gpus}-rank job exceeded --launch-timeout {args.launch_timeout:.0f} s: killing it',
+              file=sys.stderr, flush=True)
+        for sig in (signal.SIGTERM, signal.SIGKILL):
+            try:
+                os.killpg(proc.pid, sig)   # exactly the group started above
+            except ProcessLookupError:
+                break
+            try:
+                proc.wait(timeout=10)
+                break
+            except subprocess.TimeoutExpired:
+                continue
+        rc = 124
+    except KeyboardInterrupt:
+        os.killpg(proc.pid, signal.SIGTERM)
+        rc = 130
+    sys.exit(rc)
+
+
+# ---------------------------------------------------------------------------------------------
+# synthetic workloads (SURVEY.md §8d)
+# ---------------------------------------------------------------------------------------------
+def synthetic_spd(n, d, seed, device, ir=0.1, dtype=None, with_g=True):
+    """SPD.rand (spd.py:201-208): X = expm(U), ||vec U|| = ir (0.1 = the reference's init)."""
+    import torch
+    gen = torch.Generator().manual_seed(seed)
+    m = d * (d + 1) // 2
+    u = torch.randn(n, m, generator=gen, dtype=torch.float64)
+    u = u / u.norm(dim=-1, keepdim=True) * ir
+    iu = torch.triu_indices(d, d)
+    U = torch.zeros(n, d, d, dtype=torch.float64)
+    U[:, iu[0], iu[1]] = u / 2 ** 0.5
+    U[:, iu[1], iu[0]] = u / 2 ** 0.5
+    k = torch.arange(d)
+    U[:, k, k] *= 2 ** 0.5
+    X = torch.linalg.matrix_exp(U)
+    dtype = dtype or torch.float32
+    if not with_g:
+        return X.to(dtype).to(device), None
+    P = n * (n - 1) // 2
+    g = torch.randn(P, generator=gen, dtype=torch.float32)
+    return X.to(dtype).to(device), g.to(dtype).to(device)
+
+
+def cpu_baseline(seed, n=N_NODES):
+    """The oracle port (reference-faithful op sequence, oracle/ref_port.py) on this host's cores, on the
+    metric's own workload (n = 5000, 12.5 M pairs).  The thread pool is chosen on a quarter-size probe
+    (torch's intra-op pool does not scale to hundreds of threads on these element-wise ops), then the
+    full size is timed twice with it and the faster pass is reported."""
+    import torch
+    from oracle import ref_port
+    ncpu = os.cpu_count() or 1
+    man = ref_port.SPD(DIM)
+
+    def one(x, g):
+        xr = x.clone().requires_grad_()
+        t0 = time.perf_counter()
+        d2 = man.pdist(xr, squared=True)
+        d2.backward(g)
+        return time.perf_counter() - t0
+
+    xp, gp = synthetic_spd(n // 2, DIM, seed, 'cpu')
+    best_threads, best = 1, float('inf')
+    for threads in sorted({min(8, ncpu), min(32, ncpu), min(64, ncpu)}):
+        torch.set_num_threads(threads)
+        one(xp, gp)
+        dt = one(xp, gp)
+        if dt < best:
+            best, best_threads = dt, threads
+    torch.set_num_threads(best_threads)
+    x, g = synthetic_spd(n, DIM, seed, 'cpu')
+    P = n * (n - 1) // 2
+    dt = min(one(x, g), one(x, g))
+    return {'value': P / dt, 'unit': 'pairs/s', 'cores': best_threads, 'kind': 'port', 'host_cpus': ncpu,
+            'seconds_per_pass': dt,
+            'sample': f'SPD(3) fp32 reference-init, n={n} ({P} pairs), fwd+bwd, faster of 2 passes; thread pool '
+                      f'(8/32/64) picked on an n={n // 2} probe; oracle/ref_port.py (torch CPU, reference op sequence)'}
+
+
+def kernel_source_hash():
+    """sha256 over the kernel sources: PMC figures are only quoted for the build they were measured on."""
+    h = hashlib.sha256()
+    src = os.path.join(ROOT, 'matrix-manifolds_amd', 'csrc')
+    for name in sorted(os.listdir(src)):
+        if name.endswith(('.hip', '.hpp')):
+            with open(os.path.join(src, name), 'rb') as f:
+                h.update(name.encode())
+                h.update(f.read())
+    return h.hexdigest()[:16]
+
+
+def stamped_pmc():
+    """profiles/pmc_head.json (written by tools/pmc_stamp.py from rocprofv3 --pmc passes of this very
+    command) if its source hash is that of the kernels in the tree, else None."""
+    path = os.path.join(ROOT, 'profiles', 'pmc_head.json')
+    try:
+        with open(path) as f:
+            rec = json.load(f)
+    except (OSError, ValueError):
+        return None
+    return rec if rec.get('kernel_source_hash') == kernel_source_hash() else None
+
+
+# ---------------------------------------------------------------------------------------------
+# one rank
+# ---------------------------------------------------------------------------------------------
+class Fence:
+    def __init__(self, world):
+        self.world = world
+
+    def __call__(self):
+        import torch
+        if self.world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+        torch.cuda.synchronize()
+
+
+def graph_of(fn, fence, warm=3):
+    """Capture fn() (a sequence of launches on the current stream) into a hipGraph; returns (graph, outputs)."""
+    import torch
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(warm):
+            fn()
+    torch.cuda.current_stream().wait_stream(side)
+    fence()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        out = fn()
+    fence()
+    return graph, out
+
+
+def collect_kernel_us(lib, names=(('fwd', 0), ('bwd', 1))):
+    out = {}
+    for name, kid in names:
+        cnt, ms = ctypes.c_int64(0), ctypes.c_double(0.0)
+        lib.call('mm_prof_collect', kid, ctypes.byref(cnt), ctypes.byref(ms))
+        out[name] = (ms.value / cnt.value * 1e3) if cnt.value else None
+    return out
+
+
+def median(v):
+    v = sorted(v)
+    return v[len(v) // 2] if v else None
+
+
+class PdistWorkload:
+    """d2 = man.pdist(x, squared=True, rows=shard); grad = d d2 / d x . g  (+ one all-reduce for N > 1)."""
+
+    def __init__(self, d, n, dtype, ir, world, rank, dev, seed=42):
+        import torch
+        from graphembed import _backend as B
+        from graphembed.manifolds import SymmetricPositiveDefinite
+        self.d, self.n, self.world, self.rank = d, n, world, rank
+        self.dtype = dtype
+        x, g = synthetic_spd(n, d, seed, dev, ir=ir, dtype=dtype)   # replicated embedding, same on every rank
+        self.rows = B.shard_rows(n, world, rank)
+        self.lo, self.hi = B.pair_offset(n, self.rows[0]), B.pair_offset(n, self.rows[1])
+        self.g_local = g[self.lo:self.hi].contiguous()
+        del g
+        self.man = SymmetricPositiveDefinite(d)
+        self.x = x.requires_grad_()
+        self.P = n * (n - 1) // 2
+        self.esz = torch.empty(0, dtype=dtype).element_size()
+
+    def kernels(self):
+        import torch
+        d2 = self.man.pdist(self.x, squared=True, rows=self.rows)
+        grad, = torch.autograd.grad(d2, self.x, self.g_local)
+        return grad
+
+    def eager_step(self):
+        import torch.distributed as dist
+        grad = self.kernels()
+        if self.world > 1:
+            dist.all_reduce(grad)               # the single collective of a step
+        return grad
+
+
+class FusedLossWorkload:
+    """BASELINE config 5: all-pairs QuotientLoss of an SPD(4) embedding through the fused loss+gradient
+    kernel (mm_spd_pdist_loss: no pair vector of distances), pair rows sharded, ONE all-reduce of
+    {grad_x, loss, grad_scale}."""
+
+    def __init__(self, d, n, dtype, world, rank, dev, seed=7):
+        import torch
+        from graphembed import _backend as B
+        from graphembed.manifolds import SymmetricPositiveDefinite
+        from graphembed.objectives import QuotientLoss
+        self.d, self.n, self.world, self.rank = d, n, world, rank
+        self.x, _ = synthetic_spd(n, d, seed, dev, ir=0.1, dtype=dtype, with_g=False)
+        self.x.requires_grad_()
+        self.scale = torch.tensor(0.5, dtype=dtype, device=dev, requires_grad=True)
+        self.rows = B.shard_rows(n, world, rank)
+        self.lo, self.hi = B.pair_offset(n, self.rows[0]), B.pair_offset(n, self.rows[1])
+        gen = torch.Generator(device=dev).manual_seed(seed + 1000 + rank)
+        # stands in for normalised squared graph distances (SURVEY §8d): U(0.01, 1), this rank's slice only
+        self.target = torch.rand(self.hi - self.lo, generator=gen, dtype=dtype, device=dev) * 0.99 + 0.01
+        self.man = SymmetricPositiveDefinite(d)
+        self.spec = QuotientLoss().fused_spec(epoch=3, alpha=1.0)
+        self.P = n * (n - 1) // 2
+        self.flat = torch.empty(self.x.numel() + 2, dtype=dtype, device=dev)
+
+    def kernels(self):
+        import torch
+        loss = self.man.pdist_loss(self.x, self.scale, self.target, self.spec, rows=self.rows)
+        gx, gs = torch.autograd.grad(loss, (self.x, self.scale))
+        # one flat message: the point gradient, the scale gradient and the local loss
+        torch.cat([gx.reshape(-1), gs.reshape(1), loss.detach().reshape(1)], out=self.flat)
+        return self.flat
+
+    def eager_step(self):
+        import torch.distributed as dist
+        flat = self.kernels()
+        if self.world > 1:
+            dist.all_reduce(flat)
+        return flat
+
+
+def time_workload(wl, steps, warmup, fence, use_graph, graph_collective=False, rank=0, tag=''):
+    """Times `steps` steps of the workload between fences.  Returns (elapsed_s, launch_mode, phases) where
+    phases = per-step means, in us, of this rank's device time in the kernels and in the all-reduce and of
+    the rest of the step's wall time (host gap), from an instrumented pass after the timed region."""
+    import torch
+    world = wl.world
+    if world > 1:
+        import torch.distributed as dist
+    graph, static = None, None
+    mode = 'eager'
+    if use_graph:
+        try:
+            if world > 1 and graph_collective:
+                graph, static = graph_of(wl.eager_step, fence)   # RCCL all-reduce captured in the graph
+                mode = 'hipGraph replay (kernels + all-reduce)'
+            else:
+                graph, static = graph_of(wl.kernels, fence)
+                mode = 'hipGraph replay (kernels)' + (' + eager all-reduce' if world > 1 else '')
+        except Exception as exc:  # noqa: BLE001 — report and measure eagerly instead
+            if rank == 0:
+                print(f'[bench] {tag}hipGraph capture unavailable ({type(exc).__name__}: {exc}); eager launches',
+                      file=sys.stderr)
+            graph, mode = None, 'eager'
+            fence()
+    in_graph_collective = graph is not None and world > 1 and graph_collective
+
+    def run():
+        if graph is None:
+            wl.eager_step()
+            return
+        graph.replay()
+        if world > 1 and not in_graph_collective:
+            dist.all_reduce(static)
+
+    for _ in range(warmup):
+        run()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        run()
+    fence()
+    elapsed = time.perf_counter() - t0
+
+    # phase pass (not timed): events on the launch stream around the kernels and around the collective
+    k2 = max(3, min(steps, 20))
+    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(k2)]
+    fence()
+    tw = time.perf_counter()
+    for e0, e1, e2 in ev:
+        e0.record()
+        if graph is None:
+            out = wl.kernels()
+        else:
+            graph.replay()
+            out = static
+        e1.record()
+        if world > 1 and not in_graph_collective:
+            dist.all_reduce(out)
+        e2.record()
+    fence()
+    wall_us = (time.perf_counter() - tw) / k2 * 1e6
+    kern_us = median([e0.elapsed_time(e1) * 1e3 for e0, e1, _ in ev])
+    coll_us = median([e1.elapsed_time(e2) * 1e3 for _, e1, e2 in ev])
+    phases = {'kernels_us': kern_us, 'allreduce_us': coll_us if world > 1 else 0.0,
+              'host_gap_us': max(0.0, wall_us - kern_us - (coll_us if world > 1 else 0.0)),
+              'step_wall_us': wall_us}
+    if in_graph_collective:
+        phases['note'] = 'all-reduce inside the graph: kernels_us includes it'
+    return elapsed, mode, phases
+
+
+def reduce_max(value, dev, world):
+    import torch
+    t = torch.tensor([value], device=dev, dtype=torch.float64)
+    if world > 1:
+        import torch.distributed as dist
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return t.item()
+
+
+def gather_objects(obj, world):
+    if world == 1:
+        return [obj]
+    import torch.distributed as dist
+    out = [None] * world
+    dist.all_gather_object(out, obj)
+    return out
+
+
+def worker(args):
     rank = int(os.environ.get('RANK', 0))
     local_rank = int(os.environ.get('LOCAL_RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
     if world != args.gpus:
-        raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run')
+        raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}')
+
+    # a hung rank (lost peer, wedged collective) must not hang the job: hard exit, non-zero
+    def expire():
+        print(f'[bench] rank {rank}: still running after --rank-timeout {args.rank_timeout:.0f} s; exiting 3',
+              file=sys.stderr, flush=True)
+        os._exit(3)
+    watchdog = threading.Timer(args.rank_timeout, expire)
+    watchdog.daemon = True
+    watchdog.start()
+
+    import torch
     ndev = torch.cuda.device_count()
-    dev = torch.device('cuda', local_rank % max(ndev, 1))   # (one rank per GPU on the real node)
+    if ndev == 0:
+        raise SystemExit('bench.py needs an MI355X (no GPU visible); there is no CPU path in the product')
+    backend = os.environ.get('MM_BENCH_BACKEND', 'nccl')
+    if world > 1 and backend == 'nccl' and ndev < world:
+        raise SystemExit(f'--gpus {world} but {ndev} GPU(s) visible: one rank per GPU is required with RCCL '
+                         '(MM_BENCH_BACKEND=gloo shares a GPU between ranks — a dry run of the N > 1 code path)')
+    dev = torch.device('cuda', local_rank % ndev)
     torch.cuda.set_device(dev)
     if world > 1:
+        import datetime
         import torch.distributed as dist
         # "nccl" IS RCCL on ROCm.  MM_BENCH_BACKEND=gloo exists only to exercise the N > 1 code
         # path on a single-GPU development box.
-        backend = os.environ.get('MM_BENCH_BACKEND', 'nccl')
+        tmo = datetime.timedelta(seconds=min(args.rank_timeout, 300.0))
         if backend == 'nccl':
-            dist.init_process_group('nccl', device_id=dev)
+            dist.init_process_group('nccl', device_id=dev, timeout=tmo)
         else:
-            dist.init_process_group(backend)
+            dist.init_process_group(backend, timeout=tmo)
 
     from graphembed import _backend as B
-    from graphembed.manifolds import SymmetricPositiveDefinite
     lib = B.lib()
-
-    n = args.n
-    x, g = synthetic_spd(n, DIM, 42, dev)           # replicated embedding, same on every rank
-    rb, re = B.shard_rows(n, world, rank)
-    lo, hi = B.pair_offset(n, rb), B.pair_offset(n, re)
-    g_local = g[lo:hi].contiguous()
-    del g
-    man = SymmetricPositiveDefinite(DIM)
-    x.requires_grad_()
-
-    def step():
-        x.grad = None
-        d2 = man.pdist(x, squared=True, rows=(rb, re))
-        d2.backward(g_local)
-        if world > 1:
-            dist.all_reduce(x.grad)               # the single collective of a step
-        return d2
-
-    def fence():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    # The step is 4 kernels of 4-70 us: through Python autograd the host needs 130-170 us to issue
-    # them (rocprofv3 shows a 44 us host gap between the forward and the backward kernel alone), i.e.
-    # eager launches measure the host, at any N.  So the step's kernels — forward + backward — are
-    # captured once into a hipGraph and replayed; the all-reduce is issued eagerly after the replay.
-    # Falls back to eager launches if capture is unavailable.  The per-kernel HIP-event durations
-    # (roofline) and `eager_ms_per_step` come from an eager pass right after the timed region.
+    fence = Fence(world)
     use_graph = args.graph in ('on', 'auto')
-    graph = None
-    if use_graph:
-        try:
-            side = torch.cuda.Stream()
-            side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(side):
-                for _ in range(3):
-                    step()
-            torch.cuda.current_stream().wait_stream(side)
-            fence()
-            graph = torch.cuda.CUDAGraph()
-            x.grad = None
-            with torch.cuda.graph(graph):
-                d2 = man.pdist(x, squared=True, rows=(rb, re))
-                grad_static, = torch.autograd.grad(d2, x, g_local)
-            fence()
-        except Exception as exc:  # noqa: BLE001 — report and measure eagerly instead
-            if rank == 0:
-                print(f'[bench] hipGraph capture unavailable ({type(exc).__name__}: {exc}); eager launches',
-                      file=sys.stderr)
-            graph = None
-            fence()
-    if graph is not None:
-        # the collective stays OUTSIDE the captured graph (issued eagerly on the same stream right
-        # after the replay): RCCL-in-graph capture cannot be validated on a 1-GPU box
-        def run():
-            graph.replay()
-            if world > 1:
-                dist.all_reduce(grad_static)
-    else:
-        run = step
+    graph_collective = backend == 'nccl' and os.environ.get('MM_BENCH_GRAPH_COLLECTIVE', '0') == '1'
+    n = args.n
 
-    for _ in range(args.warmup):
-        run()
-    prof = (not args.no_prof) and graph is None   # event brackets cannot live inside a captured graph
-    lib.call('mm_prof_enable', int(prof))
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        run()
-    fence()
-    elapsed = time.perf_counter() - t0
-    lib.call('mm_prof_enable', 0)
-    roofline_pass = 'timed region'
-    eager_ms = None
-    if graph is not None and not args.no_prof:
-        # per-kernel durations: a short eager pass right after the timed region
+    # ---- headline ---------------------------------------------------------------------------
+    wl = PdistWorkload(DIM, n, torch.float32, 0.1, world, rank, dev)
+    elapsed, mode, phases = time_workload(wl, args.steps, args.warmup, fence, use_graph, graph_collective, rank)
+    elapsed = reduce_max(elapsed, dev, world)
+
+    # per-kernel durations: HIP events recorded on the launch stream around each kernel (csrc/prof.hpp).  Event
+    # records cannot live inside a captured graph, so they bracket the kernels of an eager pass of the same step
+    # issued right after the timed region; one discarded pass first (event creation, allocator warm-up).
+    kern, eager_ms = {'fwd': None, 'bwd': None}, None
+    if not args.no_prof:
         lib.call('mm_prof_enable', 1)
-        k_eager = min(args.steps, 20)
+        wl.eager_step()
         fence()
-        te = time.perf_counter()
-        for _ in range(k_eager):
-            step()
+        collect_kernel_us(lib)                 # discard
+        times = []
+        for _ in range(max(5, min(args.steps, 20))):
+            te = time.perf_counter()
+            wl.eager_step()
+            torch.cuda.synchronize()
+            times.append(time.perf_counter() - te)
         fence()
-        eager_ms = (time.perf_counter() - te) / k_eager * 1e3
+        eager_ms = median(times) * 1e3
         lib.call('mm_prof_enable', 0)
-        roofline_pass = 'eager pass after the (graph-replayed) timed region'
+        kern = collect_kernel_us(lib)
+    per_rank = gather_objects({'rank': rank, 'rows': list(wl.rows), 'pairs': wl.hi - wl.lo, **phases,
+                               'fwd_kernel_us': kern['fwd'], 'bwd_kernel_us': kern['bwd']}, world)
 
-    kern = {}
-    for name, kid in (('fwd', 0), ('bwd', 1)):
-        cnt, ms = ctypes.c_int64(0), ctypes.c_double(0.0)
-        lib.call('mm_prof_collect', kid, ctypes.byref(cnt), ctypes.byref(ms))
-        kern[name] = (ms.value / cnt.value * 1e-3) if cnt.value else None
-
-    t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-    if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed = t.item()
-
+    out = None
     if rank == 0:
-        P = n * (n - 1) // 2
-        pairs_local = hi - lo
+        P = wl.P
+        pairs_local = wl.hi - wl.lo
         esz = 4
         out = {
             'metric': 'pairwise manifold-dist/sec (fwd+bwd), SPD(3) 5k-node',
@@ -224,42 +475,105 @@ def main():
             'config': {'workload': f'grqc-class graph, n={n} nodes -> SPD(3) affine-invariant, all '
                                    f'{P} pairs, squared distance + backward, reference init (||log X||=0.1)',
                        'pairs_per_step': P, 'parallelism': f'pair-rows sharded x{world}, 1 all-reduce',
-                       'launch': 'hipGraph replay (fwd+bwd) + eager all-reduce' if graph is not None else 'eager'},
+                       'launch': mode, 'backend': backend if world > 1 else None},
+            'per_rank': per_rank,
+            'kernel_source_hash': kernel_source_hash(),
         }
         if eager_ms is not None:
-            out['eager_ms_per_step'] = eager_ms   # same step issued through Python autograd (host-bound)
+            # same step issued through Python autograd (host-bound); median of single synchronised steps
+            out['eager_ms_per_step'] = eager_ms
+        pmc = stamped_pmc() if (n == N_NODES and world == 1) else None
         if kern['bwd']:
-            # dominant kernel: spd_pdist_bwd.  Algorithmic HBM bytes per launch: read g (4 B per
-            # pair) + node factors in (2*6 floats) + accumulators out (2*6 floats) per node.
+            # dominant kernel: spd_pdist_bwd.  Algorithmic HBM bytes per launch: read g (4 B per pair) + node
+            # factors in (2*6 floats) + accumulators out (2*6 floats) per node.
             by = pairs_local * esz + n * 24 * esz
-            # VALU instructions per 64-pair wave iteration and HBM bytes per launch measured with
-            # rocprofv3 --pmc on this exact workload (profiles/r01_v8_pmc_summary.txt); the plain
-            # v_fma_f32 issue rate is 2.44 cycles per wave instruction per SIMD (tools/micro/valu_rate.hip)
-            iters = pairs_local / 64.0
-            issue_s = lambda instr, t: instr * iters * 2.44 / (1024 * 2.4e9) / t
-            ref_shape = (n == N_NODES and world == 1)
-            out['roofline'] = {'bound': 'hbm', 'kernel': 'spd_pdist_bwd_kernel<float,3,TI>',
-                               'achieved': by / kern['bwd'] / 1e9, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                               'frac': by / kern['bwd'] / 1e9 / HBM_PEAK_GBS,
-                               'traffic': 88.0e6 if ref_shape else None,
-                               'traffic_source': 'rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE, '
-                                                 'profiles/r01_v8_pmc_summary.txt' if ref_shape else None,
-                               'algorithmic_bytes': by,
-                               'avg_launch_us': kern['bwd'] * 1e6, 'measured_in': roofline_pass,
-                               'valu_issue_frac': issue_s(209, kern['bwd'])}
+            t = kern['bwd'] * 1e-6
+            rk = (pmc or {}).get('kernels', {}).get('spd_pdist_bwd', {})
+            out['roofline'] = {'bound': 'hbm', 'kernel': 'spd_pdist_bwd_kernel<float,3,...>',
+                               'achieved': by / t / 1e9, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                               'frac': by / t / 1e9 / HBM_PEAK_GBS,
+                               'traffic': rk.get('traffic_bytes'),
+                               'traffic_source': (pmc or {}).get('source') if rk else None,
+                               'algorithmic_bytes': by, 'avg_launch_us': kern['bwd'],
+                               'measured_in': 'eager pass after the timed region (HIP events on the launch stream)',
+                               'valu_insts_per_64_pairs': rk.get('valu_insts_per_64_pairs')}
             if kern['fwd']:
                 byf = pairs_local * esz + n * 12 * esz
-                out['roofline_fwd'] = {'bound': 'hbm', 'kernel': 'spd_pdist_fwd_kernel<float,3,8>',
-                                       'achieved': byf / kern['fwd'] / 1e9, 'peak': HBM_PEAK_GBS,
-                                       'unit': 'GB/s', 'frac': byf / kern['fwd'] / 1e9 / HBM_PEAK_GBS,
-                                       'traffic': 50.3e6 if ref_shape else None, 'algorithmic_bytes': byf,
-                                       'avg_launch_us': kern['fwd'] * 1e6,
-                                       'valu_issue_frac': issue_s(91, kern['fwd'])}
+                tf = kern['fwd'] * 1e-6
+                rf = (pmc or {}).get('kernels', {}).get('spd_pdist_fwd', {})
+                out['roofline_fwd'] = {'bound': 'hbm', 'kernel': 'spd_pdist_fwd_kernel<float,3,...>',
+                                       'achieved': byf / tf / 1e9, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                                       'frac': byf / tf / 1e9 / HBM_PEAK_GBS, 'traffic': rf.get('traffic_bytes'),
+                                       'algorithmic_bytes': byf, 'avg_launch_us': kern['fwd'],
+                                       'valu_insts_per_64_pairs': rf.get('valu_insts_per_64_pairs')}
+    del wl
+    torch.cuda.empty_cache()
+
+    # ---- secondary workloads, same JSON line ----------------------------------------------------
+    extra = []
+    if not args.no_extra:
+        k2, w2 = max(5, min(args.steps, 20)), max(2, min(args.warmup, 5))
+        cases = []
+        if world == 1 and n == N_NODES:
+            cases += [('SPD(3) n=5000 f32, mid-training spread (||log X||=0.35)', DIM, N_NODES, torch.float32, 0.35),
+                      ('SPD(3) n=5000 f64 (the dtype run.py:32-35 sets), reference init', DIM, N_NODES, torch.float64, 0.1),
+                      ('SPD(3) n=5000 f64, mid-training spread (||log X||=0.35)', DIM, N_NODES, torch.float64, 0.35),
+                      ('SPD(3) n=4158 f32 (grqc, BASELINE config 3), reference init', DIM, 4158, torch.float32, 0.1),
+                      ('SPD(4) n=2274 f32 (BASELINE config 5, small graph), reference init', 4, 2274, torch.float32, 0.1)]
+        for name, d, nn, dt, ir in cases:
+            w = PdistWorkload(d, nn, dt, ir, world, rank, dev)
+            el, md, ph = time_workload(w, k2, w2, fence, use_graph, graph_collective, rank, tag=name + ': ')
+            el = reduce_max(el, dev, world)
+            kk = {'fwd': None, 'bwd': None}
+            if not args.no_prof:
+                lib.call('mm_prof_enable', 1)
+                w.eager_step()
+                fence()
+                collect_kernel_us(lib)
+                for _ in range(5):
+                    w.eager_step()
+                fence()
+                lib.call('mm_prof_enable', 0)
+                kk = collect_kernel_us(lib)
+            rec = {'workload': name + ', pdist fwd+bwd', 'pairs_per_step': w.P, 'ms_per_step': el / k2 * 1e3,
+                   'value': w.P * k2 / el, 'unit': 'pairs/s', 'steps': k2, 'launch': md,
+                   'fwd_kernel_us': kk['fwd'], 'bwd_kernel_us': kk['bwd']}
+            if kk['bwd']:
+                np_ = d * (d + 1) // 2
+                byb = (w.hi - w.lo) * w.esz + nn * 4 * np_ * w.esz
+                rec['bwd_hbm_frac'] = byb / (kk['bwd'] * 1e-6) / 1e9 / HBM_PEAK_GBS
+            extra.append(rec)
+            del w
+            torch.cuda.empty_cache()
+        # the size where sharding pays: BASELINE config 5 (bio-wormnet-class, ~16k nodes, SPD(4), distortion loss)
+        w = FusedLossWorkload(4, 16384, torch.float32, world, rank, dev)
+        el, md, ph = time_workload(w, k2, w2, fence, use_graph, graph_collective, rank, tag='config 5: ')
+        el = reduce_max(el, dev, world)
+        ranks5 = gather_objects({'rank': rank, 'rows': list(w.rows), 'pairs': w.hi - w.lo, **ph}, world)
+        extra.append({'workload': 'BASELINE config 5: n=16384 nodes -> SPD(4), all-pairs QuotientLoss, fused '
+                                  'loss+gradient kernel, pair rows sharded, 1 all-reduce of {grad, loss, grad_scale}',
+                      'pairs_per_step': w.P, 'ms_per_step': el / k2 * 1e3, 'value': w.P * k2 / el, 'unit': 'pairs/s',
+                      'steps': k2, 'n_gpus': world, 'scaling': 'strong', 'launch': md, 'per_rank': ranks5})
+        del w
+        torch.cuda.empty_cache()
+
+    if rank == 0:
+        if extra:
+            out['extra'] = extra
         if world == 1 and not args.no_cpu_baseline:
-            out['cpu_baseline'] = cpu_baseline(42)
+            out['cpu_baseline'] = cpu_baseline(42, n)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
+    watchdog.cancel()
+
+
+def main():
+    argv = sys.argv[1:]
+    args = parse_args(argv)
+    if args.gpus > 1 and 'RANK' not in os.environ:
+        launch(args, argv)       # does not return
+    worker(args)
 
 
 if __name__ == '__main__':

@@ -160,6 +160,17 @@ def ptr(t):
     return None if t is None else ctypes.c_void_p(t.data_ptr())
 
 
+def dyn_ptr(dyn, like):
+    """Pointer of the device-resident loss schedule {alpha, eps} (QuotientLoss.on_device) — it is dereferenced by
+    the kernels launched on `like`'s device, so it must live there."""
+    if dyn is None:
+        return None
+    if dyn.device != like.device or dyn.dtype != torch.float64 or dyn.numel() < 2:
+        raise BackendError(f'loss schedule lives on {dyn.device} ({dyn.dtype}); the embedding is on {like.device}: '
+                           'call objective_fn.on_device(embedding.device)')
+    return ctypes.c_void_p(dyn.data_ptr())
+
+
 _raw_stream = getattr(torch._C, '_cuda_getCurrentRawStream', None)
 
 

@@ -102,7 +102,7 @@ class _SpdPdistLoss(torch.autograd.Function):
             out = torch.empty(2, dtype=xc.dtype, device=xc.device)
             grad = torch.empty_like(xc)
             lib.call('mm_spd_pdist_loss', dt, B.LOSS_STRESS if kind == 'stress' else B.LOSS_QUOTIENT,
-                     B.ptr(xc), B.ptr(tc), B.ptr(sc), n, n_mat, row_begin, row_end, alpha, eps, terms, B.ptr(dyn),
+                     B.ptr(xc), B.ptr(tc), B.ptr(sc), n, n_mat, row_begin, row_end, alpha, eps, terms, B.dyn_ptr(dyn, xc),
                      wmin, wmax, B.ptr(out), B.ptr(grad), B.ptr(ws), 0, B.stream_of(xc))
         ctx.grad_x = grad
         ctx.grad_s = None if scale is None else out[1].reshape(scale.shape).to(scale.dtype)

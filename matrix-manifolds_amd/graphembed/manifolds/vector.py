@@ -85,7 +85,7 @@ class _VecPdistLoss(torch.autograd.Function):
             out = torch.empty(2, dtype=xc.dtype, device=xc.device)
             grad = torch.empty_like(xc)
             lib.call('mm_vec_pdist_loss', dt, kind, B.LOSS_STRESS if lkind == 'stress' else B.LOSS_QUOTIENT,
-                     B.ptr(xc), B.ptr(tc), B.ptr(sc), n, m, row_begin, row_end, alpha, eps, terms, B.ptr(dyn),
+                     B.ptr(xc), B.ptr(tc), B.ptr(sc), n, m, row_begin, row_end, alpha, eps, terms, B.dyn_ptr(dyn, xc),
                      B.ptr(out), B.ptr(grad), B.ptr(ws), B.stream_of(xc))
         ctx.grad_x = grad.reshape(x.shape)
         ctx.grad_s = None if scale is None else out[1].reshape(scale.shape).to(scale.dtype)

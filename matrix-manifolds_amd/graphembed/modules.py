@@ -67,7 +67,7 @@ class _ProductLoss(torch.autograd.Function):
             ws = torch.empty(lib.raw('mm_product_loss_ws_bytes')(dt, k), dtype=torch.uint8, device=dev)
             lib.call('mm_product_loss', dt, B.LOSS_STRESS if kind == 'stress' else B.LOSS_QUOTIENT, k,
                      B.ptr_array([d.detach() for d in d2]), B.ptr(tc), B.ptr_array(sc), npairs, alpha, eps,
-                     terms, B.ptr(dyn), B.ptr_array(gs), B.ptr(out), B.ptr(ws), B.stream_of(xs[0]))
+                     terms, B.dyn_ptr(dyn, xs[0]), B.ptr_array(gs), B.ptr(out), B.ptr(ws), B.stream_of(xs[0]))
             grads = [torch.autograd.grad(d, x, g)[0] for d, x, g in zip(d2, leaves, gs)]
         ctx.grads = grads + [out[1 + i].reshape(s.shape).to(s.dtype) for i, s in enumerate(scales)]
         return out[0]
@@ -81,6 +81,8 @@ class _ProductLoss(torch.autograd.Function):
 # Largest node minibatch that is handled inside the mixed-manifold pair kernel (beyond it the step is
 # arithmetic again and single factors are better served by their specialised kernels).
 _SUBSET_MAX_NODES = 2048
+# Workspaces of the mixed-manifold pair kernel kept per embedding (one per distinct batch shape)
+_PAIR_WS_MAX = 8
 
 
 def _pair_kernel_factor(man):
@@ -143,17 +145,27 @@ class _ProductPairsLoss(torch.autograd.Function):
             xc = [x.detach().to(dtype).contiguous() for x in xs]
             sc = [s.detach().to(dtype).reshape(1).contiguous() for s in scales]
             out = torch.empty(1 + k, dtype=dtype, device=dev)
-            # the kernels leave the workspace's accumulators zero: kept across steps, it is cleared once
+            # The kernels leave the workspace's accumulators zero: kept across steps, it is cleared once.
+            # One workspace per (dtype, device, n, factors) — a minibatch loop has one shape, its tail batch and
+            # a full-batch validation loss others — and none is ever dropped while a captured graph may hold its
+            # address (a replay accumulates into it and relies on finding it zero): entries touched during stream
+            # capture are pinned, the oldest unpinned one goes when the table is full.
             key = (dtype, dev, n, factors)
+            capturing = torch.cuda.is_current_stream_capturing()
             entry = cache.get(key) if cache is not None else None
             if entry is None:
                 entry = [torch.empty(lib.raw('mm_product_pairs_ws_bytes')(dt, k, kinds, dims, n),
-                                     dtype=torch.uint8, device=dev), False]
+                                     dtype=torch.uint8, device=dev), False, False]
                 if cache is not None:
-                    cache.clear()  # one shape at a time (a minibatch loop has one; the full batch another)
+                    if len(cache) >= _PAIR_WS_MAX:
+                        for old in [kk for kk, e in cache.items() if not e[2]][:len(cache) - _PAIR_WS_MAX + 1]:
+                            del cache[old]
                     cache[key] = entry
-            ws, clean = entry
-            entry[1] = False  # until the call has been enqueued completely
+            ws, clean = entry[0], entry[1]
+            if capturing:
+                entry[2] = True   # a graph now refers to this workspace: keep it for the embedding's lifetime
+            else:
+                entry[1] = False  # until the call has been enqueued completely
             flags = B.WS_CLEAN if clean else 0
             if subset is None:
                 tc = target.detach().to(dtype).contiguous()
@@ -162,7 +174,7 @@ class _ProductPairsLoss(torch.autograd.Function):
                     raise ValueError(f'target has {tc.numel()} entries, the pair range has {npairs}')
                 grads = [torch.empty_like(x) for x in xc]
                 lib.call('mm_product_pairs_loss', dt, loss_code, k, kinds, dims, B.ptr_array(xc), B.ptr_array(sc),
-                         B.ptr(tc), n, rb, re, alpha, eps, terms, B.ptr(dyn), wmin, wmax, B.ptr_array(grads), B.ptr(out),
+                         B.ptr(tc), n, rb, re, alpha, eps, terms, B.dyn_ptr(dyn, xs[0]), wmin, wmax, B.ptr_array(grads), B.ptr(out),
                          B.ptr(ws), flags, B.stream_of(xs[0]))
             else:
                 idx, dense = subset
@@ -175,8 +187,11 @@ class _ProductPairsLoss(torch.autograd.Function):
                 grads = [g.view(x.shape) for g, x in zip(flat.split(sizes), xc)]
                 lib.call('mm_product_pairs_loss_subset', dt, loss_code, k, kinds, dims, B.ptr_array(xc),
                          B.ptr_array(sc), B.ptr(dense), n_total, B.ptr(idx), n, rb, re, alpha, eps, terms,
-                         B.ptr(dyn), wmin, wmax, B.ptr_array(grads), B.ptr(out), B.ptr(ws), flags, B.stream_of(xs[0]))
-            entry[1] = True
+                         B.dyn_ptr(dyn, xs[0]), wmin, wmax, B.ptr_array(grads), B.ptr(out), B.ptr(ws), flags, B.stream_of(xs[0]))
+            if not capturing:
+                # clean from here on (the kernels zero what they used) — but only a call that EXECUTES proves it: a
+                # call that was merely recorded leaves the flag as it found it
+                entry[1] = True
         ctx.grads = [g.reshape(x.shape) for g, x in zip(grads, xs)] + \
             [out[1 + i].reshape(s.shape).to(s.dtype) for i, s in enumerate(scales)]
         return out[0]
@@ -325,12 +340,31 @@ class BatchedObjective(torch.nn.Module):
         self.embedding = embedding
         self.fused = fused  # use the one-pass loss+gradient kernel when the configuration has one
 
+    check_indices = True   # validate CPU index tensors before the in-kernel minibatch path (~20 us per step)
+
+    def _distinct_in_range(self, indices, n):
+        """The in-kernel node-minibatch path (mm_product_pairs_loss_subset) addresses table rows, targets and
+        gradient rows through the index vector: the indices must be in range (the reference's `x[i]` raises
+        IndexError otherwise) and distinct (its indexing backward accumulates repeated rows; the kernel's
+        finalize writes each row once).  Slices of a `randperm` (train.py:206-209) always are; anything else
+        is checked here when the indices are host-side, and device-side index tensors — nothing to check
+        without a synchronisation — take the path as documented.  Returns False to fall back to the
+        gather / scatter path (repeats), raises IndexError when out of range."""
+        if not self.check_indices or indices.is_cuda or indices.numel() == 0:
+            return True
+        lo, hi = int(indices.min()), int(indices.max())
+        if lo < -n or hi >= n:
+            raise IndexError(f'index out of range for an embedding of {n} points: [{lo}, {hi}]')
+        if lo < 0:
+            return False
+        return bool(torch.unique(indices).numel() == indices.numel())
+
     def forward(self, indices, *args, **kwargs):
         emb = self.embedding
         if self.fused and not args and indices is not None and emb.xs[0].is_cuda \
                 and hasattr(self.objective_fn, 'fused_spec') and hasattr(self.dataset, 'pdists'):
             dense = self.dataset.pdists   # the pair kernel gathers rows and targets itself
-            if dense.is_cuda and dense.dtype == emb.xs[0].dtype:
+            if dense.is_cuda and dense.dtype == emb.xs[0].dtype and self._distinct_in_range(indices, len(emb)):
                 loss = emb.fused_objective(self.objective_fn, None, indices, dense=dense, **kwargs)
                 if loss is not None:
                     return loss

@@ -33,6 +33,8 @@ class QuotientLoss(ObjectiveFunction):
         return loss
 
     _dyn = None
+    _dyn_host = None     # pinned staging buffer of the device copy
+    _dyn_value = None    # (alpha, eps) last written to the device copy
 
     def on_device(self, device):
         """Keep {alpha, eps = 1/(epoch+1)} in device memory from now on: the fused kernels then read them
@@ -44,11 +46,29 @@ class QuotientLoss(ObjectiveFunction):
             device = torch.device('cuda', torch.cuda.current_device())
         if self._dyn is None or self._dyn.device != device:
             self._dyn = torch.tensor([1.0, 1.0], dtype=torch.float64, device=device)
+            self._dyn_host = torch.empty(2, dtype=torch.float64,
+                                         pin_memory=device.type == 'cuda' and torch.cuda.is_available())
+            self._dyn_value = (1.0, 1.0)
         return self._dyn
 
     def set_epoch(self, epoch, alpha):
-        """Writes the schedule of `epoch` into the device-resident parameters (after `on_device`)."""
-        self._dyn.copy_(torch.tensor([float(alpha), 1.0 / (epoch + 1)], dtype=torch.float64), non_blocking=False)
+        """Writes the schedule of `epoch` into the device-resident parameters (after `on_device`): nothing
+        when the values are the ones already there, else an asynchronous copy from a pinned staging buffer
+        on the current stream (stream order makes it visible to the kernels launched after it; the staging
+        buffer is rewritten only after the previous copy has been consumed)."""
+        value = (float(alpha), 1.0 / (epoch + 1))
+        if value == self._dyn_value:
+            return
+        if self._dyn.is_cuda:
+            if getattr(self, '_dyn_event', None) is not None:
+                self._dyn_event.synchronize()   # the previous copy has left the staging buffer (rarely waits)
+            self._dyn_host[0], self._dyn_host[1] = value
+            self._dyn.copy_(self._dyn_host, non_blocking=True)
+            self._dyn_event = torch.cuda.Event()
+            self._dyn_event.record()
+        else:
+            self._dyn[0], self._dyn[1] = value
+        self._dyn_value = value
 
     def fused_spec(self, *, epoch, alpha):
         """(kind, alpha, eps, terms[, device {alpha, eps}]) for the fused loss+gradient kernels

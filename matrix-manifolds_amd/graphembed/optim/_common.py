@@ -122,11 +122,16 @@ def vector_layout(p, manifold):
 class ManifoldOptimizer(torch.optim.Optimizer):
 
     def step(self, closure=None):
+        hooked = self._has_step_hooks()
+        if hooked:
+            self._run_step_hooks(True, closure)
         loss = closure() if closure is not None else None
         with torch.no_grad():
             for group in self.param_groups:
                 for p in self._params_of(group):
                     self._update(group, p, self.state[p], self.manifold_of(p))
+        if hooked:
+            self._run_step_hooks(False, closure)
         return loss
 
     def _params_of(self, group):
@@ -136,8 +141,33 @@ class ManifoldOptimizer(torch.optim.Optimizer):
 
     # torch.optim.Optimizer wraps `step` of every subclass in a profiler range plus pre/post hook
     # dispatch (~25 us of host time per call) unless it is marked as hooked already; the updates
-    # here are a few microseconds of GPU work.  (Step hooks registered on the optimizer do not run.)
+    # here are a few microseconds of GPU work.  The wrapper is skipped, the hooks are not: `step`
+    # dispatches registered step hooks (this optimizer's and the global ones) itself, in torch's
+    # order, and pays for it only when there are any.
     step.hooked = True
+
+    def _has_step_hooks(self):
+        import torch.optim.optimizer as O
+        return bool(getattr(self, '_optimizer_step_pre_hooks', None) or getattr(self, '_optimizer_step_post_hooks', None)
+                    or getattr(O, '_global_optimizer_pre_hooks', None) or getattr(O, '_global_optimizer_post_hooks', None))
+
+    def _run_step_hooks(self, pre, closure):
+        """torch.optim.Optimizer.profile_hook_step's dispatch: global hooks first, then this optimizer's;
+        hooks receive (optimizer, args, kwargs); a pre-hook may not rewrite the arguments here (step takes
+        only the closure)."""
+        import torch.optim.optimizer as O
+        args, kwargs = ((closure, ) if closure is not None else ()), {}
+        if pre:
+            hooks = list(getattr(O, '_global_optimizer_pre_hooks', {}).values()) + \
+                list(self._optimizer_step_pre_hooks.values())
+        else:
+            hooks = list(self._optimizer_step_post_hooks.values()) + \
+                list(getattr(O, '_global_optimizer_post_hooks', {}).values())
+        for hook in hooks:
+            result = hook(self, args, kwargs)
+            if pre and result is not None:
+                raise RuntimeError(f'{type(self).__name__}: step pre-hooks that replace the arguments are not '
+                                   'supported (the fused step takes only an optional closure)')
 
     def zero_grad(self, set_to_none=True):
         for group in self.param_groups:

@@ -400,20 +400,23 @@ __device__ __forceinline__ void eig3_trig(const float (&a)[6], float (&w)[3]) {
 
 // ------------------------------ log(A) near the identity, 3x3 / 4x4 (fp32)
 // For ||A - I||_F <= 0.3 (the two points of the pair are closer than ~0.3 — every pair at the
-// reference's initialisation) log(A) is evaluated WITHOUT an eigen-decomposition: with E = A - I, an
-// economised polynomial a(e) ~ log(1+e) on [-0.3,0.3] and the Cayley-Hamilton reduction
-//     E^(k+1) = p_k I + q_k E + r_k E^2,   (p,q,r)_(k+1) = (s3 r_k, p_k - s2 r_k, q_k + s1 r_k),
-//     E^3 = s1 E^2 - s2 E + s3 I,
-// so log(A) = alpha0 I + alpha1 E + alpha2 E^2 with coefficients from three-term recurrences on
-// scalars: ~95 VALU ops, branch-free, no transcendental.  Returns ||E||_F^2 for the caller's gate.
-// log(1+x) = x p(x), p of degree 7 interpolated at Chebyshev nodes of |x| <= 0.3 (max error 9.1e-8 |x|,
+// reference's initialisation) log(A) is evaluated WITHOUT an eigen-decomposition: with E = A - I and an
+// economised polynomial log(1+x) = x p(x) on [-0.3,0.3], p(E) is evaluated by HORNER'S RULE IN THE QUOTIENT
+// RING R[E]/(chi_E): every intermediate is alpha0 I + alpha1 E + alpha2 E^2, and multiplying by E uses the
+// Cayley-Hamilton identity E^3 = s1 E^2 - s2 E + s3 I,
+//     (alpha0, alpha1, alpha2) . E + c I = (alpha2 s3 + c,  alpha0 - alpha2 s2,  alpha1 + alpha2 s1),
+// three FMAs per coefficient (the power-coefficient recurrence of round 1 needed six), the first two steps
+// being constants.  ~60 VALU ops in all, branch-free, no transcendental.  Returns ||E||_F^2 for the gate.
+// p of degree 7 interpolated at Chebyshev nodes of |x| <= 0.3 (max error 9.1e-8 |x|,
 // tools/design/series_fit.py): the close-pair gate bounds the spectral radius of E by 0.3.
+// `pre` multiplies the result (the caller's 2g when it is known before the series: three multiplications
+// on the coefficients instead of six on the matrix).
 #define MM_LOG_SERIES_COEFS                                                                              \
   {9.999999337e-01f, -4.999999402e-01f, 3.333568549e-01f, -2.500212282e-01f, 1.987095623e-01f,           \
    -1.655023071e-01f, 1.650813480e-01f, -1.450413880e-01f}
 constexpr int kLogSeriesTerms = 8;
 
-__device__ __forceinline__ float log_series3(const float (&a)[6], float (&m0)[6]) {
+__device__ __forceinline__ float log_series3(const float (&a)[6], float (&m0)[6], float pre = 1.f) {
   constexpr float kA[kLogSeriesTerms] = MM_LOG_SERIES_COEFS;
   const float e00 = a[pidx(0, 0)] - 1.f, e11 = a[pidx(1, 1)] - 1.f, e22 = a[pidx(2, 2)] - 1.f;
   const float e10 = a[pidx(1, 0)], e20 = a[pidx(2, 0)], e21 = a[pidx(2, 1)];
@@ -429,20 +432,21 @@ __device__ __forceinline__ float log_series3(const float (&a)[6], float (&m0)[6]
   const float s2 = 0.5f * fmaf(s1, s1, -tr2);
   const float s3 = e00 * fmaf(e11, e22, -e21 * e21) - e10 * fmaf(e10, e22, -e21 * e20) +
                    e20 * fmaf(e10, e21, -e11 * e20);
-  float p = 0.f, q = 1.f, r = 0.f;                       // E^1
-  float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+  // Horner from the top: after the first two steps alpha = (c5, c6, c7)
+  float a0 = kA[kLogSeriesTerms - 3], a1 = kA[kLogSeriesTerms - 2], a2 = kA[kLogSeriesTerms - 1];
 #pragma unroll
-  for (int k = 0; k < kLogSeriesTerms; ++k) {
-    a0 = fmaf(kA[k], p, a0); a1 = fmaf(kA[k], q, a1); a2 = fmaf(kA[k], r, a2);
-    const float pn = s3 * r, qn = fmaf(-s2, r, p), rn = fmaf(s1, r, q);
-    p = pn; q = qn; r = rn;
+  for (int k = kLogSeriesTerms - 4; k >= 0; --k) {
+    const float n0 = fmaf(a2, s3, kA[k]), n1 = fmaf(-a2, s2, a0), n2 = fmaf(a2, s1, a1);
+    a0 = n0; a1 = n1; a2 = n2;
   }
-  m0[pidx(0, 0)] = fmaf(a2, f00, fmaf(a1, e00, a0));
-  m0[pidx(1, 1)] = fmaf(a2, f11, fmaf(a1, e11, a0));
-  m0[pidx(2, 2)] = fmaf(a2, f22, fmaf(a1, e22, a0));
-  m0[pidx(1, 0)] = fmaf(a2, f10, a1 * e10);
-  m0[pidx(2, 0)] = fmaf(a2, f20, a1 * e20);
-  m0[pidx(2, 1)] = fmaf(a2, f21, a1 * e21);
+  // log(I + E) = E p(E): one more multiplication by E (no constant), then the caller's factor
+  const float b0 = (a2 * s3) * pre, b1 = fmaf(-a2, s2, a0) * pre, b2 = fmaf(a2, s1, a1) * pre;
+  m0[pidx(0, 0)] = fmaf(b2, f00, fmaf(b1, e00, b0));
+  m0[pidx(1, 1)] = fmaf(b2, f11, fmaf(b1, e11, b0));
+  m0[pidx(2, 2)] = fmaf(b2, f22, fmaf(b1, e22, b0));
+  m0[pidx(1, 0)] = fmaf(b2, f10, b1 * e10);
+  m0[pidx(2, 0)] = fmaf(b2, f20, b1 * e20);
+  m0[pidx(2, 1)] = fmaf(b2, f21, b1 * e21);
   return tr2;
 }
 
@@ -513,13 +517,12 @@ template <typename T> __device__ __forceinline__ T log_cayley3(const T (&a)[6], 
   const T t3 = w[0] * N::fma(w[2], w[5], -w[4] * w[4]) - w[1] * N::fma(w[1], w[5], -w[4] * w[3]) +
                w[3] * N::fma(w[1], w[4], -w[2] * w[3]);
   auto coef = [&](int i) -> T { return kF32 ? T(kC32[i < 7 ? i : 0]) : T(kC64[i]); };
-  T c0 = coef(0), c1 = coef(1), c2 = coef(2);
-  T p = T(0), q = T(0), r = T(1);  // W^2 = 0 I + 0 W + 1 W^2
+  // P(W) = sum coef_i W^i by Horner's rule in R[W]/(chi_W) (see log_series3): three FMAs per coefficient
+  T c0 = coef(K - 2), c1 = coef(K - 1), c2 = coef(K);
 #pragma unroll
-  for (int i = 3; i <= K; ++i) {
-    const T pn = t3 * r, qn = N::fma(-t2, r, p), rn = N::fma(t1, r, q);
-    p = pn; q = qn; r = rn;
-    c0 = N::fma(coef(i), p, c0); c1 = N::fma(coef(i), q, c1); c2 = N::fma(coef(i), r, c2);
+  for (int i = K - 3; i >= 0; --i) {
+    const T n0 = N::fma(c2, t3, coef(i)), n1 = N::fma(-c2, t2, c0), n2 = N::fma(c2, t1, c1);
+    c0 = n0; c1 = n1; c2 = n2;
   }
   T pw[6];
   pw[0] = N::fma(c2, w2[0], N::fma(c1, w[0], c0));
@@ -617,14 +620,13 @@ template <typename T> __device__ __forceinline__ T log_cayley4(const T (&a)[10],
   const T e3 = T(1.0 / 3.0) * (N::fma(e2, p1, -e1 * p2) + p3);
   const T e4 = T(0.25) * (N::fma(e3, p1, -e2 * p2) + N::fma(e1, p3, -p4));
   auto coef = [&](int i) -> T { return kF32 ? T(kC32[i < 7 ? i : 0]) : T(kC64[i]); };
-  T al0 = coef(0), al1 = coef(1), al2 = coef(2), al3 = coef(3);
-  T p = T(0), q = T(0), r = T(0), t = T(1);  // W^3
+  // Horner in R[W]/(chi_W), W^4 = e1 W^3 - e2 W^2 + e3 W - e4 I: four FMAs per coefficient
+  T al0 = coef(K - 3), al1 = coef(K - 2), al2 = coef(K - 1), al3 = coef(K);
 #pragma unroll
-  for (int i = 4; i <= K; ++i) {
-    const T pn = -e4 * t, qn = N::fma(e3, t, p), rn = N::fma(-e2, t, q), tn = N::fma(e1, t, r);
-    p = pn; q = qn; r = rn; t = tn;
-    al0 = N::fma(coef(i), p, al0); al1 = N::fma(coef(i), q, al1); al2 = N::fma(coef(i), r, al2);
-    al3 = N::fma(coef(i), t, al3);
+  for (int i = K - 4; i >= 0; --i) {
+    const T n0 = N::fma(-al3, e4, coef(i)), n1 = N::fma(al3, e3, al0), n2 = N::fma(-al3, e2, al1),
+            n3 = N::fma(al3, e1, al2);
+    al0 = n0; al1 = n1; al2 = n2; al3 = n3;
   }
   T pw[10];
 #pragma unroll
@@ -640,9 +642,8 @@ template <typename T> __device__ __forceinline__ T log_cayley4(const T (&a)[10],
 }
 
 // d^2 = ||log A||_F^2 of a close pair (||A - I||_F <= 0.3), 3x3, straight from the invariants of
-// E = A - I:  sum_k log^2(1 + e_k) = sum_m c_m tr(E^m), with the power sums from Newton's recurrence
-// t_m = s1 t_(m-1) - s2 t_(m-2) + s3 t_(m-3) and c_m from a degree-11 economised polynomial of
-// log^2(1+e) (max abs error 8e-10).  ~90 VALU ops, no transcendental.  *e2 receives ||E||_F^2.
+// E = A - I:  sum_k log^2(1 + e_k) = tr(E^2 q(E)) with log^2(1+x) = x^2 q(x), q an economised polynomial.
+// No eigenvalues, no transcendental.  *e2 receives ||E||_F^2.
 __device__ __forceinline__ float logsq_series3(const float (&a)[6], float* e2) {
   constexpr int kTerms = 9;  // log^2(1+x) = x^2 q(x), q of degree 8 on |x| <= 0.3: max error 6.9e-8 x^2
   constexpr float kL2[kTerms] = {9.999999990e-01f, -9.999985182e-01f, 9.166654125e-01f, -8.335515341e-01f,
@@ -656,22 +657,25 @@ __device__ __forceinline__ float logsq_series3(const float (&a)[6], float* e2) {
   const float s2 = 0.5f * fmaf(s1, s1, -t2);
   const float s3 = e00 * fmaf(e11, e22, -e21 * e21) - e10 * fmaf(e10, e22, -e21 * e20) +
                    e20 * fmaf(e10, e21, -e11 * e20);
-  float tm3 = 3.f, tm2 = s1, tm1 = t2;
-  float acc = kL2[0] * t2;
+  // q(E) = h0 I + h1 E + h2 E^2 by Horner in R[E]/(chi_E) (see log_series3), then
+  // tr(E^2 q(E)) = h0 tr E^2 + h1 tr E^3 + h2 tr E^4 with the power sums from Newton's identities
+  float h0 = kL2[kTerms - 3], h1 = kL2[kTerms - 2], h2 = kL2[kTerms - 1];
 #pragma unroll
-  for (int k = 1; k < kTerms; ++k) {
-    const float t = fmaf(s1, tm1, fmaf(-s2, tm2, s3 * tm3));
-    acc = fmaf(kL2[k], t, acc);
-    tm3 = tm2; tm2 = tm1; tm1 = t;
+  for (int k = kTerms - 4; k >= 0; --k) {
+    const float n0 = fmaf(h2, s3, kL2[k]), n1 = fmaf(-h2, s2, h0), n2 = fmaf(h2, s1, h1);
+    h0 = n0; h1 = n1; h2 = n2;
   }
+  const float t3 = fmaf(3.f, s3, fmaf(s1, t2, -s2 * s1));
+  const float t4 = fmaf(s1, t3, fmaf(-s2, t2, s3 * s1));
+  const float acc = fmaf(h2, t4, fmaf(h1, t3, h0 * t2));
   *e2 = t2;
   return acc;
 }
 
-// Same for 4x4: E^(k+1) = p I + q E + r E^2 + t E^3 with
-//   (p,q,r,t)_(k+1) = (-s4 t, p + s3 t, q - s2 t, r + s1 t),  E^4 = s1 E^3 - s2 E^2 + s3 E - s4 I,
+// Same for 4x4: intermediates h0 I + h1 E + h2 E^2 + h3 E^3, multiplication by E through
+//   (h0,h1,h2,h3) . E + c I = (c - h3 s4, h0 + h3 s3, h1 - h3 s2, h2 + h3 s1),  E^4 = s1 E^3 - s2 E^2 + s3 E - s4 I,
 // s1..s4 from the power sums tr E^m (Newton's identities; tr E^3 = <E^2,E>, tr E^4 = ||E^2||_F^2).
-__device__ __forceinline__ float log_series4(const float (&a)[10], float (&m0)[10]) {
+__device__ __forceinline__ float log_series4(const float (&a)[10], float (&m0)[10], float pre = 1.f) {
   constexpr float kA[kLogSeriesTerms] = MM_LOG_SERIES_COEFS;
   float e[10], e2[10], e3[10];
 #pragma unroll
@@ -710,14 +714,14 @@ __device__ __forceinline__ float log_series4(const float (&a)[10], float (&m0)[1
   const float s2 = 0.5f * fmaf(s1, p1, -p2);
   const float s3 = (1.f / 3.f) * (fmaf(s2, p1, -s1 * p2) + p3);
   const float s4 = 0.25f * (fmaf(s3, p1, -s2 * p2) + fmaf(s1, p3, -p4));
-  float p = 0.f, q = 1.f, r = 0.f, t = 0.f;
-  float al[4] = {0.f, 0.f, 0.f, 0.f};
+  // p(E) by Horner in R[E]/(chi_E), then one more multiplication by E (log(I + E) = E p(E))
+  float h0 = kA[kLogSeriesTerms - 4], h1 = kA[kLogSeriesTerms - 3], h2 = kA[kLogSeriesTerms - 2], h3 = kA[kLogSeriesTerms - 1];
 #pragma unroll
-  for (int k = 0; k < kLogSeriesTerms; ++k) {
-    al[0] = fmaf(kA[k], p, al[0]); al[1] = fmaf(kA[k], q, al[1]); al[2] = fmaf(kA[k], r, al[2]); al[3] = fmaf(kA[k], t, al[3]);
-    const float pn = -s4 * t, qn = fmaf(s3, t, p), rn = fmaf(-s2, t, q), tn = fmaf(s1, t, r);
-    p = pn; q = qn; r = rn; t = tn;
+  for (int k = kLogSeriesTerms - 5; k >= 0; --k) {
+    const float n0 = fmaf(-h3, s4, kA[k]), n1 = fmaf(h3, s3, h0), n2 = fmaf(-h3, s2, h1), n3 = fmaf(h3, s1, h2);
+    h0 = n0; h1 = n1; h2 = n2; h3 = n3;
   }
+  const float al[4] = {(-h3 * s4) * pre, fmaf(h3, s3, h0) * pre, fmaf(-h3, s2, h1) * pre, fmaf(h3, s1, h2) * pre};
 #pragma unroll
   for (int k = 0; k < 10; ++k) m0[k] = fmaf(al[3], e3[k], fmaf(al[2], e2[k], al[1] * e[k]));
 #pragma unroll
@@ -740,138 +744,106 @@ __device__ __forceinline__ void vdvt(const T (&v)[D][D], const T (&f)[D], T (&ou
 }
 
 // ------------------------------------------------------------ wave reductions
-// Sum N independent values over the 64 lanes, level by level: the N cross-lane moves of a
-// level are issued back to back and waited for once (a per-value butterfly serialises
-// 6 N dependent LDS-crossbar round trips — measured as 31 % of the wave time in bwd).
-template <typename T, int N> __device__ __forceinline__ void wave_sum_n(T (&r)[N]) {
-#pragma unroll
-  for (int m = 32; m >= 1; m >>= 1) {
-    T t[N];
-#pragma unroll
-    for (int k = 0; k < N; ++k) t[k] = __shfl_xor(r[k], m, 64);
-#pragma unroll
-    for (int k = 0; k < N; ++k) r[k] += t[k];
-  }
+// ---- transposing reduction, general form: N values per lane -> ONE wavefront total per lane ------------
+// Level L = 0..5 works on lane bit 5-L.  A level with several live values pairs them up: of each pair (a, b)
+// a lane keeps the value its bit selects and receives the same value from its partner, so the number of live
+// values halves; an unpaired value (and the single value left at the end) is a plain butterfly.  The
+// cross-lane move of each level is the cheapest the hardware has for that bit:
+//   bit 5, 4: v_permlane32_swap / v_permlane16_swap exchange the upper half (odd rows) of a with the lower half
+//             (even rows) of b IN ONE INSTRUCTION — swap + add is the whole level for a pair, no select;
+//   bit 3   : DPP row_ror:8;   bit 2: DPP row_half_mirror (partner lane ^ 7: opposite bit 2, same bits 5..3 —
+//             any perfect matching inside the group serves);   bit 1, 0: DPP quad_perm.  DPP levels cost two
+//             selects and one add-with-DPP per pair.
+// 6 values: 6 + 5 + 3 + 3 = 17 instructions (the round-1 form, selects at every level and a two-instruction
+// xor-4, compiled to 35 with its hazard nops); 10 values: 26.  `reduce_slot<N>(lane, writer)` names the value
+// a lane ends up with; lanes with writer == false hold a duplicate.  fp64: the same moves on the two halves.
+template <int LEVEL> __device__ __forceinline__ float dpp_partner(float x) {
+  static_assert(LEVEL >= 2 && LEVEL <= 5, "levels 0 and 1 are the swap forms");
+  constexpr int ctrl = LEVEL == 2 ? 0x128 /* row_ror:8 */ : LEVEL == 3 ? 0x141 /* row_half_mirror */
+                     : LEVEL == 4 ? 0x4E /* quad_perm [2,3,0,1] */ : 0xB1 /* quad_perm [1,0,3,2] */;
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), ctrl, 0xF, 0xF, true));
 }
-
-// fp32 wavefront sum on the VALU's data-parallel-primitive lanes (no LDS crossbar, no s_waitcnt):
-// quad swaps, half-row / row mirrors, then row_bcast15 / row_bcast31 fold the four 16-lane rows;
-// the total lands in lanes 48-63 and is read from lane 63.  (The ds_bpermute butterflies cost 30 %
-// of the backward's wave time in LDS waits.)
-template <int CTRL, int ROW_MASK> __device__ __forceinline__ float dpp_add(float v) {
-  return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xF, true));
-}
-__device__ __forceinline__ float wave_sum_dpp(float v) {
-  v = dpp_add<0xB1, 0xF>(v);    // quad_perm [1,0,3,2]
-  v = dpp_add<0x4E, 0xF>(v);    // quad_perm [2,3,0,1]
-  v = dpp_add<0x141, 0xF>(v);   // row_half_mirror
-  v = dpp_add<0x140, 0xF>(v);   // row_mirror
-  v = dpp_add<0x142, 0xA>(v);   // row_bcast15 -> rows 1,3
-  v = dpp_add<0x143, 0xC>(v);   // row_bcast31 -> rows 2,3
-  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
-}
-template <int N> __device__ __forceinline__ void wave_sum_n(float (&r)[N]) {
-#pragma unroll
-  for (int k = 0; k < N; ++k) r[k] = wave_sum_dpp(r[k]);
-}
-
-// ---- transposing reduction: N values per lane -> one total per lane --------------------------
-// Summing N values over 64 lanes one value at a time costs 6 cross-lane steps each.  Instead the
-// values are halved at every butterfly level: at level s (partner = lane ^ 2^s) a lane with bit s
-// clear keeps the lower half of its values and SENDS the upper half (and vice versa), so after
-// log2(W) levels (W = N rounded up to a power of two) each lane owns ONE value — the partial sum
-// of index  idx = sum_s bit_s(lane) * W / 2^(s+1)  over its 2^log2(W)-lane group — and the remaining
-// levels are plain butterflies on that single value.  6 values: 7 + 3 cross-lane adds instead of 36.
-// Cross-lane moves: xor 1, 2 = DPP quad_perm; xor 4 = DPP row_shl:4 / row_shr:4 on complementary
-// bank masks; xor 8 = DPP row_ror:8; xor 16 / 32 = v_permlane16_swap / v_permlane32_swap (gfx950).
-// (primitives checked on hardware by tools/micro/t_perm.hip)
-template <int LEVEL> __device__ __forceinline__ float lane_xor(float x) {
-  const int xi = __float_as_int(x);
-  if constexpr (LEVEL == 0) return __int_as_float(__builtin_amdgcn_update_dpp(0, xi, 0xB1, 0xF, 0xF, false));
-  else if constexpr (LEVEL == 1) return __int_as_float(__builtin_amdgcn_update_dpp(0, xi, 0x4E, 0xF, 0xF, false));
-  else if constexpr (LEVEL == 2) {
-    int t = __builtin_amdgcn_update_dpp(0, xi, 0x104, 0xF, 0x5, false);   // lanes with bit 2 clear <- lane + 4
-    t = __builtin_amdgcn_update_dpp(t, xi, 0x114, 0xF, 0xA, false);       // lanes with bit 2 set   <- lane - 4
-    return __int_as_float(t);
-  } else {
-    static_assert(LEVEL == 3, "xor 16 / 32 use the swap forms below");
-    return __int_as_float(__builtin_amdgcn_update_dpp(0, xi, 0x128, 0xF, 0xF, false));  // row_ror:8
-  }
-}
-__device__ __forceinline__ float butterfly16(float x) {   // x + x[lane ^ 16]
-  const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
-  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
-}
-__device__ __forceinline__ float butterfly32(float x) {   // x + x[lane ^ 32]
-  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
-  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
-}
-// fp64: the same moves on the two 32-bit halves
-template <int LEVEL> __device__ __forceinline__ double lane_xor(double x) {
+template <int LEVEL> __device__ __forceinline__ double dpp_partner(double x) {
   const long long b = __double_as_longlong(x);
-  const float lo = lane_xor<LEVEL>(__int_as_float(int(b & 0xffffffffLL)));
-  const float hi = lane_xor<LEVEL>(__int_as_float(int(b >> 32)));
+  const float lo = dpp_partner<LEVEL>(__int_as_float(int(b & 0xffffffffLL)));
+  const float hi = dpp_partner<LEVEL>(__int_as_float(int(b >> 32)));
   return __longlong_as_double((static_cast<long long>(__float_as_int(hi)) << 32) |
                               static_cast<long long>(static_cast<unsigned int>(__float_as_int(lo))));
 }
-template <int WHICH> __device__ __forceinline__ double swap_partner(double x) {  // value of lane ^ 16 (WHICH = 16) / ^ 32
-  const long long b = __double_as_longlong(x);
-  const unsigned lo = static_cast<unsigned>(b & 0xffffffffLL), hi = static_cast<unsigned>(b >> 32);
-  unsigned plo, phi;
-  if constexpr (WHICH == 16) {
-    const auto r0 = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
-    const auto r1 = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
-    plo = r0[0] ^ r0[1] ^ lo; phi = r1[0] ^ r1[1] ^ hi;  // {own, partner} in some order: xor out the own value
+// lanes whose bit is clear: a + a[partner]; lanes whose bit is set: b + b[partner]   (LEVEL 0: bit 5, 1: bit 4)
+template <int LEVEL> __device__ __forceinline__ float swap_sum(float a, float b) {
+  if constexpr (LEVEL == 0) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
   } else {
-    const auto r0 = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
-    const auto r1 = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
-    plo = r0[0] ^ r0[1] ^ lo; phi = r1[0] ^ r1[1] ^ hi;
+    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
   }
-  return __longlong_as_double((static_cast<long long>(phi) << 32) | static_cast<long long>(plo));
 }
-__device__ __forceinline__ double butterfly16(double x) { return x + swap_partner<16>(x); }
-__device__ __forceinline__ double butterfly32(double x) { return x + swap_partner<32>(x); }
-
-template <int W> __device__ __forceinline__ int transposed_index(int lane) {
+template <int LEVEL> __device__ __forceinline__ double swap_sum(double a, double b) {
+  const long long ba = __double_as_longlong(a), bb = __double_as_longlong(b);
+  const unsigned alo = unsigned(ba & 0xffffffffLL), ahi = unsigned(ba >> 32);
+  const unsigned blo = unsigned(bb & 0xffffffffLL), bhi = unsigned(bb >> 32);
+  unsigned x0, x1, y0, y1;
+  if constexpr (LEVEL == 0) {
+    const auto l = __builtin_amdgcn_permlane32_swap(alo, blo, false, false);
+    const auto h = __builtin_amdgcn_permlane32_swap(ahi, bhi, false, false);
+    x0 = l[0]; y0 = l[1]; x1 = h[0]; y1 = h[1];
+  } else {
+    const auto l = __builtin_amdgcn_permlane16_swap(alo, blo, false, false);
+    const auto h = __builtin_amdgcn_permlane16_swap(ahi, bhi, false, false);
+    x0 = l[0]; y0 = l[1]; x1 = h[0]; y1 = h[1];
+  }
+  return __longlong_as_double((static_cast<long long>(x1) << 32) | static_cast<long long>(x0)) +
+         __longlong_as_double((static_cast<long long>(y1) << 32) | static_cast<long long>(y0));
+}
+template <int LEVEL, int N, typename T> __device__ __forceinline__ T wave_reduce_level(const T (&v)[N], int lane) {
+  if constexpr (LEVEL == 6) {
+    static_assert(N == 1, "64 lanes hold at most 64 values");
+    return v[0];
+  } else {
+    constexpr int M = (N + 1) / 2;
+    T o[M];
+    const bool up = (lane >> (5 - LEVEL)) & 1;
+#pragma unroll
+    for (int k = 0; k < N / 2; ++k) {
+      if constexpr (LEVEL <= 1) {
+        o[k] = swap_sum<LEVEL>(v[2 * k], v[2 * k + 1]);
+      } else {
+        const T keep = up ? v[2 * k + 1] : v[2 * k];
+        const T send = up ? v[2 * k] : v[2 * k + 1];
+        o[k] = keep + dpp_partner<LEVEL>(send);
+      }
+    }
+    if constexpr (N & 1) {
+      if constexpr (LEVEL <= 1) o[M - 1] = swap_sum<LEVEL>(v[N - 1], v[N - 1]);
+      else o[M - 1] = v[N - 1] + dpp_partner<LEVEL>(v[N - 1]);
+    }
+    return wave_reduce_level<LEVEL + 1, M, T>(o, lane);
+  }
+}
+// The wavefront total of value reduce_slot<N>(lane) lands in every lane.
+template <int N, typename T> __device__ __forceinline__ T wave_reduce_transposed(const T (&v)[N], int lane) {
+  static_assert(N >= 1 && N <= 64, "");
+  return wave_reduce_level<0, N, T>(v, lane);
+}
+// Index of the value `wave_reduce_transposed<N>` leaves in `lane`; writer = false for lanes that hold a duplicate
+// (every value has exactly one writer lane).
+template <int N> __device__ __forceinline__ int reduce_slot(int lane, bool& writer) {
+  int cnt[7];
+  cnt[0] = N;
+#pragma unroll
+  for (int l = 0; l < 6; ++l) cnt[l + 1] = (cnt[l] + 1) / 2;
   int idx = 0;
+  writer = true;
 #pragma unroll
-  for (int s = 0; (W >> (s + 1)) > 0; ++s) idx += ((lane >> s) & 1) * (W >> (s + 1));
-  return idx;
-}
-template <int LEVEL, int H, typename T> __device__ __forceinline__ void halve_level(T (&r)[2 * H], T (&o)[H], int lane) {
-  const bool up = (lane >> LEVEL) & 1;
-#pragma unroll
-  for (int k = 0; k < H; ++k) {
-    const T keep = up ? r[H + k] : r[k];
-    const T send = up ? r[k] : r[H + k];
-    o[k] = keep + lane_xor<LEVEL>(send);
+  for (int l = 5; l >= 0; --l) {
+    const int n = cnt[l], m = cnt[l + 1];
+    const int bit = (lane >> (5 - l)) & 1;
+    if ((n & 1) && idx == m - 1) { idx = n - 1; writer = writer && !bit; }   // came through a butterfly
+    else idx = 2 * idx + bit;
   }
-}
-// N <= 8: returns the wavefront total of value transposed_index<8>(lane) (zero for indices >= N).
-template <int N, typename T> __device__ __forceinline__ T wave_sum_transposed8(const T (&v)[N], int lane) {
-  static_assert(N <= 8, "");
-  T r8[8], r4[4], r2[2], r1[1];
-#pragma unroll
-  for (int k = 0; k < 8; ++k) r8[k] = (k < N) ? v[k < N ? k : 0] : T(0);
-  halve_level<0, 4>(r8, r4, lane);
-  halve_level<1, 2>(r4, r2, lane);
-  halve_level<2, 1>(r2, r1, lane);
-  T x = r1[0];
-  x += lane_xor<3>(x);
-  x = butterfly16(x);
-  return butterfly32(x);
-}
-// N <= 16
-template <int N, typename T> __device__ __forceinline__ T wave_sum_transposed16(const T (&v)[N], int lane) {
-  static_assert(N <= 16, "");
-  T r16[16], r8[8], r4[4], r2[2], r1[1];
-#pragma unroll
-  for (int k = 0; k < 16; ++k) r16[k] = (k < N) ? v[k < N ? k : 0] : T(0);
-  halve_level<0, 8>(r16, r8, lane);
-  halve_level<1, 4>(r8, r4, lane);
-  halve_level<2, 2>(r4, r2, lane);
-  halve_level<3, 1>(r2, r1, lane);
-  return butterfly32(butterfly16(r1[0]));
+  return idx;
 }
 
 template <typename T> __device__ __forceinline__ T wave_sum(T x) {

@@ -23,6 +23,8 @@
 
 #include "../../include/mm_manifolds.h"
 #include "prof.hpp"
+#include <algorithm>
+#include <cstdint>
 #include <cstdlib>
 #include <type_traits>
 
@@ -95,14 +97,7 @@ __device__ __forceinline__ T pair_core(const TL (&li)[Packed<D>::NP], const T (&
   // eigenvalues only: sum log^2 w is second-order in the residual coupling -> tol2 = eps;
   // with eigenvectors: residual coupling <= 8 eps relative (gradient error ~1e-6, a quarter of
   // the wavefronts at the reference init would otherwise run a 4th sweep for the last bit)
-#if defined(MM_ABL) && MM_ABL == 3   // ablation: no eigensolve (timing only)
-#pragma unroll
-  for (int r = 0; r < D; ++r)
-#pragma unroll
-    for (int c = 0; c < D; ++c) v[r][c] = (r == c) ? T(1) : a[pidx(r, c)];
-#else
   jacobi_eig<T, D, WITH_V, true>(a, v, WITH_V ? T(64) * Num<T>::eps() * Num<T>::eps() : Num<T>::eps());
-#endif
   T s = T(0);
 #pragma unroll
   for (int k = 0; k < D; ++k) {
@@ -147,13 +142,9 @@ template <int D> __device__ __forceinline__ float close_gate(const float (&a)[Pa
     return p2;
   }
 }
-template <int D> __device__ __forceinline__ void log_close(const float (&a)[Packed<D>::NP], float (&m0)[Packed<D>::NP]) {
-#if defined(MM_ABL) && MM_ABL == 11  // ablation: no series (timing only)
-#pragma unroll
-  for (int k = 0; k < Packed<D>::NP; ++k) m0[k] = a[k];
-#else
-  if constexpr (D == 3) log_series3(a, m0); else log_series4(a, m0);
-#endif
+template <int D> __device__ __forceinline__ void log_close(const float (&a)[Packed<D>::NP], float (&m0)[Packed<D>::NP],
+                                                          float pre = 1.f) {
+  if constexpr (D == 3) log_series3(a, m0, pre); else log_series4(a, m0, pre);
 }
 template <typename T, int D> __device__ __forceinline__ T log_cayley(const T (&a)[Packed<D>::NP], T (&m0)[Packed<D>::NP]) {
   if constexpr (D == 3) return log_cayley3<T>(a, m0); else return log_cayley4<T>(a, m0);
@@ -266,6 +257,25 @@ __device__ __forceinline__ T upstream_of(T loaded, T dsq, bool valid, int square
 }
 
 // ------------------------------------------------------------------ backward
+// One row of the pair vector for this lane: element (row, j) lives at pair_off(n, row) - base + (j - row - 1).
+// The row's base is wave-uniform (scalar registers), the lane part is a 32-bit byte offset, so the load is
+// `global_load_dword v, v_off, s[base]` with ONE vector instruction of address arithmetic (a clamp).  Lanes at or
+// below the diagonal and beyond n read the row's first / last element instead — unconditional loads: a predicated
+// one is an exec-masked branch behind which the compiler waits for vmcnt(0), exposing the HBM latency — and
+// their value is masked at use.
+template <typename T>
+__device__ __forceinline__ T pair_row_load(const T* __restrict__ g, int n, int64_t base, int row, int j) {
+  const char* grow = reinterpret_cast<const char*>(g + (pair_off(n, row) - base - row - 1));   // wave-uniform
+  const unsigned off = unsigned(min(max(j, row + 1), n - 1)) * unsigned(sizeof(T));
+  return *reinterpret_cast<const T*>(grow + off);
+}
+
+#ifdef MM_BWD_STAMP   // diagnostic build only (tools/build_variant.sh stamp -DMM_BWD_STAMP): per-workgroup start / end clocks
+__device__ unsigned long long g_bwd_stamps[4 * 16384];
+#endif
+// Backward: a launch of (at most) as many workgroups as the device holds at once; workgroup w walks its share of the
+// balanced column walk (spd_ws.hpp, ColWalk): down one 64-column block, chunk after chunk of up to NW x TI rows (each
+// wavefront a contiguous slice of the chunk's rows, its lanes the block's 64 columns), then on to the next block.
 template <typename T, int D, int TI, int LOSS>
 __global__ __launch_bounds__((64 * bwd_waves<T, D>())) void spd_pdist_bwd_kernel(const T* __restrict__ nodeL,
                                                                const T* __restrict__ nodeY /* chol(X_j) */,
@@ -281,189 +291,241 @@ __global__ __launch_bounds__((64 * bwd_waves<T, D>())) void spd_pdist_bwd_kernel
   T sp = T(1), loss_acc = T(0), ds_acc = T(0);
   loss_resolve<T, LOSS>(la);
   if constexpr (LOSS != MM_LOSS_NONE) sp = softplus_of(la.scale_raw);
-  // Workgroup tile: 64 columns x (NW waves x TI rows).  The wavefronts share the columns, so
-  // their column-side partial sums are combined through LDS and flushed with ONE set of atomics:
-  // float atomics are a per-CU serial resource (~50 ns per wave instruction) and at TI = 8 the
-  // 36 column-side atomics of the old 256-column tile cost as much CU time as its arithmetic.
+  // The wavefronts of a workgroup share the 64 columns: their column-side partial sums are combined through LDS
+  // and leave with ONE set of atomics per column block (float atomics are a per-CU serial resource, ~50 ns per
+  // wave instruction).
   __shared__ T redM[NW][TI][NP];
   __shared__ T colS[NW][D * D][64];
-#if defined(MM_BWD_LDS_PAD)  // occupancy experiment (timing only): pad the workgroup's LDS footprint
-  __shared__ float lds_pad[MM_BWD_LDS_PAD / 4];
-  if (threadIdx.x == 0 && n < 0) lds_pad[0] = 1.f;
+#ifdef MM_BWD_STAMP
+  const unsigned long long stamp0 = __builtin_amdgcn_s_memrealtime();
+  const unsigned long long stampc0 = __builtin_amdgcn_s_memtime();
 #endif
-  const TileId tile = fold_tile<NW * TI, 64>(n, row_begin, row_end);
-  if (!tile.ok) return;  // block-uniform
+  const ColWalk walk(n, row_begin, row_end);
+  const int64_t total = walk.total();
+  int64_t pos = ColWalk::share_begin(total, blockIdx.x, gridDim.x);
+  int64_t rem = ColWalk::share_begin(total, int64_t(blockIdx.x) + 1, gridDim.x) - pos;  // block-uniform
+#ifdef MM_BWD_TILEMODE   // experiment: one tile of MM_BWD_TILEMODE rows per workgroup, handed out by the dispatcher (grid = blocks x column blocks)
+  {
+    const int cbt = blockIdx.y, r0 = row_begin + int(blockIdx.x) * MM_BWD_TILEMODE;
+    if (cbt < walk.c0 || r0 >= walk.hi(cbt)) return;
+    pos = walk.prefix(cbt) + (r0 - row_begin);
+    rem = min(MM_BWD_TILEMODE, walk.hi(cbt) - r0);
+  }
+#endif
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform -> row operands stay scalar loads
-  const int jbase = tile.jbase;
-  const int i0 = tile.i0 + wave * TI, i1 = max(i0, min(i0 + TI, min(tile.i0 + NW * TI, row_end)));
-  const bool wave_live = i0 < i1 && jbase + 63 > i0;  // else no pair of this wave is above the diagonal
-  const int j = jbase + lane;
-  const bool jin = j < n;
-
-  T xj[NP], accJ[D][D];
-#pragma unroll
-  for (int k = 0; k < NP; ++k) xj[k] = T(0);
-#pragma unroll
-  for (int r = 0; r < D; ++r)
-#pragma unroll
-    for (int c = 0; c < D; ++c) accJ[r][c] = T(0);
-#pragma unroll
-  for (int k = 0; k < D; ++k) xj[pidx(k, k)] = T(1);
-  if (jin) {
-#pragma unroll
-    for (int k = 0; k < NP; ++k) xj[k] = nodeY[size_t(j) * NP + k];
-  }
+  bool red_writer;
+  const int red_slot = reduce_slot<NP>(lane, red_writer);  // which entry of M this lane holds after the row reduction
   const int64_t base = pair_off(n, row_begin);
-  if (wave_live) {
-    T li_next[NP], lc_next[NP];  // row operands are fetched one row ahead (scalar loads overlap the math)
+  int cb = rem > 0 ? walk.find(pos) : 0;                 // current column block
+  int r = row_begin + int(pos - walk.prefix(cb));        // next row of it
+  // Vector issue is arbitrated oldest wavefront first: of equal shares started together, the oldest workgroup of a
+  // CU finishes when the youngest is barely half way, and the rest of the launch runs at one or two wavefronts per
+  // SIMD (measured: five completion steps of 256 workgroups, the last 20 us at <= 40 % residency).  Priority outranks
+  // age, so every wavefront LOWERS its priority as it advances through its share (3 until 40 %, 2 until 70 %,
+  // 1 until 90 %, then 0): whoever is ahead yields to whoever is behind, and all of them enter the last tenth together.
+  const int64_t share = rem;
+#ifndef MM_BWD_PRIO
+#define MM_BWD_PRIO 1
+#endif
+  int64_t next_mark = MM_BWD_PRIO == 1 ? (share * 2) / 5 : MM_BWD_PRIO == 2 ? (share * 17) / 20 : INT64_MAX;
+  int phase = MM_BWD_PRIO == 2 ? 2 : 0;
+  if (MM_BWD_PRIO) __builtin_amdgcn_s_setprio(3);
+
+  while (rem > 0) {   // one pass per column block of this workgroup's share
+    const int jbase = cb * 64;
+    const int j = jbase + lane;
+    const bool jin = j < n;
+    T xj[NP], accJ[D][D];
 #pragma unroll
-    for (int k = 0; k < NP; ++k) { li_next[k] = nodeL[size_t(i0) * NP + k]; lc_next[k] = nodeC[size_t(i0) * NP + k]; }
-    // The pair-vector loads are UNCONDITIONAL (clamped address, value masked at use): a predicated load
-    // compiles to an exec-masked branch, after which the compiler can no longer count outstanding loads
-    // and waits for vmcnt(0) right behind the prefetch — exposing the HBM latency it was meant to hide.
-    auto g_at = [&](int row) -> T {
-      const int64_t off = pair_off(n, row) - base + (j - row - 1);
-      return g[(jin && j > row) ? off : int64_t(0)];
-    };
-    // ... and kGAhead rows ahead: with 8 wavefronts interleaved on a SIMD one row of work is ~1.7 us of wall
-    // time, the loaded HBM latency is longer than that (SQ_WAIT_INST_ANY was 36 % of the wave cycles).
-    constexpr int kGAhead = MM_BWD_G_AHEAD;
-    T gq[kGAhead];
+    for (int k = 0; k < NP; ++k) xj[k] = T(0);
 #pragma unroll
-    for (int a = 0; a < kGAhead; ++a) gq[a] = g_at(min(i0 + a, i1 - 1));
-    for (int i = i0; i < i1; ++i) {
-      T li[NP], lc[NP];
+    for (int rr = 0; rr < D; ++rr)
 #pragma unroll
-      for (int k = 0; k < NP; ++k) { li[k] = li_next[k]; lc[k] = lc_next[k]; }
-      const int inext = min(i + 1, i1 - 1);
+      for (int c = 0; c < D; ++c) accJ[rr][c] = T(0);
 #pragma unroll
-      for (int k = 0; k < NP; ++k) {
-        li_next[k] = nodeL[size_t(inext) * NP + k];
-        lc_next[k] = nodeC[size_t(inext) * NP + k];
-      }
-      T gs = (jin && j > i) ? gq[0] : T(0);  // upstream gradient (or target) of this row
+    for (int k = 0; k < D; ++k) xj[pidx(k, k)] = T(1);
+    if (jin) {
 #pragma unroll
-      for (int a = 0; a + 1 < kGAhead; ++a) gq[a] = gq[a + 1];
-      gq[kGAhead - 1] = g_at(min(i + kGAhead, i1 - 1));
-      T m[NP];
-      bool series = false;
-      auto jacobi_path = [&]() {
-        T w[D], lw[D], v[D][D];
-        const T s = pair_core<T, D, true, true>(li, xj, wmin, wmax, w, lw, v);
-        gs = upstream_of<T, LOSS>(gs, s, jin && j > i, squared, wmin, sp, la, loss_acc, ds_acc);
-        T cm[D];
+      for (int k = 0; k < NP; ++k) xj[k] = nodeY[size_t(j) * NP + k];
+    }
+    const int hi = walk.hi(cb);
+    while (rem > 0 && r < hi) {   // chunks of up to NW x TI rows of this block
+      const int chunk = int(min(int64_t(min(hi - r, NW * TI)), rem));
+      const int tw = (chunk + NW - 1) / NW;
+      const int i0 = r + wave * tw, i1 = min(i0 + tw, r + chunk);
+      if (i0 < i1) {
+        T li_next[NP], lc_next[NP];  // row operands are fetched one row ahead (scalar loads overlap the math)
 #pragma unroll
-        for (int k = 0; k < D; ++k) cm[k] = (gs + gs) * lw[k];
-        vdvt<T, D>(v, cm, m);
-      };
-      if constexpr (D == 3 || D == 4) {
-        // Eigen-free paths, chosen per wavefront: close pairs (||A - I||_F <= 0.3, fp32) take the
-        // Cayley-Hamilton series of log(I + E); anything with tr(Z^2) <= 0.36 (eigenvalue ratios up
-        // to ~16: every pair of an embedding with O(1) distances) the Cayley-transform logarithm.
-        // What is left (very wide spectra, NaN, non-PD) goes to the Jacobi path.
-        // Written as an if / else-if / else chain with complete arms so that the likely arm is the
-        // fall-through (a taken branch per pair costs ~4 % of this kernel).
-        T a[NP], m0[NP];
-        congr_chol<T, D>(li, xj, a);
-        auto finish = [&]() {
-          T s = T(0);
-          if (LOSS != MM_LOSS_NONE || __builtin_expect(!squared, 0)) s = frob2<T, D>(m0);
-          gs = upstream_of<T, LOSS>(gs, s, jin && j > i, squared, wmin, sp, la, loss_acc, ds_acc);
-          const T g2 = gs + gs;
-#pragma unroll
-          for (int k = 0; k < NP; ++k) m[k] = g2 * m0[k];
+        for (int k = 0; k < NP; ++k) { li_next[k] = nodeL[size_t(i0) * NP + k]; lc_next[k] = nodeC[size_t(i0) * NP + k]; }
+        // The pair vector is requested kAhead rows ahead into a rotating set of registers, and the row loop is unrolled
+        // kAhead times so that the rotation is a renaming: rotating with register moves would wait for the NEWEST
+        // request at every row (s_waitcnt vmcnt(0)), i.e. never be more than one row ahead.
+        // Element (row, j) lives at pair_off(n, row) - base + (j - row - 1): the row part is a wave-uniform running
+        // pointer (scalar registers; the next row starts n - row - 2 elements further), the lane part a 32-bit byte
+        // offset, so a request is `global_load_dword v, v_off, s[ptr]` behind ONE vector instruction of address
+        // arithmetic (a clamp).  Lanes at or below the diagonal and beyond n read the row's first / last element
+        // instead — requests are unconditional: a predicated one is an exec-masked branch behind which the compiler
+        // waits for vmcnt(0) — and their value is masked at use.
+        constexpr int kAhead = MM_BWD_AHEAD;
+        const char* gp = reinterpret_cast<const char*>(g + (pair_off(n, i0) - base - i0 - 1));
+        int gr = i0;
+        auto request = [&]() -> T {
+          const unsigned off = unsigned(min(max(j, gr + 1), n - 1)) * unsigned(sizeof(T));
+          const T v = *reinterpret_cast<const T*>(gp + off);
+          const bool more = gr + 1 < i1;   // wave-uniform; the last row of the slice is simply requested again
+          gp += more ? int64_t(n - gr - 2) * int64_t(sizeof(T)) : int64_t(0);
+          gr += more ? 1 : 0;
+          return v;
         };
-        bool close = false;
-        if constexpr (std::is_same<T, float>::value) close = !__any(!(close_gate<D>(a) <= 0.09f));
-        if (__builtin_expect(close, 1)) {
-          if constexpr (std::is_same<T, float>::value) log_close<D>(a, m0);
-          finish();
-        } else {
-          const T gate = log_cayley<T, D>(a, m0);
-          if (__builtin_expect(!__any(!(gate <= T(kCayleyGate))), 1)) finish(); else jacobi_path();
+        T gq[kAhead];
+#pragma unroll
+        for (int u = 0; u < kAhead; ++u) gq[u] = request();
+        for (int ib = i0; ib < i1; ib += kAhead) {
+#pragma unroll
+         for (int u = 0; u < kAhead; ++u) {
+          // (a slice with a number of rows that is not a multiple of kAhead runs its last unrolled slots on a masked
+          // row: an early exit here would make the number of outstanding requests path-dependent and the compiler
+          // falls back to vmcnt(0))
+          const int i = min(ib + u, i1 - 1);
+          const bool row_live = ib + u < i1;
+          if (__builtin_expect((share - rem) + int64_t(ib + u - i0) * NW >= next_mark, 0)) {   // wave-uniform
+            ++phase;
+            if (phase == 1) { __builtin_amdgcn_s_setprio(2); next_mark = (share * 7) / 10; }
+            else if (phase == 2) { __builtin_amdgcn_s_setprio(1); next_mark = (share * 9) / 10; }
+            else { __builtin_amdgcn_s_setprio(0); next_mark = INT64_MAX; }
+          }
+          T li[NP], lc[NP];
+#pragma unroll
+          for (int k = 0; k < NP; ++k) { li[k] = li_next[k]; lc[k] = lc_next[k]; }
+          const int inext = min(i + 1, i1 - 1);
+#pragma unroll
+          for (int k = 0; k < NP; ++k) {
+            li_next[k] = nodeL[size_t(inext) * NP + k];
+            lc_next[k] = nodeC[size_t(inext) * NP + k];
+          }
+          const bool valid = jin && j > i && row_live;
+          T gs = valid ? gq[u] : T(0);  // upstream gradient (or target) of this row
+          gq[u] = request();
+          T m[NP];
+          bool series = false;
+          auto jacobi_path = [&]() {
+            T w[D], lw[D], v[D][D];
+            const T s = pair_core<T, D, true, true>(li, xj, wmin, wmax, w, lw, v);
+            gs = upstream_of<T, LOSS>(gs, s, valid, squared, wmin, sp, la, loss_acc, ds_acc);
+            T cm[D];
+#pragma unroll
+            for (int k = 0; k < D; ++k) cm[k] = (gs + gs) * lw[k];
+            vdvt<T, D>(v, cm, m);
+          };
+          if constexpr (D == 3 || D == 4) {
+            // Eigen-free paths, chosen per wavefront: close pairs (||A - I||_F <= 0.3, fp32) take the
+            // Cayley-Hamilton series of log(I + E); anything with tr(Z^2) <= 0.36 (eigenvalue ratios up
+            // to ~16: every pair of an embedding with O(1) distances) the Cayley-transform logarithm.
+            // What is left (very wide spectra, NaN, non-PD) goes to the Jacobi path.
+            // Written as an if / else-if / else chain with complete arms so that the likely arm is the
+            // fall-through (a taken branch per pair costs ~4 % of this kernel).
+            T a[NP], m0[NP];
+            congr_chol<T, D>(li, xj, a);
+            // the upstream gradient is known before log(A) unless it depends on the distance (fused loss, d instead of d^2)
+            const bool g_first = LOSS == MM_LOSS_NONE && squared;
+            auto finish = [&](bool scaled) {
+              if (scaled) {
+#pragma unroll
+                for (int k = 0; k < NP; ++k) m[k] = m0[k];
+                return;
+              }
+              T s = T(0);
+              if (LOSS != MM_LOSS_NONE || __builtin_expect(!squared, 0)) s = frob2<T, D>(m0);
+              gs = upstream_of<T, LOSS>(gs, s, valid, squared, wmin, sp, la, loss_acc, ds_acc);
+              const T g2 = gs + gs;
+#pragma unroll
+              for (int k = 0; k < NP; ++k) m[k] = g2 * m0[k];
+            };
+            bool close = false;
+            if constexpr (std::is_same<T, float>::value) close = !__any(!(close_gate<D>(a) <= 0.09f));
+            if (__builtin_expect(close, 1)) {
+              if constexpr (std::is_same<T, float>::value) log_close<D>(a, m0, g_first ? gs + gs : 1.f);
+              finish(g_first);
+            } else {
+              const T gate = log_cayley<T, D>(a, m0);
+              if (__builtin_expect(!__any(!(gate <= T(kCayleyGate))), 1)) finish(false); else jacobi_path();
+            }
+            series = true;
+          }
+          if (!series) jacobi_path();
+          T cj[D][D];
+          lt_m_lt<T, D>(li, lc, m, cj);
+#pragma unroll
+          for (int rr = 0; rr < D; ++rr)
+#pragma unroll
+            for (int c = 0; c < D; ++c) {
+              accJ[rr][c] += cj[rr][c];
+              // pinned here: the column side must have consumed M before the reduction below, whose first levels
+              // (v_permlane*_swap) overwrite their operands — otherwise the compiler sinks the congruence behind the
+              // reduction and pays a register copy per entry of M to keep them alive
+              asm volatile("" : "+v"(accJ[rr][c]));
+            }
+          // row side: transposing reduction — every lane ends up with the wavefront total of ONE entry of M
+          const T tot = wave_reduce_transposed<NP, T>(m, lane);
+          if (red_writer) redM[wave][ib + u - i0][red_slot] = tot;
+         }
         }
-        series = true;
+        // row side: each wavefront owns the rows of its slice
+        __builtin_amdgcn_wave_barrier();
+        for (int t = lane; t < tw * NP; t += 64) {
+          const int k = t / tw, il = t - k * tw;
+          if (i0 + il < i1) atomic_add(&accM[size_t(k) * n + i0 + il], redM[wave][il][k]);
+        }
+        __builtin_amdgcn_wave_barrier();   // redM is rewritten by the next chunk
       }
-      if (!series) jacobi_path();
-      T cj[D][D];
-#if defined(MM_ABL) && MM_ABL == 10  // ablation: no column-side congruence (timing only)
+      r += chunk;
+      rem -= chunk;
+    }
+    // column side of this block: combine the wavefronts, then 256-B contiguous atomics per entry
 #pragma unroll
-      for (int r = 0; r < D; ++r)
+    for (int rr = 0; rr < D; ++rr)
 #pragma unroll
-        for (int c = 0; c < D; ++c) cj[r][c] = m[pidx(r, c)];
-#else
-      lt_m_lt<T, D>(li, lc, m, cj);
-#endif
+      for (int c = 0; c < D; ++c) colS[wave][rr * D + c][lane] = accJ[rr][c];
+    __syncthreads();
+    if (jin) {
+      for (int k = wave; k < D * D; k += NW) {
+        T sum = colS[0][k][lane];
 #pragma unroll
-      for (int r = 0; r < D; ++r)
-#pragma unroll
-        for (int c = 0; c < D; ++c) accJ[r][c] += cj[r][c];
-      if constexpr (NP <= 16) {
-        // transposing reduction: every lane ends up with the wavefront total of ONE entry of M
-        constexpr int W = NP <= 8 ? 8 : 16;
-        T tot;
-#if defined(MM_ABL) && MM_ABL == 8   // ablation: no cross-lane reduction (timing only)
-        tot = m[0];
-#pragma unroll
-        for (int k = 1; k < NP; ++k) tot += m[k];
-#else
-        if constexpr (NP <= 8) tot = wave_sum_transposed8<NP>(m, lane); else tot = wave_sum_transposed16<NP>(m, lane);
-#endif
-        const int k = transposed_index<W>(lane);
-        if (lane < W && k < NP) redM[wave][i - i0][k] = tot;
-      } else {
-        wave_sum_n(m);  // fp64: LDS-crossbar butterflies
-        if (lane == 0) {
-#pragma unroll
-          for (int k = 0; k < NP; ++k) redM[wave][i - i0][k] = m[k];
-        }
+        for (int wv = 1; wv < NW; ++wv) sum += colS[wv][k][lane];
+        atomic_add(&accS[size_t(k) * n + j], sum);
       }
     }
+    ++cb;
+    r = row_begin;
+    if (rem > 0) __syncthreads();   // colS is rewritten by the next block
   }
-  // row side: each wavefront owns its TI rows
-  if (wave_live) {
-    __builtin_amdgcn_wave_barrier();
-    for (int t = lane; t < TI * NP; t += 64) {
-      const int k = t / TI, il = t % TI;
-#if !defined(MM_ABL) || (MM_ABL != 7 && MM_ABL != 9 && MM_ABL != 12)
-      if (i0 + il < i1) atomic_add(&accM[size_t(k) * n + i0 + il], redM[wave][il][k]);
-#endif
-    }
-  }
-  // column side: combine the wavefronts, then 256-B contiguous atomics per entry
-#pragma unroll
-  for (int r = 0; r < D; ++r)
-#pragma unroll
-    for (int c = 0; c < D; ++c) colS[wave][r * D + c][lane] = accJ[r][c];
-  __shared__ T lossW[NW][2];
   if constexpr (LOSS != MM_LOSS_NONE) {
+    __shared__ T lossW[NW][2];
     const T l = wave_sum(loss_acc), d = wave_sum(ds_acc);
     if (lane == 0) { lossW[wave][0] = l; lossW[wave][1] = d; }
-  }
-  __syncthreads();
-  if constexpr (LOSS != MM_LOSS_NONE) {
+    __syncthreads();
     if (threadIdx.x == 0) {
-      T l = lossW[0][0], d = lossW[0][1];
+      T ls = lossW[0][0], dd = lossW[0][1];
 #pragma unroll
-      for (int wv = 1; wv < NW; ++wv) { l += lossW[wv][0]; d += lossW[wv][1]; }
+      for (int wv = 1; wv < NW; ++wv) { ls += lossW[wv][0]; dd += lossW[wv][1]; }
       const int slot = (blockIdx.x + blockIdx.y * gridDim.x) & (kLossSlots - 1);
-      atomic_add(&la.slots[slot], l);
-      atomic_add(&la.slots[kLossSlots + slot], d);
+      atomic_add(&la.slots[slot], ls);
+      atomic_add(&la.slots[kLossSlots + slot], dd);
     }
   }
-  if (jin) {
-    for (int k = wave; k < D * D; k += NW) {
-      T sum = colS[0][k][lane];
-#pragma unroll
-      for (int wv = 1; wv < NW; ++wv) sum += colS[wv][k][lane];
-#if !defined(MM_ABL) || (MM_ABL != 7 && MM_ABL != 9 && MM_ABL != 13)
-      atomic_add(&accS[size_t(k) * n + j], sum);
-#else
-      if (sum == T(12345.678)) accS[j] = sum;
+#ifdef MM_BWD_STAMP
+  if (threadIdx.x == 0) {
+    const unsigned wg = blockIdx.x + blockIdx.y * gridDim.x;
+    if (wg < 16384) {
+      g_bwd_stamps[4 * wg + 0] = stamp0;
+      g_bwd_stamps[4 * wg + 1] = __builtin_amdgcn_s_memrealtime();
+      g_bwd_stamps[4 * wg + 2] = (static_cast<unsigned long long>(__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11))) << 32) |
+                                 __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11));   // HW_ID | XCC_ID
+      g_bwd_stamps[4 * wg + 3] = __builtin_amdgcn_s_memtime() - stampc0;
+    }
+  }
 #endif
-    }
-  }
 }
 
 // grad_x[i] = sym(accS_i X_i^-1) - L_i^-T accM_i L_i^-1   (symmetric, full DxD)
@@ -829,9 +891,7 @@ int spd_pdist_prepare(const T* x, int64_t n, Ws<T>& ws, int flags, hipStream_t s
   return MM_OK;
 }
 
-// Rows per wavefront of a tile.  Forward: 8 (MM_SPD_TI = 8 | 16 | 32 overrides).  Backward: 16 once the
-// launch still fills the machine at that height (>= 2048 workgroups of 64 x 64 pairs), else 8; measured at
-// n = 5000 (12.5 M pairs): 8 -> 70.8 us, 16 -> 67.9 us, 32 -> 74.4 us (MM_SPD_BWD_TI overrides).
+// Rows per wavefront of a forward tile: 8 (MM_SPD_TI = 8 | 16 | 32 overrides).
 inline int env_tile_rows(const char* name) {
   const char* e = std::getenv(name);
   const int t = e ? std::atoi(e) : 0;
@@ -841,12 +901,6 @@ inline int tile_rows() {
   static const int v = env_tile_rows("MM_SPD_TI");
   return v ? v : 8;
 }
-inline int bwd_tile_rows(int64_t pairs) {
-  static const int v = env_tile_rows("MM_SPD_BWD_TI");
-  if (v) return v;
-  return pairs >= int64_t(2048) * 64 * 64 ? 16 : 8;
-}
-
 template <typename T, int D, int TI>
 int spd_pdist_fwd_ti(Ws<T>& ws, int64_t n, int64_t rb, int64_t re, int squared, double wmin, double wmax, T* out,
                      hipStream_t st) {
@@ -873,13 +927,28 @@ int spd_pdist_fwd_t(const T* x, int64_t n, int64_t rb, int64_t re, int squared, 
   }
 }
 
-template <typename T, int D, int TI, int LOSS = MM_LOSS_NONE>
-int spd_pdist_bwd_ti(Ws<T>& ws, const T* g, int64_t n, int64_t rb, int64_t re, int squared, double wmin, double wmax,
-                     hipStream_t st, LossArgs<T> la = LossArgs<T>{nullptr, T(1), T(0), 0, nullptr}) {
+// One launch of (at most) the resident capacity; fewer workgroups when the row range is small (>= 8 rows of a column
+// block per workgroup, two per wavefront).
+constexpr int kBwdTI = 16;   // rows per wavefront and chunk
+template <typename T, int D, int LOSS = MM_LOSS_NONE>
+int spd_pdist_bwd_launch(Ws<T>& ws, const T* g, int64_t n, int64_t rb, int64_t re, int squared, double wmin, double wmax,
+                         hipStream_t st, LossArgs<T> la = LossArgs<T>{nullptr, T(1), T(0), 0, nullptr}) {
+  constexpr int kThreads = 64 * bwd_waves<T, D>();
+  auto kernel = spd_pdist_bwd_kernel<T, D, kBwdTI, LOSS>;
+  const int64_t units = ColWalk(int(n), int(rb), int(re)).total();
+  if (units <= 0) return MM_OK;
+  int64_t grid = resident_workgroups(kernel, kThreads);
+  static const int64_t env_grid = std::getenv("MM_SPD_BWD_GRID") ? std::atoll(std::getenv("MM_SPD_BWD_GRID")) : 0;
+  if (env_grid > 0) grid = env_grid;   // (experiments: over- / under-subscription of the device)
+  grid = std::max<int64_t>(1, std::min<int64_t>(grid, (units + 7) / 8));
+  dim3 g3{unsigned(grid), 1, 1};
+#ifdef MM_BWD_TILEMODE
+  g3 = dim3(unsigned((re - rb + MM_BWD_TILEMODE - 1) / MM_BWD_TILEMODE), unsigned((n + 63) / 64));
+#endif
   {
     ProfScope prof(PROF_SPD_BWD, st);
-    spd_pdist_bwd_kernel<T, D, TI, LOSS><<<fold_grid<bwd_waves<T, D>() * TI, 64>(n, rb, re), dim3(64 * bwd_waves<T, D>()), 0, st>>>(
-        ws.nodeL, ws.nodeC, ws.nodeC, g, int(n), int(rb), int(re), squared, T(wmin), T(wmax), ws.accM, ws.accS, la);
+    kernel<<<g3, dim3(kThreads), 0, st>>>(ws.nodeL, ws.nodeC, ws.nodeC, g, int(n), int(rb), int(re), squared,
+                                                            T(wmin), T(wmax), ws.accM, ws.accS, la);
   }
   MM_CHECK_LAUNCH();
   return MM_OK;
@@ -895,13 +964,8 @@ int spd_pdist_loss_t(int kind, const T* x, const T* target, const T* scale_raw, 
   if (rc) return rc;
   if (re > rb && pair_off(n, re) > pair_off(n, rb)) {
     LossArgs<T> la{scale_raw, T(alpha), T(eps), terms, ws.loss, loss_params};
-    const bool tall = bwd_tile_rows(pair_off(n, re) - pair_off(n, rb)) >= 16;
-    if (kind == MM_LOSS_STRESS)
-      rc = tall ? spd_pdist_bwd_ti<T, D, 16, MM_LOSS_STRESS>(ws, target, n, rb, re, 1, wmin, wmax, st, la)
-                : spd_pdist_bwd_ti<T, D, 8, MM_LOSS_STRESS>(ws, target, n, rb, re, 1, wmin, wmax, st, la);
-    else
-      rc = tall ? spd_pdist_bwd_ti<T, D, 16, MM_LOSS_QUOTIENT>(ws, target, n, rb, re, 1, wmin, wmax, st, la)
-                : spd_pdist_bwd_ti<T, D, 8, MM_LOSS_QUOTIENT>(ws, target, n, rb, re, 1, wmin, wmax, st, la);
+    if (kind == MM_LOSS_STRESS) rc = spd_pdist_bwd_launch<T, D, MM_LOSS_STRESS>(ws, target, n, rb, re, 1, wmin, wmax, st, la);
+    else rc = spd_pdist_bwd_launch<T, D, MM_LOSS_QUOTIENT>(ws, target, n, rb, re, 1, wmin, wmax, st, la);
     if (rc) return rc;
   }
   spd_pdist_finalize_kernel<T, D><<<dim3((n + 127) / 128), dim3(128), 0, st>>>(ws.nodeL, ws.accM, ws.accS, int(n),
@@ -918,11 +982,7 @@ int spd_pdist_bwd_t(const T* x, const T* g, int64_t n, int64_t rb, int64_t re, i
   int rc = spd_pdist_prepare<T, D>(x, n, ws, flags, st);
   if (rc) return rc;
   if (re > rb && pair_off(n, re) > pair_off(n, rb)) {
-    switch (bwd_tile_rows(pair_off(n, re) - pair_off(n, rb))) {
-      case 8: rc = spd_pdist_bwd_ti<T, D, 8>(ws, g, n, rb, re, squared, wmin, wmax, st); break;
-      case 32: rc = spd_pdist_bwd_ti<T, D, 32>(ws, g, n, rb, re, squared, wmin, wmax, st); break;
-      default: rc = spd_pdist_bwd_ti<T, D, 16>(ws, g, n, rb, re, squared, wmin, wmax, st); break;
-    }
+    rc = spd_pdist_bwd_launch<T, D>(ws, g, n, rb, re, squared, wmin, wmax, st);
     if (rc) return rc;
   }
   spd_pdist_finalize_kernel<T, D><<<dim3((n + 127) / 128), dim3(128), 0, st>>>(
@@ -970,6 +1030,12 @@ int launch_pointwise(K kernel, int64_t m, hipStream_t st, A... args) {
 using namespace mm;
 
 extern "C" {
+
+#ifdef MM_BWD_STAMP
+int mm_dbg_read_bwd_stamps(void* host, size_t bytes) {
+  return int(hipMemcpyFromSymbol(host, HIP_SYMBOL(mm::g_bwd_stamps), bytes));
+}
+#endif
 
 int mm_spd_max_dim(void) { return kSpdMaxD; }
 

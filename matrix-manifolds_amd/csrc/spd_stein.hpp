@@ -75,6 +75,8 @@ __global__ __launch_bounds__(kBlock) void spd_stein_bwd_kernel(const T* __restri
   const bool wave_live = i0 < i1 && jbase + 63 > i0;
   const int j = jbase + lane;
   const bool jin = j < n;
+  bool red_writer;
+  const int red_slot = reduce_slot<NV>(lane, red_writer);
   T xj[NP], ldj = T(0), accJ[NV];
 #pragma unroll
   for (int k = 0; k < NP; ++k) xj[k] = T(0);
@@ -94,7 +96,7 @@ __global__ __launch_bounds__(kBlock) void spd_stein_bwd_kernel(const T* __restri
 #pragma unroll
       for (int k = 0; k < NP; ++k) xi[k] = nodeX[size_t(i) * NP + k];
       const bool valid = jin && j > i;
-      T gs = g[valid ? pair_off(n, i) - base + (j - i - 1) : int64_t(0)];
+      T gs = pair_row_load<T>(g, n, base, i, j);
       gs = valid ? gs : T(0);
       const T div = stein_pair<T, D>(xi, xj, nodeLd[i] + ldj, l);
       if (!squared) gs *= T(0.5) * Num<T>::rsqrt(Num<T>::max(div, wmin));  // d sqrt(clamp(S)) / dS, clamp transparent
@@ -113,11 +115,8 @@ __global__ __launch_bounds__(kBlock) void spd_stein_bwd_kernel(const T* __restri
 #pragma unroll
       for (int k = 0; k < NV; ++k) accJ[k] += v[k];
       // row side: transposing reduction, every lane ends with the wavefront total of ONE of the NV values
-      constexpr int W = NV <= 8 ? 8 : 16;
-      T tot;
-      if constexpr (NV <= 8) tot = wave_sum_transposed8<NV>(v, lane); else tot = wave_sum_transposed16<NV>(v, lane);
-      const int k = transposed_index<W>(lane);
-      if (lane < W && k < NV) redR[wave][i - i0][k] = tot;
+      const T tot = wave_reduce_transposed<NV, T>(v, lane);
+      if (red_writer) redR[wave][i - i0][red_slot] = tot;
     }
     __builtin_amdgcn_wave_barrier();
     for (int t = lane; t < TI * NV; t += 64) {

@@ -16,8 +16,8 @@ constexpr int kBlock = 256;  // 4 wavefronts
 // 70.0 / 73.5 us; wavefronts per workgroup 8 -> +1.5 us.  Persistent workgroups (one launch-filling grid that
 // loops over tiles) were measured slower too: 118 us with a global atomic tile counter (same-address returning
 // atomics serialise at ~18 ns each), 75-81 us with a static round-robin (78 VGPRs -> 6 wavefronts per SIMD).
-#ifndef MM_BWD_G_AHEAD
-#define MM_BWD_G_AHEAD 3   // rows of the pair vector requested ahead of their use in the backward
+#ifndef MM_BWD_AHEAD
+#define MM_BWD_AHEAD 2   // rows of the pair vector requested ahead of their use in the backward (= unroll of its row loop)
 #endif
 #ifndef MM_BWD_WAVES
 #define MM_BWD_WAVES 4
@@ -106,6 +106,69 @@ template <int TI, int BW = kBlock> inline dim3 fold_grid(int64_t n, int64_t rb, 
     gx = c > gx ? c : gx;
   }
   return dim3(gx > 0 ? gx : 1, (gy + 1) / 2 > 0 ? (gy + 1) / 2 : 1);
+}
+
+
+// ---- balanced walk of the upper triangle (backward kernels) ---------------------------------------------------------
+// Work is measured in ROWS OF 64-COLUMN BLOCKS: column block c (columns 64c .. 64c+63) owns the rows [rb, hi(c)),
+// hi(c) = min(re, 64c + 63) (row i has a pair in the block iff i < 64c + 63; re = min(row_end, n-1)).  The blocks' row
+// ranges, concatenated block after block, form a line of W units, and workgroup w of G takes the units
+// [start(w), start(w+1)), start(w) = floor(W/G) w + min(w, W mod G): every workgroup gets the same amount of arithmetic
+// to within one row, so a launch of exactly the resident capacity has no tail (with tiles handed out by the dispatcher
+// the last 40 % of the backward's duration ran at half occupancy — profiles/r02_timeline.txt), and a workgroup walks DOWN
+// a column block, so the column-side sums stay in registers until the block changes.
+// counts: 0 for c < c0 = (rb+1)/64; 64c + 63 - rb for c0 <= c < c1 = max(c0, re/64); R = re - rb from c1 on.
+struct ColWalk {
+  int rb, re, ncb, c0, c1;
+  __host__ __device__ ColWalk(int n, int row_begin, int row_end) {
+    rb = row_begin;
+    re = row_end < n - 1 ? row_end : n - 1;
+    if (re < rb) re = rb;
+    ncb = (n + 63) / 64;
+    c0 = (rb + 1) / 64;
+    c1 = re / 64 > c0 ? re / 64 : c0;
+    if (c1 > ncb) c1 = ncb;
+    if (c0 > ncb) c0 = ncb;
+  }
+  __host__ __device__ int hi(int c) const { const int d = 64 * c + 63; return d < re ? d : re; }
+  __host__ __device__ int64_t prefix(int c) const {   // units before column block c
+    if (c <= c0 || re == rb) return 0;
+    const int64_t m = c < c1 ? c : c1;
+    int64_t s = 32 * (m * (m - 1) - int64_t(c0) * (c0 - 1)) + (m - c0) * int64_t(63 - rb);
+    if (c > c1) s += int64_t(c - c1) * (re - rb);
+    return s;
+  }
+  __host__ __device__ int64_t total() const { return prefix(ncb); }
+  __host__ __device__ int find(int64_t p) const {     // the column block holding unit p (0 <= p < total())
+    int lo = c0, hi_ = ncb - 1;
+    while (lo < hi_) {
+      const int mid = (lo + hi_ + 1) / 2;
+      if (prefix(mid) <= p) lo = mid; else hi_ = mid - 1;
+    }
+    return lo;
+  }
+  static __host__ __device__ int64_t share_begin(int64_t total, int64_t w, int64_t g) {
+    const int64_t q = total / g, r = total % g;
+    return q * w + (w < r ? w : r);
+  }
+};
+
+// Workgroups of `kernel` that are resident at once on the current device (occupancy x compute units), cached per
+// kernel and device.  hipOccupancyMaxActiveBlocksPerMultiprocessor can report one block too many per CU for kernels
+// with 81-96 scalar registers (MI355X_MICROARCH.md, Residency): capped at 7 blocks of 256 threads.
+template <typename K> inline int resident_workgroups(K kernel, int block_threads) {
+  static int cache[64] = {0};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+  if (cache[dev] == 0) {
+    int per_cu = 0, cus = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, block_threads, 0) != hipSuccess || per_cu < 1) per_cu = 4;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;
+    const int cap = (7 * 256) / block_threads > 0 ? (7 * 256) / block_threads : 1;
+    if (per_cu > cap) per_cu = cap;
+    cache[dev] = per_cu * cus;
+  }
+  return cache[dev];
 }
 
 }  // namespace mm

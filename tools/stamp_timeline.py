@@ -1,0 +1,68 @@
+#!/usr/bin/env python3
+"""Diagnostic: timeline of the SPD backward kernel's workgroups from in-kernel clock stamps (build
+`tools/build_variant.sh stamp -DMM_BWD_STAMP`, run with MM_MANIFOLDS_LIB=.../libmm_stamp.so).
+Prints residency over time, workgroup durations and the per-CU load."""
+import ctypes
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, 'matrix-manifolds_amd')):
+    sys.path.insert(0, p)
+import torch  # noqa: E402
+import bench  # noqa: E402
+from graphembed import _backend as B  # noqa: E402
+
+
+def main():
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 5000
+    dev = torch.device('cuda', 0)
+    wl = bench.PdistWorkload(3, n, torch.float32, 0.1, 1, 0, dev)
+    for _ in range(5):
+        wl.kernels()
+    torch.cuda.synchronize()
+    wl.kernels()
+    torch.cuda.synchronize()
+    raw = B.lib()._lib
+    buf = np.zeros(4 * 16384, dtype=np.uint64)
+    fn = raw.mm_dbg_read_bwd_stamps
+    fn.restype, fn.argtypes = ctypes.c_int, [ctypes.c_void_p, ctypes.c_size_t]
+    assert fn(buf.ctypes.data, buf.nbytes) == 0
+    st = buf.reshape(-1, 4)
+    st = st[st[:, 1] > 0]
+    t0, t1 = st[:, 0].astype(np.int64), st[:, 1].astype(np.int64)
+    base = t0.min()
+    t0, t1 = (t0 - base) / 100.0, (t1 - base) / 100.0      # s_memrealtime ticks at 100 MHz -> us
+    hw = (st[:, 2] >> np.uint64(32)).astype(np.int64)
+    xcc = (st[:, 2] & np.uint64(0xffffffff)).astype(np.int64) & 0xf
+    cu = ((hw >> 8) & 0xf) | (((hw >> 12) & 1) << 4) | (((hw >> 13) & 7) << 5) | (xcc << 8)
+    dur = t1 - t0
+    cyc = st[:, 3].astype(np.int64)
+    print(f'{len(st)} workgroups; kernel span {t1.max():.1f} us; workgroup duration us: min {dur.min():.1f} median {np.median(dur):.1f} '
+          f'max {dur.max():.1f}; shader clock {np.median(cyc / np.maximum(dur, 1e-3)) / 1e3:.2f} GHz (median cycles / us)')
+    print('start times us: percentiles 10/50/90/99/100:', np.percentile(t0, [10, 50, 90, 99, 100]).round(1))
+    edges = np.linspace(0, t1.max(), 41)
+    res = [(np.minimum(t1, b) - np.maximum(t0, a)).clip(min=0).sum() / (b - a) for a, b in zip(edges[:-1], edges[1:])]
+    print('resident workgroups per 1/40 of the span:', ' '.join(f'{r:.0f}' for r in res))
+    ncu = len(np.unique(cu))
+    per = np.bincount(np.unique(cu, return_inverse=True)[1])
+    print(f'{ncu} distinct CUs; workgroups per CU: min {per.min()} median {np.median(per):.0f} max {per.max()}')
+    busy = np.zeros(ncu)
+    inv = np.unique(cu, return_inverse=True)[1]
+    np.add.at(busy, inv, dur)
+    print(f'sum of workgroup durations per CU us: min {busy.min():.0f} median {np.median(busy):.0f} max {busy.max():.0f}')
+    # concurrency per CU at the median time
+    tm = 0.5 * t1.max()
+    live = (t0 <= tm) & (t1 > tm)
+    print(f'at t = {tm:.1f} us: {live.sum()} workgroups live, per CU max {np.bincount(inv[live], minlength=ncu).max()} '
+          f'median {np.median(np.bincount(inv[live], minlength=ncu)):.0f}')
+    first = t0 < 2.0
+    print(f'workgroups started in the first 2 us: {first.sum()}; their durations us: min {dur[first].min():.1f} median {np.median(dur[first]):.1f} max {dur[first].max():.1f}')
+    order = np.argsort(t0)
+    print('first 12 starts:', t0[order][:12].round(2), ' last 12 ends:', np.sort(t1)[-12:].round(1))
+
+
+if __name__ == '__main__':
+    main()

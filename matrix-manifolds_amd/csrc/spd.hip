@@ -24,6 +24,7 @@
 #include "../../include/mm_manifolds.h"
 #include "prof.hpp"
 #include <algorithm>
+#include <climits>
 #include <cstdint>
 #include <cstdlib>
 #include <type_traits>
@@ -40,7 +41,8 @@ namespace mm {
 template <typename T, int D>
 __global__ void spd_prep_kernel(const T* __restrict__ x, int n, T* __restrict__ nodeL, T* __restrict__ nodeX,
                                 T* __restrict__ nodeC, T* __restrict__ accM, T* __restrict__ accS,
-                                T* __restrict__ loss, int* __restrict__ bad, T* __restrict__ nodeLd) {
+                                T* __restrict__ loss, int* __restrict__ bad, T* __restrict__ nodeLd,
+                                T* __restrict__ nodeLC) {
   constexpr int NP = Packed<D>::NP;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (blockIdx.x == 0)
@@ -55,6 +57,8 @@ __global__ void spd_prep_kernel(const T* __restrict__ x, int n, T* __restrict__ 
     nodeL[size_t(i) * NP + k] = li[k];
     nodeX[size_t(i) * NP + k] = xs[k];
     nodeC[size_t(i) * NP + k] = l[k];
+    nodeLC[size_t(i) * 2 * NP + k] = li[k];
+    nodeLC[size_t(i) * 2 * NP + NP + k] = l[k];
     accM[size_t(k) * n + i] = T(0);
   }
 #pragma unroll
@@ -276,24 +280,25 @@ __device__ unsigned long long g_bwd_stamps[4 * 16384];
 // Backward: a launch of (at most) as many workgroups as the device holds at once; workgroup w walks its share of the
 // balanced column walk (spd_ws.hpp, ColWalk): down one 64-column block, chunk after chunk of up to NW x TI rows (each
 // wavefront a contiguous slice of the chunk's rows, its lanes the block's 64 columns), then on to the next block.
-template <typename T, int D, int TI, int LOSS>
-__global__ __launch_bounds__((64 * bwd_waves<T, D>())) void spd_pdist_bwd_kernel(const T* __restrict__ nodeL,
+template <typename T, int D, int TI, int LOSS, bool SQ>
+__global__ __launch_bounds__((64 * bwd_waves<T, D>())) void spd_pdist_bwd_kernel(const T* __restrict__ nodeLC /* {L_i^-1, L_i} */,
                                                                const T* __restrict__ nodeY /* chol(X_j) */,
-                                                               const T* __restrict__ nodeC,
                                                                const T* __restrict__ g, int n, int row_begin,
-                                                               int row_end, int squared, T wmin, T wmax,
+                                                               int row_end, T wmin, T wmax,
                                                                T* __restrict__ accM, T* __restrict__ accS,
                                                                LossArgs<T> la) {
   constexpr int NP = Packed<D>::NP;
   constexpr int NW = bwd_waves<T, D>();
   // LOSS != 0: `g` holds the TARGET (graph) squared distances; the upstream gradient of each pair is
   // derived in registers from the loss, and the loss / scale-gradient sums leave through la.slots.
+  constexpr int squared = SQ ? 1 : 0;   // (a template parameter: as a run-time flag it cost two vector instructions per row)
   T sp = T(1), loss_acc = T(0), ds_acc = T(0);
   loss_resolve<T, LOSS>(la);
   if constexpr (LOSS != MM_LOSS_NONE) sp = softplus_of(la.scale_raw);
   // The wavefronts of a workgroup share the 64 columns: their column-side partial sums are combined through LDS
   // and leave with ONE set of atomics per column block (float atomics are a per-CU serial resource, ~50 ns per
   // wave instruction).
+  static_assert(TI % 2 == 0, "the row loop is unrolled twice");
   __shared__ T redM[NW][TI][NP];
   __shared__ T colS[NW][D * D][64];
 #ifdef MM_BWD_STAMP
@@ -303,7 +308,7 @@ __global__ __launch_bounds__((64 * bwd_waves<T, D>())) void spd_pdist_bwd_kernel
   const ColWalk walk(n, row_begin, row_end);
   const int64_t total = walk.total();
   int64_t pos = ColWalk::share_begin(total, blockIdx.x, gridDim.x);
-  int64_t rem = ColWalk::share_begin(total, int64_t(blockIdx.x) + 1, gridDim.x) - pos;  // block-uniform
+  int rem = int(ColWalk::share_begin(total, int64_t(blockIdx.x) + 1, gridDim.x) - pos);  // block-uniform (a share is < 2^31 rows)
 #ifdef MM_BWD_TILEMODE   // experiment: one tile of MM_BWD_TILEMODE rows per workgroup, handed out by the dispatcher (grid = blocks x column blocks)
   {
     const int cbt = blockIdx.y, r0 = row_begin + int(blockIdx.x) * MM_BWD_TILEMODE;
@@ -324,18 +329,25 @@ __global__ __launch_bounds__((64 * bwd_waves<T, D>())) void spd_pdist_bwd_kernel
   // SIMD (measured: five completion steps of 256 workgroups, the last 20 us at <= 40 % residency).  Priority outranks
   // age, so every wavefront LOWERS its priority as it advances through its share (3 until 40 %, 2 until 70 %,
   // 1 until 90 %, then 0): whoever is ahead yields to whoever is behind, and all of them enter the last tenth together.
-  const int64_t share = rem;
-#ifndef MM_BWD_PRIO
-#define MM_BWD_PRIO 1
-#endif
-  int64_t next_mark = MM_BWD_PRIO == 1 ? (share * 2) / 5 : MM_BWD_PRIO == 2 ? (share * 17) / 20 : INT64_MAX;
-  int phase = MM_BWD_PRIO == 2 ? 2 : 0;
-  if (MM_BWD_PRIO) __builtin_amdgcn_s_setprio(3);
+  // Progress is counted in rows of THIS wavefront (a quarter of the share's), one scalar compare per row.
+  const int wave_rows = (rem + NW - 1) / NW;
+  int rows_left = (wave_rows * 2) / 5 + 1;   // rows until the next priority step
+  int phase = 0;
+  __builtin_amdgcn_s_setprio(3);
+  // The row reduction leaves one total per lane; NP of the lanes hold distinct entries, the others duplicates.  All
+  // lanes store (an exec-masked store costs two scalar instructions per row): writers into redM, advancing by one row
+  // per row, the others into a slot of their own that does not move.
+  __shared__ T redJunk[NW][64];
+  T* red_ptr = red_writer ? &redM[wave][0][red_slot] : &redJunk[wave][lane];
+  const int red_step = red_writer ? NP : 0;
+  const int jv_none = INT32_MIN;
 
   while (rem > 0) {   // one pass per column block of this workgroup's share
     const int jbase = cb * 64;
     const int j = jbase + lane;
     const bool jin = j < n;
+    const int jv = jin ? j : jv_none;          // j for the validity test (never above a row for lanes beyond n)
+    const unsigned joff = unsigned(min(j, n - 1)) * unsigned(sizeof(T));
     T xj[NP], accJ[D][D];
 #pragma unroll
     for (int k = 0; k < NP; ++k) xj[k] = T(0);
@@ -351,31 +363,41 @@ __global__ __launch_bounds__((64 * bwd_waves<T, D>())) void spd_pdist_bwd_kernel
     }
     const int hi = walk.hi(cb);
     while (rem > 0 && r < hi) {   // chunks of up to NW x TI rows of this block
-      const int chunk = int(min(int64_t(min(hi - r, NW * TI)), rem));
+      const int chunk = min(min(hi - r, NW * TI), rem);
       const int tw = (chunk + NW - 1) / NW;
       const int i0 = r + wave * tw, i1 = min(i0 + tw, r + chunk);
       if (i0 < i1) {
-        T li_next[NP], lc_next[NP];  // row operands are fetched one row ahead (scalar loads overlap the math)
+        // EVERY instruction of a wavefront — scalar ones included — takes an issue slot of its SIMD (measured: these
+        // kernels run at 2.0 cycles per instruction of any kind), so the row loop is written for the smallest TOTAL:
+        // * row operands {L_i^-1, L_i}: one interleaved table, one running scalar pointer, two scalar loads per row
+        //   into one of two register sets that alternate with the unrolled slots (no copies);
+        // * the pair vector: element (row, j) lives at pair_off(n, row) - base + (j - row - 1); the row part is a
+        //   running scalar pointer (the next row starts n - row - 2 elements further), the lane part a 32-bit byte
+        //   offset clamped into the row (one vector instruction), i.e. `global_load_dword v, v_off, s[ptr]`.  Lanes at or
+        //   below the diagonal and beyond n read the row's first / last element instead — requests are unconditional:
+        //   a predicated one is an exec-masked branch behind which the compiler waits for vmcnt(0) — and their value
+        //   is masked at use.  Requests run kAhead rows ahead into registers that rotate by RENAMING (the loop is
+        //   unrolled kAhead times): rotating with moves would wait for the NEWEST request at every row.
+        constexpr int kAhead = 2;
+        const T* rowp = nodeLC + size_t(i0) * (2 * NP);
+        T lrow[2][2 * NP];
 #pragma unroll
-        for (int k = 0; k < NP; ++k) { li_next[k] = nodeL[size_t(i0) * NP + k]; lc_next[k] = nodeC[size_t(i0) * NP + k]; }
-        // The pair vector is requested kAhead rows ahead into a rotating set of registers, and the row loop is unrolled
-        // kAhead times so that the rotation is a renaming: rotating with register moves would wait for the NEWEST
-        // request at every row (s_waitcnt vmcnt(0)), i.e. never be more than one row ahead.
-        // Element (row, j) lives at pair_off(n, row) - base + (j - row - 1): the row part is a wave-uniform running
-        // pointer (scalar registers; the next row starts n - row - 2 elements further), the lane part a 32-bit byte
-        // offset, so a request is `global_load_dword v, v_off, s[ptr]` behind ONE vector instruction of address
-        // arithmetic (a clamp).  Lanes at or below the diagonal and beyond n read the row's first / last element
-        // instead — requests are unconditional: a predicated one is an exec-masked branch behind which the compiler
-        // waits for vmcnt(0) — and their value is masked at use.
-        constexpr int kAhead = MM_BWD_AHEAD;
-        const char* gp = reinterpret_cast<const char*>(g + (pair_off(n, i0) - base - i0 - 1));
-        int gr = i0;
+        for (int k = 0; k < 2 * NP; ++k) lrow[0][k] = rowp[k];
+        // Row pointer of the pair vector: slice base (64-bit, once per slice) + a 32-bit running offset that stops at
+        // the slice's last row (requests past it — the unrolled loop issues kAhead - 1 of them — read that row again:
+        // rows beyond the launch's range may lie outside the caller's buffer).  The lane offset is fixed for the whole
+        // slice: clamp(j, i0 + 1, n - 1) elements — for a later row of the slice a lane at or below the diagonal then
+        // reads an element of an earlier row, still inside the buffer (its value is masked anyway).
+        const int glast = min(i1, walk.re) - 1;
+        const int64_t gk = glast - i0;
+        const unsigned gmax = unsigned((gk * (n - 2) - (int64_t(i0) * gk + gk * (gk - 1) / 2)) * int64_t(sizeof(T)));
+        const char* gslice = reinterpret_cast<const char*>(g + (pair_off(n, i0) - base - i0 - 1));
+        unsigned goff = 0, gstep = unsigned(n - i0 - 2) * unsigned(sizeof(T));   // bytes from the current row to the next
+        const unsigned jslice = max(joff, unsigned(i0 + 1) * unsigned(sizeof(T)));
         auto request = [&]() -> T {
-          const unsigned off = unsigned(min(max(j, gr + 1), n - 1)) * unsigned(sizeof(T));
-          const T v = *reinterpret_cast<const T*>(gp + off);
-          const bool more = gr + 1 < i1;   // wave-uniform; the last row of the slice is simply requested again
-          gp += more ? int64_t(n - gr - 2) * int64_t(sizeof(T)) : int64_t(0);
-          gr += more ? 1 : 0;
+          const T v = *reinterpret_cast<const T*>(gslice + goff + jslice);
+          goff = min(goff + gstep, gmax);
+          gstep -= unsigned(sizeof(T));
           return v;
         };
         T gq[kAhead];
@@ -384,27 +406,24 @@ __global__ __launch_bounds__((64 * bwd_waves<T, D>())) void spd_pdist_bwd_kernel
         for (int ib = i0; ib < i1; ib += kAhead) {
 #pragma unroll
          for (int u = 0; u < kAhead; ++u) {
-          // (a slice with a number of rows that is not a multiple of kAhead runs its last unrolled slots on a masked
-          // row: an early exit here would make the number of outstanding requests path-dependent and the compiler
-          // falls back to vmcnt(0))
-          const int i = min(ib + u, i1 - 1);
-          const bool row_live = ib + u < i1;
-          if (__builtin_expect((share - rem) + int64_t(ib + u - i0) * NW >= next_mark, 0)) {   // wave-uniform
-            ++phase;
-            if (phase == 1) { __builtin_amdgcn_s_setprio(2); next_mark = (share * 7) / 10; }
-            else if (phase == 2) { __builtin_amdgcn_s_setprio(1); next_mark = (share * 9) / 10; }
-            else { __builtin_amdgcn_s_setprio(0); next_mark = INT64_MAX; }
-          }
+          // (a slice with an odd number of rows runs its last unrolled slot on a masked row: an early exit here would
+          // make the number of outstanding requests path-dependent and the compiler falls back to vmcnt(0))
+          const int irow = ib + u;
+          const int ieff = irow < i1 ? irow : INT32_MAX;   // scalar
+          const T (&lcur)[2 * NP] = lrow[u];
+          rowp += 2 * NP;                                   // the row after the slice is inside the table (i1 <= n - 1)
+#pragma unroll
+          for (int k = 0; k < 2 * NP; ++k) lrow[u ^ 1][k] = rowp[k];
           T li[NP], lc[NP];
 #pragma unroll
-          for (int k = 0; k < NP; ++k) { li[k] = li_next[k]; lc[k] = lc_next[k]; }
-          const int inext = min(i + 1, i1 - 1);
-#pragma unroll
-          for (int k = 0; k < NP; ++k) {
-            li_next[k] = nodeL[size_t(inext) * NP + k];
-            lc_next[k] = nodeC[size_t(inext) * NP + k];
+          for (int k = 0; k < NP; ++k) { li[k] = lcur[k]; lc[k] = lcur[NP + k]; }
+          if (__builtin_expect(--rows_left == 0, 0)) {   // wave-uniform
+            ++phase;
+            if (phase == 1) { __builtin_amdgcn_s_setprio(2); rows_left = (wave_rows * 3) / 10 + 1; }
+            else if (phase == 2) { __builtin_amdgcn_s_setprio(1); rows_left = wave_rows / 5 + 1; }
+            else { __builtin_amdgcn_s_setprio(0); rows_left = INT32_MAX; }
           }
-          const bool valid = jin && j > i && row_live;
+          const bool valid = jv > ieff;
           T gs = valid ? gq[u] : T(0);  // upstream gradient (or target) of this row
           gq[u] = request();
           T m[NP];
@@ -467,11 +486,12 @@ __global__ __launch_bounds__((64 * bwd_waves<T, D>())) void spd_pdist_bwd_kernel
               asm volatile("" : "+v"(accJ[rr][c]));
             }
           // row side: transposing reduction — every lane ends up with the wavefront total of ONE entry of M
-          const T tot = wave_reduce_transposed<NP, T>(m, lane);
-          if (red_writer) redM[wave][ib + u - i0][red_slot] = tot;
+          *red_ptr = wave_reduce_transposed<NP, T>(m, lane);
+          red_ptr += red_step;
          }
         }
         // row side: each wavefront owns the rows of its slice
+        red_ptr -= red_step * ((i1 - i0 + kAhead - 1) / kAhead * kAhead);
         __builtin_amdgcn_wave_barrier();
         for (int t = lane; t < tw * NP; t += 64) {
           const int k = t / tw, il = t - k * tw;
@@ -885,7 +905,7 @@ template <typename T, int D>
 int spd_pdist_prepare(const T* x, int64_t n, Ws<T>& ws, int flags, hipStream_t st) {
   if (!(flags & MM_WS_PREPARED)) {
     spd_prep_kernel<T, D><<<dim3((n + 127) / 128), dim3(128), 0, st>>>(x, int(n), ws.nodeL, ws.nodeX, ws.nodeC,
-                                                                       ws.accM, ws.accS, ws.loss, ws.bad, ws.nodeLd);
+                                                                       ws.accM, ws.accS, ws.loss, ws.bad, ws.nodeLd, ws.nodeLC);
     MM_CHECK_LAUNCH();
   }
   return MM_OK;
@@ -930,11 +950,11 @@ int spd_pdist_fwd_t(const T* x, int64_t n, int64_t rb, int64_t re, int squared, 
 // One launch of (at most) the resident capacity; fewer workgroups when the row range is small (>= 8 rows of a column
 // block per workgroup, two per wavefront).
 constexpr int kBwdTI = 16;   // rows per wavefront and chunk
-template <typename T, int D, int LOSS = MM_LOSS_NONE>
-int spd_pdist_bwd_launch(Ws<T>& ws, const T* g, int64_t n, int64_t rb, int64_t re, int squared, double wmin, double wmax,
-                         hipStream_t st, LossArgs<T> la = LossArgs<T>{nullptr, T(1), T(0), 0, nullptr}) {
+template <typename T, int D, int LOSS, bool SQ>
+int spd_pdist_bwd_launch_sq(Ws<T>& ws, const T* g, int64_t n, int64_t rb, int64_t re, double wmin, double wmax,
+                            hipStream_t st, LossArgs<T> la) {
   constexpr int kThreads = 64 * bwd_waves<T, D>();
-  auto kernel = spd_pdist_bwd_kernel<T, D, kBwdTI, LOSS>;
+  auto kernel = spd_pdist_bwd_kernel<T, D, kBwdTI, LOSS, SQ>;
   const int64_t units = ColWalk(int(n), int(rb), int(re)).total();
   if (units <= 0) return MM_OK;
   int64_t grid = resident_workgroups(kernel, kThreads);
@@ -947,11 +967,17 @@ int spd_pdist_bwd_launch(Ws<T>& ws, const T* g, int64_t n, int64_t rb, int64_t r
 #endif
   {
     ProfScope prof(PROF_SPD_BWD, st);
-    kernel<<<g3, dim3(kThreads), 0, st>>>(ws.nodeL, ws.nodeC, ws.nodeC, g, int(n), int(rb), int(re), squared,
-                                                            T(wmin), T(wmax), ws.accM, ws.accS, la);
+    kernel<<<g3, dim3(kThreads), 0, st>>>(ws.nodeLC, ws.nodeC, g, int(n), int(rb), int(re), T(wmin), T(wmax), ws.accM, ws.accS, la);
   }
   MM_CHECK_LAUNCH();
   return MM_OK;
+}
+template <typename T, int D, int LOSS = MM_LOSS_NONE>
+int spd_pdist_bwd_launch(Ws<T>& ws, const T* g, int64_t n, int64_t rb, int64_t re, int squared, double wmin, double wmax,
+                         hipStream_t st, LossArgs<T> la = LossArgs<T>{nullptr, T(1), T(0), 0, nullptr}) {
+  if constexpr (LOSS != MM_LOSS_NONE) return spd_pdist_bwd_launch_sq<T, D, LOSS, true>(ws, g, n, rb, re, wmin, wmax, st, la);
+  else return squared ? spd_pdist_bwd_launch_sq<T, D, LOSS, true>(ws, g, n, rb, re, wmin, wmax, st, la)
+                      : spd_pdist_bwd_launch_sq<T, D, LOSS, false>(ws, g, n, rb, re, wmin, wmax, st, la);
 }
 
 // loss + gradients in one pass over the pairs (no pair vector of distances is ever written)

@@ -39,6 +39,7 @@ __host__ __device__ inline int64_t pair_off(int64_t n, int64_t row) { return row
 //   accS   T[D*D][n]  column-side accumulators  sum_i L_i^-T M_ij L_i^T
 //   loss   T[2][256]  fused-loss partial sums (loss, d loss / d softplus(scale)), spread over 256 slots
 //   nodeLd T[n]       log det X_i = 2 sum log diag L_i (Stein divergence, spd_stein.hip)
+//   nodeLC T[n][2NP]  {L_i^-1, L_i} interleaved: the backward's row operand, ONE scalar pointer and two scalar loads per row
 // The gradient w.r.t. the column point is L_i^-T [M A^-1] L_i^-1 with A^-1 = L_i^T X_j^-1 L_i, i.e.
 // (L_i^-T M L_i^T) X_j^-1: the factor X_j^-1 is common to the whole column, so only M is formed per
 // pair and X_j^-1 is applied once per point in finalize.
@@ -54,10 +55,11 @@ template <typename T> struct Ws {
   T* accS;
   T* loss;
   T* nodeLd;  // log det X_i (Stein divergence)
+  T* nodeLC;  // {L_i^-1, L_i} per node (backward row operand)
   static size_t bad_bytes(int64_t n) { return (size_t(n) * sizeof(int) + 63) / 64 * 64; }
   static size_t bytes(int64_t n, int d) {
     const int np = d * (d + 1) / 2;
-    return 64 + bad_bytes(n) + sizeof(T) * (size_t(n) * (4 * np + d * d + 1) + 2 * kLossSlots);
+    return 64 + bad_bytes(n) + sizeof(T) * (size_t(n) * (6 * np + d * d + 1) + 2 * kLossSlots);
   }
   Ws(void* base, int64_t n, int d) {
     const int np = d * (d + 1) / 2;
@@ -71,6 +73,7 @@ template <typename T> struct Ws {
     accS = accM + n * np;
     loss = accS + n * d * d;
     nodeLd = loss + 2 * kLossSlots;
+    nodeLC = nodeLd + n;
   }
 };
 

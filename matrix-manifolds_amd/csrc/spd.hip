@@ -280,6 +280,22 @@ __device__ unsigned long long g_bwd_stamps[4 * 16384];
 // Backward: a launch of (at most) as many workgroups as the device holds at once; workgroup w walks its share of the
 // balanced column walk (spd_ws.hpp, ColWalk): down one 64-column block, chunk after chunk of up to NW x TI rows (each
 // wavefront a contiguous slice of the chunk's rows, its lanes the block's 64 columns), then on to the next block.
+// Compile-time loop: f(integral_constant<int, 0>) ... f(integral_constant<int, N - 1>).  The per-column loops of the
+// backward are written with it and NOT as `#pragma unroll` loops: a loop is unrolled late, after inlining, and until then
+// the per-column arrays are indexed by a variable — they are not split into registers early, and the kernels came out
+// with up to twice the vector registers (fp32 SPD(3): 152 instead of 87 for one column).
+template <int N, typename F> __device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (N > 0) {
+    static_for<N - 1>(f);
+    f(std::integral_constant<int, N - 1>{});
+  }
+}
+
+// Columns per lane of the backward: two for fp32 SPD(2), SPD(3) — the second pair of a row shares the row operand's
+// scalar loads, the loop's scalar bookkeeping and the row-side reduction (one reduction of M_a + M_b), which is a fifth of the
+// instructions of a one-column row; wider matrices and fp64 do not have the registers for it.
+template <typename T, int D> constexpr int bwd_cols() { return (sizeof(T) == 4 && D <= 3) ? 2 : 1; }
+
 template <typename T, int D, int TI, int LOSS, bool SQ>
 __global__ __launch_bounds__((64 * bwd_waves<T, D>())) void spd_pdist_bwd_kernel(const T* __restrict__ nodeLC /* {L_i^-1, L_i} */,
                                                                const T* __restrict__ nodeY /* chol(X_j) */,
@@ -289,34 +305,27 @@ __global__ __launch_bounds__((64 * bwd_waves<T, D>())) void spd_pdist_bwd_kernel
                                                                LossArgs<T> la) {
   constexpr int NP = Packed<D>::NP;
   constexpr int NW = bwd_waves<T, D>();
+  constexpr int NC = bwd_cols<T, D>();   // lane l owns the columns jbase + 64 q + l, q < NC
   // LOSS != 0: `g` holds the TARGET (graph) squared distances; the upstream gradient of each pair is
   // derived in registers from the loss, and the loss / scale-gradient sums leave through la.slots.
   constexpr int squared = SQ ? 1 : 0;   // (a template parameter: as a run-time flag it cost two vector instructions per row)
   T sp = T(1), loss_acc = T(0), ds_acc = T(0);
   loss_resolve<T, LOSS>(la);
   if constexpr (LOSS != MM_LOSS_NONE) sp = softplus_of(la.scale_raw);
-  // The wavefronts of a workgroup share the 64 columns: their column-side partial sums are combined through LDS
+  // The wavefronts of a workgroup share the columns: their column-side partial sums are combined through LDS
   // and leave with ONE set of atomics per column block (float atomics are a per-CU serial resource, ~50 ns per
   // wave instruction).
   static_assert(TI % 2 == 0, "the row loop is unrolled twice");
   __shared__ T redM[NW][TI][NP];
-  __shared__ T colS[NW][D * D][64];
+  __shared__ T colS[NW][NC][D * D][64];
 #ifdef MM_BWD_STAMP
   const unsigned long long stamp0 = __builtin_amdgcn_s_memrealtime();
   const unsigned long long stampc0 = __builtin_amdgcn_s_memtime();
 #endif
-  const ColWalk walk(n, row_begin, row_end);
+  const ColWalk walk(n, row_begin, row_end, 64 * NC);
   const int64_t total = walk.total();
   int64_t pos = ColWalk::share_begin(total, blockIdx.x, gridDim.x);
   int rem = int(ColWalk::share_begin(total, int64_t(blockIdx.x) + 1, gridDim.x) - pos);  // block-uniform (a share is < 2^31 rows)
-#ifdef MM_BWD_TILEMODE   // experiment: one tile of MM_BWD_TILEMODE rows per workgroup, handed out by the dispatcher (grid = blocks x column blocks)
-  {
-    const int cbt = blockIdx.y, r0 = row_begin + int(blockIdx.x) * MM_BWD_TILEMODE;
-    if (cbt < walk.c0 || r0 >= walk.hi(cbt)) return;
-    pos = walk.prefix(cbt) + (r0 - row_begin);
-    rem = min(MM_BWD_TILEMODE, walk.hi(cbt) - r0);
-  }
-#endif
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform -> row operands stay scalar loads
   bool red_writer;
@@ -340,69 +349,76 @@ __global__ __launch_bounds__((64 * bwd_waves<T, D>())) void spd_pdist_bwd_kernel
   __shared__ T redJunk[NW][64];
   T* red_ptr = red_writer ? &redM[wave][0][red_slot] : &redJunk[wave][lane];
   const int red_step = red_writer ? NP : 0;
-  const int jv_none = INT32_MIN;
 
   while (rem > 0) {   // one pass per column block of this workgroup's share
-    const int jbase = cb * 64;
-    const int j = jbase + lane;
-    const bool jin = j < n;
-    const int jv = jin ? j : jv_none;          // j for the validity test (never above a row for lanes beyond n)
-    const unsigned joff = unsigned(min(j, n - 1)) * unsigned(sizeof(T));
-    T xj[NP], accJ[D][D];
+    const int jbase = cb * (64 * NC);
+    int jv[NC];          // column for the validity test (never above a row for lanes beyond n)
+    unsigned joff[NC];   // byte offset of min(column, n - 1) in a row of the pair vector
+    T xj[NC][NP], accJ[NC][D][D];
+    static_for<NC>([&](auto qc) {
+      constexpr int q = decltype(qc)::value;
+      const int j = jbase + 64 * q + lane;
+      const bool jin = j < n;
+      jv[q] = jin ? j : INT32_MIN;
+      joff[q] = unsigned(min(j, n - 1)) * unsigned(sizeof(T));
 #pragma unroll
-    for (int k = 0; k < NP; ++k) xj[k] = T(0);
+      for (int k = 0; k < NP; ++k) xj[q][k] = T(0);
 #pragma unroll
-    for (int rr = 0; rr < D; ++rr)
+      for (int k = 0; k < D; ++k) xj[q][pidx(k, k)] = T(1);
+      if (jin) {
 #pragma unroll
-      for (int c = 0; c < D; ++c) accJ[rr][c] = T(0);
+        for (int k = 0; k < NP; ++k) xj[q][k] = nodeY[size_t(j) * NP + k];
+      }
 #pragma unroll
-    for (int k = 0; k < D; ++k) xj[pidx(k, k)] = T(1);
-    if (jin) {
+      for (int rr = 0; rr < D; ++rr)
 #pragma unroll
-      for (int k = 0; k < NP; ++k) xj[k] = nodeY[size_t(j) * NP + k];
-    }
+        for (int c = 0; c < D; ++c) accJ[q][rr][c] = T(0);
+    });
     const int hi = walk.hi(cb);
     while (rem > 0 && r < hi) {   // chunks of up to NW x TI rows of this block
       const int chunk = min(min(hi - r, NW * TI), rem);
       const int tw = (chunk + NW - 1) / NW;
       const int i0 = r + wave * tw, i1 = min(i0 + tw, r + chunk);
       if (i0 < i1) {
-        // EVERY instruction of a wavefront — scalar ones included — takes an issue slot of its SIMD (measured: these
-        // kernels run at 2.0 cycles per instruction of any kind), so the row loop is written for the smallest TOTAL:
+        // EVERY instruction of a wavefront — scalar ones included — takes an issue slot of its SIMD (these kernels run
+        // at 2.0 - 2.4 cycles per instruction of any kind), so the row loop is written for the smallest TOTAL:
         // * row operands {L_i^-1, L_i}: one interleaved table, one running scalar pointer, two scalar loads per row
         //   into one of two register sets that alternate with the unrolled slots (no copies);
-        // * the pair vector: element (row, j) lives at pair_off(n, row) - base + (j - row - 1); the row part is a
-        //   running scalar pointer (the next row starts n - row - 2 elements further), the lane part a 32-bit byte
-        //   offset clamped into the row (one vector instruction), i.e. `global_load_dword v, v_off, s[ptr]`.  Lanes at or
-        //   below the diagonal and beyond n read the row's first / last element instead — requests are unconditional:
-        //   a predicated one is an exec-masked branch behind which the compiler waits for vmcnt(0) — and their value
-        //   is masked at use.  Requests run kAhead rows ahead into registers that rotate by RENAMING (the loop is
-        //   unrolled kAhead times): rotating with moves would wait for the NEWEST request at every row.
+        // * the pair vector: element (row, j) lives at pair_off(n, row) - base + (j - row - 1).  Requests are
+        //   `global_load_dword v, v_off, s[ptr]`: a slice base (64-bit, once per slice) plus a 32-bit running row offset
+        //   that stops at the slice's last row (requests past it — the unrolled loop issues kAhead - 1 of them — read
+        //   that row again: rows beyond the launch's range may lie outside the caller's buffer), and a lane offset that
+        //   is FIXED for the slice, clamp(j, i0 + 1, n - 1) elements: for a later row of the slice a lane at or below
+        //   the diagonal then reads an element of an earlier row, still inside the buffer, and its value is masked at
+        //   use.  Requests are unconditional (a predicated one is an exec-masked branch behind which the compiler waits
+        //   for vmcnt(0)) and run kAhead rows ahead into registers that rotate by RENAMING (the loop is unrolled kAhead
+        //   times): rotating with moves would wait for the NEWEST request at every row.
         constexpr int kAhead = 2;
         const T* rowp = nodeLC + size_t(i0) * (2 * NP);
         T lrow[2][2 * NP];
 #pragma unroll
         for (int k = 0; k < 2 * NP; ++k) lrow[0][k] = rowp[k];
-        // Row pointer of the pair vector: slice base (64-bit, once per slice) + a 32-bit running offset that stops at
-        // the slice's last row (requests past it — the unrolled loop issues kAhead - 1 of them — read that row again:
-        // rows beyond the launch's range may lie outside the caller's buffer).  The lane offset is fixed for the whole
-        // slice: clamp(j, i0 + 1, n - 1) elements — for a later row of the slice a lane at or below the diagonal then
-        // reads an element of an earlier row, still inside the buffer (its value is masked anyway).
         const int glast = min(i1, walk.re) - 1;
         const int64_t gk = glast - i0;
         const unsigned gmax = unsigned((gk * (n - 2) - (int64_t(i0) * gk + gk * (gk - 1) / 2)) * int64_t(sizeof(T)));
         const char* gslice = reinterpret_cast<const char*>(g + (pair_off(n, i0) - base - i0 - 1));
         unsigned goff = 0, gstep = unsigned(n - i0 - 2) * unsigned(sizeof(T));   // bytes from the current row to the next
-        const unsigned jslice = max(joff, unsigned(i0 + 1) * unsigned(sizeof(T)));
-        auto request = [&]() -> T {
-          const T v = *reinterpret_cast<const T*>(gslice + goff + jslice);
+        unsigned jslice[NC];
+        static_for<NC>([&](auto qc) {
+          constexpr int q = decltype(qc)::value;
+          jslice[q] = max(joff[q], unsigned(i0 + 1) * unsigned(sizeof(T)));
+        });
+        T gq[kAhead][NC];
+        auto request = [&](T (&dst)[NC]) __attribute__((always_inline)) {
+          static_for<NC>([&](auto qc) {
+            constexpr int q = decltype(qc)::value;
+            dst[q] = *reinterpret_cast<const T*>(gslice + goff + jslice[q]);
+          });
           goff = min(goff + gstep, gmax);
           gstep -= unsigned(sizeof(T));
-          return v;
         };
-        T gq[kAhead];
 #pragma unroll
-        for (int u = 0; u < kAhead; ++u) gq[u] = request();
+        for (int u = 0; u < kAhead; ++u) request(gq[u]);
         for (int ib = i0; ib < i1; ib += kAhead) {
 #pragma unroll
          for (int u = 0; u < kAhead; ++u) {
@@ -423,70 +439,96 @@ __global__ __launch_bounds__((64 * bwd_waves<T, D>())) void spd_pdist_bwd_kernel
             else if (phase == 2) { __builtin_amdgcn_s_setprio(1); rows_left = wave_rows / 5 + 1; }
             else { __builtin_amdgcn_s_setprio(0); rows_left = INT32_MAX; }
           }
-          const bool valid = jv > ieff;
-          T gs = valid ? gq[u] : T(0);  // upstream gradient (or target) of this row
-          gq[u] = request();
-          T m[NP];
-          bool series = false;
-          auto jacobi_path = [&]() {
+          bool valid[NC];
+          T gs[NC], m[NC][NP];
+          static_for<NC>([&](auto qc) {
+            constexpr int q = decltype(qc)::value;
+            valid[q] = jv[q] > ieff;
+            gs[q] = valid[q] ? gq[u][q] : T(0);  // upstream gradient (or target) of this row
+          });
+          request(gq[u]);
+          // the upstream gradient is known before log(A) unless it depends on the distance (fused loss, d instead of d^2)
+          constexpr bool g_first = LOSS == MM_LOSS_NONE && SQ;
+          auto jacobi_path = [&](auto qc) __attribute__((always_inline)) {
+            constexpr int q = decltype(qc)::value;
             T w[D], lw[D], v[D][D];
-            const T s = pair_core<T, D, true, true>(li, xj, wmin, wmax, w, lw, v);
-            gs = upstream_of<T, LOSS>(gs, s, valid, squared, wmin, sp, la, loss_acc, ds_acc);
+            const T s = pair_core<T, D, true, true>(li, xj[q], wmin, wmax, w, lw, v);
+            gs[q] = upstream_of<T, LOSS>(gs[q], s, valid[q], squared, wmin, sp, la, loss_acc, ds_acc);
             T cm[D];
 #pragma unroll
-            for (int k = 0; k < D; ++k) cm[k] = (gs + gs) * lw[k];
-            vdvt<T, D>(v, cm, m);
+            for (int k = 0; k < D; ++k) cm[k] = (gs[q] + gs[q]) * lw[k];
+            vdvt<T, D>(v, cm, m[q]);
+          };
+          auto finish = [&](auto qc, const T (&m0)[NP], bool scaled) __attribute__((always_inline)) {
+            constexpr int q = decltype(qc)::value;
+            if (scaled) {
+#pragma unroll
+              for (int k = 0; k < NP; ++k) m[q][k] = m0[k];
+              return;
+            }
+            T s = T(0);
+            if (LOSS != MM_LOSS_NONE || !SQ) s = frob2<T, D>(m0);
+            gs[q] = upstream_of<T, LOSS>(gs[q], s, valid[q], squared, wmin, sp, la, loss_acc, ds_acc);
+            const T g2 = gs[q] + gs[q];
+#pragma unroll
+            for (int k = 0; k < NP; ++k) m[q][k] = g2 * m0[k];
           };
           if constexpr (D == 3 || D == 4) {
             // Eigen-free paths, chosen per wavefront: close pairs (||A - I||_F <= 0.3, fp32) take the
             // Cayley-Hamilton series of log(I + E); anything with tr(Z^2) <= 0.36 (eigenvalue ratios up
             // to ~16: every pair of an embedding with O(1) distances) the Cayley-transform logarithm.
             // What is left (very wide spectra, NaN, non-PD) goes to the Jacobi path.
-            // Written as an if / else-if / else chain with complete arms so that the likely arm is the
-            // fall-through (a taken branch per pair costs ~4 % of this kernel).
-            T a[NP], m0[NP];
-            congr_chol<T, D>(li, xj, a);
-            // the upstream gradient is known before log(A) unless it depends on the distance (fused loss, d instead of d^2)
-            const bool g_first = LOSS == MM_LOSS_NONE && squared;
-            auto finish = [&](bool scaled) {
-              if (scaled) {
-#pragma unroll
-                for (int k = 0; k < NP; ++k) m[k] = m0[k];
-                return;
+            T a[NC][NP];
+            bool far = false;   // some pair of this row is outside the close-pair gate
+            static_for<NC>([&](auto qc) {
+              constexpr int q = decltype(qc)::value;
+              congr_chol<T, D>(li, xj[q], a[q]);
+              if constexpr (std::is_same<T, float>::value) far = far || !(close_gate<D>(a[q]) <= 0.09f);
+              else far = true;
+            });
+            if (__builtin_expect(!__any(far), 1)) {
+              if constexpr (std::is_same<T, float>::value) {
+                static_for<NC>([&](auto qc) {
+                  constexpr int q = decltype(qc)::value;
+                  T m0[NP];
+                  log_close<D>(a[q], m0, g_first ? gs[q] + gs[q] : 1.f);
+                  finish(qc, m0, g_first);
+                });
               }
-              T s = T(0);
-              if (LOSS != MM_LOSS_NONE || __builtin_expect(!squared, 0)) s = frob2<T, D>(m0);
-              gs = upstream_of<T, LOSS>(gs, s, valid, squared, wmin, sp, la, loss_acc, ds_acc);
-              const T g2 = gs + gs;
-#pragma unroll
-              for (int k = 0; k < NP; ++k) m[k] = g2 * m0[k];
-            };
-            bool close = false;
-            if constexpr (std::is_same<T, float>::value) close = !__any(!(close_gate<D>(a) <= 0.09f));
-            if (__builtin_expect(close, 1)) {
-              if constexpr (std::is_same<T, float>::value) log_close<D>(a, m0, g_first ? gs + gs : 1.f);
-              finish(g_first);
             } else {
-              const T gate = log_cayley<T, D>(a, m0);
-              if (__builtin_expect(!__any(!(gate <= T(kCayleyGate))), 1)) finish(false); else jacobi_path();
+              static_for<NC>([&](auto qc) {
+                constexpr int q = decltype(qc)::value;
+                T m0[NP];
+                const T gate = log_cayley<T, D>(a[q], m0);
+                if (__builtin_expect(!__any(!(gate <= T(kCayleyGate))), 1)) finish(qc, m0, false); else jacobi_path(qc);
+              });
             }
-            series = true;
+          } else {
+            static_for<NC>([&](auto qc) { jacobi_path(qc); });
           }
-          if (!series) jacobi_path();
-          T cj[D][D];
-          lt_m_lt<T, D>(li, lc, m, cj);
+          static_for<NC>([&](auto qc) {
+            constexpr int q = decltype(qc)::value;
+            T cj[D][D];
+            lt_m_lt<T, D>(li, lc, m[q], cj);
 #pragma unroll
-          for (int rr = 0; rr < D; ++rr)
+            for (int rr = 0; rr < D; ++rr)
 #pragma unroll
-            for (int c = 0; c < D; ++c) {
-              accJ[rr][c] += cj[rr][c];
-              // pinned here: the column side must have consumed M before the reduction below, whose first levels
-              // (v_permlane*_swap) overwrite their operands — otherwise the compiler sinks the congruence behind the
-              // reduction and pays a register copy per entry of M to keep them alive
-              asm volatile("" : "+v"(accJ[rr][c]));
-            }
-          // row side: transposing reduction — every lane ends up with the wavefront total of ONE entry of M
-          *red_ptr = wave_reduce_transposed<NP, T>(m, lane);
+              for (int c = 0; c < D; ++c) {
+                accJ[q][rr][c] += cj[rr][c];
+                // pinned here: the column side must have consumed M before the reduction below, whose first levels
+                // (v_permlane*_swap) overwrite their operands — otherwise the compiler sinks the congruence behind the
+                // reduction and pays a register copy per entry of M to keep them alive
+                asm volatile("" : "+v"(accJ[q][rr][c]));
+              }
+          });
+          // row side: ONE transposing reduction of the lane's NC matrices added up — every lane ends up with the
+          // wavefront total of one entry of M
+          static_for<NC - 1>([&](auto qc) {
+            constexpr int q = decltype(qc)::value + 1;
+#pragma unroll
+            for (int k = 0; k < NP; ++k) m[0][k] += m[q][k];
+          });
+          *red_ptr = wave_reduce_transposed<NP, T>(m[0], lane);
           red_ptr += red_step;
          }
         }
@@ -503,18 +545,21 @@ __global__ __launch_bounds__((64 * bwd_waves<T, D>())) void spd_pdist_bwd_kernel
       rem -= chunk;
     }
     // column side of this block: combine the wavefronts, then 256-B contiguous atomics per entry
+    static_for<NC>([&](auto qc) {
+      constexpr int q = decltype(qc)::value;
 #pragma unroll
-    for (int rr = 0; rr < D; ++rr)
+      for (int rr = 0; rr < D; ++rr)
 #pragma unroll
-      for (int c = 0; c < D; ++c) colS[wave][rr * D + c][lane] = accJ[rr][c];
+        for (int c = 0; c < D; ++c) colS[wave][q][rr * D + c][lane] = accJ[q][rr][c];
+    });
     __syncthreads();
-    if (jin) {
-      for (int k = wave; k < D * D; k += NW) {
-        T sum = colS[0][k][lane];
+    for (int t = wave; t < NC * D * D; t += NW) {
+      const int q = t / (D * D), k = t - q * (D * D);
+      const int j = jbase + 64 * q + lane;
+      T sum = colS[0][q][k][lane];
 #pragma unroll
-        for (int wv = 1; wv < NW; ++wv) sum += colS[wv][k][lane];
-        atomic_add(&accS[size_t(k) * n + j], sum);
-      }
+      for (int wv = 1; wv < NW; ++wv) sum += colS[wv][q][k][lane];
+      if (j < n) atomic_add(&accS[size_t(k) * n + j], sum);
     }
     ++cb;
     r = row_begin;
@@ -529,14 +574,14 @@ __global__ __launch_bounds__((64 * bwd_waves<T, D>())) void spd_pdist_bwd_kernel
       T ls = lossW[0][0], dd = lossW[0][1];
 #pragma unroll
       for (int wv = 1; wv < NW; ++wv) { ls += lossW[wv][0]; dd += lossW[wv][1]; }
-      const int slot = (blockIdx.x + blockIdx.y * gridDim.x) & (kLossSlots - 1);
+      const int slot = blockIdx.x & (kLossSlots - 1);
       atomic_add(&la.slots[slot], ls);
       atomic_add(&la.slots[kLossSlots + slot], dd);
     }
   }
 #ifdef MM_BWD_STAMP
   if (threadIdx.x == 0) {
-    const unsigned wg = blockIdx.x + blockIdx.y * gridDim.x;
+    const unsigned wg = blockIdx.x;
     if (wg < 16384) {
       g_bwd_stamps[4 * wg + 0] = stamp0;
       g_bwd_stamps[4 * wg + 1] = __builtin_amdgcn_s_memrealtime();
@@ -955,16 +1000,13 @@ int spd_pdist_bwd_launch_sq(Ws<T>& ws, const T* g, int64_t n, int64_t rb, int64_
                             hipStream_t st, LossArgs<T> la) {
   constexpr int kThreads = 64 * bwd_waves<T, D>();
   auto kernel = spd_pdist_bwd_kernel<T, D, kBwdTI, LOSS, SQ>;
-  const int64_t units = ColWalk(int(n), int(rb), int(re)).total();
+  const int64_t units = ColWalk(int(n), int(rb), int(re), 64 * bwd_cols<T, D>()).total();
   if (units <= 0) return MM_OK;
   int64_t grid = resident_workgroups(kernel, kThreads);
   static const int64_t env_grid = std::getenv("MM_SPD_BWD_GRID") ? std::atoll(std::getenv("MM_SPD_BWD_GRID")) : 0;
   if (env_grid > 0) grid = env_grid;   // (experiments: over- / under-subscription of the device)
   grid = std::max<int64_t>(1, std::min<int64_t>(grid, (units + 7) / 8));
   dim3 g3{unsigned(grid), 1, 1};
-#ifdef MM_BWD_TILEMODE
-  g3 = dim3(unsigned((re - rb + MM_BWD_TILEMODE - 1) / MM_BWD_TILEMODE), unsigned((n + 63) / 64));
-#endif
   {
     ProfScope prof(PROF_SPD_BWD, st);
     kernel<<<g3, dim3(kThreads), 0, st>>>(ws.nodeLC, ws.nodeC, g, int(n), int(rb), int(re), T(wmin), T(wmax), ws.accM, ws.accS, la);

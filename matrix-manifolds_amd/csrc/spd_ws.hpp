@@ -113,31 +113,32 @@ template <int TI, int BW = kBlock> inline dim3 fold_grid(int64_t n, int64_t rb, 
 
 
 // ---- balanced walk of the upper triangle (backward kernels) ---------------------------------------------------------
-// Work is measured in ROWS OF 64-COLUMN BLOCKS: column block c (columns 64c .. 64c+63) owns the rows [rb, hi(c)),
-// hi(c) = min(re, 64c + 63) (row i has a pair in the block iff i < 64c + 63; re = min(row_end, n-1)).  The blocks' row
+// Work is measured in ROWS OF COLUMN BLOCKS of bw = 64 or 128 columns: block c (columns bw c .. bw c + bw - 1) owns the
+// rows [rb, hi(c)), hi(c) = min(re, bw c + bw - 1) (row i has a pair in the block iff i < bw c + bw - 1; re = min(row_end, n-1)).  The blocks' row
 // ranges, concatenated block after block, form a line of W units, and workgroup w of G takes the units
 // [start(w), start(w+1)), start(w) = floor(W/G) w + min(w, W mod G): every workgroup gets the same amount of arithmetic
 // to within one row, so a launch of exactly the resident capacity has no tail (with tiles handed out by the dispatcher
 // the last 40 % of the backward's duration ran at half occupancy — profiles/r02_timeline.txt), and a workgroup walks DOWN
 // a column block, so the column-side sums stay in registers until the block changes.
-// counts: 0 for c < c0 = (rb+1)/64; 64c + 63 - rb for c0 <= c < c1 = max(c0, re/64); R = re - rb from c1 on.
+// counts: 0 for c < c0 = (rb+1)/bw; bw c + bw - 1 - rb for c0 <= c < c1 = max(c0, re/bw); R = re - rb from c1 on.
 struct ColWalk {
-  int rb, re, ncb, c0, c1;
-  __host__ __device__ ColWalk(int n, int row_begin, int row_end) {
+  int rb, re, ncb, c0, c1, bw;   // bw = columns per block (64 per column a lane owns)
+  __host__ __device__ ColWalk(int n, int row_begin, int row_end, int block_width = 64) {
+    bw = block_width;
     rb = row_begin;
     re = row_end < n - 1 ? row_end : n - 1;
     if (re < rb) re = rb;
-    ncb = (n + 63) / 64;
-    c0 = (rb + 1) / 64;
-    c1 = re / 64 > c0 ? re / 64 : c0;
+    ncb = (n + bw - 1) / bw;
+    c0 = (rb + 1) / bw;
+    c1 = re / bw > c0 ? re / bw : c0;
     if (c1 > ncb) c1 = ncb;
     if (c0 > ncb) c0 = ncb;
   }
-  __host__ __device__ int hi(int c) const { const int d = 64 * c + 63; return d < re ? d : re; }
+  __host__ __device__ int hi(int c) const { const int d = bw * c + bw - 1; return d < re ? d : re; }
   __host__ __device__ int64_t prefix(int c) const {   // units before column block c
     if (c <= c0 || re == rb) return 0;
     const int64_t m = c < c1 ? c : c1;
-    int64_t s = 32 * (m * (m - 1) - int64_t(c0) * (c0 - 1)) + (m - c0) * int64_t(63 - rb);
+    int64_t s = (bw / 2) * (m * (m - 1) - int64_t(c0) * (c0 - 1)) + (m - c0) * int64_t(bw - 1 - rb);
     if (c > c1) s += int64_t(c - c1) * (re - rb);
     return s;
   }

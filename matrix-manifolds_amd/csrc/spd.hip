@@ -203,43 +203,86 @@ __device__ __forceinline__ T pair_value(const TL (&li)[Packed<D>::NP], const T (
 }
 
 // ------------------------------------------------------------------ forward
-template <typename T, int D, int TI>
+// Compile-time loop: f(integral_constant<int, 0>) ... f(integral_constant<int, N - 1>).  The per-column loops of the pair
+// kernels are written with it and NOT as `#pragma unroll` loops: a loop is unrolled late, after inlining, and until then
+// the per-column arrays are indexed by a variable — they are not split into registers early, and the kernels came out
+// with up to twice the vector registers (fp32 SPD(3) backward: 152 instead of 87 for one column).
+template <int N, typename F> __device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (N > 0) {
+    static_for<N - 1>(f);
+    f(std::integral_constant<int, N - 1>{});
+  }
+}
+
+// Columns per lane of the pair kernels: two for fp32 SPD(2), SPD(3) — the second pair of a row shares the row operand's
+// scalar loads and the loop's scalar bookkeeping (every instruction of a wavefront, scalar ones included, takes an issue
+// slot of its SIMD) and, in the backward, the row-side reduction (one reduction of M_a + M_b); wider matrices and fp64
+// do not have the registers for it.
+template <typename T, int D> constexpr int pair_cols() { return (sizeof(T) == 4 && D <= 3) ? 2 : 1; }
+
+// Tile: TI rows x (256 x NC) columns per workgroup; lane l of wavefront w owns the columns jbase + 64 (NC w + q) + l.
+// The row loop is unrolled twice with two alternating scalar register sets for the row operand L_i^-1 (no copies), the
+// output row is a running scalar pointer (row i + 1 starts n - i - 2 elements after row i) plus a fixed lane offset:
+// `global_store_dword v_off, v, s[ptr]`, lanes on consecutive j -> 256-B coalesced segments of the row-major pair vector.
+template <typename T, int D, int TI, bool SQ>
 __global__ __launch_bounds__(kBlock) void spd_pdist_fwd_kernel(const T* __restrict__ nodeL,
                                                                const T* __restrict__ nodeY /* column operand: chol(X_j) */, int n, int row_begin,
-                                                               int row_end, int squared, T wmin, T wmax,
-                                                               T* __restrict__ out) {
+                                                               int row_end, T wmin, T wmax, T* __restrict__ out) {
   constexpr int NP = Packed<D>::NP;
-  const TileId tile = fold_tile<TI>(n, row_begin, row_end);
+  constexpr int NC = pair_cols<T, D>();
+  static_assert(TI % 2 == 0, "the row loop is unrolled twice");
+  const TileId tile = fold_tile<TI, kBlock * NC>(n, row_begin, row_end);
   if (!tile.ok) return;
-  const int i0 = tile.i0, i1 = min(i0 + TI, row_end), jbase = tile.jbase;
-  const int wave_j0 = jbase + (threadIdx.x & ~63);
-  if (wave_j0 + 63 <= i0) return;  // whole wavefront below the diagonal
-  const int j = jbase + threadIdx.x;
-  const bool jin = j < n;
-
-  T xj[NP];
+  const int i0 = tile.i0, i1 = min(i0 + TI, row_end);
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wave_j0 = tile.jbase + wave * (64 * NC);
+  if (wave_j0 + 64 * NC - 1 <= i0) return;  // whole wavefront below the diagonal
+  int jv[NC];          // column for the validity test (never above a row for lanes beyond n)
+  unsigned joff[NC];   // byte offset of the column in a row of the pair vector
+  T xj[NC][NP];
+  static_for<NC>([&](auto qc) {
+    constexpr int q = decltype(qc)::value;
+    const int j = wave_j0 + 64 * q + lane;
+    const bool jin = j < n;
+    jv[q] = jin ? j : INT32_MIN;
+    joff[q] = unsigned(j) * unsigned(sizeof(T));
 #pragma unroll
-  for (int k = 0; k < NP; ++k) xj[k] = T(0);
+    for (int k = 0; k < NP; ++k) xj[q][k] = T(0);
 #pragma unroll
-  for (int k = 0; k < D; ++k) xj[pidx(k, k)] = T(1);
-  if (jin) {
+    for (int k = 0; k < D; ++k) xj[q][pidx(k, k)] = T(1);
+    if (jin) {
 #pragma unroll
-    for (int k = 0; k < NP; ++k) xj[k] = nodeY[size_t(j) * NP + k];
-  }
+      for (int k = 0; k < NP; ++k) xj[q][k] = nodeY[size_t(j) * NP + k];
+    }
+  });
   const int64_t base = pair_off(n, row_begin);
-  T li_next[NP];  // wave-uniform -> scalar loads, issued one row ahead
+  char* op = reinterpret_cast<char*>(out + (pair_off(n, i0) - base - i0 - 1));   // element (i0, j) lives at op + j sizeof(T)
+  unsigned ostep = unsigned(n - i0 - 2) * unsigned(sizeof(T));                    // bytes from row i to row i + 1
+  // row operand: wave-uniform -> scalar loads, issued one row ahead (the row after the tile's last is read too: inside the
+  // workspace — nodeL is followed by nodeX — and never used)
+  const T* rowp = nodeL + size_t(i0) * NP;
+  T lrow[2][NP];
 #pragma unroll
-  for (int k = 0; k < NP; ++k) li_next[k] = nodeL[size_t(i0) * NP + k];
-  for (int i = i0; i < i1; ++i) {
-    T li[NP];
+  for (int k = 0; k < NP; ++k) lrow[0][k] = rowp[k];
+  for (int ib = i0; ib < i1; ib += 2) {
 #pragma unroll
-    for (int k = 0; k < NP; ++k) li[k] = li_next[k];
-    const int inext = min(i + 1, i1 - 1);
+    for (int u = 0; u < 2; ++u) {
+      const int irow = ib + u;
+      const int ieff = irow < i1 ? irow : INT32_MAX;   // (the second slot of an odd last pair of rows stores nothing)
+      rowp += NP;
 #pragma unroll
-    for (int k = 0; k < NP; ++k) li_next[k] = nodeL[size_t(inext) * NP + k];
-    T s = Num<T>::max(pair_value<T, D, true>(li, xj, wmin, wmax), wmin);
-    if (!squared) s = Num<T>::sqrt(s);
-    if (jin && j > i) out[pair_off(n, i) - base + (j - i - 1)] = s;
+      for (int k = 0; k < NP; ++k) lrow[u ^ 1][k] = rowp[k];
+      const T (&li)[NP] = lrow[u];
+      static_for<NC>([&](auto qc) {
+        constexpr int q = decltype(qc)::value;
+        T s = Num<T>::max(pair_value<T, D, true>(li, xj[q], wmin, wmax), wmin);
+        if constexpr (!SQ) s = Num<T>::sqrt(s);
+        if (jv[q] > ieff) *reinterpret_cast<T*>(op + joff[q]) = s;
+      });
+      op += ostep;
+      ostep -= unsigned(sizeof(T));
+    }
   }
 }
 
@@ -280,22 +323,6 @@ __device__ unsigned long long g_bwd_stamps[4 * 16384];
 // Backward: a launch of (at most) as many workgroups as the device holds at once; workgroup w walks its share of the
 // balanced column walk (spd_ws.hpp, ColWalk): down one 64-column block, chunk after chunk of up to NW x TI rows (each
 // wavefront a contiguous slice of the chunk's rows, its lanes the block's 64 columns), then on to the next block.
-// Compile-time loop: f(integral_constant<int, 0>) ... f(integral_constant<int, N - 1>).  The per-column loops of the
-// backward are written with it and NOT as `#pragma unroll` loops: a loop is unrolled late, after inlining, and until then
-// the per-column arrays are indexed by a variable — they are not split into registers early, and the kernels came out
-// with up to twice the vector registers (fp32 SPD(3): 152 instead of 87 for one column).
-template <int N, typename F> __device__ __forceinline__ void static_for(F&& f) {
-  if constexpr (N > 0) {
-    static_for<N - 1>(f);
-    f(std::integral_constant<int, N - 1>{});
-  }
-}
-
-// Columns per lane of the backward: two for fp32 SPD(2), SPD(3) — the second pair of a row shares the row operand's
-// scalar loads, the loop's scalar bookkeeping and the row-side reduction (one reduction of M_a + M_b), which is a fifth of the
-// instructions of a one-column row; wider matrices and fp64 do not have the registers for it.
-template <typename T, int D> constexpr int bwd_cols() { return (sizeof(T) == 4 && D <= 3) ? 2 : 1; }
-
 template <typename T, int D, int TI, int LOSS, bool SQ>
 __global__ __launch_bounds__((64 * bwd_waves<T, D>())) void spd_pdist_bwd_kernel(const T* __restrict__ nodeLC /* {L_i^-1, L_i} */,
                                                                const T* __restrict__ nodeY /* chol(X_j) */,
@@ -305,7 +332,7 @@ __global__ __launch_bounds__((64 * bwd_waves<T, D>())) void spd_pdist_bwd_kernel
                                                                LossArgs<T> la) {
   constexpr int NP = Packed<D>::NP;
   constexpr int NW = bwd_waves<T, D>();
-  constexpr int NC = bwd_cols<T, D>();   // lane l owns the columns jbase + 64 q + l, q < NC
+  constexpr int NC = pair_cols<T, D>();   // lane l owns the columns jbase + 64 q + l, q < NC
   // LOSS != 0: `g` holds the TARGET (graph) squared distances; the upstream gradient of each pair is
   // derived in registers from the loss, and the loss / scale-gradient sums leave through la.slots.
   constexpr int squared = SQ ? 1 : 0;   // (a template parameter: as a run-time flag it cost two vector instructions per row)
@@ -956,28 +983,7 @@ int spd_pdist_prepare(const T* x, int64_t n, Ws<T>& ws, int flags, hipStream_t s
   return MM_OK;
 }
 
-// Rows per wavefront of a forward tile: 8 (MM_SPD_TI = 8 | 16 | 32 overrides).
-inline int env_tile_rows(const char* name) {
-  const char* e = std::getenv(name);
-  const int t = e ? std::atoi(e) : 0;
-  return (t == 8 || t == 16 || t == 32) ? t : 0;
-}
-inline int tile_rows() {
-  static const int v = env_tile_rows("MM_SPD_TI");
-  return v ? v : 8;
-}
-template <typename T, int D, int TI>
-int spd_pdist_fwd_ti(Ws<T>& ws, int64_t n, int64_t rb, int64_t re, int squared, double wmin, double wmax, T* out,
-                     hipStream_t st) {
-  {
-    ProfScope prof(PROF_SPD_FWD, st);
-    spd_pdist_fwd_kernel<T, D, TI><<<fold_grid<TI>(n, rb, re), dim3(kBlock), 0, st>>>(
-        ws.nodeL, ws.nodeC, int(n), int(rb), int(re), squared, T(wmin), T(wmax), out);
-  }
-  MM_CHECK_LAUNCH();
-  return MM_OK;
-}
-
+constexpr int kFwdTI = 8;   // rows of a forward tile (sweep on MI355X, SPD(3) fp32, n = 5000: 8 / 16 / 32 rows -> 28.8 / 30.1 / 33.0 us)
 template <typename T, int D>
 int spd_pdist_fwd_t(const T* x, int64_t n, int64_t rb, int64_t re, int squared, double wmin, double wmax, T* out,
                     void* wsp, int flags, hipStream_t st) {
@@ -985,11 +991,18 @@ int spd_pdist_fwd_t(const T* x, int64_t n, int64_t rb, int64_t re, int squared, 
   int rc = spd_pdist_prepare<T, D>(x, n, ws, flags, st);
   if (rc) return rc;
   if (re <= rb || pair_off(n, re) == pair_off(n, rb)) return MM_OK;
-  switch (tile_rows()) {
-    case 8: return spd_pdist_fwd_ti<T, D, 8>(ws, n, rb, re, squared, wmin, wmax, out, st);
-    case 32: return spd_pdist_fwd_ti<T, D, 32>(ws, n, rb, re, squared, wmin, wmax, out, st);
-    default: return spd_pdist_fwd_ti<T, D, 16>(ws, n, rb, re, squared, wmin, wmax, out, st);
+  const dim3 grid = fold_grid<kFwdTI, kBlock * pair_cols<T, D>()>(n, rb, re);
+  {
+    ProfScope prof(PROF_SPD_FWD, st);
+    if (squared)
+      spd_pdist_fwd_kernel<T, D, kFwdTI, true><<<grid, dim3(kBlock), 0, st>>>(ws.nodeL, ws.nodeC, int(n), int(rb), int(re), T(wmin),
+                                                                               T(wmax), out);
+    else
+      spd_pdist_fwd_kernel<T, D, kFwdTI, false><<<grid, dim3(kBlock), 0, st>>>(ws.nodeL, ws.nodeC, int(n), int(rb), int(re), T(wmin),
+                                                                                T(wmax), out);
   }
+  MM_CHECK_LAUNCH();
+  return MM_OK;
 }
 
 // One launch of (at most) the resident capacity; fewer workgroups when the row range is small (>= 8 rows of a column
@@ -1000,7 +1013,7 @@ int spd_pdist_bwd_launch_sq(Ws<T>& ws, const T* g, int64_t n, int64_t rb, int64_
                             hipStream_t st, LossArgs<T> la) {
   constexpr int kThreads = 64 * bwd_waves<T, D>();
   auto kernel = spd_pdist_bwd_kernel<T, D, kBwdTI, LOSS, SQ>;
-  const int64_t units = ColWalk(int(n), int(rb), int(re), 64 * bwd_cols<T, D>()).total();
+  const int64_t units = ColWalk(int(n), int(rb), int(re), 64 * pair_cols<T, D>()).total();
   if (units <= 0) return MM_OK;
   int64_t grid = resident_workgroups(kernel, kThreads);
   static const int64_t env_grid = std::getenv("MM_SPD_BWD_GRID") ? std::atoll(std::getenv("MM_SPD_BWD_GRID")) : 0;

@@ -411,42 +411,56 @@ __device__ __forceinline__ void eig3_trig(const float (&a)[6], float (&w)[3]) {
 // tools/design/series_fit.py): the close-pair gate bounds the spectral radius of E by 0.3.
 // `pre` multiplies the result (the caller's 2g when it is known before the series: three multiplications
 // on the coefficients instead of six on the matrix).
-#define MM_LOG_SERIES_COEFS                                                                              \
-  {9.999999337e-01f, -4.999999402e-01f, 3.333568549e-01f, -2.500212282e-01f, 1.987095623e-01f,           \
-   -1.655023071e-01f, 1.650813480e-01f, -1.450413880e-01f}
-constexpr int kLogSeriesTerms = 8;
+// fp32: p of degree 7 interpolated at Chebyshev nodes of |x| <= 0.3 (max error 9.1e-8 |x|, tools/design/series_fit.py);
+// fp64: degree 19 (7.7e-18 |x|, tools/design/series_fit64.py, extended-precision fit).
+template <typename T> struct LogSeries;
+template <> struct LogSeries<float> {
+  static constexpr int kTerms = 8;
+  static constexpr float kA[kTerms] = {9.999999337e-01f, -4.999999402e-01f, 3.333568549e-01f, -2.500212282e-01f,
+                                       1.987095623e-01f, -1.655023071e-01f, 1.650813480e-01f, -1.450413880e-01f};
+};
+template <> struct LogSeries<double> {
+  static constexpr int kTerms = 20;
+  static constexpr double kA[kTerms] = {
+    1.00000000000000000e+00, -4.99999999999999944e-01, 3.33333333333343085e-01, -2.50000000000014155e-01,
+    1.99999999996232608e-01, -1.66666666663750795e-01, 1.42857143404437337e-01, -1.25000000386766896e-01,
+    1.11111071374215928e-01, -9.99999703591583217e-02, 9.09107326619259803e-02, -8.33346464041358065e-02,
+    7.68821017515587124e-02, -7.13938378893102243e-02, 6.72936081364212679e-02, -6.30553787420979894e-02,
+    5.31216751520414421e-02, -5.03380364382464973e-02, 8.02156472153527783e-02, -7.58480457039158590e-02};
+};
 
-__device__ __forceinline__ float log_series3(const float (&a)[6], float (&m0)[6], float pre = 1.f) {
-  constexpr float kA[kLogSeriesTerms] = MM_LOG_SERIES_COEFS;
-  const float e00 = a[pidx(0, 0)] - 1.f, e11 = a[pidx(1, 1)] - 1.f, e22 = a[pidx(2, 2)] - 1.f;
-  const float e10 = a[pidx(1, 0)], e20 = a[pidx(2, 0)], e21 = a[pidx(2, 1)];
+template <typename T> __device__ __forceinline__ T log_series3(const T (&a)[6], T (&m0)[6], T pre = T(1)) {
+  using N = Num<T>;
+  using S = LogSeries<T>;
+  const T e00 = a[pidx(0, 0)] - T(1), e11 = a[pidx(1, 1)] - T(1), e22 = a[pidx(2, 2)] - T(1);
+  const T e10 = a[pidx(1, 0)], e20 = a[pidx(2, 0)], e21 = a[pidx(2, 1)];
   // E^2 (symmetric)
-  const float f00 = fmaf(e00, e00, fmaf(e10, e10, e20 * e20));
-  const float f11 = fmaf(e10, e10, fmaf(e11, e11, e21 * e21));
-  const float f22 = fmaf(e20, e20, fmaf(e21, e21, e22 * e22));
-  const float f10 = fmaf(e10, e00, fmaf(e11, e10, e21 * e20));
-  const float f20 = fmaf(e20, e00, fmaf(e21, e10, e22 * e20));
-  const float f21 = fmaf(e20, e10, fmaf(e21, e11, e22 * e21));
-  const float tr2 = f00 + f11 + f22;                      // ||E||_F^2
-  const float s1 = e00 + e11 + e22;
-  const float s2 = 0.5f * fmaf(s1, s1, -tr2);
-  const float s3 = e00 * fmaf(e11, e22, -e21 * e21) - e10 * fmaf(e10, e22, -e21 * e20) +
-                   e20 * fmaf(e10, e21, -e11 * e20);
-  // Horner from the top: after the first two steps alpha = (c5, c6, c7)
-  float a0 = kA[kLogSeriesTerms - 3], a1 = kA[kLogSeriesTerms - 2], a2 = kA[kLogSeriesTerms - 1];
+  const T f00 = N::fma(e00, e00, N::fma(e10, e10, e20 * e20));
+  const T f11 = N::fma(e10, e10, N::fma(e11, e11, e21 * e21));
+  const T f22 = N::fma(e20, e20, N::fma(e21, e21, e22 * e22));
+  const T f10 = N::fma(e10, e00, N::fma(e11, e10, e21 * e20));
+  const T f20 = N::fma(e20, e00, N::fma(e21, e10, e22 * e20));
+  const T f21 = N::fma(e20, e10, N::fma(e21, e11, e22 * e21));
+  const T tr2 = f00 + f11 + f22;                      // ||E||_F^2
+  const T s1 = e00 + e11 + e22;
+  const T s2 = T(0.5) * N::fma(s1, s1, -tr2);
+  const T s3 = e00 * N::fma(e11, e22, -e21 * e21) - e10 * N::fma(e10, e22, -e21 * e20) +
+               e20 * N::fma(e10, e21, -e11 * e20);
+  // Horner from the top: after the first two steps alpha = (c_{n-3}, c_{n-2}, c_{n-1})
+  T a0 = T(S::kA[S::kTerms - 3]), a1 = T(S::kA[S::kTerms - 2]), a2 = T(S::kA[S::kTerms - 1]);
 #pragma unroll
-  for (int k = kLogSeriesTerms - 4; k >= 0; --k) {
-    const float n0 = fmaf(a2, s3, kA[k]), n1 = fmaf(-a2, s2, a0), n2 = fmaf(a2, s1, a1);
+  for (int k = S::kTerms - 4; k >= 0; --k) {
+    const T n0 = N::fma(a2, s3, T(S::kA[k])), n1 = N::fma(-a2, s2, a0), n2 = N::fma(a2, s1, a1);
     a0 = n0; a1 = n1; a2 = n2;
   }
   // log(I + E) = E p(E): one more multiplication by E (no constant), then the caller's factor
-  const float b0 = (a2 * s3) * pre, b1 = fmaf(-a2, s2, a0) * pre, b2 = fmaf(a2, s1, a1) * pre;
-  m0[pidx(0, 0)] = fmaf(b2, f00, fmaf(b1, e00, b0));
-  m0[pidx(1, 1)] = fmaf(b2, f11, fmaf(b1, e11, b0));
-  m0[pidx(2, 2)] = fmaf(b2, f22, fmaf(b1, e22, b0));
-  m0[pidx(1, 0)] = fmaf(b2, f10, b1 * e10);
-  m0[pidx(2, 0)] = fmaf(b2, f20, b1 * e20);
-  m0[pidx(2, 1)] = fmaf(b2, f21, b1 * e21);
+  const T b0 = (a2 * s3) * pre, b1 = N::fma(-a2, s2, a0) * pre, b2 = N::fma(a2, s1, a1) * pre;
+  m0[pidx(0, 0)] = N::fma(b2, f00, N::fma(b1, e00, b0));
+  m0[pidx(1, 1)] = N::fma(b2, f11, N::fma(b1, e11, b0));
+  m0[pidx(2, 2)] = N::fma(b2, f22, N::fma(b1, e22, b0));
+  m0[pidx(1, 0)] = N::fma(b2, f10, b1 * e10);
+  m0[pidx(2, 0)] = N::fma(b2, f20, b1 * e20);
+  m0[pidx(2, 1)] = N::fma(b2, f21, b1 * e21);
   return tr2;
 }
 
@@ -644,86 +658,100 @@ template <typename T> __device__ __forceinline__ T log_cayley4(const T (&a)[10],
 // d^2 = ||log A||_F^2 of a close pair (||A - I||_F <= 0.3), 3x3, straight from the invariants of
 // E = A - I:  sum_k log^2(1 + e_k) = tr(E^2 q(E)) with log^2(1+x) = x^2 q(x), q an economised polynomial.
 // No eigenvalues, no transcendental.  *e2 receives ||E||_F^2.
-__device__ __forceinline__ float logsq_series3(const float (&a)[6], float* e2) {
-  constexpr int kTerms = 9;  // log^2(1+x) = x^2 q(x), q of degree 8 on |x| <= 0.3: max error 6.9e-8 x^2
-  constexpr float kL2[kTerms] = {9.999999990e-01f, -9.999985182e-01f, 9.166654125e-01f, -8.335515341e-01f,
-                                 7.613116690e-01f, -6.914147801e-01f, 6.401787542e-01f, -7.263483416e-01f,
-                                 6.811261199e-01f};
-  const float e00 = a[pidx(0, 0)] - 1.f, e11 = a[pidx(1, 1)] - 1.f, e22 = a[pidx(2, 2)] - 1.f;
-  const float e10 = a[pidx(1, 0)], e20 = a[pidx(2, 0)], e21 = a[pidx(2, 1)];
-  float t2 = fmaf(e00, e00, fmaf(e11, e11, e22 * e22));
-  t2 = fmaf(2.f, fmaf(e10, e10, fmaf(e20, e20, e21 * e21)), t2);
-  const float s1 = e00 + e11 + e22;
-  const float s2 = 0.5f * fmaf(s1, s1, -t2);
-  const float s3 = e00 * fmaf(e11, e22, -e21 * e21) - e10 * fmaf(e10, e22, -e21 * e20) +
-                   e20 * fmaf(e10, e21, -e11 * e20);
+template <typename T> struct LogSqSeries;
+template <> struct LogSqSeries<float> {   // log^2(1+x) = x^2 q(x), q of degree 8 on |x| <= 0.3: max error 6.9e-8 x^2
+  static constexpr int kTerms = 9;
+  static constexpr float kQ[kTerms] = {9.999999990e-01f, -9.999985182e-01f, 9.166654125e-01f, -8.335515341e-01f,
+                                       7.613116690e-01f, -6.914147801e-01f, 6.401787542e-01f, -7.263483416e-01f,
+                                       6.811261199e-01f};
+};
+template <> struct LogSqSeries<double> {  // degree 19: max error 4.7e-17 x^2 (tools/design/series_fit64.py)
+  static constexpr int kTerms = 20;
+  static constexpr double kQ[kTerms] = {
+    1.00000000000000000e+00, -9.99999999999999889e-01, 9.16666666666741459e-01, -8.33333333333411308e-01,
+    7.61111111083523362e-01, -6.99999999974005638e-01, 6.48214289636532492e-01, -6.03968257620789650e-01,
+    5.65793368886221559e-01, -5.32539418364275541e-01, 5.03324479906769540e-01, -4.77427984436160913e-01,
+    4.54016324988081366e-01, -4.33266732950779887e-01, 4.19186214916998590e-01, -4.01958766939621959e-01,
+    3.42135448468324777e-01, -3.29342696720597350e-01, 5.48091271953506265e-01, -5.29456865029041324e-01};
+};
+template <typename T> __device__ __forceinline__ T logsq_series3(const T (&a)[6], T* e2) {
+  using N = Num<T>;
+  using S = LogSqSeries<T>;
+  const T e00 = a[pidx(0, 0)] - T(1), e11 = a[pidx(1, 1)] - T(1), e22 = a[pidx(2, 2)] - T(1);
+  const T e10 = a[pidx(1, 0)], e20 = a[pidx(2, 0)], e21 = a[pidx(2, 1)];
+  T t2 = N::fma(e00, e00, N::fma(e11, e11, e22 * e22));
+  t2 = N::fma(T(2), N::fma(e10, e10, N::fma(e20, e20, e21 * e21)), t2);
+  const T s1 = e00 + e11 + e22;
+  const T s2 = T(0.5) * N::fma(s1, s1, -t2);
+  const T s3 = e00 * N::fma(e11, e22, -e21 * e21) - e10 * N::fma(e10, e22, -e21 * e20) +
+               e20 * N::fma(e10, e21, -e11 * e20);
   // q(E) = h0 I + h1 E + h2 E^2 by Horner in R[E]/(chi_E) (see log_series3), then
   // tr(E^2 q(E)) = h0 tr E^2 + h1 tr E^3 + h2 tr E^4 with the power sums from Newton's identities
-  float h0 = kL2[kTerms - 3], h1 = kL2[kTerms - 2], h2 = kL2[kTerms - 1];
+  T h0 = T(S::kQ[S::kTerms - 3]), h1 = T(S::kQ[S::kTerms - 2]), h2 = T(S::kQ[S::kTerms - 1]);
 #pragma unroll
-  for (int k = kTerms - 4; k >= 0; --k) {
-    const float n0 = fmaf(h2, s3, kL2[k]), n1 = fmaf(-h2, s2, h0), n2 = fmaf(h2, s1, h1);
+  for (int k = S::kTerms - 4; k >= 0; --k) {
+    const T n0 = N::fma(h2, s3, T(S::kQ[k])), n1 = N::fma(-h2, s2, h0), n2 = N::fma(h2, s1, h1);
     h0 = n0; h1 = n1; h2 = n2;
   }
-  const float t3 = fmaf(3.f, s3, fmaf(s1, t2, -s2 * s1));
-  const float t4 = fmaf(s1, t3, fmaf(-s2, t2, s3 * s1));
-  const float acc = fmaf(h2, t4, fmaf(h1, t3, h0 * t2));
+  const T t3 = N::fma(T(3), s3, N::fma(s1, t2, -s2 * s1));
+  const T t4 = N::fma(s1, t3, N::fma(-s2, t2, s3 * s1));
   *e2 = t2;
-  return acc;
+  return N::fma(h2, t4, N::fma(h1, t3, h0 * t2));
 }
 
 // Same for 4x4: intermediates h0 I + h1 E + h2 E^2 + h3 E^3, multiplication by E through
 //   (h0,h1,h2,h3) . E + c I = (c - h3 s4, h0 + h3 s3, h1 - h3 s2, h2 + h3 s1),  E^4 = s1 E^3 - s2 E^2 + s3 E - s4 I,
 // s1..s4 from the power sums tr E^m (Newton's identities; tr E^3 = <E^2,E>, tr E^4 = ||E^2||_F^2).
-__device__ __forceinline__ float log_series4(const float (&a)[10], float (&m0)[10], float pre = 1.f) {
-  constexpr float kA[kLogSeriesTerms] = MM_LOG_SERIES_COEFS;
-  float e[10], e2[10], e3[10];
+template <typename T> __device__ __forceinline__ T log_series4(const T (&a)[10], T (&m0)[10], T pre = T(1)) {
+  using N = Num<T>;
+  using S = LogSeries<T>;
+  T e[10], e2[10], e3[10];
 #pragma unroll
   for (int k = 0; k < 10; ++k) e[k] = a[k];
 #pragma unroll
-  for (int r = 0; r < 4; ++r) e[pidx(r, r)] -= 1.f;
+  for (int r = 0; r < 4; ++r) e[pidx(r, r)] -= T(1);
 #pragma unroll
   for (int r = 0; r < 4; ++r)
 #pragma unroll
     for (int c = 0; c <= r; ++c) {
-      float acc = e[pidx(r, 0)] * e[pidx(0, c)];
+      T acc = e[pidx(r, 0)] * e[pidx(0, c)];
 #pragma unroll
-      for (int k = 1; k < 4; ++k) acc = fmaf(e[pidx(r, k)], e[pidx(k, c)], acc);
+      for (int k = 1; k < 4; ++k) acc = N::fma(e[pidx(r, k)], e[pidx(k, c)], acc);
       e2[pidx(r, c)] = acc;
     }
 #pragma unroll
   for (int r = 0; r < 4; ++r)
 #pragma unroll
     for (int c = 0; c <= r; ++c) {
-      float acc = e2[pidx(r, 0)] * e[pidx(0, c)];
+      T acc = e2[pidx(r, 0)] * e[pidx(0, c)];
 #pragma unroll
-      for (int k = 1; k < 4; ++k) acc = fmaf(e2[pidx(r, k)], e[pidx(k, c)], acc);
+      for (int k = 1; k < 4; ++k) acc = N::fma(e2[pidx(r, k)], e[pidx(k, c)], acc);
       e3[pidx(r, c)] = acc;
     }
-  float p1 = 0.f, p2 = 0.f, p3 = 0.f, p4 = 0.f;
+  T p1 = T(0), p2 = T(0), p3 = T(0), p4 = T(0);
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     p1 += e[pidx(r, r)];
     p2 += e2[pidx(r, r)];
     p3 += e3[pidx(r, r)];
-    p4 = fmaf(e2[pidx(r, r)], e2[pidx(r, r)], p4);
+    p4 = N::fma(e2[pidx(r, r)], e2[pidx(r, r)], p4);
 #pragma unroll
-    for (int c = 0; c < r; ++c) p4 = fmaf(2.f * e2[pidx(r, c)], e2[pidx(r, c)], p4);
+    for (int c = 0; c < r; ++c) p4 = N::fma(T(2) * e2[pidx(r, c)], e2[pidx(r, c)], p4);
   }
-  const float s1 = p1;
-  const float s2 = 0.5f * fmaf(s1, p1, -p2);
-  const float s3 = (1.f / 3.f) * (fmaf(s2, p1, -s1 * p2) + p3);
-  const float s4 = 0.25f * (fmaf(s3, p1, -s2 * p2) + fmaf(s1, p3, -p4));
+  const T s1 = p1;
+  const T s2 = T(0.5) * N::fma(s1, p1, -p2);
+  const T s3 = T(1.0 / 3.0) * (N::fma(s2, p1, -s1 * p2) + p3);
+  const T s4 = T(0.25) * (N::fma(s3, p1, -s2 * p2) + N::fma(s1, p3, -p4));
   // p(E) by Horner in R[E]/(chi_E), then one more multiplication by E (log(I + E) = E p(E))
-  float h0 = kA[kLogSeriesTerms - 4], h1 = kA[kLogSeriesTerms - 3], h2 = kA[kLogSeriesTerms - 2], h3 = kA[kLogSeriesTerms - 1];
+  T h0 = T(S::kA[S::kTerms - 4]), h1 = T(S::kA[S::kTerms - 3]), h2 = T(S::kA[S::kTerms - 2]), h3 = T(S::kA[S::kTerms - 1]);
 #pragma unroll
-  for (int k = kLogSeriesTerms - 5; k >= 0; --k) {
-    const float n0 = fmaf(-h3, s4, kA[k]), n1 = fmaf(h3, s3, h0), n2 = fmaf(-h3, s2, h1), n3 = fmaf(h3, s1, h2);
+  for (int k = S::kTerms - 5; k >= 0; --k) {
+    const T n0 = N::fma(-h3, s4, T(S::kA[k])), n1 = N::fma(h3, s3, h0), n2 = N::fma(-h3, s2, h1), n3 = N::fma(h3, s1, h2);
     h0 = n0; h1 = n1; h2 = n2; h3 = n3;
   }
-  const float al[4] = {(-h3 * s4) * pre, fmaf(h3, s3, h0) * pre, fmaf(-h3, s2, h1) * pre, fmaf(h3, s1, h2) * pre};
+  const T al[4] = {(-h3 * s4) * pre, N::fma(h3, s3, h0) * pre, N::fma(-h3, s2, h1) * pre, N::fma(h3, s1, h2) * pre};
 #pragma unroll
-  for (int k = 0; k < 10; ++k) m0[k] = fmaf(al[3], e3[k], fmaf(al[2], e2[k], al[1] * e[k]));
+  for (int k = 0; k < 10; ++k) m0[k] = N::fma(al[3], e3[k], N::fma(al[2], e2[k], al[1] * e[k]));
 #pragma unroll
   for (int rr = 0; rr < 4; ++rr) m0[pidx(rr, rr)] += al[0];
   return p2;  // ||E||_F^2

@@ -125,30 +125,33 @@ template <typename T, int D> __device__ __forceinline__ T frob2(const T (&m)[Pac
   return s;
 }
 // ||A - I||_F^2 with the arithmetic of log_series3/4 (so the gate shares it with the series)
-template <int D> __device__ __forceinline__ float close_gate(const float (&a)[Packed<D>::NP]) {
-  float e[Packed<D>::NP];
+template <typename T, int D> __device__ __forceinline__ T close_gate(const T (&a)[Packed<D>::NP]) {
+  using N = Num<T>;
+  T e[Packed<D>::NP];
 #pragma unroll
   for (int k = 0; k < Packed<D>::NP; ++k) e[k] = a[k];
 #pragma unroll
-  for (int r = 0; r < D; ++r) e[pidx(r, r)] -= 1.f;
+  for (int r = 0; r < D; ++r) e[pidx(r, r)] -= T(1);
   if constexpr (D == 3) {
-    return fmaf(e[0], e[0], fmaf(e[1], e[1], e[3] * e[3])) + fmaf(e[1], e[1], fmaf(e[2], e[2], e[4] * e[4])) +
-           fmaf(e[3], e[3], fmaf(e[4], e[4], e[5] * e[5]));
+    return N::fma(e[0], e[0], N::fma(e[1], e[1], e[3] * e[3])) + N::fma(e[1], e[1], N::fma(e[2], e[2], e[4] * e[4])) +
+           N::fma(e[3], e[3], N::fma(e[4], e[4], e[5] * e[5]));
   } else {
-    float p2 = 0.f;
+    T p2 = T(0);
 #pragma unroll
     for (int r = 0; r < D; ++r) {
-      float acc = e[pidx(r, 0)] * e[pidx(0, r)];
+      T acc = e[pidx(r, 0)] * e[pidx(0, r)];
 #pragma unroll
-      for (int k = 1; k < D; ++k) acc = fmaf(e[pidx(r, k)], e[pidx(k, r)], acc);
+      for (int k = 1; k < D; ++k) acc = N::fma(e[pidx(r, k)], e[pidx(k, r)], acc);
       p2 += acc;
     }
     return p2;
   }
 }
-template <int D> __device__ __forceinline__ void log_close(const float (&a)[Packed<D>::NP], float (&m0)[Packed<D>::NP],
-                                                          float pre = 1.f) {
-  if constexpr (D == 3) log_series3(a, m0, pre); else log_series4(a, m0, pre);
+// close pairs: ||A - I||_F <= 0.3 (the series' polynomials are fitted on a spectral radius of 0.3)
+constexpr double kCloseGate = 0.09;
+template <typename T, int D> __device__ __forceinline__ void log_close(const T (&a)[Packed<D>::NP], T (&m0)[Packed<D>::NP],
+                                                                     T pre = T(1)) {
+  if constexpr (D == 3) log_series3<T>(a, m0, pre); else log_series4<T>(a, m0, pre);
 }
 template <typename T, int D> __device__ __forceinline__ T log_cayley(const T (&a)[Packed<D>::NP], T (&m0)[Packed<D>::NP]) {
   if constexpr (D == 3) return log_cayley3<T>(a, m0); else return log_cayley4<T>(a, m0);
@@ -164,8 +167,8 @@ __device__ __forceinline__ T pair_value(const TL (&li)[Packed<D>::NP], const T (
     pair_a<float, 3, CHOL>(li, xj, a);
     {  // close pairs (whole wavefront within ||A - I||_F <= 0.3): invariants-only series
       float e2;
-      const float sq = logsq_series3(a, &e2);
-      if (!__any(!(e2 <= 0.09f))) return sq;
+      const float sq = logsq_series3<float>(a, &e2);
+      if (!__any(!(e2 <= float(kCloseGate)))) return sq;
     }
     eig3_trig(a, w);
     const bool wide = !(w[0] * 32.f > w[2]);  // true for NaN / non-positive spectra too
@@ -181,16 +184,21 @@ __device__ __forceinline__ T pair_value(const TL (&li)[Packed<D>::NP], const T (
     }
     return s;
   } else if constexpr (D == 3 || D == 4) {
-    // SPD(4), and SPD(3) in fp64: ||log A||_F^2 without an eigensolve — close-pair series (fp32), then
-    // the Cayley-transform logarithm; Jacobi only if a pair of the wavefront has a very wide spectrum
+    // SPD(4), and SPD(3) in fp64: ||log A||_F^2 without an eigensolve — close-pair series (SPD(3) fp64: straight
+    // from the invariants, like fp32), then the Cayley-transform logarithm; Jacobi only if a pair of the wavefront
+    // has a very wide spectrum
     constexpr int NP = Packed<D>::NP;
     T a[NP], m0[NP];
     pair_a<T, D, CHOL>(li, xj, a);
-    bool close = false;
-    if constexpr (std::is_same<T, float>::value) close = !__any(!(close_gate<D>(a) <= 0.09f));
-    if (__builtin_expect(close, 1)) {
-      if constexpr (std::is_same<T, float>::value) log_close<D>(a, m0);
-      return frob2<T, D>(m0);
+    if constexpr (D == 3) {
+      T e2;
+      const T sq = logsq_series3<T>(a, &e2);
+      if (__builtin_expect(!__any(!(e2 <= T(kCloseGate))), 1)) return sq;
+    } else {
+      if (__builtin_expect(!__any(!(close_gate<T, D>(a) <= T(kCloseGate))), 1)) {
+        log_close<T, D>(a, m0);
+        return frob2<T, D>(m0);
+      }
     }
     const T gate = log_cayley<T, D>(a, m0);
     if (__builtin_expect(!__any(!(gate <= T(kCayleyGate))), 1)) return frob2<T, D>(m0);
@@ -501,8 +509,8 @@ __global__ __launch_bounds__((64 * bwd_waves<T, D>())) void spd_pdist_bwd_kernel
             for (int k = 0; k < NP; ++k) m[q][k] = g2 * m0[k];
           };
           if constexpr (D == 3 || D == 4) {
-            // Eigen-free paths, chosen per wavefront: close pairs (||A - I||_F <= 0.3, fp32) take the
-            // Cayley-Hamilton series of log(I + E); anything with tr(Z^2) <= 0.36 (eigenvalue ratios up
+            // Eigen-free paths, chosen per wavefront: close pairs (||A - I||_F <= 0.3) take the
+            // Cayley-Hamilton series of log(I + E) (degree 7 in fp32, 19 in fp64); anything with tr(Z^2) <= 0.36 (eigenvalue ratios up
             // to ~16: every pair of an embedding with O(1) distances) the Cayley-transform logarithm.
             // What is left (very wide spectra, NaN, non-PD) goes to the Jacobi path.
             T a[NC][NP];
@@ -510,18 +518,15 @@ __global__ __launch_bounds__((64 * bwd_waves<T, D>())) void spd_pdist_bwd_kernel
             static_for<NC>([&](auto qc) {
               constexpr int q = decltype(qc)::value;
               congr_chol<T, D>(li, xj[q], a[q]);
-              if constexpr (std::is_same<T, float>::value) far = far || !(close_gate<D>(a[q]) <= 0.09f);
-              else far = true;
+              far = far || !(close_gate<T, D>(a[q]) <= T(kCloseGate));
             });
             if (__builtin_expect(!__any(far), 1)) {
-              if constexpr (std::is_same<T, float>::value) {
-                static_for<NC>([&](auto qc) {
-                  constexpr int q = decltype(qc)::value;
-                  T m0[NP];
-                  log_close<D>(a[q], m0, g_first ? gs[q] + gs[q] : 1.f);
-                  finish(qc, m0, g_first);
-                });
-              }
+              static_for<NC>([&](auto qc) {
+                constexpr int q = decltype(qc)::value;
+                T m0[NP];
+                log_close<T, D>(a[q], m0, g_first ? gs[q] + gs[q] : T(1));
+                finish(qc, m0, g_first);
+              });
             } else {
               static_for<NC>([&](auto qc) {
                 constexpr int q = decltype(qc)::value;

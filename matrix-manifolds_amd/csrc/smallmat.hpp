@@ -284,8 +284,11 @@ __device__ __forceinline__ void jacobi_eig(T (&a)[Packed<D>::NP], T (&v)[D][D], 
   // loop back-edge: -16 % kernel time on MI355X), and no convergence test before the
   // sweeps every 3x3+ matrix needs anyway (one sweep is exact only for D = 2).
   constexpr int kMinSweeps = D >= 3 ? 2 : 1;
-#pragma unroll
-  for (int sweep = 0; sweep < N::kMaxSweeps; ++sweep) {
+  // (D >= 6: the sweeps stay a loop — unrolled, a 9x9 solve with eigenvectors is ~30 000 instructions per call site —
+  // and get a few more of them: the quadratic convergence of cyclic Jacobi starts later for larger matrices)
+  constexpr int kSweeps = D <= 5 ? N::kMaxSweeps : N::kMaxSweeps + 4;
+#pragma unroll(D <= 5 ? N::kMaxSweeps : 1)
+  for (int sweep = 0; sweep < kSweeps; ++sweep) {
     bool active = sweep < kMinSweeps;
     if (active) {
     } else if (REL) {

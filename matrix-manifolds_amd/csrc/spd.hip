@@ -1086,12 +1086,22 @@ template <typename T, int D> int spd_prepare_t(const T* x, int64_t n, void* wsp,
   return spd_pdist_prepare<T, D>(x, n, ws, 0, st);
 }
 
+#if MM_SPD_MAX_D >= 9
+#define MM_DISPATCH_D_HI(CALL)                    \
+    case 6: { constexpr int D = 6; return CALL; } \
+    case 7: { constexpr int D = 7; return CALL; } \
+    case 8: { constexpr int D = 8; return CALL; } \
+    case 9: { constexpr int D = 9; return CALL; }
+#else
+#define MM_DISPATCH_D_HI(CALL)
+#endif
 #define MM_DISPATCH_D(T, d, CALL)                \
   switch (d) {                                   \
     case 2: { constexpr int D = 2; return CALL; } \
     case 3: { constexpr int D = 3; return CALL; } \
     case 4: { constexpr int D = 4; return CALL; } \
     case 5: { constexpr int D = 5; return CALL; } \
+    MM_DISPATCH_D_HI(CALL)                       \
     default: return MM_ERR_UNSUPPORTED;          \
   }
 

@@ -24,8 +24,14 @@ constexpr int kBlock = 256;  // 4 wavefronts
 #endif
 // backward: wavefronts that share one 64-column tile (one column-side atomic flush per workgroup);
 // 4 where the LDS combine buffer of 8 would not fit (fp64, D = 5)
-template <typename T, int D> constexpr int bwd_waves() { return (sizeof(T) == 4 && D <= 4) ? MM_BWD_WAVES : 4; }
-constexpr int kSpdMaxD = 5;
+template <typename T, int D> constexpr int bwd_waves() {
+  // (the column-side combine buffer is D^2 x 64 values per wavefront: 4 wavefronts up to 64 KB of it, else 2, else 1)
+  return int(sizeof(T)) * D * D * 64 * 4 <= 65536 ? 4 : (int(sizeof(T)) * D * D * 64 * 2 <= 65536 ? 2 : 1);
+}
+#ifndef MM_SPD_MAX_D
+#define MM_SPD_MAX_D 9   // (development builds: -DMM_SPD_MAX_D=5 compiles spd.hip three times faster)
+#endif
+constexpr int kSpdMaxD = MM_SPD_MAX_D;   // the reference's tests go to 9 (tests/test_spd.py:15,26,62,70); D >= 6 spills to scratch
 
 __host__ __device__ inline int64_t pair_off(int64_t n, int64_t row) { return row * (2 * n - row - 1) / 2; }
 

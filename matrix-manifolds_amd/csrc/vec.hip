@@ -26,7 +26,7 @@
 namespace mm {
 
 constexpr int kVBlock = 256;
-constexpr int kVecMaxDim = 32;
+constexpr int kVecMaxDim = 64;
 __host__ __device__ inline int64_t vpair_off(int64_t n, int64_t row) { return row * (2 * n - row - 1) / 2; }
 
 // q for one pair from register/scalar operands
@@ -543,7 +543,7 @@ int vec_loss_t(int loss_kind, const T* x, const T* target, const T* scale_raw, i
   return vec_bwd_t<T, KIND, MP, MM_LOSS_QUOTIENT>(x, target, n, m, rb, re, 1, grad, ws, st, la, loss_out);
 }
 
-constexpr int pad_dim(int m) { return m <= 4 ? 4 : m <= 8 ? 8 : m <= 12 ? 12 : m <= 16 ? 16 : m <= 24 ? 24 : 32; }
+constexpr int pad_dim(int m) { return m <= 4 ? 4 : m <= 8 ? 8 : m <= 12 ? 12 : m <= 16 ? 16 : m <= 24 ? 24 : m <= 32 ? 32 : m <= 48 ? 48 : 64; }
 
 #define MMV_DISPATCH_MP(m, ...)                             \
   switch (pad_dim(m)) {                                     \
@@ -552,7 +552,9 @@ constexpr int pad_dim(int m) { return m <= 4 ? 4 : m <= 8 ? 8 : m <= 12 ? 12 : m
     case 12: { constexpr int MP = 12; return __VA_ARGS__; } \
     case 16: { constexpr int MP = 16; return __VA_ARGS__; } \
     case 24: { constexpr int MP = 24; return __VA_ARGS__; } \
-    default: { constexpr int MP = 32; return __VA_ARGS__; } \
+    case 32: { constexpr int MP = 32; return __VA_ARGS__; } \
+    case 48: { constexpr int MP = 48; return __VA_ARGS__; } \
+    default: { constexpr int MP = 64; return __VA_ARGS__; } \
   }
 
 #define MMV_DISPATCH_KIND(kind, ...)                                         \

@@ -47,7 +47,7 @@ class _VecPdist(torch.autograd.Function):
         with B.on_device(xc.device):
             grad = torch.empty_like(xc)
             f32 = xc.dtype == torch.float32
-            mfma = n <= 32768 and ((ctx.use_gram and kind in (B.LORENTZ, B.SPHERE) and (f32 or m <= 16)) or
+            mfma = n <= 32768 and ((ctx.use_gram and kind in (B.LORENTZ, B.SPHERE) and m <= (32 if f32 else 16)) or
                                    (f32 and kind == B.EUCLIDEAN and squared and m <= 31))
             if mfma:
                 # matrix-core backward (inner-product manifolds, fp32): W^T X, no workspace

@@ -41,7 +41,10 @@ class FlatRule:
         if not x.is_cuda:
             return None
         width = x.shape[-1] if x.ndim else 1
-        if width > 32 or x.dtype not in (torch.float32, torch.float64):
+        if x.dtype not in (torch.float32, torch.float64):
+            return None
+        from graphembed import _backend as B
+        if width > B.lib().raw("mm_vec_max_dim")():
             return None
         from graphembed import _backend as B
         xd = x.detach()
@@ -116,7 +119,7 @@ def vector_layout(p, manifold):
         kind, m = manifold._kind, manifold._m
     else:
         return None
-    return (kind, m) if 1 <= m <= 32 else None
+    return (kind, m) if 1 <= m <= B.lib().raw("mm_vec_max_dim")() else None
 
 
 class ManifoldOptimizer(torch.optim.Optimizer):

@@ -23,7 +23,7 @@
 #include <omp.h>
 #endif
 
-#define DMAX 8
+#define DMAX 9
 
 static void jacobi(int d, double a[DMAX][DMAX], double v[DMAX][DMAX], double w[DMAX]) {
   for (int r = 0; r < d; ++r) for (int c = 0; c < d; ++c) v[r][c] = (r == c);

@@ -91,7 +91,7 @@ int main(void) {
   printf("euclidean(4): pdist and RSGD step ok\n");
   /* argument errors are return codes, never exceptions */
   if (mm_spd_pdist_fwd(MM_F64, NULL, n, d, 0, n, 1, 1e-8, 1e8, dout, ws, 0, st) != MM_ERR_ARG) return 9;
-  if (mm_spd_pdist_fwd(MM_F64, dx, n, 9, 0, n, 1, 1e-8, 1e8, dout, ws, 0, st) != MM_ERR_UNSUPPORTED) return 9;
+  if (mm_spd_pdist_fwd(MM_F64, dx, n, 10, 0, n, 1, 1e-8, 1e8, dout, ws, 0, st) != MM_ERR_UNSUPPORTED) return 9;   /* SPD(2..9) */
   printf("C ABI smoke: ok\n");
   return 0;
 }

@@ -14,6 +14,7 @@ import gzip
 import itertools
 import os
 import sys
+import zlib
 
 import numpy as np
 import torch
@@ -37,6 +38,11 @@ def np_(t):
     return t.detach().cpu().numpy()
 
 
+def seed_of(*parts):
+    """A seed that is the same in every process (the built-in hash() of a tuple of strings is salted per process)."""
+    return zlib.crc32(repr(parts).encode()) % (2**31)
+
+
 def rand_spd(n, d):  # tests/conftest.py:36-43 of the reference
     x = torch.rand(n, d, d)
     return (x @ x.transpose(1, 2)).add_(torch.eye(d))
@@ -48,9 +54,16 @@ MANIFOLDS = {
     'spd3': (lambda: RM.SymmetricPositiveDefinite(3), None),
     'spd4': (lambda: RM.SymmetricPositiveDefinite(4), None),
     'spd5': (lambda: RM.SymmetricPositiveDefinite(5), None),
+    'spd6': (lambda: RM.SymmetricPositiveDefinite(6), None),
+    'spd7': (lambda: RM.SymmetricPositiveDefinite(7), None),
+    'spd8': (lambda: RM.SymmetricPositiveDefinite(8), None),
+    'spd9': (lambda: RM.SymmetricPositiveDefinite(9), None),
     'lorentz11': (lambda: RM.Lorentz(11), None),
     'lorentz6': (lambda: RM.Lorentz(6), None),
     'lorentz3': (lambda: RM.Lorentz(3), None),
+    'lorentz48': (lambda: RM.Lorentz(48), None),
+    'sphere64': (lambda: RM.Sphere(64), None),
+    'euclidean40': (lambda: RM.Euclidean(40), None),
     'sphere6': (lambda: RM.Sphere(6), None),
     'euclidean10': (lambda: RM.Euclidean(10), None),
     'grassmann52': (lambda: RM.Grassmann(5, 2), None),
@@ -83,7 +96,7 @@ def record_manifold(key, n, out):
     ctor, _ = MANIFOLDS[key]
     for dname, init in itertools.product(DT, ['rand', 'wide']):
         torch.set_default_dtype(DT[dname])
-        torch.manual_seed(hash((key, dname, init, n)) % (2**31))
+        torch.manual_seed(seed_of(key, dname, init, n))
         man = ctor()
         x = make_points(key, man, n, init).detach().clone()
         tag = f'{dname}/{init}/n{n}'
@@ -139,11 +152,14 @@ def record_rsgd(key, n, out):
     ctor, _ = MANIFOLDS[key]
     for dname in DT:
         torch.set_default_dtype(DT[dname])
-        torch.manual_seed(hash((key, dname, 'rsgd')) % (2**31))
+        torch.manual_seed(seed_of(key, dname, 'rsgd'))
         man = ctor()
         x0 = make_points(key, man, n, 'wide').detach().clone()
-        g1 = torch.randn_like(x0) * 3.0
-        g2 = torch.randn_like(x0) * 3.0
+        # (SPD(6..9): smaller Euclidean gradients — the Riemannian gradient X G X grows with the dimension, and the
+        # reference's unclipped second-order retraction leaves the cone for steps that large)
+        gscale = {'spd5': 1.0, 'spd6': 0.3, 'spd7': 0.3, 'spd8': 0.3, 'spd9': 0.3}.get(key, 3.0)
+        g1 = torch.randn_like(x0) * gscale
+        g2 = torch.randn_like(x0) * gscale
         if key.startswith('spd'):
             g1 = g1 + g1.transpose(-2, -1)
             g2 = g2 + g2.transpose(-2, -1)
@@ -162,6 +178,7 @@ def record_rsgd(key, n, out):
             p.grad = g2.clone()
             opt.step()
             out[f'{tag}/x2'] = np_(p.data)
+            assert np.isfinite(out[f'{tag}/x2']).all(), f'{key} {tag}: the reference itself left the manifold (reduce gscale)'
             if mom > 0:
                 out[f'{tag}/buf2'] = np_(opt.state[p]['momentum_buffer'])
 
@@ -255,8 +272,16 @@ def record_product(out):
 
 
 def main():
+    """`gen_golden.py` regenerates everything; `gen_golden.py key [key ...]` only the named manifold files (seeds are per
+    key, so a partial run reproduces exactly what a full run writes for those keys)."""
     torch.set_num_threads(4)
+    only = set(sys.argv[1:])
+    unknown = only - set(MANIFOLDS) - {'callers'}
+    if unknown:
+        raise SystemExit(f'unknown keys {sorted(unknown)}')
     for key in MANIFOLDS:
+        if only and key not in only:
+            continue
         out = {}
         record_manifold(key, 33, out)
         if key in ('spd3', 'lorentz11'):
@@ -264,11 +289,12 @@ def main():
         record_rsgd(key, 17, out)
         np.savez_compressed(os.path.join(HERE, f'{key}.npz'), **out)
         print(key, len(out), 'arrays')
-    out = {}
-    record_product(out)
-    record_training(out)
-    np.savez_compressed(os.path.join(HERE, 'callers.npz'), **out)
-    print('callers', len(out), 'arrays')
+    if not only or 'callers' in only:
+        out = {}
+        record_product(out)
+        record_training(out)
+        np.savez_compressed(os.path.join(HERE, 'callers.npz'), **out)
+        print('callers', len(out), 'arrays')
     torch.set_default_dtype(torch.float32)
 
 

@@ -9,7 +9,7 @@ from oracle import exact
 from oracle import ref_port as rp
 
 
-@pytest.mark.parametrize('d', [2, 3, 4, 5])
+@pytest.mark.parametrize('d', [2, 3, 4, 5, 6, 7, 8, 9])
 @pytest.mark.parametrize('init', ['rand', 'wide'])
 def test_spd_against_reference_golden(d, init):
     G = load_golden(f'spd{d}')
@@ -26,7 +26,8 @@ def test_spd_against_reference_golden(d, init):
     assert np.abs(gr - np.swapaxes(gr, 1, 2)).max() <= 1e-12 * np.abs(gr).max()
 
 
-@pytest.mark.parametrize('key,kind,m', [('lorentz11', 'lorentz', 11), ('sphere6', 'sphere', 6), ('euclidean10', 'euclidean', 10)])
+@pytest.mark.parametrize('key,kind,m', [('lorentz11', 'lorentz', 11), ('sphere6', 'sphere', 6), ('euclidean10', 'euclidean', 10),
+                                          ('lorentz48', 'lorentz', 48), ('sphere64', 'sphere', 64), ('euclidean40', 'euclidean', 40)])
 @pytest.mark.parametrize('init', ['rand', 'wide'])
 def test_vec_against_reference_golden(key, kind, m, init):
     G = load_golden(key)

@@ -16,7 +16,9 @@ TOL = {'f64': 1e-9, 'f32': 2e-4}
 
 MANS = {
     'spd2': ('spd', 2), 'spd3': ('spd', 3), 'spd4': ('spd', 4), 'spd5': ('spd', 5),
+    'spd6': ('spd', 6), 'spd7': ('spd', 7), 'spd8': ('spd', 8), 'spd9': ('spd', 9),
     'lorentz11': ('lorentz', 11), 'lorentz6': ('lorentz', 6), 'lorentz3': ('lorentz', 3),
+    'lorentz48': ('lorentz', 48), 'sphere64': ('sphere', 64), 'euclidean40': ('euclidean', 40),
     'sphere6': ('sphere', 6), 'euclidean10': ('euclidean', 10),
     'grassmann52': ('grassmann', 5, 2), 'grassmann63': ('grassmann', 6, 3),
     'stiefel52': ('stiefel', 5, 2),

@@ -39,7 +39,26 @@ def check_rel(got, ref, tol, what):
     assert err <= tol, f'{what}: {err:.3e} > {tol:.1e}'
 
 
-@pytest.mark.parametrize('d', [2, 3, 4, 5])
+def check_grad(got, ref, x_np, g_np, squared, dname, tol, what):
+    """Gradient against the reference's recorded one, within `tol` of max|grad| — or, in fp32, where the reference's own
+    eps-fudged closed forms are further than that from the truth (close pairs: d ~ 0.1, the gradient of d divides by
+    it), at least as close to the exact fp64 gradient of the same fp32 inputs (oracle/exact.c) as the
+    reference's fp32 result is, with 3x slack."""
+    got = got.detach().double().cpu().numpy()
+    ref = np.asarray(ref, np.float64)
+    scale = max(np.abs(ref).max(), 1e-30)
+    err = np.abs(got - ref).max() / scale
+    if err <= tol:
+        return
+    assert dname == 'f32', f'{what}: {err:.3e} > {tol:.1e}'
+    from oracle import exact
+    x64 = np.asarray(x_np, np.float64)
+    ex = exact.spd_pdist_grad(x64, np.asarray(g_np, np.float64), squared=squared)
+    e_ours, e_ref = np.abs(got - ex).max() / scale, np.abs(ref - ex).max() / scale
+    assert e_ours <= max(tol, 3 * e_ref), f'{what}: ours {e_ours:.3e} from exact, the reference {e_ref:.3e} (tol {tol:.1e})'
+
+
+@pytest.mark.parametrize('d', [2, 3, 4, 5, 6, 7, 8, 9])
 @pytest.mark.parametrize('dname,init', list(itertools.product(DT, ['rand', 'wide'])))
 def test_pdist_vs_reference_golden(d, dname, init):
     from graphembed.manifolds import SymmetricPositiveDefinite as SPD
@@ -55,17 +74,17 @@ def test_pdist_vs_reference_golden(d, dname, init):
         check_d2(d2, G[f'{tag}/d2'], dname, f'd2 {tag}')
         gr, = torch.autograd.grad((d2 * g).sum(), x)
         assert torch.equal(gr, gr.transpose(-2, -1))
-        check_rel(gr, sym(G[f'{tag}/grad_d2']), GRAD_TOL[dname], f'grad_d2 {tag}')
+        check_grad(gr, sym(G[f'{tag}/grad_d2']), G[f'{tag}/x'], G[f'{tag}/g'], True, dname, GRAD_TOL[dname], f'grad_d2 {tag}')
         d1 = man.pdist(x, squared=False)
         # sqrt amplifies the reference's eps bias for close pairs: compare d1^2 under the d2 rule
         check_d2(d1 * d1, np.asarray(G[f'{tag}/d1'], np.float64)**2, dname, f'd1^2 {tag}')
         gr, = torch.autograd.grad((d1 * g).sum(), x)
-        check_rel(gr, sym(G[f'{tag}/grad_d1']), GRAD_TOL[dname] * 5, f'grad_d1 {tag}')
+        check_grad(gr, sym(G[f'{tag}/grad_d1']), G[f'{tag}/x'], G[f'{tag}/g'], False, dname, GRAD_TOL[dname] * 5, f'grad_d1 {tag}')
         dxy = man.dist(x.detach(), x.detach().flip(0), squared=True)
         check_d2(dxy, G[f'{tag}/dist_xy'], dname, f'dist_xy {tag}')
 
 
-@pytest.mark.parametrize('d', [2, 3, 4, 5])
+@pytest.mark.parametrize('d', [2, 3, 4, 5, 6, 7, 8, 9])
 @pytest.mark.parametrize('dname,init', list(itertools.product(DT, ['rand', 'wide'])))
 def test_maps_vs_reference_golden(d, dname, init):
     from graphembed.manifolds import SymmetricPositiveDefinite as SPD
@@ -90,7 +109,7 @@ def test_maps_vs_reference_golden(d, dname, init):
         check_rel(man.transp(x, man.retr(x, pu), pu), G[f'{tag}/transp'], tol, 'transp')
 
 
-@pytest.mark.parametrize('d', [2, 3, 4, 5])
+@pytest.mark.parametrize('d', [2, 3, 4, 5, 6, 7, 8, 9])
 @pytest.mark.parametrize('dname', list(DT))
 def test_rsgd_vs_reference_golden(d, dname):
     from graphembed.manifolds import SymmetricPositiveDefinite as SPD
@@ -115,7 +134,7 @@ def test_rsgd_vs_reference_golden(d, dname):
             check_rel(opt.state[p]['momentum_buffer'], G[f'{tag}/buf2'], tol, tag + '/buf2')
 
 
-@pytest.mark.parametrize('d,n', [(2, 257), (3, 300), (3, 1000), (4, 130), (5, 70)])
+@pytest.mark.parametrize('d,n', [(2, 257), (3, 300), (3, 1000), (4, 130), (5, 70), (6, 67), (9, 65)])
 @pytest.mark.parametrize('dname', list(DT))
 def test_pdist_vs_oracle_seeded(d, n, dname):
     """Sizes that exercise several tiles, the diagonal blocks and ragged edges."""
@@ -335,7 +354,7 @@ def _losses():
             'quotient_l2': (QuotientLoss(inc_l1=False), dict(epoch=7, alpha=1.0))}
 
 
-@pytest.mark.parametrize('d,n', [(2, 257), (3, 300), (3, 1000), (4, 130), (5, 70)])
+@pytest.mark.parametrize('d,n', [(2, 257), (3, 300), (3, 1000), (4, 130), (5, 70), (6, 67), (9, 65)])
 @pytest.mark.parametrize('dname', list(DT))
 @pytest.mark.parametrize('loss_name', ['stress', 'quotient', 'quotient_l1', 'quotient_l2'])
 def test_fused_loss_vs_oracle_seeded(d, n, dname, loss_name):

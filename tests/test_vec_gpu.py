@@ -13,6 +13,7 @@ pytestmark = pytest.mark.gpu
 
 DT = {'f32': torch.float32, 'f64': torch.float64}
 KEYS = {'lorentz11': ('Lorentz', 11), 'lorentz6': ('Lorentz', 6), 'lorentz3': ('Lorentz', 3),
+        'lorentz48': ('Lorentz', 48), 'sphere64': ('Sphere', 64), 'euclidean40': ('Euclidean', 40),
         'sphere6': ('Sphere', 6), 'euclidean10': ('Euclidean', 10)}
 # Stated tolerances.  The distance maps are evaluated next to their singular points at the
 # reference's own init (acosh at 1, acos at 1), where an fp32 ulp of the inner product moves
@@ -109,7 +110,8 @@ def test_maps_vs_reference_golden(key, dname, init):
     G = load_golden(key)
     man = make(key)
     tag = f'{dname}/{init}/n33'
-    tol = 2e-5 if dname == 'f32' else 1e-11
+    # (fp32 inner products of m terms: the rounding of both implementations grows with the dimension)
+    tol = 2e-5 * max(1, KEYS[key][1] // 8) if dname == 'f32' else 1e-11
     x = dev(G[f'{tag}/x'])
     with torch.no_grad():
         check_rel(man.egrad2rgrad(x, dev(G[f'{tag}/grad_d2'])), G[f'{tag}/rgrad'], tol, 'egrad2rgrad')
@@ -133,7 +135,7 @@ def test_rsgd_vs_reference_golden(key, dname):
     G = load_golden(key)
     man = make(key)
     base = f'{dname}/rsgd'
-    tol = 5e-5 if dname == 'f32' else 1e-10
+    tol = 5e-5 * max(1, KEYS[key][1] // 8) if dname == 'f32' else 1e-10
     for exact, clip, mom in itertools.product([0, 1], [0, 1], [0, 1]):
         tag = f'{base}/exact{exact}_clip{clip}_mom{mom}'
         p = ManifoldParameter(dev(G[f'{base}/x0']), manifold=man)

@@ -2,7 +2,7 @@
 OUT=$GRAFT_REPO_ROOT/gpurun_out
 mkdir -p $OUT
 cd $GRAFT_REPO_ROOT
-timeout 1500 python3 -m pytest tests -m gpu -x -q > $OUT/r02l_pytest.log 2>&1; echo "pytest rc=$?"; tail -6 $OUT/r02l_pytest.log
+timeout 1500 python3 -m pytest tests -m gpu -q > $OUT/r02l_pytest.log 2>&1; echo "pytest rc=$?"; tail -6 $OUT/r02l_pytest.log
 python3 - <<'PY'
 import json, subprocess, sys
 r = subprocess.run([sys.executable, 'bench.py', '--no-cpu-baseline', '--steps', '30', '--warmup', '10'], capture_output=True, text=True)

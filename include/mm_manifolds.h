@@ -371,6 +371,47 @@ int mm_graph_layer_f1(const int* order, const int* hops, int64_t n, const int* i
                       int max_degree, int per_tree_average, int num_layers, double* m1, double* m2,
                       double* counts, mm_stream_t stream);
 
+/* ---- one training step per call ------------------------------------------------ */
+/* The body of the reference's training loop for one full batch (graphembed/graphembed/train.py:198-222:
+ * objective(dataset[idx], embedding.compute_dists(idx)) -> backward -> optimizer.step() for the point and the
+ * scale parameter groups), issued by ONE call: the fused objective kernel of the embedding (mm_spd_pdist_loss /
+ * mm_vec_pdist_loss / mm_product_pairs_loss) followed by the fused optimizer kernels of every parameter
+ * (mm_*_rsgd_step, mm_*_rsgd_momentum_step, mm_*_radam_step[_multi]).  Nothing is allocated, nothing synchronises;
+ * a caller whose loop is not captured in a HIP graph pays one foreign-function call per step instead of ~15.
+ * Parameters are updated IN PLACE; gradients are left in the `grad` buffers (the scales' gradients in
+ * loss_out[1 + k]); loss_out[0] is the loss BEFORE the update, as the reference logs it. */
+enum { MM_OPT_RSGD = 0, MM_OPT_RADAM = 1 };
+typedef struct mm_step_param {
+  int kind;              /* MM_EUCLIDEAN / MM_LORENTZ / MM_SPHERE, or MM_FACTOR_SPD; flat parameters: MM_EUCLIDEAN */
+  int dim;               /* m of a vector point, d of an SPD(d) point, 1 for a scalar                              */
+  int64_t count;         /* points                                                                                */
+  void* x;               /* the parameter (device), updated in place                                              */
+  void* grad;            /* its Euclidean gradient (device): written by the objective, read by the optimizer       */
+  int optimizer;         /* MM_OPT_RSGD (optim/rsgd.py:10-82) or MM_OPT_RADAM (optim/radam.py:12-98)               */
+  double lr, momentum, dampening, max_grad_norm /* <= 0: no clipping */, beta1, beta2, adam_eps;
+  int nc, exact;
+  void* state0;          /* RSGD: momentum buffer (NULL when momentum == 0); Adam: exp_avg                         */
+  void* state1;          /* Adam: exp_avg_sq                                                                       */
+  double* step;          /* Adam: state['step'], device fp64                                                       */
+  unsigned* ticket;      /* Adam: device counter, zero between calls                                               */
+} mm_step_param;
+typedef struct mm_train_step {
+  int dtype, loss_kind, terms;
+  double alpha, eps;             /* quotient loss: target scale and 1 / (epoch + 1)                                */
+  const double* loss_params;     /* optional device {alpha, eps} overriding the two values above                   */
+  double wmin, wmax;             /* SPD eigenvalue clamps (spd.py:29-30)                                           */
+  int64_t n;                     /* points per factor                                                              */
+  int nf;                        /* factors of the product manifold, 1..4                                          */
+  mm_step_param points[4];       /* one per factor                                                                 */
+  mm_step_param scales[4];       /* the factors' raw scale parameters (kind MM_EUCLIDEAN, dim 1, count 1;
+                                    .grad is ignored: the gradient is loss_out[1 + k])                             */
+  const void* target;            /* squared graph distances, pair-vector order [n(n-1)/2]                          */
+  void* loss_out;                /* [1 + nf]                                                                       */
+  void* ws;                      /* workspace of the embedding's objective kernel (mm_*_ws_bytes)                  */
+  int ws_flags;                  /* MM_WS_CLEAN when a product workspace is known to be clean                      */
+} mm_train_step;
+int mm_train_step_run(const mm_train_step* step, mm_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

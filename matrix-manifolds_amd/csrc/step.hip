@@ -1,0 +1,134 @@
+// One training step per call: the objective kernel of the embedding and the optimizer kernels of its parameters,
+// issued back to back from C++ (include/mm_manifolds.h, mm_train_step_run).  The reference's loop body
+// (graphembed/graphembed/train.py:198-222) is ~60 framework launches driven from Python; captured in a HIP graph
+// (graphembed/graphed.py) this package replays it as one launch, and for callers that cannot capture — the
+// reference's own eager loop — this entry point removes the ~15 foreign-function calls, tensor wrappers and
+// autograd nodes a step otherwise costs on the host (130-400 us of Python for 100 us of kernels).
+#include <hip/hip_runtime.h>
+
+#include "../../include/mm_manifolds.h"
+
+namespace {
+
+inline size_t esize(int dtype) { return dtype == MM_F64 ? 8 : 4; }
+
+int optimizer_step(int dtype, const mm_step_param& p, const void* grad, mm_stream_t st) {
+  if (!p.x || !grad || p.count <= 0) return p.count == 0 ? MM_OK : MM_ERR_ARG;
+  const bool spd = p.kind == MM_FACTOR_SPD;
+  if (p.optimizer == MM_OPT_RSGD) {
+    if (p.momentum == 0.0)
+      return spd ? mm_spd_rsgd_step(dtype, p.x, grad, p.count, p.dim, p.lr, p.max_grad_norm, p.exact, p.x, st)
+                 : mm_vec_rsgd_step(dtype, p.kind, p.x, grad, p.count, p.dim, p.lr, p.max_grad_norm, p.exact, p.x, st);
+    if (!p.state0) return MM_ERR_ARG;
+    return spd ? mm_spd_rsgd_momentum_step(dtype, p.x, grad, p.state0, p.count, p.dim, p.lr, p.momentum, p.dampening,
+                                           p.max_grad_norm, p.exact, p.x, st)
+               : mm_vec_rsgd_momentum_step(dtype, p.kind, p.x, grad, p.state0, p.count, p.dim, p.lr, p.momentum,
+                                           p.dampening, p.max_grad_norm, p.exact, p.x, st);
+  }
+  if (p.optimizer == MM_OPT_RADAM) {
+    if (!p.state0 || !p.state1 || !p.step || !p.ticket) return MM_ERR_ARG;
+    return spd ? mm_spd_radam_step(dtype, p.x, grad, p.state0, p.state1, p.step, p.ticket, p.count, p.dim, p.lr, p.beta1,
+                                   p.beta2, p.nc, p.adam_eps, p.max_grad_norm, p.exact, p.x, st)
+               : mm_vec_radam_step(dtype, p.kind, p.x, grad, p.state0, p.state1, p.step, p.ticket, p.count, p.dim, p.lr,
+                                   p.beta1, p.beta2, p.nc, p.adam_eps, p.max_grad_norm, p.exact, p.x, st);
+  }
+  return MM_ERR_ARG;
+}
+
+// parameters that can share one multi-parameter launch: same update rule and hyper-parameters, vector space
+bool same_rule(const mm_step_param& a, const mm_step_param& b) {
+  return a.optimizer == b.optimizer && a.lr == b.lr && a.max_grad_norm == b.max_grad_norm && a.exact == b.exact &&
+         a.momentum == b.momentum && a.beta1 == b.beta1 && a.beta2 == b.beta2 && a.nc == b.nc && a.adam_eps == b.adam_eps;
+}
+
+// all vector-space parameters of `ps` (with gradients gs) that share a rule go out in one launch
+int vector_group_step(int dtype, const mm_step_param* const* ps, const void* const* gs, int count, mm_stream_t st) {
+  if (count == 1) return optimizer_step(dtype, *ps[0], gs[0], st);
+  int kinds[8], ms[8];
+  const void* xs[8];
+  const void* gr[8];
+  void* xn[8];
+  void* m0[8];
+  void* m1[8];
+  double* steps[8];
+  unsigned* tickets[8];
+  int64_t cnts[8];
+  for (int t = 0; t < count; ++t) {
+    const mm_step_param& p = *ps[t];
+    kinds[t] = p.kind; ms[t] = p.dim; xs[t] = p.x; gr[t] = gs[t]; xn[t] = p.x; cnts[t] = p.count;
+    m0[t] = p.state0; m1[t] = p.state1; steps[t] = p.step; tickets[t] = p.ticket;
+  }
+  const mm_step_param& p = *ps[0];
+  if (p.optimizer == MM_OPT_RSGD)
+    return mm_vec_rsgd_step_multi(dtype, count, kinds, xs, gr, cnts, ms, p.lr, p.max_grad_norm, p.exact, xn, st);
+  return mm_vec_radam_step_multi(dtype, count, kinds, xs, gr, m0, m1, steps, tickets, cnts, ms, p.lr, p.beta1, p.beta2, p.nc,
+                                 p.adam_eps, p.max_grad_norm, p.exact, xn, st);
+}
+
+}  // namespace
+
+extern "C" int mm_train_step_run(const mm_train_step* s, mm_stream_t st) {
+  if (!s || s->nf < 1 || s->nf > 4 || !s->loss_out || !s->target || s->n < 0) return MM_ERR_ARG;
+  if (s->dtype != MM_F32 && s->dtype != MM_F64) return MM_ERR_ARG;
+  const int nf = s->nf;
+  int rc;
+  // ---- objective and gradients
+  if (nf == 1) {
+    const mm_step_param& p = s->points[0];
+    if (!p.x || !p.grad) return MM_ERR_ARG;
+    if (p.kind == MM_FACTOR_SPD)
+      rc = mm_spd_pdist_loss(s->dtype, s->loss_kind, p.x, s->target, s->scales[0].x, s->n, p.dim, 0, s->n, s->alpha, s->eps,
+                             s->terms, s->loss_params, s->wmin, s->wmax, s->loss_out, p.grad, s->ws, 0, st);
+    else
+      rc = mm_vec_pdist_loss(s->dtype, p.kind, s->loss_kind, p.x, s->target, s->scales[0].x, s->n, p.dim, 0, s->n, s->alpha,
+                             s->eps, s->terms, s->loss_params, s->loss_out, p.grad, s->ws, st);
+  } else {
+    int kinds[4], dims[4];
+    const void* xs[4];
+    const void* sc[4];
+    void* grads[4];
+    for (int k = 0; k < nf; ++k) {
+      kinds[k] = s->points[k].kind; dims[k] = s->points[k].dim; xs[k] = s->points[k].x; sc[k] = s->scales[k].x;
+      grads[k] = s->points[k].grad;
+      if (!xs[k] || !grads[k]) return MM_ERR_ARG;
+    }
+    rc = mm_product_pairs_loss(s->dtype, s->loss_kind, nf, kinds, dims, xs, sc, s->target, s->n, 0, s->n, s->alpha, s->eps,
+                               s->terms, s->loss_params, s->wmin, s->wmax, grads, s->loss_out, s->ws, s->ws_flags, st);
+  }
+  if (rc != MM_OK) return rc;
+  // ---- optimizer: SPD points one launch each; vector-space parameters (points and scales) grouped by rule
+  const mm_step_param* vec[8];
+  const void* vgrad[8];
+  int nv = 0;
+  for (int k = 0; k < nf; ++k) {
+    const mm_step_param& p = s->points[k];
+    if (p.kind == MM_FACTOR_SPD) {
+      rc = optimizer_step(s->dtype, p, p.grad, st);
+      if (rc != MM_OK) return rc;
+    } else {
+      vec[nv] = &p; vgrad[nv++] = p.grad;
+    }
+  }
+  for (int k = 0; k < nf; ++k) {
+    const mm_step_param& q = s->scales[k];
+    if (!q.x) continue;   // a factor without a trainable scale
+    vec[nv] = &q;
+    vgrad[nv++] = static_cast<const char*>(s->loss_out) + size_t(1 + k) * esize(s->dtype);
+  }
+  bool done[8] = {false, false, false, false, false, false, false, false};
+  const int most = mm_vec_rsgd_multi_max();
+  for (int a = 0; a < nv; ++a) {
+    if (done[a]) continue;
+    const mm_step_param* grp[8];
+    const void* gg[8];
+    int cnt = 0;
+    const bool multi_ok = vec[a]->optimizer == MM_OPT_RADAM || vec[a]->momentum == 0.0;   // (no multi heavy-ball kernel)
+    for (int b = a; b < nv && cnt < most; ++b)
+      if (!done[b] && (b == a || (multi_ok && same_rule(*vec[a], *vec[b])))) {
+        grp[cnt] = vec[b]; gg[cnt++] = vgrad[b]; done[b] = true;
+      }
+    rc = vector_group_step(s->dtype, grp, gg, cnt, st);
+    if (rc != MM_OK) return rc;
+  }
+  return MM_OK;
+}

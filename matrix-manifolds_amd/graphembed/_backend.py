@@ -44,6 +44,7 @@ SIGNATURES = {
                                     _vp, _i64, _i64, _i64, _dbl, _dbl, _i, _vp, _dbl, _dbl, _c.POINTER(_vp), _vp, _vp,
                                     _i, _vp]),
     'mm_spd_prepare': (_i, [_i, _vp, _i64, _i, _vp, _vp]),
+    'mm_train_step_run': (_i, [_vp, _vp]),
     'mm_vec_rsgd_multi_max': (_i, []),
     'mm_vec_rsgd_step_multi': (_i, [_i, _i, _c.POINTER(_i), _c.POINTER(_vp), _c.POINTER(_vp), _c.POINTER(_i64),
                                      _c.POINTER(_i), _dbl, _dbl, _i, _c.POINTER(_vp), _vp]),

@@ -1,0 +1,207 @@
+"""A full-batch training step issued by ONE call into the HIP library (`mm_train_step_run`, csrc/step.hip): the fused
+objective kernel of the embedding followed by the fused optimizer kernels of all its parameters.
+
+The reference's loop body (graphembed/graphembed/train.py:198-222)
+
+    loss = objective(None, epoch=epoch, alpha=alpha); optimizer.zero_grad(); loss.backward(); optimizer.step()
+
+costs 130-400 us of Python per step on this package's classes (tensor wrappers, autograd nodes, ~15 foreign-function
+calls) for ~100 us of kernels.  Callers that replay a captured HIP graph (`graphembed.graphed.GraphedTrainStep`) do
+not pay that; callers that cannot capture — changing shapes, host logic between steps, debuggers — use this:
+
+    step = NativeTrainStep(embedding, objective_fn, targets, [opt_points, opt_scales])
+    for epoch in range(n_epochs):
+        loss = step(epoch=epoch, alpha=1.0)      # device scalar, the loss before the update
+
+The optimizers stay the owners of hyper-parameters and state (learning-rate schedulers, `state_dict`, momentum buffers
+and Adam moments are the optimizers' own tensors); `p.grad` of every parameter is a persistent buffer that the step
+overwrites.  Supported: what the fused objective kernels support — one SPD or vector factor, or a product of up to
+three vector factors (dimension <= 16) and one SPD(2)/SPD(3) factor — with StressLoss / QuotientLoss, RiemannianSGD
+(with or without momentum) and RiemannianAdam.  Anything else raises `ValueError` at construction."""
+import ctypes
+
+import torch
+
+from graphembed import _backend as B
+
+_c = ctypes
+
+
+class _StepParam(_c.Structure):
+    _fields_ = [('kind', _c.c_int), ('dim', _c.c_int), ('count', _c.c_int64), ('x', _c.c_void_p), ('grad', _c.c_void_p),
+                ('optimizer', _c.c_int), ('lr', _c.c_double), ('momentum', _c.c_double), ('dampening', _c.c_double),
+                ('max_grad_norm', _c.c_double), ('beta1', _c.c_double), ('beta2', _c.c_double), ('adam_eps', _c.c_double),
+                ('nc', _c.c_int), ('exact', _c.c_int), ('state0', _c.c_void_p), ('state1', _c.c_void_p),
+                ('step', _c.c_void_p), ('ticket', _c.c_void_p)]
+
+
+class _TrainStep(_c.Structure):
+    _fields_ = [('dtype', _c.c_int), ('loss_kind', _c.c_int), ('terms', _c.c_int), ('alpha', _c.c_double),
+                ('eps', _c.c_double), ('loss_params', _c.c_void_p), ('wmin', _c.c_double), ('wmax', _c.c_double),
+                ('n', _c.c_int64), ('nf', _c.c_int), ('points', _StepParam * 4), ('scales', _StepParam * 4),
+                ('target', _c.c_void_p), ('loss_out', _c.c_void_p), ('ws', _c.c_void_p), ('ws_flags', _c.c_int)]
+
+
+OPT_RSGD, OPT_RADAM = 0, 1
+
+
+def _factor_of(man):
+    """(kind, dim) of a manifold for the C ABI."""
+    from graphembed.manifolds.vector import VectorManifold
+    if isinstance(man, VectorManifold):
+        return man._kind, man._m
+    if hasattr(man, 'wmin') and hasattr(man, 'n') and not getattr(man, 'use_stein_div', False):
+        return B.FACTOR_SPD, man.n
+    raise ValueError(f'no fused training step for {man}')
+
+
+class NativeTrainStep:
+
+    def __init__(self, embedding, objective_fn, targets, optimizers):
+        from graphembed.modules import _pair_kernel_factors
+        from graphembed.optim import RiemannianAdam, RiemannianSGD
+        if not hasattr(objective_fn, 'fused_spec'):
+            raise ValueError(f'{objective_fn} has no fused objective kernel')
+        xs, scales = list(embedding.xs), list(embedding.scales)
+        if not xs or not all(x.is_cuda for x in xs):
+            raise ValueError('NativeTrainStep needs the embedding in GPU memory')
+        k = len(xs)
+        dtype, dev = xs[0].dtype, xs[0].device
+        if dtype not in (torch.float32, torch.float64) or any(p.dtype != dtype or not p.is_contiguous() for p in xs + scales):
+            raise ValueError('parameters must be contiguous tensors of one floating-point dtype')
+        factors = [_factor_of(m) for m in embedding.manifolds]
+        if k > 1:
+            if k > 4 or _pair_kernel_factors(embedding.manifolds) is None:
+                raise ValueError('products are served by the mixed-manifold pair kernel only: at most three vector '
+                                 'factors of dimension <= 16 and one SPD(2) / SPD(3) factor')
+        else:
+            kind, dim = factors[0]
+            cap = B.lib().raw('mm_spd_max_dim')() if kind == B.FACTOR_SPD else B.lib().raw('mm_vec_max_dim')()
+            if dim > cap:
+                raise ValueError(f'dimension {dim} exceeds the kernels\' range ({cap})')
+        n = xs[0].shape[0]
+        npairs = n * (n - 1) // 2
+        if targets.numel() != npairs:
+            raise ValueError(f'targets has {targets.numel()} entries, the embedding has {npairs} pairs')
+        self.embedding, self.objective_fn, self.optimizers = embedding, objective_fn, list(optimizers)
+        self.n, self.k, self.dtype, self.device = n, k, dtype, dev
+        self._opt_of = {}
+        for o in self.optimizers:
+            if not isinstance(o, (RiemannianSGD, RiemannianAdam)):
+                raise ValueError(f'{type(o).__name__}: only RiemannianSGD / RiemannianAdam have fused update kernels')
+            for g in o.param_groups:
+                for p in g['params']:
+                    self._opt_of[id(p)] = (o, g)
+        lib = B.lib()
+        dt = B.dtype_code(xs[0])
+        with B.on_device(dev):
+            self.target = targets.detach().to(device=dev, dtype=dtype).contiguous()
+            self.loss_out = torch.zeros(1 + k, dtype=dtype, device=dev)
+            self.grads = [torch.zeros_like(x) for x in xs]
+            kinds = (_c.c_int * k)(*[f[0] for f in factors])
+            dims = (_c.c_int * k)(*[f[1] for f in factors])
+            if k > 1:
+                nbytes = lib.raw('mm_product_pairs_ws_bytes')(dt, k, kinds, dims, n)
+            elif factors[0][0] == B.FACTOR_SPD:
+                nbytes = lib.raw('mm_spd_pdist_ws_bytes')(dt, n, factors[0][1])
+            else:
+                nbytes = lib.raw('mm_vec_pdist_ws_bytes')(dt, n, factors[0][1])
+            self.ws = torch.zeros(max(int(nbytes), 64), dtype=torch.uint8, device=dev)
+        for x, g in zip(xs, self.grads):
+            x.grad = g                                        # persistent: the step overwrites it
+        for i, s in enumerate(scales):
+            s.grad = self.loss_out[1 + i].view(s.shape)        # the scale gradients live in loss_out
+        self._desc = d = _TrainStep()
+        d.dtype, d.n, d.nf = dt, n, k
+        d.wmin, d.wmax = 1e-8, 1e8
+        for man in embedding.manifolds:
+            if hasattr(man, 'wmin'):
+                d.wmin, d.wmax = man.wmin, man.wmax
+        d.target, d.loss_out, d.ws = self.target.data_ptr(), self.loss_out.data_ptr(), self.ws.data_ptr()
+        d.ws_flags = 0
+        for i, (x, f) in enumerate(zip(xs, factors)):
+            q = d.points[i]
+            q.kind, q.dim, q.count, q.x, q.grad = f[0], f[1], n, x.data_ptr(), self.grads[i].data_ptr()
+        for i, s in enumerate(scales):
+            q = d.scales[i]
+            q.kind, q.dim, q.count = B.EUCLIDEAN, 1, 1
+            q.x = s.data_ptr()
+            q.grad = None
+        self._keep = []     # optimizer state tensors referenced by the descriptor
+        self._params = xs + scales
+        self._slots = [d.points[i] for i in range(k)] + [d.scales[i] for i in range(k)]
+        self._trainable_scale = [True] * k
+
+    # ------------------------------------------------------------------------------------------------------------
+    def _bind_optimizer(self, p, q):
+        """Hyper-parameters (read every step: schedulers change them) and state pointers of parameter `p`."""
+        from graphembed.optim import RiemannianAdam
+        from graphembed.utils import EPS
+        entry = self._opt_of.get(id(p))
+        if entry is None or not p.requires_grad:
+            return False
+        o, g = entry
+        clip = g['max_grad_norm']
+        q.lr, q.max_grad_norm, q.exact = float(g['lr']), (-1.0 if clip is None else float(clip)), int(bool(g['exact']))
+        if isinstance(o, RiemannianAdam):
+            m, v, t = o._moments(p)
+            ticket = o._ticket(p)
+            q.optimizer = OPT_RADAM
+            q.beta1 = float(g['betas'][0])
+            q.beta2 = float(g['betas'][1] if g['betas'][1] is not None else 0.0)
+            q.nc, q.adam_eps = int(bool(g['nc'])), float(EPS[p.dtype])
+            q.state0, q.state1, q.step, q.ticket = m.data_ptr(), v.data_ptr(), t.data_ptr(), ticket.data_ptr()
+        else:
+            q.optimizer = OPT_RSGD
+            q.momentum, q.dampening = float(g['momentum']), float(g['dampening'])
+            if g['momentum'] != 0:
+                st = o.state[p]
+                if 'momentum_buffer' not in st:
+                    # the reference starts the buffer as a clone of the first EUCLIDEAN gradient (rsgd.py:53-54):
+                    # that gradient exists only after the objective of this step — the first step runs unfused
+                    return None
+                q.state0 = st['momentum_buffer'].data_ptr()
+            else:
+                q.state0 = None
+        return True
+
+    def __call__(self, **objective_kwargs):
+        spec = self.objective_fn.fused_spec(**objective_kwargs)
+        d = self._desc
+        d.loss_kind = B.LOSS_STRESS if spec[0] == 'stress' else B.LOSS_QUOTIENT
+        d.alpha, d.eps, d.terms = float(spec[1]), float(spec[2]), int(spec[3])
+        dyn = spec[4] if len(spec) > 4 else None
+        d.loss_params = None if dyn is None else B.dyn_ptr(dyn, self.target).value
+        need_first = False
+        for i, (p, q) in enumerate(zip(self._params, self._slots)):
+            q.x = p.data_ptr()              # (an eager optimizer step in between rebinds the parameter's storage)
+            ok = self._bind_optimizer(p, q)
+            if ok is None:
+                need_first = True
+            elif ok is False:
+                if i < self.k:
+                    raise ValueError('every point parameter needs an optimizer')
+                q.x = p.data_ptr()          # a frozen scale (burn-in): read by the objective, not stepped
+                q.optimizer, q.lr = OPT_RSGD, 0.0
+                q.momentum, q.state0, q.max_grad_norm = 0.0, None, -1.0
+        if need_first:
+            return self._first_step_unfused(**objective_kwargs)
+        with B.on_device(self.device):
+            B.lib().call('mm_train_step_run', ctypes.byref(d), B.stream_of(self.target))
+        if self.k > 1:
+            d.ws_flags = B.WS_CLEAN      # the pair kernel leaves its workspace clean
+        return self.loss_out[0]
+
+    def _first_step_unfused(self, **objective_kwargs):
+        """First step of a heavy-ball RSGD: the momentum buffers do not exist yet — run it through the optimizers."""
+        loss = self.embedding.fused_objective(self.objective_fn, self.target, None, **objective_kwargs)
+        for o in self.optimizers:
+            o.zero_grad(set_to_none=True)
+        loss.backward()
+        for o in self.optimizers:
+            o.step()
+        for x, g in zip(self.embedding.xs, self.grads):
+            x.grad = g
+        for i, s in enumerate(self.embedding.scales):
+            s.grad = self.loss_out[1 + i].view(s.shape)
+        return loss.detach()

@@ -156,3 +156,128 @@ def test_fuzz_slice(script, argv, monkeypatch, capsys):
     finally:
         torch.set_default_dtype(dtype)
     assert 'ok' in capsys.readouterr().out
+
+
+# ------------------------------------------------------------------ one C-ABI call per training step
+@pytest.mark.parametrize('case', ['spd3_rsgd', 'lorentz11_adam', 'product_momentum', 'spd4_adam_f32'])
+def test_native_train_step_matches_eager_loop(case):
+    """`NativeTrainStep` (mm_train_step_run: objective + optimizer kernels issued from C++) advances the parameters,
+    the optimizer state and the losses exactly like the eager loop of train.py:198-222 on the same classes."""
+    import copy
+    from graphembed import manifolds as M
+    from graphembed.modules import ManifoldEmbedding
+    from graphembed.native_step import NativeTrainStep
+    from graphembed.objectives import QuotientLoss, StressLoss
+    from graphembed.optim import RiemannianAdam, RiemannianSGD
+    dt = torch.float32 if case.endswith('f32') else torch.float64
+    mk = {'spd3_rsgd': lambda: [M.SymmetricPositiveDefinite(3)], 'lorentz11_adam': lambda: [M.Lorentz(11)],
+          'product_momentum': lambda: [M.Lorentz(6), M.Sphere(6), M.SymmetricPositiveDefinite(2)],
+          'spd4_adam_f32': lambda: [M.SymmetricPositiveDefinite(4)]}[case]
+    n = 150
+    torch.set_default_dtype(dt)
+    try:
+        torch.manual_seed(3)
+        with torch.device('cuda'):
+            emb_a = ManifoldEmbedding(n, mk())
+            with torch.no_grad():
+                emb_a.perturb(0.3)
+            target = torch.rand(n * (n - 1) // 2) * 0.9 + 0.05
+        emb_b = copy.deepcopy(emb_a)
+        fn = QuotientLoss() if 'adam' in case else StressLoss()
+
+        def opts(emb):
+            if 'adam' in case:
+                return [RiemannianAdam(list(emb.xs), lr=1e-2, exact=True, max_grad_norm=20),
+                        RiemannianAdam(list(emb.scales), lr=1e-3, max_grad_norm=500)]
+            mom = 0.9 if 'momentum' in case else 0
+            return [RiemannianSGD(list(emb.xs), lr=0.01, momentum=mom, dampening=0.1 if mom else 0, exact=True, max_grad_norm=20),
+                    RiemannianSGD(list(emb.scales), lr=1e-4, max_grad_norm=500)]
+        oa, ob = opts(emb_a), opts(emb_b)
+        la, lb = [], []
+        for epoch in range(6):               # eager reference loop
+            loss = emb_a.fused_objective(fn, target, None, epoch=epoch, alpha=1.0)
+            for o in oa:
+                o.zero_grad(set_to_none=True)
+            loss.backward()
+            for o in oa:
+                o.step()
+            la.append(loss.item())
+        step = NativeTrainStep(emb_b, fn, target, ob)
+        lib, calls = step and __import__('graphembed')._backend.lib(), []
+        orig = lib.call
+        lib.call = lambda name, *a: (calls.append(name), orig(name, *a))[1]
+        try:
+            for epoch in range(6):
+                lb.append(step(epoch=epoch, alpha=1.0).item())
+        finally:
+            del lib.call
+        if 'momentum' not in case:
+            assert calls == ['mm_train_step_run'] * 6, calls
+        else:   # the first heavy-ball step creates the buffers through the optimizers
+            assert calls.count('mm_train_step_run') == 5, calls
+        tol = 1e-4 if dt == torch.float32 else 1e-10
+        np.testing.assert_allclose(lb, la, rtol=tol)
+        for a, b in zip(list(emb_a.xs) + list(emb_a.scales), list(emb_b.xs) + list(emb_b.scales)):
+            np.testing.assert_allclose(b.detach().cpu().numpy(), a.detach().cpu().numpy(), rtol=tol * 10, atol=tol)
+        # frozen scales (burn-in, modules.py:36-39): read by the objective, not stepped
+        emb_b.burnin(True)
+        before = [s.detach().clone() for s in emb_b.scales]
+        step(epoch=6, alpha=1.0)
+        for s, s0 in zip(emb_b.scales, before):
+            assert torch.equal(s.detach(), s0)
+    finally:
+        torch.set_default_dtype(torch.float32)
+
+
+def test_native_train_step_host_cost():
+    """The point of the entry point: an eager (un-captured) training step whose host side is one call.  Wall time per
+    step of the native step within 1.35x of the replayed graph's, where the Python-driven eager loop is several times
+    slower (SPD(3), n = 2000: the kernels are ~25 us)."""
+    import copy
+    import time
+    from graphembed import manifolds as M
+    from graphembed.graphed import GraphedTrainStep
+    from graphembed.modules import ManifoldEmbedding
+    from graphembed.native_step import NativeTrainStep
+    from graphembed.objectives import StressLoss
+    from graphembed.optim import RiemannianSGD
+    n = 2000
+    torch.manual_seed(0)
+    with torch.device('cuda'):
+        emb = ManifoldEmbedding(n, [M.SymmetricPositiveDefinite(3)])
+        target = torch.rand(n * (n - 1) // 2) * 0.9 + 0.05
+    fn = StressLoss()
+
+    def opts(e):
+        return [RiemannianSGD(list(e.xs), lr=1e-3, exact=True, max_grad_norm=20), RiemannianSGD(list(e.scales), lr=1e-4, max_grad_norm=500)]
+
+    def timed(f, k=200):
+        for _ in range(20):
+            f()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(k):
+            f()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / k * 1e6
+    e1, e2, e3 = emb, copy.deepcopy(emb), copy.deepcopy(emb)
+    o1 = opts(e1)
+
+    def eager():
+        loss = e1.fused_objective(fn, target, None)
+        for o in o1:
+            o.zero_grad(set_to_none=True)
+        loss.backward()
+        for o in o1:
+            o.step()
+    t_eager = timed(eager)
+    native = NativeTrainStep(e2, fn, target, opts(e2))
+    t_native = timed(lambda: native())
+    graphed = GraphedTrainStep(lambda: e3.fused_objective(fn, target, None), opts(e3)).capture()
+    t_graph = timed(lambda: graphed())
+    print(f'step wall us: eager {t_eager:.1f}  native {t_native:.1f}  graph replay {t_graph:.1f}')
+    os.makedirs(os.path.join(ROOT, 'gpurun_out'), exist_ok=True)
+    with open(os.path.join(ROOT, 'gpurun_out', 'native_step_host_cost.json'), 'w') as f:
+        json.dump({'n': n, 'eager_us': t_eager, 'native_us': t_native, 'graph_us': t_graph}, f)
+    assert t_native <= 1.35 * t_graph + 5.0, (t_native, t_graph)
+    assert t_native < t_eager

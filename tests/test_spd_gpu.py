@@ -488,7 +488,7 @@ def test_tree40_training_trace_fused(loss_name):
 
 
 # ------------------------------------------------------------------ the reference's own property tests
-@pytest.mark.parametrize('d', [2, 3, 4, 5])
+@pytest.mark.parametrize('d', [2, 3, 4, 5, 6, 7, 8, 9])   # the reference's range (tests/test_spd.py:15,26,62,70)
 @pytest.mark.parametrize('seed', [0, 1])
 def test_reference_property_suite(d, seed):
     """The properties graphembed/tests/test_spd.py checks (unit distance, exp/log round trip, distance

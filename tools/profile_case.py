@@ -1,0 +1,30 @@
+#!/usr/bin/env python3
+"""One workload of bench.py, alone in a process, for rocprofv3 (kernel names do not carry n):
+    python3 tools/profile_case.py pdist D N f32|f64 IR [steps]      # SPD(D).pdist fwd + bwd, ||log X|| = IR
+    python3 tools/profile_case.py loss  D N f32|f64 [steps]         # fused QuotientLoss step (BASELINE config 5)"""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, 'matrix-manifolds_amd')):
+    sys.path.insert(0, p)
+import torch  # noqa: E402
+import bench  # noqa: E402
+
+
+def main():
+    kind, d, n, dt = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), {'f32': torch.float32, 'f64': torch.float64}[sys.argv[4]]
+    dev = torch.device('cuda', 0)
+    if kind == 'pdist':
+        wl = bench.PdistWorkload(d, n, dt, float(sys.argv[5]), 1, 0, dev)
+        steps = int(sys.argv[6]) if len(sys.argv) > 6 else 10
+    else:
+        wl = bench.FusedLossWorkload(d, n, dt, 1, 0, dev)
+        steps = int(sys.argv[5]) if len(sys.argv) > 5 else 10
+    for _ in range(steps):
+        wl.kernels()
+    torch.cuda.synchronize()
+
+
+if __name__ == '__main__':
+    main()

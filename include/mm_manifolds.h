@@ -362,14 +362,22 @@ int mm_graph_average_precision(int dtype, const void* dist, int64_t n, const int
 
 /* Layer-wise F1 scores of the embedding's ordering against the shortest-path trees of the graph —
  * FastPrecision::LayerMeanF1Scores / LayerMeanAverageF1Scores (pyx/impl/precision.cpp:300-429), unweighted
- * graphs.  order [n,n] int32: row u = all nodes sorted by embedding distance to u (stable: ties by node id);
- * hops [n,n] int32 hop distances; indptr CSR row pointers (degrees, for the min/max filter);
+ * AND weighted graphs.  order [n,n] int32: row u = all nodes sorted by embedding distance to u (stable: ties by node id);
+ * hops [n,n] int32: the LAYER of v in the shortest-path tree rooted at u = the dense rank of the graph distance d(u,v)
+ * among the distinct distances from u (precision.cpp:150-166; for unweighted graphs that is the hop distance); indptr CSR row pointers (degrees, for the min/max filter);
  * num_layers = diameter + 1 (<= 2048).  ACCUMULATES into the device arrays m1, m2, counts (double[num_layers-1],
  * zeroed by the caller): per layer the sum of F1, of F1^2 and the number of terms (per_tree_average = 0), or
  * the same over per-tree layer means (per_tree_average = 1). */
 int mm_graph_layer_f1(const int* order, const int* hops, int64_t n, const int* indptr, int min_degree,
                       int max_degree, int per_tree_average, int num_layers, double* m1, double* m2,
                       double* counts, mm_stream_t stream);
+
+/* Row-wise stable argsort of the dense embedding-distance matrix: order[u][k] = the node with the k-th smallest
+ * distance to u, ties in node order (SortNodeDists, pyx/impl/precision.cpp:107-121) — the input of mm_graph_layer_f1.
+ * dist [n,n] (device), order int32 [n,n], ws of mm_graph_sort_rows_ws_bytes bytes; n <= 46340. */
+size_t mm_graph_sort_rows_ws_bytes(int dtype, int64_t n);
+int mm_graph_sort_rows(int dtype, const void* dist, int64_t n, int* order, void* ws, size_t ws_bytes,
+                       mm_stream_t stream);
 
 /* ---- one training step per call ------------------------------------------------ */
 /* The body of the reference's training loop for one full batch (graphembed/graphembed/train.py:198-222:

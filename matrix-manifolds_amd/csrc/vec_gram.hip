@@ -386,6 +386,242 @@ void vec_gram_bwd_f32_kernel(const float* __restrict__ x, const float* __restric
   }
 }
 
+
+// ------------------------------------------------------------------ backward, symmetric tiles (fp32)
+// Every UNORDERED 32 x 32 tile of the pair matrix is visited once: its W = g * dout/dq(Q) feeds BOTH gradient
+// blocks, ACC_J += W^T X_I (the accumulator is the A operand as it lies, as above) and ACC_I += W X_J (W turned
+// through a 32 x 33 LDS tile into the A-operand layout).  Against the ordered-tile kernel above this halves the reads
+// of g (its mirrored tile re-read every upstream gradient, transposed through LDS), the Gram products and — the
+// vector-ALU bulk of the kernel — the evaluations of dout/dq (acosh / acos derivatives: sqrt, log, rcp per pair).
+// One of the two output blocks of a tile can stay in accumulator registers along a walk, the other cannot, so a
+// workgroup owns a SUPER-TILE of 4 x 4 tiles (128 rows x 128 columns): wavefront w keeps ACC_J of column block w in
+// registers, the four row blocks' ACC_I live in LDS (16 KB), and at step t wavefront w works on tile
+// (row block (w + t) mod 4, column block w) — the four wavefronts always add into four different row blocks, so
+// the LDS accumulation needs no atomics, only a barrier between steps.  Both accumulators leave once per
+// super-tile as contiguous 32 x m float atomics.  Super-tiles on the diagonal run their 10 upper tiles.
+// Variants measured and dropped (n = 4039, m = 11, this kernel 36.8 us): requesting the next step's operands before the
+// current step computes (176 VGPRs, 2 wavefronts per SIMD: 43.5 us); 2 x 4 super-tiles with a private LDS accumulator
+// set per wavefront and no barrier (twice the workgroups, half the tiles each: 53 us); LDS float atomics on one shared
+// accumulator set (100 us).
+template <int KIND, int KS, int LOSS>
+__global__ __launch_bounds__(64 * kGramBwdWaves) __attribute__((amdgpu_waves_per_eu(MM_GRAM_BWD_MIN_WAVES)))
+void vec_gram_bwd_sym_f32_kernel(const float* __restrict__ x, const float* __restrict__ g, int n, int m, int row_begin,
+                                 int row_end, int squared, float* __restrict__ grad, LossArgs<float> la) {
+  __shared__ float sT[kGramBwdWaves][32][33];     // per-wavefront transpose tile
+  __shared__ float accI[kGramBwdWaves][32][32];   // row-side accumulators of the super-tile's four row blocks
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int r = lane & 31, h = lane >> 5;
+  using u32 = unsigned int;
+  // super-tile (A, B), A <= B, from the linear workgroup index: id = B (B + 1) / 2 + A
+  const int id = blockIdx.x;
+  int Bs = int((__builtin_sqrtf(8.f * float(id) + 1.f) - 1.f) * 0.5f);
+  while (Bs * (Bs + 1) / 2 > id) --Bs;
+  while ((Bs + 1) * (Bs + 2) / 2 <= id) ++Bs;
+  const int As = id - Bs * (Bs + 1) / 2;
+  const int nT = (n + 31) / 32;
+  if (As * 128 >= row_end || As * 128 + 127 < row_begin) return;   // no pair of this super-tile has its row in the shard
+  constexpr bool kEuclid = KIND == MM_EUCLIDEAN;
+  const int rc = r < m ? r : m - 1;
+  const int jb = Bs * 4 + wave, J = jb * 32;   // this wavefront's column block
+  const bool j_live = jb < nT;                  // (ragged last super-tile)
+  float bJ[KS];      // B operand of the Gram: x[J + r][2 s + h]
+  float xJ[16];      // B operand of W X_J: rows J + 2 s + h, lane = feature
+  {
+    const int jr = J + r;
+    const u32 xb = u32(jr < n ? jr : n - 1) * u32(m);
+    if constexpr (!kEuclid) {
+#pragma unroll
+      for (int s = 0; s < KS; ++s) {
+        const int k = 2 * s + h;
+        const float v = x[xb + u32(k < m ? k : m - 1)];
+        bJ[s] = (jr < n && k < m) ? v : 0.f;
+      }
+    }
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+      const int jj = J + 2 * s + h;
+      const float v = x[u32(jj < n ? jj : n - 1) * u32(m) + u32(rc)];
+      xJ[s] = (jj < n && r < m) ? v : 0.f;
+      if (kEuclid && r == m) xJ[s] = jj < n ? 1.f : 0.f;   // ones column: row sums of W
+    }
+  }
+  f32x16 accJ;
+#pragma unroll
+  for (int q = 0; q < 16; ++q) accJ[q] = 0.f;
+  for (int e = threadIdx.x; e < kGramBwdWaves * 32 * 32; e += 64 * kGramBwdWaves) (&accI[0][0][0])[e] = 0.f;
+  float sp = 1.f, loss_acc = 0.f, ds_acc = 0.f;
+  loss_resolve<float, LOSS>(la);
+  if constexpr (LOSS != MM_LOSS_NONE) sp = softplus_of(la.scale_raw);
+  const float kInvalid = LOSS != MM_LOSS_NONE ? __builtin_nanf("") : 0.f;
+  const u32 base = u32(gpair_off(n, row_begin));
+  const u32 gmax = u32(gpair_off(n, row_end)) - base - 1u;  // last valid index of this shard's slice
+  __syncthreads();
+  for (int t = 0; t < 4; ++t) {
+    const int a = (wave + t) & 3;          // row block of this step (distinct per wavefront)
+    const int ib = As * 4 + a, I = ib * 32;
+    const bool live = j_live && ib < nT && ib <= jb;   // wave-uniform; below-diagonal tiles belong to their mirror
+    if (live) {
+      const bool diag = ib == jb;
+      // ---- loads: upstream gradients in accumulator layout, Gram A operand (rows of X_I), B operand of W^T X_I
+      float gr[16], xa[KS], bI[16];
+      if (!diag) {   // pair (i, j) lies in row i of the pair vector, contiguous in j
+        const int col = J + r < n ? J + r : n - 1;
+        int row = I + 4 * h;
+        u32 o = u32(row) * u32(2 * n - row - 1) / 2u - base + u32(col - row - 1);
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+          gr[s] = g[o > gmax ? gmax : o];   // (clamp: ragged edges and rows outside the shard, masked at use)
+          const int step = (s & 3) == 3 ? 5 : 1;
+#pragma unroll
+          for (int d = 0; d < 5; ++d)
+            if (d < step) { o += u32(n - row - 2); ++row; }
+        }
+      } else {
+        const int j = J + r;
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+          const int i = I + mfma_row(s, h);
+          const int lo = i < j ? i : j, hi = i < j ? j : i;
+          const int hc = hi < n ? (hi > lo ? hi : lo + 1) : n - 1;
+          const u32 o = u32(lo) * u32(2 * n - lo - 1) / 2u - base + u32(hc - lo - 1);
+          gr[s] = g[o > gmax ? gmax : o];
+        }
+      }
+      if constexpr (!kEuclid) {
+        const int ia = I + r;
+        const u32 xo = u32(ia < n ? ia : n - 1) * u32(m);
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+          const int k = 2 * s + h;
+          xa[s] = x[xo + u32(k < m ? k : m - 1)];
+        }
+      }
+      {
+        const u32 xlast = u32(n - 1) * u32(m) + u32(rc);
+        u32 xo = u32(I + 4 * h) * u32(m) + u32(rc);
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+          bI[s] = x[xo < xlast ? xo : xlast];
+          xo += u32((s & 3) == 3 ? 5 : 1) * u32(m);
+        }
+      }
+      // ---- validity: each unordered pair once (i < j), inside the matrix, row inside the shard
+      const bool interior = !diag && I + 32 <= n && J + 32 <= n && I >= row_begin && I + 32 <= row_end;
+      float gv[16];
+      if (__builtin_expect(interior, 1)) {
+#pragma unroll
+        for (int s = 0; s < 16; ++s) gv[s] = gr[s];
+      } else {
+        const int j = J + r;
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+          const int i = I + mfma_row(s, h);
+          const bool valid = i < j && j < n && i >= row_begin && i < row_end;
+          gv[s] = valid ? gr[s] : kInvalid;
+        }
+      }
+      // ---- 1. Gram tile
+      f32x16 q;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) q[k] = 0.f;
+      if constexpr (!kEuclid) {
+        const bool ia_ok = I + r < n;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+          const int k = 2 * s + h;
+          float av = (ia_ok && k < m) ? xa[s] : 0.f;
+          if (KIND == MM_LORENTZ && k != 0) av = -av;
+          q = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bJ[s], q, 0, 0, 0);
+        }
+      }
+      // ---- 2. w = g * dout/dq(Q) on the accumulator registers
+      float w[16];
+#pragma unroll
+      for (int s = 0; s < 16; ++s) {
+        if constexpr (kEuclid) {
+          w[s] = gv[s];
+        } else if constexpr (LOSS == MM_LOSS_NONE) {
+          w[s] = gv[s] * PairFn<float, KIND>::dq(q[s], squared);
+        } else {
+          const bool ok = gv[s] == gv[s];
+          const float d2 = PairFn<float, KIND>::value(q[s], 1);
+          float dldm;
+          const float l = loss_term<float, LOSS>(sp * d2, gv[s], la, dldm);
+          loss_acc += ok ? l : 0.f;
+          ds_acc += ok ? dldm * d2 : 0.f;
+          w[s] = ok ? dldm * sp * PairFn<float, KIND>::dq(q[s], 1) : 0.f;
+        }
+      }
+      // ---- 3. ACC_J += W^T X_I (the accumulator as the A operand) ...
+      const bool rows_in = I + 32 <= n;
+#pragma unroll
+      for (int s = 0; s < 16; ++s) {
+        float b = ((rows_in || I + mfma_row(s, h) < n) && r < m) ? bI[s] : 0.f;
+        if (kEuclid && r == m) b = 1.f;  // ones column (w is 0 for rows outside the matrix)
+        accJ = __builtin_amdgcn_mfma_f32_32x32x2f32(w[s], b, accJ, 0, 0, 0);
+      }
+      // ---- 4. ... and P = W X_J: W[i][j] from accumulator layout (lane = j) to A-operand layout (lane = i)
+#pragma unroll
+      for (int s = 0; s < 16; ++s) sT[wave][mfma_row(s, h)][r] = w[s];
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      f32x16 pacc;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) pacc[k] = 0.f;
+#pragma unroll
+      for (int s = 0; s < 16; ++s) pacc = __builtin_amdgcn_mfma_f32_32x32x2f32(sT[wave][r][2 * s + h], xJ[s], pacc, 0, 0, 0);
+      __builtin_amdgcn_wave_barrier();
+      // row block a of the super-tile belongs to this wavefront during this step
+#pragma unroll
+      for (int k = 0; k < 16; ++k) accI[a][mfma_row(k, h)][r] += pacc[k];
+    }
+    __syncthreads();
+  }
+  // ---- flush: wavefront w writes its column block's ACC_J and row block w's ACC_I, 32 x m contiguous floats each
+  if constexpr (LOSS != MM_LOSS_NONE) {
+    __shared__ float lossW[kGramBwdWaves][2];
+    const float l = wave_sum(loss_acc), d = wave_sum(ds_acc);
+    if (lane == 0) { lossW[wave][0] = l; lossW[wave][1] = d; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      float ls = 0.f, dd = 0.f;
+#pragma unroll
+      for (int wv = 0; wv < kGramBwdWaves; ++wv) { ls += lossW[wv][0]; dd += lossW[wv][1]; }
+      const int slot = blockIdx.x & (kLossSlots - 1);
+      atomic_add(&la.slots[slot], ls);
+      atomic_add(&la.slots[kLossSlots + slot], dd);
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 16; ++k) sT[wave][mfma_row(k, h)][r] = accJ[k];
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  auto flush = [&](const float (&acc)[32][33], int R0) {   // acc[row][c] -> grad[(R0 + row) * m + c]
+    if (R0 >= n) return;
+    const int cnt = min(32, n - R0) * m;
+    for (int e = lane; e < cnt; e += 64) {
+      const int row = e / m, c = e - row * m;
+      float sum = acc[row][c];
+      if (KIND == MM_LORENTZ && c != 0) sum = -sum;                            // d q / d x = -J x'
+      if constexpr (kEuclid) sum = 2.f * fmaf(acc[row][m], x[size_t(R0) * m + e], -sum);   // 2 (x sum w - sum w x')
+      atomic_add(&grad[size_t(R0) * m + e], sum);
+    }
+  };
+  if (j_live) flush(sT[wave], J);
+  __builtin_amdgcn_wave_barrier();
+  {   // row block `wave` of the super-tile (accI is 32 wide: through the transpose tile for one flush routine)
+    const int I = (As * 4 + wave) * 32;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) sT[wave][mfma_row(k, h)][r] = accI[wave][mfma_row(k, h)][r];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    flush(sT[wave], I);
+  }
+}
+
 #include "vec_gram_bwd64.hpp"
 
 }  // namespace mm
@@ -450,11 +686,26 @@ int vec_gram_bwd_launch(int kind, int loss_kind, const float* xp, const float* g
   while (tpw_env <= 0 && tpw > 1 && int64_t(nT) * ((nT + kGramBwdWaves * tpw - 1) / (kGramBwdWaves * tpw)) < 768) tpw >>= 1;
   const dim3 grid(nT, (nT + kGramBwdWaves * tpw - 1) / (kGramBwdWaves * tpw));
   const dim3 block(64 * kGramBwdWaves);
+  // Symmetric tiles for the inner-product manifolds (half the reads of g, the Gram products and the dout/dq evaluations;
+  // measured at n = 4039, m = 11: 36.8 us and 45 MB fetched against 35.7 us and 96 MB for the ordered kernel — both are
+  // bound by the per-wavefront chain load -> MFMA -> dout/dq -> MFMA at <= 4 wavefronts per SIMD, not by bandwidth; the
+  // halved traffic pays where g does not sit in the Infinity Cache).  The squared Euclidean distance has neither Gram nor
+  // dout/dq to halve and keeps the ordered kernel (24 us against 30 us).  MM_GRAM_BWD_ORDERED = 1 / 0 forces one.
+  static const int forced = [] { const char* e = std::getenv("MM_GRAM_BWD_ORDERED"); return e ? (e[0] == '1' ? 1 : 0) : -1; }();
+  const bool ordered = forced >= 0 ? forced == 1 : kind == MM_EUCLIDEAN;
+  const int nS = (nT + 3) / 4;                       // super-tiles of 4 x 4 tiles per side
+  const dim3 sgrid(unsigned(nS * (nS + 1) / 2));     // unordered pairs of super-tile indices
   {
     ProfScope prof(PROF_VEC_BWD, st);
 #define MM_GRAM_BWD(KIND_, KS_, LOSS_)                                                                        \
-  vec_gram_bwd_f32_kernel<KIND_, KS_, LOSS_><<<grid, block, 0, st>>>(xp, gp, int(n), m, int(row_begin),     \
-                                                                    int(row_end), squared, tpw, op, la)
+  do {                                                                                                        \
+    if (ordered)                                                                                              \
+      vec_gram_bwd_f32_kernel<KIND_, KS_, LOSS_><<<grid, block, 0, st>>>(xp, gp, int(n), m, int(row_begin), \
+                                                                        int(row_end), squared, tpw, op, la);  \
+    else                                                                                                      \
+      vec_gram_bwd_sym_f32_kernel<KIND_, KS_, LOSS_><<<sgrid, block, 0, st>>>(xp, gp, int(n), m,            \
+                                                                        int(row_begin), int(row_end), squared, op, la); \
+  } while (0)
 #define MM_GRAM_BWD_KS(KIND_, LOSS_)                        \
   do {                                                      \
     const int ks = (m + 1) / 2;                             \

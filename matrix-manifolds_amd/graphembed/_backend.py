@@ -35,6 +35,8 @@ SIGNATURES = {
     'mm_graph_layer_f1': (_i, [_vp, _vp, _i64, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     'mm_graph_average_precision': (_i, [_i, _vp, _i64, _vp, _vp, _vp, _vp, _vp]),
     'mm_pair_gather': (_i, [_i, _vp, _i64, _vp, _i64, _vp, _vp]),
+    'mm_graph_sort_rows_ws_bytes': (_sz, [_i, _i64]),
+    'mm_graph_sort_rows': (_i, [_i, _vp, _i64, _vp, _vp, _sz, _vp]),
     'mm_product_max_factors': (_i, []),
     'mm_product_loss_ws_bytes': (_sz, [_i, _i]),
     'mm_product_loss': (_i, [_i, _i, _i, _c.POINTER(_vp), _vp, _c.POINTER(_vp), _i64, _dbl, _dbl, _i, _vp,

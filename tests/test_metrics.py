@@ -172,3 +172,106 @@ def test_gpu_f1_long_paths():
         rmeans, rvar = rp.layer_f1_scores(squareform(pd), hops, degrees=np.array([g.degree(u) for u in range(m)]))
         np.testing.assert_allclose(means, rmeans, rtol=1e-10, atol=1e-12)
         np.testing.assert_allclose(var, rvar, rtol=1e-8, atol=1e-12)
+
+
+# ------------------------------------------------------------------ weighted graphs (precision.cpp:76-92, 150-166)
+def _weighted_er(n, p, seed, wmax=4):
+    g = _er(n, p, seed)
+    rng = np.random.default_rng(seed + 100)
+    for u, v in g.edges():
+        g[u][v]['weight'] = int(rng.integers(1, wmax + 1))
+    return g
+
+
+def _weighted_layers(g):
+    """Layers of every shortest-path tree of a weighted graph, restated from precision.cpp:76-92 (Dijkstra with a heap)
+    and 150-166 (a new layer wherever the sorted distances increase) — plain Python, independent of the package."""
+    import heapq
+    n = len(g)
+    dist = np.zeros((n, n), dtype=np.int64)
+    layers = np.zeros((n, n), dtype=np.int64)
+    for u in range(n):
+        d = [np.iinfo(np.int64).max] * n
+        d[u] = 0
+        q = [(0, u)]
+        while q:
+            du, node = heapq.heappop(q)
+            if du != d[node]:
+                continue
+            for nb, attr in g[node].items():
+                nd = du + int(attr['weight'])
+                if nd < d[nb]:
+                    d[nb] = nd
+                    heapq.heappush(q, (nd, nb))
+        dist[u] = d
+        order = sorted(range(n), key=lambda v: d[v])
+        layer = 0
+        for i in range(1, n):
+            if d[order[i]] > d[order[i - 1]]:
+                layer += 1
+            layers[u, order[i]] = layer
+    return dist, layers
+
+
+def test_weighted_layers_host_side():
+    """graphembed.pyx.tree_layers (dense ranks of the scipy Dijkstra distances) == the reference's construction."""
+    import networkx as nx
+    from scipy.sparse.csgraph import shortest_path
+    from graphembed.pyx import tree_layers
+    g = _weighted_er(60, 0.08, 3)
+    dist, layers = _weighted_layers(g)
+    sp = shortest_path(nx.to_scipy_sparse_array(g, nodelist=range(len(g)), weight='weight'), method='D')
+    np.testing.assert_array_equal(sp.astype(np.int64), dist)
+    np.testing.assert_array_equal(tree_layers(sp), layers)
+    # unweighted: the layers are the hop distances
+    h = _hops(_er(60, 0.08, 3))
+    np.testing.assert_array_equal(tree_layers(h), h)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('n,p', [(70, 0.08), (250, 0.03)])
+def test_gpu_f1_weighted_graph(n, p):
+    """Weighted graphs: the perfect embedding (embedding distance = weighted graph distance) scores F1 = 1 on every
+    layer (the reference's known answer, tests/test_metrics.py:27-35, carried over), random distances agree with the
+    numpy restatement on the weighted layers, and MAP only looks at the adjacency."""
+    from scipy.spatial.distance import squareform
+    from graphembed.pyx import FastPrecision
+    from oracle import ref_port as rp
+    g = _weighted_er(n, p, 5)
+    m = g.number_of_nodes()
+    dist, layers = _weighted_layers(g)
+    fp = FastPrecision(g)
+    assert fp.weighted and fp.num_layers == layers.max() + 1
+    assert fp.nodes_per_layer() == [int(c) for c in np.bincount(layers.reshape(-1))]
+    perfect = torch.from_numpy(squareform(dist.astype(np.float64), checks=False))
+    for means, var in (fp.layer_mean_f1_scores(perfect), fp.layer_mean_average_f1_scores(perfect)):
+        np.testing.assert_allclose(means[np.isfinite(means)], 1.0, atol=1e-10)
+    rng = np.random.default_rng(6)
+    pd = rng.random(m * (m - 1) // 2)
+    pd[::4] = pd[1]
+    means, var = fp.layer_mean_f1_scores(torch.from_numpy(pd))
+    rmeans, rvar = rp.layer_f1_scores(squareform(pd), layers, degrees=np.array([g.degree(u) for u in range(m)]))
+    np.testing.assert_allclose(means, rmeans, rtol=1e-10, atol=1e-12)
+    np.testing.assert_allclose(var, rvar, rtol=1e-8, atol=1e-12)
+    nb = [set(g.neighbors(u)) for u in range(m)]
+    assert abs(fp.mean_average_precision(torch.from_numpy(pd)) - rp.mean_average_precision(squareform(pd), nb)) <= 1e-9
+
+
+@pytest.mark.gpu
+def test_gpu_row_sort_is_a_stable_argsort():
+    """mm_graph_sort_rows == a stable argsort of every row (ties in node order), fp32 and fp64."""
+    from graphembed import _backend as B
+    lib = B.lib()
+    for dt in (torch.float32, torch.float64):
+        n = 777
+        torch.manual_seed(1)
+        d = torch.rand(n, n, dtype=dt, device='cuda')
+        d[:, ::3] = d[:, :1]          # many ties per row
+        d[5] = 0.25
+        code = B.dtype_code(d)
+        nbytes = lib.raw('mm_graph_sort_rows_ws_bytes')(code, n)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device='cuda')
+        order = torch.empty(n, n, dtype=torch.int32, device='cuda')
+        lib.call('mm_graph_sort_rows', code, B.ptr(d), n, B.ptr(order), B.ptr(ws), nbytes, B.stream_of(d))
+        want = torch.sort(d, dim=1, stable=True).indices.to(torch.int32)
+        assert torch.equal(order, want)

@@ -1,0 +1,62 @@
+#!/usr/bin/env python3
+"""Text summary of a tools/gpu_profile_r02.sh output directory: per case and kernel the average duration
+(rocprofv3 --kernel-trace --stats), the PMC counters per launch, HBM traffic (2 x FETCH_SIZE + WRITE_SIZE, KiB) and the
+algorithmic-bytes roofline fraction of the pair kernels."""
+import collections
+import csv
+import glob
+import os
+import sys
+
+root = sys.argv[1]
+HBM = 8000.0  # GB/s
+
+
+def stats(d):
+    out = {}
+    for f in glob.glob(os.path.join(d, '**', '*kernel_stats.csv'), recursive=True):
+        for r in csv.DictReader(open(f)):
+            if 'mm::' in r['Name']:
+                out[r['Name'].split('(')[0].replace('void mm::', '')] = (int(r['Calls']), float(r['AverageNs']) / 1e3,
+                                                                          float(r['MinNs']) / 1e3, float(r['MaxNs']) / 1e3)
+    return out
+
+
+def pmc(dirs):
+    acc = collections.defaultdict(lambda: collections.defaultdict(list))
+    for d in dirs:
+        for f in glob.glob(os.path.join(d, '**', '*counter_collection.csv'), recursive=True):
+            for r in csv.DictReader(open(f)):
+                if 'mm::' in r['Kernel_Name']:
+                    acc[r['Kernel_Name'].split('(')[0].replace('void mm::', '')][r['Counter_Name']].append(float(r['Counter_Value']))
+    return {k: {c: sum(v) / len(v) for c, v in cs.items()} for k, cs in acc.items()}
+
+
+CASES = {'bench': ('SPD(3) f32 n=5000 reference init (headline; python3 bench.py)', 3, 5000, 4),
+         'case_pdist_3_5000_f64_0_1': ('SPD(3) f64 n=5000 reference init', 3, 5000, 8),
+         'case_pdist_3_5000_f32_0_35': ('SPD(3) f32 n=5000 mid-training spread (||log X|| = 0.35)', 3, 5000, 4),
+         'case_pdist_4_2274_f32_0_1': ('SPD(4) f32 n=2274 (BASELINE config 5, small graph)', 4, 2274, 4),
+         'case_pdist_4_16384_f32_0_1': ('SPD(4) f32 n=16384 pdist fwd + bwd', 4, 16384, 4),
+         'case_loss_4_16384_f32': ('SPD(4) f32 n=16384 fused QuotientLoss step (BASELINE config 5)', 4, 16384, 4)}
+for key, (title, d, n, esz) in CASES.items():
+    st = stats(os.path.join(root, key + '_stats'))
+    if not st:
+        continue
+    pm = pmc([os.path.join(root, key + s) for s in ('_pmc_sq', '_pmc_fetch', '_pmc_write')])
+    pairs = n * (n - 1) // 2
+    npk = d * (d + 1) // 2
+    print(f'== {title}: {pairs} pairs')
+    for name, (calls, avg, mn, mx) in sorted(st.items(), key=lambda kv: -kv[1][1]):
+        line = f'  {name[:58]:58s} calls {calls:3d}  avg {avg:8.1f} us  (min {mn:.1f}, max {mx:.1f})'
+        c = pm.get(name, {})
+        if 'pdist_bwd' in name or 'pdist_fwd' in name:
+            alg = pairs * esz + n * (4 if 'bwd' in name else 2) * npk * esz
+            line += f'  | algorithmic {alg / 1e6:.1f} MB -> {alg / avg / 1e3:.0f} GB/s = {alg / avg / 1e3 / HBM:.3f} of HBM peak'
+            if 'FETCH_SIZE' in c and 'WRITE_SIZE' in c:
+                tr = (2 * c['FETCH_SIZE'] + c['WRITE_SIZE']) * 1024
+                line += f'; traffic {tr / 1e6:.1f} MB (2 x FETCH {2 * c["FETCH_SIZE"] * 1024 / 1e6:.1f} + WRITE {c["WRITE_SIZE"] * 1024 / 1e6:.1f}) = {tr / alg:.2f} x algorithmic'
+            if 'SQ_INSTS_VALU' in c:
+                line += f'; VALU {c["SQ_INSTS_VALU"] / (pairs / 64):.0f} / all {c.get("SQ_ACTIVE_INST_ANY", 0) / (pairs / 64):.0f} instructions per 64 pairs'
+            if 'SQ_WAVE_CYCLES' in c and c['SQ_WAVE_CYCLES']:
+                line += f'; wait {c.get("SQ_WAIT_ANY", 0) / c["SQ_WAVE_CYCLES"]:.0%} issue-wait {c.get("SQ_WAIT_INST_ANY", 0) / c["SQ_WAVE_CYCLES"]:.0%} of wave cycles'
+        print(line)

@@ -300,7 +300,7 @@ class FusedLossWorkload:
         return flat
 
 
-def time_workload(wl, steps, warmup, fence, use_graph, graph_collective=False, rank=0, tag=''):
+def time_workload(wl, steps, warmup, fence, use_graph, graph_collective=False, rank=0, tag='', warm_seconds=0.0):
     """Times `steps` steps of the workload between fences.  Returns (elapsed_s, launch_mode, phases) where
     phases = per-step means, in us, of this rank's device time in the kernels and in the all-reduce and of
     the rest of the step's wall time (host gap), from an instrumented pass after the timed region."""
@@ -336,6 +336,15 @@ def time_workload(wl, steps, warmup, fence, use_graph, graph_collective=False, r
 
     for _ in range(warmup):
         run()
+    if warm_seconds > 0:
+        # secondary workloads follow seconds of host-side input generation with an idle GPU: a handful of warm-up steps
+        # ends before the clocks are back up (a 1.4 ms step measured 2.2 ms), so they also warm up for a minimum TIME
+        torch.cuda.synchronize()
+        tw0 = time.perf_counter()
+        while time.perf_counter() - tw0 < warm_seconds:
+            for _ in range(4):
+                run()
+            torch.cuda.synchronize()
     fence()
     t0 = time.perf_counter()
     for _ in range(steps):
@@ -522,7 +531,7 @@ def worker(args):
                       ('SPD(4) n=2274 f32 (BASELINE config 5, small graph), reference init', 4, 2274, torch.float32, 0.1)]
         for name, d, nn, dt, ir in cases:
             w = PdistWorkload(d, nn, dt, ir, world, rank, dev)
-            el, md, ph = time_workload(w, k2, w2, fence, use_graph, graph_collective, rank, tag=name + ': ')
+            el, md, ph = time_workload(w, k2, w2, fence, use_graph, graph_collective, rank, tag=name + ': ', warm_seconds=0.05)
             el = reduce_max(el, dev, world)
             kk = {'fwd': None, 'bwd': None}
             if not args.no_prof:
@@ -547,7 +556,7 @@ def worker(args):
             torch.cuda.empty_cache()
         # the size where sharding pays: BASELINE config 5 (bio-wormnet-class, ~16k nodes, SPD(4), distortion loss)
         w = FusedLossWorkload(4, 16384, torch.float32, world, rank, dev)
-        el, md, ph = time_workload(w, k2, w2, fence, use_graph, graph_collective, rank, tag='config 5: ')
+        el, md, ph = time_workload(w, k2, w2, fence, use_graph, graph_collective, rank, tag='config 5: ', warm_seconds=0.1)
         el = reduce_max(el, dev, world)
         ranks5 = gather_objects({'rank': rank, 'rows': list(w.rows), 'pairs': w.hi - w.lo, **ph}, world)
         extra.append({'workload': 'BASELINE config 5: n=16384 nodes -> SPD(4), all-pairs QuotientLoss, fused '

@@ -35,6 +35,14 @@ template <> struct Num<float> {
   static __device__ __forceinline__ float exp(float x) { return ::expf(x); }
   static __device__ __forceinline__ float abs(float x) { return ::fabsf(x); }
   static __device__ __forceinline__ float max(float a, float b) { return ::fmaxf(a, b); }
+  // max without the two canonicalising `v_max x, x, x` that fmaxf gets for operands the compiler cannot prove quiet
+  // (a kernel argument, a value merged from several paths); same result: the non-NaN operand
+  // (b wave-uniform: a scalar register operand)
+  static __device__ __forceinline__ float max_raw_s(float a, float b) {
+    float r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "s"(b));
+    return r;
+  }
   static __device__ __forceinline__ float min(float a, float b) { return ::fminf(a, b); }
   static __device__ __forceinline__ float copysign(float a, float b) { return ::copysignf(a, b); }
   static __device__ __forceinline__ float fma(float a, float b, float c) { return ::fmaf(a, b, c); }
@@ -46,6 +54,11 @@ template <> struct Num<double> {
   static __device__ __forceinline__ double sqrt(double x) { return ::sqrt(x); }
   static __device__ __forceinline__ double rsqrt(double x) { return 1.0 / ::sqrt(x); }
   static __device__ __forceinline__ double rcp(double x) { return 1.0 / x; }
+  static __device__ __forceinline__ double max_raw_s(double a, double b) {
+    double r;
+    asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "s"(b));
+    return r;
+  }
   static __device__ __forceinline__ double log(double x) { return ::log(x); }
   static __device__ __forceinline__ double exp(double x) { return ::exp(x); }
   static __device__ __forceinline__ double abs(double x) { return ::fabs(x); }
@@ -758,6 +771,55 @@ template <typename T> __device__ __forceinline__ T log_series4(const T (&a)[10],
 #pragma unroll
   for (int rr = 0; rr < 4; ++rr) m0[pidx(rr, rr)] += al[0];
   return p2;  // ||E||_F^2
+}
+
+// d^2 = ||log A||_F^2 of a close 4x4 pair from the invariants (the 4x4 counterpart of logsq_series3): tr(E^2 q(E)) with
+// q(E) = h0 I + h1 E + h2 E^2 + h3 E^3 by Horner in R[E]/(chi_E) and the power sums p2..p5 (p5 from Newton's identity).
+// Only E^2 is formed: 100 multiply-adds against 180 for log_series4 followed by the Frobenius norm.
+template <typename T> __device__ __forceinline__ T logsq_series4(const T (&a)[10]) {
+  using N = Num<T>;
+  using S = LogSqSeries<T>;
+  T e[10], e2[10];
+#pragma unroll
+  for (int k = 0; k < 10; ++k) e[k] = a[k];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) e[pidx(r, r)] -= T(1);
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+#pragma unroll
+    for (int c = 0; c <= r; ++c) {
+      T acc = e[pidx(r, 0)] * e[pidx(0, c)];
+#pragma unroll
+      for (int k = 1; k < 4; ++k) acc = N::fma(e[pidx(r, k)], e[pidx(k, c)], acc);
+      e2[pidx(r, c)] = acc;
+    }
+  T p1 = T(0), p2 = T(0), p3 = T(0), p4 = T(0), o3 = T(0), o4 = T(0);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    p1 += e[pidx(r, r)];
+    p2 += e2[pidx(r, r)];
+    p3 = N::fma(e2[pidx(r, r)], e[pidx(r, r)], p3);
+    p4 = N::fma(e2[pidx(r, r)], e2[pidx(r, r)], p4);
+#pragma unroll
+    for (int c = 0; c < r; ++c) {
+      o3 = N::fma(e2[pidx(r, c)], e[pidx(r, c)], o3);
+      o4 = N::fma(e2[pidx(r, c)], e2[pidx(r, c)], o4);
+    }
+  }
+  p3 = N::fma(T(2), o3, p3);
+  p4 = N::fma(T(2), o4, p4);
+  const T s1 = p1;
+  const T s2 = T(0.5) * N::fma(s1, p1, -p2);
+  const T s3 = T(1.0 / 3.0) * (N::fma(s2, p1, -s1 * p2) + p3);
+  const T s4 = T(0.25) * (N::fma(s3, p1, -s2 * p2) + N::fma(s1, p3, -p4));
+  const T p5 = N::fma(s1, p4, -s2 * p3) + N::fma(s3, p2, -s4 * p1);
+  T h0 = T(S::kQ[S::kTerms - 4]), h1 = T(S::kQ[S::kTerms - 3]), h2 = T(S::kQ[S::kTerms - 2]), h3 = T(S::kQ[S::kTerms - 1]);
+#pragma unroll
+  for (int k = S::kTerms - 5; k >= 0; --k) {
+    const T n0 = N::fma(-h3, s4, T(S::kQ[k])), n1 = N::fma(h3, s3, h0), n2 = N::fma(-h3, s2, h1), n3 = N::fma(h3, s1, h2);
+    h0 = n0; h1 = n1; h2 = n2; h3 = n3;
+  }
+  return N::fma(h3, p5, N::fma(h2, p4, N::fma(h1, p3, h0 * p2)));
 }
 
 // out (packed) = V diag(f) V^T

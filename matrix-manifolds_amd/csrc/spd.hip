@@ -195,10 +195,7 @@ __device__ __forceinline__ T pair_value(const TL (&li)[Packed<D>::NP], const T (
       const T sq = logsq_series3<T>(a, &e2);
       if (__builtin_expect(!__any(!(e2 <= T(kCloseGate))), 1)) return sq;
     } else {
-      if (__builtin_expect(!__any(!(close_gate<T, D>(a) <= T(kCloseGate))), 1)) {
-        log_close<T, D>(a, m0);
-        return frob2<T, D>(m0);
-      }
+      if (__builtin_expect(!__any(!(close_gate<T, D>(a) <= T(kCloseGate))), 1)) return logsq_series4<T>(a);
     }
     const T gate = log_cayley<T, D>(a, m0);
     if (__builtin_expect(!__any(!(gate <= T(kCayleyGate))), 1)) return frob2<T, D>(m0);
@@ -233,7 +230,7 @@ template <typename T, int D> constexpr int pair_cols() { return (sizeof(T) == 4 
 // output row is a running scalar pointer (row i + 1 starts n - i - 2 elements after row i) plus a fixed lane offset:
 // `global_store_dword v_off, v, s[ptr]`, lanes on consecutive j -> 256-B coalesced segments of the row-major pair vector.
 template <typename T, int D, int TI, bool SQ>
-__global__ __launch_bounds__(kBlock) void spd_pdist_fwd_kernel(const T* __restrict__ nodeL,
+__global__ __launch_bounds__(kBlock, (fwd_min_waves<T, D>())) void spd_pdist_fwd_kernel(const T* __restrict__ nodeL,
                                                                const T* __restrict__ nodeY /* column operand: chol(X_j) */, int n, int row_begin,
                                                                int row_end, T wmin, T wmax, T* __restrict__ out) {
   constexpr int NP = Packed<D>::NP;
@@ -284,8 +281,11 @@ __global__ __launch_bounds__(kBlock) void spd_pdist_fwd_kernel(const T* __restri
       const T (&li)[NP] = lrow[u];
       static_for<NC>([&](auto qc) {
         constexpr int q = decltype(qc)::value;
-        T s = Num<T>::max(pair_value<T, D, true>(li, xj[q], wmin, wmax), wmin);
+        T s = Num<T>::max_raw_s(pair_value<T, D, true>(li, xj[q], wmin, wmax), wmin);
         if constexpr (!SQ) s = Num<T>::sqrt(s);
+        // (re-defined in this block: a zero-extension hoisted out of the loop hides from instruction selection that the
+        // lane offset is 32 bits wide, and the store gets a 64-bit vector address instead of `v_off, s[ptr]`)
+        asm volatile("" : "+v"(joff[q]));
         if (jv[q] > ieff) *reinterpret_cast<T*>(op + joff[q]) = s;
       });
       op += ostep;
@@ -332,7 +332,7 @@ __device__ unsigned long long g_bwd_stamps[4 * 16384];
 // balanced column walk (spd_ws.hpp, ColWalk): down one 64-column block, chunk after chunk of up to NW x TI rows (each
 // wavefront a contiguous slice of the chunk's rows, its lanes the block's 64 columns), then on to the next block.
 template <typename T, int D, int TI, int LOSS, bool SQ>
-__global__ __launch_bounds__((64 * bwd_waves<T, D>())) void spd_pdist_bwd_kernel(const T* __restrict__ nodeLC /* {L_i^-1, L_i} */,
+__global__ __launch_bounds__((64 * bwd_waves<T, D>()), (bwd_min_waves<T, D>())) void spd_pdist_bwd_kernel(const T* __restrict__ nodeLC /* {L_i^-1, L_i} */,
                                                                const T* __restrict__ nodeY /* chol(X_j) */,
                                                                const T* __restrict__ g, int n, int row_begin,
                                                                int row_end, T wmin, T wmax,
@@ -447,6 +447,7 @@ __global__ __launch_bounds__((64 * bwd_waves<T, D>())) void spd_pdist_bwd_kernel
         auto request = [&](T (&dst)[NC]) __attribute__((always_inline)) {
           static_for<NC>([&](auto qc) {
             constexpr int q = decltype(qc)::value;
+            asm volatile("" : "+v"(jslice[q]));   // (see the forward's store: keeps the `v_off, s[ptr]` form inside the loop)
             dst[q] = *reinterpret_cast<const T*>(gslice + goff + jslice[q]);
           });
           goff = min(goff + gstep, gmax);
@@ -518,7 +519,7 @@ __global__ __launch_bounds__((64 * bwd_waves<T, D>())) void spd_pdist_bwd_kernel
             static_for<NC>([&](auto qc) {
               constexpr int q = decltype(qc)::value;
               congr_chol<T, D>(li, xj[q], a[q]);
-              far = far || !(close_gate<T, D>(a[q]) <= T(kCloseGate));
+              far = far | !(close_gate<T, D>(a[q]) <= T(kCloseGate));   // (| : no exec-masked short circuit)
             });
             if (__builtin_expect(!__any(far), 1)) {
               static_for<NC>([&](auto qc) {

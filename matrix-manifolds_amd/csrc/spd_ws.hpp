@@ -24,6 +24,18 @@ constexpr int kBlock = 256;  // 4 wavefronts
 #endif
 // backward: wavefronts that share one 64-column tile (one column-side atomic flush per workgroup);
 // 4 where the LDS combine buffer of 8 would not fit (fp64, D = 5)
+// Wavefronts per SIMD the backward is compiled for (the second __launch_bounds__ argument): fp32 SPD(4) needs 129 - 138
+// vector registers left alone — one allocation granule above the 128 that let four wavefronts share a SIMD instead of three.
+#ifndef MM_F64_BWD_W
+#define MM_F64_BWD_W 1
+#endif
+#ifndef MM_F64_FWD_W
+#define MM_F64_FWD_W 1
+#endif
+template <typename T, int D> constexpr int bwd_min_waves() {
+  return (sizeof(T) == 4 && (D == 3 || D == 4)) ? 4 : ((sizeof(T) == 8 && D == 3) ? MM_F64_BWD_W : 1);
+}
+template <typename T, int D> constexpr int fwd_min_waves() { return (sizeof(T) == 8 && D == 3) ? MM_F64_FWD_W : 1; }
 template <typename T, int D> constexpr int bwd_waves() {
   // (the column-side combine buffer is D^2 x 64 values per wavefront: 4 wavefronts up to 64 KB of it, else 2, else 1)
   return int(sizeof(T)) * D * D * 64 * 4 <= 65536 ? 4 : (int(sizeof(T)) * D * D * 64 * 2 <= 65536 ? 2 : 1);

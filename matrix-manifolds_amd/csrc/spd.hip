@@ -251,6 +251,7 @@ __global__ __launch_bounds__(kBlock, (fwd_min_waves<T, D>())) void spd_pdist_fwd
     const int j = wave_j0 + 64 * q + lane;
     const bool jin = j < n;
     jv[q] = jin ? j : INT32_MIN;
+    asm volatile("" : "+v"(jv[q]));   // (or the select is undone into `jin && j > row`: a scalar AND per row and column)
     joff[q] = unsigned(j) * unsigned(sizeof(T));
 #pragma unroll
     for (int k = 0; k < NP; ++k) xj[q][k] = T(0);
@@ -266,16 +267,18 @@ __global__ __launch_bounds__(kBlock, (fwd_min_waves<T, D>())) void spd_pdist_fwd
   unsigned ostep = unsigned(n - i0 - 2) * unsigned(sizeof(T));                    // bytes from row i to row i + 1
   // row operand: wave-uniform -> scalar loads, issued one row ahead (the row after the tile's last is read too: inside the
   // workspace — nodeL is followed by nodeX — and never used)
-  const T* rowp = nodeL + size_t(i0) * NP;
+  unsigned roff = unsigned(i0) * unsigned(NP * sizeof(T));
   T lrow[2][NP];
 #pragma unroll
-  for (int k = 0; k < NP; ++k) lrow[0][k] = rowp[k];
+  for (int k = 0; k < NP; ++k) lrow[0][k] = nodeL[size_t(i0) * NP + k];
   for (int ib = i0; ib < i1; ib += 2) {
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
       const int irow = ib + u;
-      const int ieff = irow < i1 ? irow : INT32_MAX;   // (the second slot of an odd last pair of rows stores nothing)
-      rowp += NP;
+      const int ieff = (u == 0 || irow < i1) ? irow : INT32_MAX;   // (the second slot of an odd last pair of rows stores nothing)
+      roff += unsigned(NP * sizeof(T));
+      asm volatile("" : "+s"(roff));   // (pinned: scalar loads at small positive offsets of the running offset)
+      const T* rowp = reinterpret_cast<const T*>(reinterpret_cast<const char*>(nodeL) + roff);
 #pragma unroll
       for (int k = 0; k < NP; ++k) lrow[u ^ 1][k] = rowp[k];
       const T (&li)[NP] = lrow[u];
@@ -395,6 +398,7 @@ __global__ __launch_bounds__((64 * bwd_waves<T, D>()), (bwd_min_waves<T, D>())) 
       const int j = jbase + 64 * q + lane;
       const bool jin = j < n;
       jv[q] = jin ? j : INT32_MIN;
+      asm volatile("" : "+v"(jv[q]));   // (or the select is undone into `jin && j > row`: a scalar AND per row and column)
       joff[q] = unsigned(min(j, n - 1)) * unsigned(sizeof(T));
 #pragma unroll
       for (int k = 0; k < NP; ++k) xj[q][k] = T(0);
@@ -429,10 +433,10 @@ __global__ __launch_bounds__((64 * bwd_waves<T, D>()), (bwd_min_waves<T, D>())) 
         //   for vmcnt(0)) and run kAhead rows ahead into registers that rotate by RENAMING (the loop is unrolled kAhead
         //   times): rotating with moves would wait for the NEWEST request at every row.
         constexpr int kAhead = 2;
-        const T* rowp = nodeLC + size_t(i0) * (2 * NP);
+        unsigned roff = unsigned(i0) * unsigned(2 * NP * sizeof(T));   // byte offset of the row's operands (the table is < 4 GB)
         T lrow[2][2 * NP];
 #pragma unroll
-        for (int k = 0; k < 2 * NP; ++k) lrow[0][k] = rowp[k];
+        for (int k = 0; k < 2 * NP; ++k) lrow[0][k] = nodeLC[size_t(i0) * (2 * NP) + k];
         const int glast = min(i1, walk.re) - 1;
         const int64_t gk = glast - i0;
         const unsigned gmax = unsigned((gk * (n - 2) - (int64_t(i0) * gk + gk * (gk - 1) / 2)) * int64_t(sizeof(T)));
@@ -461,9 +465,13 @@ __global__ __launch_bounds__((64 * bwd_waves<T, D>()), (bwd_min_waves<T, D>())) 
           // (a slice with an odd number of rows runs its last unrolled slot on a masked row: an early exit here would
           // make the number of outstanding requests path-dependent and the compiler falls back to vmcnt(0))
           const int irow = ib + u;
-          const int ieff = irow < i1 ? irow : INT32_MAX;   // scalar
+          const int ieff = (u == 0 || irow < i1) ? irow : INT32_MAX;   // scalar; only the slot after the first can be past the slice
           const T (&lcur)[2 * NP] = lrow[u];
-          rowp += 2 * NP;                                   // the row after the slice is inside the table (i1 <= n - 1)
+          // the row after the slice is inside the table (i1 <= n - 1).  The running offset is pinned: otherwise the loop
+          // runs on a pointer one iteration ahead and every scalar load pays a 64-bit add for its negative offset
+          roff += unsigned(2 * NP * sizeof(T));
+          asm volatile("" : "+s"(roff));
+          const T* rowp = reinterpret_cast<const T*>(reinterpret_cast<const char*>(nodeLC) + roff);
 #pragma unroll
           for (int k = 0; k < 2 * NP; ++k) lrow[u ^ 1][k] = rowp[k];
           T li[NP], lc[NP];
@@ -1142,7 +1150,7 @@ size_t mm_spd_pdist_ws_bytes(int dtype, int64_t n, int d) {
 
 int mm_spd_pdist_fwd(int dtype, const void* x, int64_t n, int d, int64_t row_begin, int64_t row_end, int squared,
                      double wmin, double wmax, void* out, void* ws, int flags, mm_stream_t stream) {
-  if (!x || !ws || n < 0 || row_begin < 0 || row_end > n || row_begin > row_end || n > (1 << 30)) return MM_ERR_ARG;
+  if (!x || !ws || n < 0 || row_begin < 0 || row_end > n || row_begin > row_end || n > kSpdMaxNodes) return MM_ERR_ARG;
   if (n == 0) return MM_OK;
   if (!out && mm_pair_offset(n, row_end) > mm_pair_offset(n, row_begin)) return MM_ERR_ARG;
   hipStream_t st = static_cast<hipStream_t>(stream);
@@ -1152,7 +1160,7 @@ int mm_spd_pdist_fwd(int dtype, const void* x, int64_t n, int d, int64_t row_beg
 }
 
 int mm_spd_prepare(int dtype, const void* x, int64_t n, int d, void* ws, mm_stream_t stream) {
-  if (!x || !ws || n < 0 || n > (1 << 30)) return MM_ERR_ARG;
+  if (!x || !ws || n < 0 || n > kSpdMaxNodes) return MM_ERR_ARG;
   if (n == 0) return MM_OK;
   hipStream_t st = static_cast<hipStream_t>(stream);
   MM_DISPATCH(dtype, d, (spd_prepare_t<T, D>(static_cast<const T*>(x), n, ws, st)));
@@ -1160,7 +1168,7 @@ int mm_spd_prepare(int dtype, const void* x, int64_t n, int d, void* ws, mm_stre
 
 int mm_spd_pdist_bwd(int dtype, const void* x, const void* g, int64_t n, int d, int64_t row_begin, int64_t row_end,
                      int squared, double wmin, double wmax, void* grad_x, void* ws, int flags, mm_stream_t stream) {
-  if (!x || !ws || !grad_x || n < 0 || row_begin < 0 || row_end > n || row_begin > row_end || n > (1 << 30))
+  if (!x || !ws || !grad_x || n < 0 || row_begin < 0 || row_end > n || row_begin > row_end || n > kSpdMaxNodes)
     return MM_ERR_ARG;
   if (n == 0) return MM_OK;
   if (!g && mm_pair_offset(n, row_end) > mm_pair_offset(n, row_begin)) return MM_ERR_ARG;
@@ -1174,7 +1182,7 @@ int mm_spd_pdist_loss(int dtype, int loss_kind, const void* x, const void* targe
                       int d, int64_t row_begin, int64_t row_end, double alpha, double eps, int terms, const double* loss_params, double wmin,
                       double wmax, void* loss_out, void* grad_x, void* ws, int flags, mm_stream_t stream) {
   if (!x || !ws || !grad_x || !loss_out || n < 0 || row_begin < 0 || row_end > n || row_begin > row_end ||
-      n > (1 << 30))
+      n > kSpdMaxNodes)
     return MM_ERR_ARG;
   if (loss_kind != MM_LOSS_STRESS && loss_kind != MM_LOSS_QUOTIENT) return MM_ERR_UNSUPPORTED;
   if (loss_kind == MM_LOSS_QUOTIENT && !(terms & 3)) return MM_ERR_ARG;
@@ -1280,7 +1288,7 @@ int mm_spd_radam_step(int dtype, const void* x, const void* egrad, void* exp_avg
 
 int mm_spd_stein_pdiv_fwd(int dtype, const void* x, int64_t n, int d, int64_t row_begin, int64_t row_end, int squared,
                           double wmin, void* out, void* ws, int flags, mm_stream_t stream) {
-  if (!x || !ws || n < 0 || row_begin < 0 || row_end > n || row_begin > row_end || n > (1 << 30)) return MM_ERR_ARG;
+  if (!x || !ws || n < 0 || row_begin < 0 || row_end > n || row_begin > row_end || n > kSpdMaxNodes) return MM_ERR_ARG;
   if (n == 0) return MM_OK;
   if (!out && mm_pair_offset(n, row_end) > mm_pair_offset(n, row_begin)) return MM_ERR_ARG;
   hipStream_t st = static_cast<hipStream_t>(stream);
@@ -1291,7 +1299,7 @@ int mm_spd_stein_pdiv_fwd(int dtype, const void* x, int64_t n, int d, int64_t ro
 
 int mm_spd_stein_pdiv_bwd(int dtype, const void* x, const void* g, int64_t n, int d, int64_t row_begin, int64_t row_end,
                           int squared, double wmin, void* grad_x, void* ws, int flags, mm_stream_t stream) {
-  if (!x || !ws || !grad_x || n < 0 || row_begin < 0 || row_end > n || row_begin > row_end || n > (1 << 30))
+  if (!x || !ws || !grad_x || n < 0 || row_begin < 0 || row_end > n || row_begin > row_end || n > kSpdMaxNodes)
     return MM_ERR_ARG;
   if (n == 0) return MM_OK;
   if (!g && mm_pair_offset(n, row_end) > mm_pair_offset(n, row_begin)) return MM_ERR_ARG;

@@ -32,6 +32,9 @@ constexpr int kBlock = 256;  // 4 wavefronts
 #ifndef MM_F64_FWD_W
 #define MM_F64_FWD_W 1
 #endif
+// Most nodes of one call: the pair kernels address the node tables and a row of the pair vector with 32-bit byte offsets
+// (2 NP sizeof(T) <= 720 bytes of row operands per node).  4 M nodes are 8.8e12 pairs — 35 TB of fp32 distances.
+constexpr int64_t kSpdMaxNodes = int64_t(1) << 22;
 template <typename T, int D> constexpr int bwd_min_waves() {
   return (sizeof(T) == 4 && (D == 3 || D == 4)) ? 4 : ((sizeof(T) == 8 && D == 3) ? MM_F64_BWD_W : 1);
 }

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """One workload of bench.py, alone in a process, for rocprofv3 (kernel names do not carry n):
     python3 tools/profile_case.py pdist D N f32|f64 IR [steps]      # SPD(D).pdist fwd + bwd, ||log X|| = IR
-    python3 tools/profile_case.py loss  D N f32|f64 [steps]         # fused QuotientLoss step (BASELINE config 5)"""
+    python3 tools/profile_case.py loss  D N f32|f64 [steps]         # fused QuotientLoss step (BASELINE config 5)
+    python3 tools/profile_case.py vec   M N f32|f64 KIND [steps]    # KIND = lorentz | sphere | euclidean: pdist fwd + bwd"""
 import os
 import sys
 
@@ -12,9 +13,24 @@ import torch  # noqa: E402
 import bench  # noqa: E402
 
 
+def vec_case(m, n, dt, which, steps, dev):
+    """facebook-class graph, BASELINE config 2 (n = 4039, Lorentz(11)): squared distances and their backward."""
+    from graphembed import manifolds as M
+    man = {'lorentz': M.Lorentz, 'sphere': M.Sphere, 'euclidean': M.Euclidean}[which](m)
+    torch.manual_seed(0)
+    x = man.rand(n, out=torch.empty(0, device=dev, dtype=dt)).requires_grad_()
+    g = torch.randn(n * (n - 1) // 2, device=dev, dtype=dt)
+    for _ in range(steps):
+        d2 = man.pdist(x, squared=True)
+        torch.autograd.grad(d2, x, g)
+    torch.cuda.synchronize()
+
+
 def main():
     kind, d, n, dt = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), {'f32': torch.float32, 'f64': torch.float64}[sys.argv[4]]
     dev = torch.device('cuda', 0)
+    if kind == 'vec':
+        return vec_case(d, n, dt, sys.argv[5], int(sys.argv[6]) if len(sys.argv) > 6 else 10, dev)
     if kind == 'pdist':
         wl = bench.PdistWorkload(d, n, dt, float(sys.argv[5]), 1, 0, dev)
         steps = int(sys.argv[6]) if len(sys.argv) > 6 else 10

@@ -37,7 +37,8 @@ CASES = {'bench': ('SPD(3) f32 n=5000 reference init (headline; python3 bench.py
          'case_pdist_3_5000_f32_0_35': ('SPD(3) f32 n=5000 mid-training spread (||log X|| = 0.35)', 3, 5000, 4),
          'case_pdist_4_2274_f32_0_1': ('SPD(4) f32 n=2274 (BASELINE config 5, small graph)', 4, 2274, 4),
          'case_pdist_4_16384_f32_0_1': ('SPD(4) f32 n=16384 pdist fwd + bwd', 4, 16384, 4),
-         'case_loss_4_16384_f32': ('SPD(4) f32 n=16384 fused QuotientLoss step (BASELINE config 5)', 4, 16384, 4)}
+         'case_loss_4_16384_f32': ('SPD(4) f32 n=16384 fused QuotientLoss step (BASELINE config 5)', 4, 16384, 4),
+         'case_vec_11_4039_f32_lorentz': ('Lorentz(11) f32 n=4039 (BASELINE config 2) pdist fwd + bwd', 11, 4039, 4)}
 for key, (title, d, n, esz) in CASES.items():
     st = stats(os.path.join(root, key + '_stats'))
     if not st:
@@ -49,7 +50,13 @@ for key, (title, d, n, esz) in CASES.items():
     for name, (calls, avg, mn, mx) in sorted(st.items(), key=lambda kv: -kv[1][1]):
         line = f'  {name[:58]:58s} calls {calls:3d}  avg {avg:8.1f} us  (min {mn:.1f}, max {mx:.1f})'
         c = pm.get(name, {})
-        if 'pdist_bwd' in name or 'pdist_fwd' in name:
+        if 'vec_gram' in name:   # matrix-core Gram kernels: d is the vector dimension
+            alg = pairs * esz + n * d * esz * 2
+            line += f'  | algorithmic {alg / 1e6:.1f} MB -> {alg / avg / 1e3:.0f} GB/s = {alg / avg / 1e3 / HBM:.3f} of HBM peak'
+            if 'FETCH_SIZE' in c and 'WRITE_SIZE' in c:
+                tr = (2 * c['FETCH_SIZE'] + c['WRITE_SIZE']) * 1024
+                line += f'; traffic {tr / 1e6:.1f} MB (2 x FETCH {2 * c["FETCH_SIZE"] * 1024 / 1e6:.1f} + WRITE {c["WRITE_SIZE"] * 1024 / 1e6:.1f}) = {tr / alg:.2f} x algorithmic'
+        elif 'pdist_bwd' in name or 'pdist_fwd' in name:
             alg = pairs * esz + n * (4 if 'bwd' in name else 2) * npk * esz
             line += f'  | algorithmic {alg / 1e6:.1f} MB -> {alg / avg / 1e3:.0f} GB/s = {alg / avg / 1e3 / HBM:.3f} of HBM peak'
             if 'FETCH_SIZE' in c and 'WRITE_SIZE' in c:

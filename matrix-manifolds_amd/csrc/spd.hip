@@ -230,7 +230,7 @@ template <typename T, int D> constexpr int pair_cols() { return (sizeof(T) == 4 
 // output row is a running scalar pointer (row i + 1 starts n - i - 2 elements after row i) plus a fixed lane offset:
 // `global_store_dword v_off, v, s[ptr]`, lanes on consecutive j -> 256-B coalesced segments of the row-major pair vector.
 template <typename T, int D, int TI, bool SQ>
-__global__ __launch_bounds__(kBlock, (fwd_min_waves<T, D>())) void spd_pdist_fwd_kernel(const T* __restrict__ nodeL,
+__global__ __launch_bounds__(kBlock) void spd_pdist_fwd_kernel(const T* __restrict__ nodeL,
                                                                const T* __restrict__ nodeY /* column operand: chol(X_j) */, int n, int row_begin,
                                                                int row_end, T wmin, T wmax, T* __restrict__ out) {
   constexpr int NP = Packed<D>::NP;

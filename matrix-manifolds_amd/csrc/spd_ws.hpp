@@ -12,33 +12,19 @@
 namespace mm {
 
 constexpr int kBlock = 256;  // 4 wavefronts
-// Tile-shape sweep on MI355X (SPD(3) fp32, n = 5000, backward): rows per wavefront 4 / 6 / 8 / 12 -> 90.7 / 81.5 /
-// 70.0 / 73.5 us; wavefronts per workgroup 8 -> +1.5 us.  Persistent workgroups (one launch-filling grid that
-// loops over tiles) were measured slower too: 118 us with a global atomic tile counter (same-address returning
-// atomics serialise at ~18 ns each), 75-81 us with a static round-robin (78 VGPRs -> 6 wavefronts per SIMD).
-#ifndef MM_BWD_AHEAD
-#define MM_BWD_AHEAD 2   // rows of the pair vector requested ahead of their use in the backward (= unroll of its row loop)
-#endif
-#ifndef MM_BWD_WAVES
-#define MM_BWD_WAVES 4
-#endif
-// backward: wavefronts that share one 64-column tile (one column-side atomic flush per workgroup);
-// 4 where the LDS combine buffer of 8 would not fit (fp64, D = 5)
-// Wavefronts per SIMD the backward is compiled for (the second __launch_bounds__ argument): fp32 SPD(4) needs 129 - 138
-// vector registers left alone — one allocation granule above the 128 that let four wavefronts share a SIMD instead of three.
-#ifndef MM_F64_BWD_W
-#define MM_F64_BWD_W 1
-#endif
-#ifndef MM_F64_FWD_W
-#define MM_F64_FWD_W 1
-#endif
+// Launch shape of the backward (MI355X, SPD(3) fp32, n = 5000).  Round 1 dispatched tiles (rows per wavefront 4 / 6 / 8 / 12:
+// 90.7 / 81.5 / 70.0 / 73.5 us); a persistent grid with a global atomic tile counter ran 118 us (same-address returning
+// atomics serialise at ~18 ns each).  Round 2: ONE resident grid with statically balanced shares (ColWalk below), 50 us.
 // Most nodes of one call: the pair kernels address the node tables and a row of the pair vector with 32-bit byte offsets
 // (2 NP sizeof(T) <= 720 bytes of row operands per node).  4 M nodes are 8.8e12 pairs — 35 TB of fp32 distances.
 constexpr int64_t kSpdMaxNodes = int64_t(1) << 22;
-template <typename T, int D> constexpr int bwd_min_waves() {
-  return (sizeof(T) == 4 && (D == 3 || D == 4)) ? 4 : ((sizeof(T) == 8 && D == 3) ? MM_F64_BWD_W : 1);
-}
-template <typename T, int D> constexpr int fwd_min_waves() { return (sizeof(T) == 8 && D == 3) ? MM_F64_FWD_W : 1; }
+// Wavefronts per SIMD the pair kernels are compiled for (the second __launch_bounds__ argument).  The fp32 SPD(3) / SPD(4)
+// backward needs 121 - 138 vector registers left alone — for several instantiations one allocation granule above the 128
+// that let four wavefronts share a SIMD instead of three (SPD(4), n = 16384: 1157 -> 1069 us; the few spills land in the
+// Jacobi fallback).  fp64 SPD(3) (forward 138, backward 217 registers) capped at 128 / 168 was measured and NOT adopted:
+// reference init -4 % but the mid-training spread +15 % (spills in the Cayley path).
+template <typename T, int D> constexpr int bwd_min_waves() { return (sizeof(T) == 4 && (D == 3 || D == 4)) ? 4 : 1; }
+// Wavefronts of a backward workgroup: they share one column block and flush its column-side sums once
 template <typename T, int D> constexpr int bwd_waves() {
   // (the column-side combine buffer is D^2 x 64 values per wavefront: 4 wavefronts up to 64 KB of it, else 2, else 1)
   return int(sizeof(T)) * D * D * 64 * 4 <= 65536 ? 4 : (int(sizeof(T)) * D * D * 64 * 2 <= 65536 ? 2 : 1);

@@ -80,7 +80,9 @@ int mm_spd_prepare(int dtype, const void* x, int64_t n, int d, void* ws, mm_stre
  * (sqrt of it if !squared), eigenvalues value-clamped to [wmin,wmax], result
  * value-clamped >= wmin.
  *   x    [n,d,d]   out  [mm_pair_offset(n,row_end)-mm_pair_offset(n,row_begin)]
- * A non-positive-definite x[i] sets the status word (mm_spd_status). */
+ * A non-positive-definite x[i] sets the status word (mm_spd_status).
+ * n <= 2^22 in every SPD entry point (32-bit byte offsets into the node tables; 2^22 nodes are 8.8e12 pairs):
+ * MM_ERR_ARG beyond, as for null pointers and row ranges outside [0, n]. */
 int mm_spd_pdist_fwd(int dtype, const void* x, int64_t n, int d, int64_t row_begin,
                      int64_t row_end, int squared, double wmin, double wmax, void* out,
                      void* ws, int flags, mm_stream_t stream);

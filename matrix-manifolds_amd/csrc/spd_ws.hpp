@@ -124,8 +124,8 @@ template <int TI, int BW = kBlock> inline dim3 fold_grid(int64_t n, int64_t rb, 
 // rows [rb, hi(c)), hi(c) = min(re, bw c + bw - 1) (row i has a pair in the block iff i < bw c + bw - 1; re = min(row_end, n-1)).  The blocks' row
 // ranges, concatenated block after block, form a line of W units, and workgroup w of G takes the units
 // [start(w), start(w+1)), start(w) = floor(W/G) w + min(w, W mod G): every workgroup gets the same amount of arithmetic
-// to within one row, so a launch of exactly the resident capacity has no tail (with tiles handed out by the dispatcher
-// the last 40 % of the backward's duration ran at half occupancy — profiles/r02_timeline.txt), and a workgroup walks DOWN
+// to within one row, so a launch of exactly the resident capacity has no tail (tiles handed out by the dispatcher never
+// filled the machine and ended below half occupancy — profiles/r02_timeline_tiles64.txt), and a workgroup walks DOWN
 // a column block, so the column-side sums stay in registers until the block changes.
 // counts: 0 for c < c0 = (rb+1)/bw; bw c + bw - 1 - rb for c0 <= c < c1 = max(c0, re/bw); R = re - rb from c1 on.
 struct ColWalk {

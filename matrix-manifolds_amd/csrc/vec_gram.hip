@@ -52,10 +52,16 @@ constexpr int kGramWaves = 4;
 // fp32: 32x32 tiles, kGramFwdTiles consecutive column tiles per wavefront (the row-block operand stays in
 // registers; one tile per wavefront made the kernel wave-launch-bound: 8 k wavefronts of ~1 us each)
 constexpr int kGramFwdTiles = 4;
-template <int KIND>
+// Operand loads are UNCONDITIONAL, from clamped addresses, and masked after they arrive: written as `valid ? x[..] : 0`
+// every load is sunk under its lane condition — an exec-masked branch with `s_waitcnt vmcnt(0)` behind it — and the
+// kernel walked through 6 serial memory round trips per tile (load, wait, MFMA, load, wait, MFMA ...).  The next tile's B
+// operand is requested before the current tile's epilogue (acosh + 16 stores).  KS = MFMA k-steps (ceil(m / 2), rounded up
+// to a dispatch class) is a template parameter so that the operand arrays stay in registers.
+template <int KIND, int KS>
 __global__ __launch_bounds__(64 * kGramWaves) void vec_gram_fwd_f32_kernel(const float* __restrict__ x, int n, int m,
                                                                          int row_begin, int row_end, int squared,
                                                                          float* __restrict__ out) {
+  using u32 = unsigned int;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r = lane & 31, h = lane >> 5;
   const int i0 = row_begin + blockIdx.y * 32;
@@ -63,13 +69,29 @@ __global__ __launch_bounds__(64 * kGramWaves) void vec_gram_fwd_f32_kernel(const
   if (jt0 * 32 >= n) return;  // wave-uniform
   const int ia = i0 + r;
   const bool ia_ok = ia < n;
-  const float* xa = x + size_t(ia_ok ? ia : 0) * m;
-  const int ksteps = (m + 1) / 2;
-  float av[16];  // A operand: x[i0 + r][2 s + h] (Lorentz: space-like part negated), m <= 32
+  const u32 xao = u32(ia_ok ? ia : n - 1) * u32(m);
+  float av[KS];  // A operand: x[i0 + r][2 s + h] (Lorentz: space-like part negated)
 #pragma unroll
-  for (int s = 0; s < 16; ++s) {
+  for (int s = 0; s < KS; ++s) {
     const int k = 2 * s + h;
-    float a = (s < ksteps && ia_ok && k < m) ? xa[k < m ? k : 0] : 0.f;
+    av[s] = x[xao + u32(k < m ? k : m - 1)];
+  }
+  auto request_b = [&](int t, float (&bv)[KS]) __attribute__((always_inline)) {   // B operand of tile t: x[j0 + r][2 s + h]
+    const int jb = (jt0 + t) * 32 + r;
+    const u32 xbo = u32(jb < n ? jb : n - 1) * u32(m);
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      const int k = 2 * s + h;
+      bv[s] = x[xbo + u32(k < m ? k : m - 1)];
+    }
+  };
+  float b_next[KS];
+  request_b(0, b_next);
+#pragma unroll
+  for (int s = 0; s < KS; ++s) {
+    asm volatile("" : "+v"(av[s]));
+    const int k = 2 * s + h;
+    float a = (ia_ok && k < m) ? av[s] : 0.f;
     if (KIND == MM_LORENTZ && k != 0) a = -a;
     av[s] = a;
   }
@@ -77,19 +99,22 @@ __global__ __launch_bounds__(64 * kGramWaves) void vec_gram_fwd_f32_kernel(const
   for (int t = 0; t < kGramFwdTiles; ++t) {
     const int j0 = (jt0 + t) * 32;
     if (j0 >= n) break;  // wave-uniform
-    const int jb = j0 + r;
-    const bool jb_ok = jb < n;
-    const float* xb = x + size_t(jb_ok ? jb : 0) * m;
+    const bool jb_ok = j0 + r < n;
+    float bv[KS];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      bv[s] = b_next[s];
+      asm volatile("" : "+v"(bv[s]));
+    }
+    if (t + 1 < kGramFwdTiles) request_b(t + 1, b_next);
     f32x16 acc;
 #pragma unroll
     for (int q = 0; q < 16; ++q) acc[q] = 0.f;
 #pragma unroll
-    for (int s = 0; s < 16; ++s) {
-      if (s < ksteps) {
-        const int k = 2 * s + h;
-        const float b = (jb_ok && k < m) ? xb[k < m ? k : 0] : 0.f;
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s], b, acc, 0, 0, 0);
-      }
+    for (int s = 0; s < KS; ++s) {
+      const int k = 2 * s + h;
+      const float b = (jb_ok && k < m) ? bv[s] : 0.f;
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s], b, acc, 0, 0, 0);
     }
     const int j = j0 + r;
     // offsets advance by additions: rows in register order are i0 + 4h + {0,1,2,3, 8,...}, and
@@ -126,8 +151,11 @@ __global__ __launch_bounds__(64 * kGramWaves) void vec_gram_fwd_f64_kernel(const
   const int ksteps = (m + 3) / 4;
   for (int s = 0; s < ksteps; ++s) {
     const int k = 4 * s + h;
-    double a = (ia_ok && k < m) ? xa[k] : 0.0;
-    const double b = (jb_ok && k < m) ? xb[k] : 0.0;
+    const int kc = k < m ? k : m - 1;
+    double a = xa[kc], b = xb[kc];        // unconditional, pinned, masked after (see the fp32 kernel)
+    asm volatile("" : "+v"(a), "+v"(b));
+    a = (ia_ok && k < m) ? a : 0.0;
+    b = (jb_ok && k < m) ? b : 0.0;
     if (KIND == MM_LORENTZ && k != 0) a = -a;
     acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
   }
@@ -194,8 +222,12 @@ void vec_gram_bwd_f32_kernel(const float* __restrict__ x, const float* __restric
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
       const int k = 2 * s + h;
-      const float v = x[xb + u32(k < m ? k : m - 1)];
-      bJ[s] = (jr < n && k < m) ? v : 0.f;
+      bJ[s] = x[xb + u32(k < m ? k : m - 1)];
+    }
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {   // (pinned, then masked: `valid ? x[..] : 0` serialises the loads — see the forward kernel)
+      asm volatile("" : "+v"(bJ[s]));
+      bJ[s] = (jr < n && 2 * s + h < m) ? bJ[s] : 0.f;
     }
   }
   f32x16 accJ;
@@ -403,6 +435,15 @@ void vec_gram_bwd_f32_kernel(const float* __restrict__ x, const float* __restric
 // current step computes (176 VGPRs, 2 wavefronts per SIMD: 43.5 us); 2 x 4 super-tiles with a private LDS accumulator
 // set per wavefront and no barrier (twice the workgroups, half the tiles each: 53 us); LDS float atomics on one shared
 // accumulator set (100 us).
+#ifdef MM_GRAM_STAMP   // diagnostic build only: per-wavefront phase clocks of the symmetric backward (tools/gram_timeline.py)
+__device__ unsigned long long g_gram_stamps[1024 * 4 * 26];
+#define MM_GSTAMP(k)                                                                                              \
+  do {                                                                                                            \
+    if (lane == 0 && blockIdx.x < 1024) g_gram_stamps[(blockIdx.x * 4 + wave) * 26 + (k)] = __builtin_amdgcn_s_memtime(); \
+  } while (0)
+#else
+#define MM_GSTAMP(k)
+#endif
 template <int KIND, int KS, int LOSS>
 __global__ __launch_bounds__(64 * kGramBwdWaves) __attribute__((amdgpu_waves_per_eu(MM_GRAM_BWD_MIN_WAVES)))
 void vec_gram_bwd_sym_f32_kernel(const float* __restrict__ x, const float* __restrict__ g, int n, int m, int row_begin,
@@ -412,36 +453,109 @@ void vec_gram_bwd_sym_f32_kernel(const float* __restrict__ x, const float* __res
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int r = lane & 31, h = lane >> 5;
   using u32 = unsigned int;
-  // super-tile (A, B), A <= B, from the linear workgroup index: id = B (B + 1) / 2 + A
-  const int id = blockIdx.x;
-  int Bs = int((__builtin_sqrtf(8.f * float(id) + 1.f) - 1.f) * 0.5f);
-  while (Bs * (Bs + 1) / 2 > id) --Bs;
-  while ((Bs + 1) * (Bs + 2) / 2 <= id) ++Bs;
-  const int As = id - Bs * (Bs + 1) / 2;
+  MM_GSTAMP(0);
+  // super-tile (A, B), A <= B, from the linear workgroup index.  OFF-DIAGONAL super-tiles first (id = B (B - 1) / 2 + A,
+  // A < B: 16 tiles each), the diagonal ones (10 tiles) last: workgroups are placed in index order, breadth first over
+  // the CUs, and a launch of slightly more than two workgroups per CU (n = 4039: 528 on 256 CUs) leaves a third one on a
+  // few CUs, which then decide the kernel's duration (measured: wavefront life 80 k cycles there against 56 k on the
+  // others, tools/gram_timeline.py) — so the last workgroups placed are the lightest.
   const int nT = (n + 31) / 32;
+  const int nS = (nT + 3) / 4;
+  const int id = blockIdx.x, nOff = nS * (nS - 1) / 2;
+  int As, Bs;
+  if (id < nOff) {
+    Bs = int((__builtin_sqrtf(8.f * float(id) + 1.f) + 1.f) * 0.5f);
+    while (Bs * (Bs - 1) / 2 > id) --Bs;
+    while ((Bs + 1) * Bs / 2 <= id) ++Bs;
+    As = id - Bs * (Bs - 1) / 2;
+  } else {
+    As = Bs = id - nOff;
+  }
   if (As * 128 >= row_end || As * 128 + 127 < row_begin) return;   // no pair of this super-tile has its row in the shard
   constexpr bool kEuclid = KIND == MM_EUCLIDEAN;
   const int rc = r < m ? r : m - 1;
   const int jb = Bs * 4 + wave, J = jb * 32;   // this wavefront's column block
   const bool j_live = jb < nT;                  // (ragged last super-tile)
+  const u32 base = u32(gpair_off(n, row_begin));
+  const u32 gmax = u32(gpair_off(n, row_end)) - base - 1u;  // last valid index of this shard's slice
+  // Upstream gradients (accumulator layout) and the Gram A operand (rows of X_I) of step t.  Issued ONE STEP AHEAD into a
+  // second register set (the first request before the prologue's barrier): a wavefront spent a quarter of its life
+  // waiting for these loads at the top of every step (tools/gram_timeline.py).  Unconditional, from clamped offsets: for a
+  // step this wavefront skips they read some valid element that nobody uses.
+  auto request = [&](int t, float (&gr)[16], float (&xa)[KS]) __attribute__((always_inline)) {
+    const int ib = As * 4 + ((wave + t) & 3), I = ib * 32;
+    if (ib != jb) {   // pair (i, j) lies in row i of the pair vector, contiguous in j
+      const int col = J + r < n ? J + r : n - 1;
+      int row = I + 4 * h;
+      u32 o = u32(row) * u32(2 * n - row - 1) / 2u - base + u32(col - row - 1);
+#pragma unroll
+      for (int s = 0; s < 16; ++s) {
+        gr[s] = g[o > gmax ? gmax : o];   // (clamp: ragged edges and rows outside the shard, masked at use)
+        const int step = (s & 3) == 3 ? 5 : 1;
+#pragma unroll
+        for (int d = 0; d < 5; ++d)
+          if (d < step) { o += u32(n - row - 2); ++row; }
+      }
+    } else {
+      const int j = J + r;
+#pragma unroll
+      for (int s = 0; s < 16; ++s) {
+        const int i = I + mfma_row(s, h);
+        const int lo = i < j ? i : j, hi = i < j ? j : i;
+        const int hc = hi < n ? (hi > lo ? hi : lo + 1) : n - 1;
+        const u32 o = u32(lo) * u32(2 * n - lo - 1) / 2u - base + u32(hc - lo - 1);
+        gr[s] = g[o > gmax ? gmax : o];
+      }
+    }
+    if constexpr (!kEuclid) {
+      const int ia = I + r;
+      const u32 xo = u32(ia < n ? ia : n - 1) * u32(m);
+#pragma unroll
+      for (int s = 0; s < KS; ++s) {
+        const int k = 2 * s + h;
+        xa[s] = x[xo + u32(k < m ? k : m - 1)];
+      }
+    }
+  };
   float bJ[KS];      // B operand of the Gram: x[J + r][2 s + h]
   float xJ[16];      // B operand of W X_J: rows J + 2 s + h, lane = feature
+  // (the fused-loss instantiations need 185 - 233 registers with the second set: two wavefronts per SIMD, i.e. fewer
+  // workgroup slots than a 4039-node launch has workgroups — they request at the top of the step)
+  constexpr bool kAhead = LOSS == MM_LOSS_NONE;
+  float gr_next[16], xa_next[KS];
   {
+    // All loads first, from clamped addresses, PINNED below the last of them, masks afterwards: written as
+    // `valid ? x[..] : 0` each load is sunk under its condition — an exec-masked branch with a `vmcnt(0)` behind every
+    // one of the 22 loads (measured: a 7 k-cycle prologue, tools/gram_timeline.py).
     const int jr = J + r;
     const u32 xb = u32(jr < n ? jr : n - 1) * u32(m);
     if constexpr (!kEuclid) {
 #pragma unroll
       for (int s = 0; s < KS; ++s) {
         const int k = 2 * s + h;
-        const float v = x[xb + u32(k < m ? k : m - 1)];
-        bJ[s] = (jr < n && k < m) ? v : 0.f;
+        bJ[s] = x[xb + u32(k < m ? k : m - 1)];
       }
     }
 #pragma unroll
     for (int s = 0; s < 16; ++s) {
       const int jj = J + 2 * s + h;
-      const float v = x[u32(jj < n ? jj : n - 1) * u32(m) + u32(rc)];
-      xJ[s] = (jj < n && r < m) ? v : 0.f;
+      xJ[s] = x[u32(jj < n ? jj : n - 1) * u32(m) + u32(rc)];
+    }
+    if constexpr (kAhead) request(0, gr_next, xa_next);   // the first step's operands, in flight together with the column block's
+    if constexpr (!kEuclid) {
+#pragma unroll
+      for (int s = 0; s < KS; ++s) asm volatile("" : "+v"(bJ[s]));
+    }
+#pragma unroll
+    for (int s = 0; s < 16; ++s) asm volatile("" : "+v"(xJ[s]));
+    if constexpr (!kEuclid) {
+#pragma unroll
+      for (int s = 0; s < KS; ++s) bJ[s] = (jr < n && 2 * s + h < m) ? bJ[s] : 0.f;
+    }
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+      const int jj = J + 2 * s + h;
+      xJ[s] = (jj < n && r < m) ? xJ[s] : 0.f;
       if (kEuclid && r == m) xJ[s] = jj < n ? 1.f : 0.f;   // ones column: row sums of W
     }
   }
@@ -453,49 +567,24 @@ void vec_gram_bwd_sym_f32_kernel(const float* __restrict__ x, const float* __res
   loss_resolve<float, LOSS>(la);
   if constexpr (LOSS != MM_LOSS_NONE) sp = softplus_of(la.scale_raw);
   const float kInvalid = LOSS != MM_LOSS_NONE ? __builtin_nanf("") : 0.f;
-  const u32 base = u32(gpair_off(n, row_begin));
-  const u32 gmax = u32(gpair_off(n, row_end)) - base - 1u;  // last valid index of this shard's slice
   __syncthreads();
+  MM_GSTAMP(1);
   for (int t = 0; t < 4; ++t) {
     const int a = (wave + t) & 3;          // row block of this step (distinct per wavefront)
     const int ib = As * 4 + a, I = ib * 32;
     const bool live = j_live && ib < nT && ib <= jb;   // wave-uniform; below-diagonal tiles belong to their mirror
+    float gr[16], xa[KS];
+    if constexpr (kAhead) {
+#pragma unroll
+      for (int s = 0; s < 16; ++s) gr[s] = gr_next[s];
+#pragma unroll
+      for (int s = 0; s < KS; ++s) xa[s] = xa_next[s];
+      if (t < 3) request(t + 1, gr_next, xa_next);
+    }
     if (live) {
+      if constexpr (!kAhead) request(t, gr, xa);
       const bool diag = ib == jb;
-      // ---- loads: upstream gradients in accumulator layout, Gram A operand (rows of X_I), B operand of W^T X_I
-      float gr[16], xa[KS], bI[16];
-      if (!diag) {   // pair (i, j) lies in row i of the pair vector, contiguous in j
-        const int col = J + r < n ? J + r : n - 1;
-        int row = I + 4 * h;
-        u32 o = u32(row) * u32(2 * n - row - 1) / 2u - base + u32(col - row - 1);
-#pragma unroll
-        for (int s = 0; s < 16; ++s) {
-          gr[s] = g[o > gmax ? gmax : o];   // (clamp: ragged edges and rows outside the shard, masked at use)
-          const int step = (s & 3) == 3 ? 5 : 1;
-#pragma unroll
-          for (int d = 0; d < 5; ++d)
-            if (d < step) { o += u32(n - row - 2); ++row; }
-        }
-      } else {
-        const int j = J + r;
-#pragma unroll
-        for (int s = 0; s < 16; ++s) {
-          const int i = I + mfma_row(s, h);
-          const int lo = i < j ? i : j, hi = i < j ? j : i;
-          const int hc = hi < n ? (hi > lo ? hi : lo + 1) : n - 1;
-          const u32 o = u32(lo) * u32(2 * n - lo - 1) / 2u - base + u32(hc - lo - 1);
-          gr[s] = g[o > gmax ? gmax : o];
-        }
-      }
-      if constexpr (!kEuclid) {
-        const int ia = I + r;
-        const u32 xo = u32(ia < n ? ia : n - 1) * u32(m);
-#pragma unroll
-        for (int s = 0; s < KS; ++s) {
-          const int k = 2 * s + h;
-          xa[s] = x[xo + u32(k < m ? k : m - 1)];
-        }
-      }
+      float bI[16];   // B operand of W^T X_I
       {
         const u32 xlast = u32(n - 1) * u32(m) + u32(rc);
         u32 xo = u32(I + 4 * h) * u32(m) + u32(rc);
@@ -505,6 +594,10 @@ void vec_gram_bwd_sym_f32_kernel(const float* __restrict__ x, const float* __res
           xo += u32((s & 3) == 3 ? 5 : 1) * u32(m);
         }
       }
+#ifdef MM_GRAM_STAMP
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+      MM_GSTAMP(2 + 5 * t);
       // ---- validity: each unordered pair once (i < j), inside the matrix, row inside the shard
       const bool interior = !diag && I + 32 <= n && J + 32 <= n && I >= row_begin && I + 32 <= row_end;
       float gv[16];
@@ -552,11 +645,17 @@ void vec_gram_bwd_sym_f32_kernel(const float* __restrict__ x, const float* __res
           w[s] = ok ? dldm * sp * PairFn<float, KIND>::dq(q[s], 1) : 0.f;
         }
       }
+#ifdef MM_GRAM_STAMP
+      asm volatile("" : "+v"(w[15]));
+#endif
+      MM_GSTAMP(3 + 5 * t);
       // ---- 3. ACC_J += W^T X_I (the accumulator as the A operand) ...
-      const bool rows_in = I + 32 <= n;
+      // The B operand needs no masking: rows outside the matrix were loaded from the last row (finite) and meet w = 0;
+      // lanes r >= m hold a copy of column m - 1 and only feed output columns >= m, which are never flushed.  (The masks
+      // used to cost a dozen scalar branch instructions per element of the tile.)
 #pragma unroll
       for (int s = 0; s < 16; ++s) {
-        float b = ((rows_in || I + mfma_row(s, h) < n) && r < m) ? bI[s] : 0.f;
+        float b = bI[s];
         if (kEuclid && r == m) b = 1.f;  // ones column (w is 0 for rows outside the matrix)
         accJ = __builtin_amdgcn_mfma_f32_32x32x2f32(w[s], b, accJ, 0, 0, 0);
       }
@@ -566,6 +665,7 @@ void vec_gram_bwd_sym_f32_kernel(const float* __restrict__ x, const float* __res
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      MM_GSTAMP(4 + 5 * t);
       f32x16 pacc;
 #pragma unroll
       for (int k = 0; k < 16; ++k) pacc[k] = 0.f;
@@ -575,8 +675,13 @@ void vec_gram_bwd_sym_f32_kernel(const float* __restrict__ x, const float* __res
       // row block a of the super-tile belongs to this wavefront during this step
 #pragma unroll
       for (int k = 0; k < 16; ++k) accI[a][mfma_row(k, h)][r] += pacc[k];
+#ifdef MM_GRAM_STAMP
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
+      MM_GSTAMP(5 + 5 * t);
     }
     __syncthreads();
+    MM_GSTAMP(6 + 5 * t);
   }
   // ---- flush: wavefront w writes its column block's ACC_J and row block w's ACC_I, 32 x m contiguous floats each
   if constexpr (LOSS != MM_LOSS_NONE) {
@@ -620,6 +725,15 @@ void vec_gram_bwd_sym_f32_kernel(const float* __restrict__ x, const float* __res
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     flush(sT[wave], I);
   }
+  MM_GSTAMP(22);
+#ifdef MM_GRAM_STAMP
+  if (lane == 0 && blockIdx.x < 1024) {
+    unsigned long long* out = &g_gram_stamps[(blockIdx.x * 4 + wave) * 26];
+    out[23] = __builtin_amdgcn_s_memrealtime();
+    out[24] = (static_cast<unsigned long long>(__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11))) << 32) |
+              __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11));   // HW_ID | XCC_ID
+  }
+#endif
 }
 
 #include "vec_gram_bwd64.hpp"
@@ -646,10 +760,22 @@ extern "C" int mm_vec_pdist_fwd_gram(int dtype, int kind, const void* x, int64_t
     if (dtype == MM_F32) {
       auto* xp = static_cast<const float*>(x);
       auto* op = static_cast<float*>(out);
-      if (kind == MM_LORENTZ)
-        vec_gram_fwd_f32_kernel<MM_LORENTZ><<<grid, block, 0, st>>>(xp, int(n), m, int(row_begin), int(row_end), squared, op);
-      else
-        vec_gram_fwd_f32_kernel<MM_SPHERE><<<grid, block, 0, st>>>(xp, int(n), m, int(row_begin), int(row_end), squared, op);
+      if (m > 32) return MM_ERR_UNSUPPORTED;   // 16 k-steps of 2
+      const int ks = (m + 1) / 2;
+#define MM_GRAM_FWD_LAUNCH(KS_)                                                                                          \
+  do {                                                                                                                   \
+    if (kind == MM_LORENTZ)                                                                                              \
+      vec_gram_fwd_f32_kernel<MM_LORENTZ, KS_><<<grid, block, 0, st>>>(xp, int(n), m, int(row_begin), int(row_end), squared, op); \
+    else                                                                                                                 \
+      vec_gram_fwd_f32_kernel<MM_SPHERE, KS_><<<grid, block, 0, st>>>(xp, int(n), m, int(row_begin), int(row_end), squared, op);  \
+  } while (0)
+      if (ks <= 2) MM_GRAM_FWD_LAUNCH(2);
+      else if (ks <= 4) MM_GRAM_FWD_LAUNCH(4);
+      else if (ks <= 6) MM_GRAM_FWD_LAUNCH(6);
+      else if (ks <= 8) MM_GRAM_FWD_LAUNCH(8);
+      else if (ks <= 12) MM_GRAM_FWD_LAUNCH(12);
+      else MM_GRAM_FWD_LAUNCH(16);
+#undef MM_GRAM_FWD_LAUNCH
     } else if (dtype == MM_F64) {
       auto* xp = static_cast<const double*>(x);
       auto* op = static_cast<double*>(out);
@@ -811,6 +937,12 @@ int vec_gram_loss(int dtype, int kind, int loss_kind, const void* x, const void*
 }
 
 }  // namespace mm
+
+#ifdef MM_GRAM_STAMP
+extern "C" int mm_dbg_read_gram_stamps(void* host, size_t bytes) {
+  return int(hipMemcpyFromSymbol(host, HIP_SYMBOL(mm::g_gram_stamps), bytes));
+}
+#endif
 
 extern "C" int mm_vec_pdist_bwd_gram(int dtype, int kind, const void* x, const void* g, int64_t n, int m,
                                      int64_t row_begin, int64_t row_end, int squared, void* grad_x,

@@ -27,8 +27,12 @@ __global__ __launch_bounds__(64 * kGramBwdWaves) void vec_gram_bwd_f64_kernel(co
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
       const int k = 4 * s + h;
-      const double v = x[xb + u32(k < m ? k : m - 1)];
-      bJ[s] = (jr < n && k < m) ? v : 0.0;
+      bJ[s] = x[xb + u32(k < m ? k : m - 1)];
+    }
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {   // (pinned, then masked: `valid ? x[..] : 0` would serialise the loads)
+      asm volatile("" : "+v"(bJ[s]));
+      bJ[s] = (jr < n && 4 * s + h < m) ? bJ[s] : 0.0;
     }
   }
   f64x4 accJ = {0.0, 0.0, 0.0, 0.0};

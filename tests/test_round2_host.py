@@ -149,3 +149,20 @@ def test_pmc_stamp_goes_stale_with_the_sources(tmp_path, monkeypatch):
     assert bench.stamped_pmc() is not None
     (tmp_path / 'matrix-manifolds_amd' / 'csrc' / 'k.hip').write_text('// v2\n')
     assert bench.stamped_pmc() is None
+
+
+def test_spd_entry_points_validate_arguments_before_touching_the_gpu():
+    """Argument errors come back as MM_ERR_ARG from the C ABI without a launch (no GPU needed): null pointers, row
+    ranges outside [0, n], more nodes than the 32-bit table offsets address (include/mm_manifolds.h, mm_spd_pdist_fwd)."""
+    import ctypes as C
+    lib = C.CDLL(os.path.join(ROOT, 'matrix-manifolds_amd', 'lib', 'libmm_manifolds.so'))
+    f = lib.mm_spd_pdist_fwd
+    f.restype = C.c_int
+    f.argtypes = [C.c_int, C.c_void_p, C.c_int64, C.c_int, C.c_int64, C.c_int64, C.c_int, C.c_double, C.c_double,
+                  C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+    fake = C.c_void_p(4096)          # never dereferenced: every call below is rejected first
+    MM_F32, MM_ERR_ARG = 0, -1
+    assert f(MM_F32, fake, (1 << 22) + 1, 3, 0, 1, 1, 1e-8, 1e8, fake, fake, 0, None) == MM_ERR_ARG
+    assert f(MM_F32, None, 10, 3, 0, 10, 1, 1e-8, 1e8, fake, fake, 0, None) == MM_ERR_ARG
+    assert f(MM_F32, fake, 10, 3, 0, 11, 1, 1e-8, 1e8, fake, fake, 0, None) == MM_ERR_ARG
+    assert f(MM_F32, fake, 10, 3, 5, 4, 1, 1e-8, 1e8, fake, fake, 0, None) == MM_ERR_ARG

@@ -9,3 +9,4 @@ echo "pytest rc=$?"; tail -3 gpurun_out/$TAG/pytest_gpu.log
 bash tools/gpu_profile_r02.sh $TAG > gpurun_out/$TAG/profile.log 2>&1
 tail -c 1500 gpurun_out/$TAG/profile.log
 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2
+timeout 900 python tools/bench_configs.py > gpurun_out/$TAG/configs.json 2> gpurun_out/$TAG/configs.err; echo "configs rc=$?"

@@ -51,22 +51,37 @@ constexpr int kGramWaves = 4;
 
 // fp32: 32x32 tiles, kGramFwdTiles consecutive column tiles per wavefront (the row-block operand stays in
 // registers; one tile per wavefront made the kernel wave-launch-bound: 8 k wavefronts of ~1 us each)
+// row of a 32x32 accumulator tile held by register q of lane half h
+__device__ __forceinline__ int mfma_row(int q, int h) { return (q & 3) + 8 * (q >> 2) + 4 * h; }
 constexpr int kGramFwdTiles = 4;
+typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));   // four floats at any 4-byte offset (rows of the pair vector)
 // Operand loads are UNCONDITIONAL, from clamped addresses, and masked after they arrive: written as `valid ? x[..] : 0`
 // every load is sunk under its lane condition — an exec-masked branch with `s_waitcnt vmcnt(0)` behind it — and the
 // kernel walked through 6 serial memory round trips per tile (load, wait, MFMA, load, wait, MFMA ...).  The next tile's B
 // operand is requested before the current tile's epilogue (acosh + 16 stores).  KS = MFMA k-steps (ceil(m / 2), rounded up
 // to a dispatch class) is a template parameter so that the operand arrays stay in registers.
+#ifdef MM_GRAM_STAMP   // diagnostic build only: per-wavefront phase clocks of the forward (tools/gram_timeline.py fwd)
+__device__ unsigned long long g_gramf_stamps[2048 * 4 * 16];
+#define MM_FSTAMP(k)                                                                                              \
+  do {                                                                                                            \
+    const unsigned wg_ = blockIdx.y * gridDim.x + blockIdx.x;                                                     \
+    if (lane == 0 && wg_ < 2048) g_gramf_stamps[(wg_ * 4 + wave) * 16 + (k)] = __builtin_amdgcn_s_memtime();    \
+  } while (0)
+#else
+#define MM_FSTAMP(k)
+#endif
 template <int KIND, int KS>
 __global__ __launch_bounds__(64 * kGramWaves) void vec_gram_fwd_f32_kernel(const float* __restrict__ x, int n, int m,
                                                                          int row_begin, int row_end, int squared,
                                                                          float* __restrict__ out) {
   using u32 = unsigned int;
+  __shared__ __attribute__((aligned(16))) float sO[kGramWaves][32][36];   // output tile per wavefront (rows of 144 B: 16-B aligned quads)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r = lane & 31, h = lane >> 5;
   const int i0 = row_begin + blockIdx.y * 32;
   const int jt0 = ((i0 + 1) / 32) + (blockIdx.x * kGramWaves + wave) * kGramFwdTiles;
   if (jt0 * 32 >= n) return;  // wave-uniform
+  MM_FSTAMP(0);
   const int ia = i0 + r;
   const bool ia_ok = ia < n;
   const u32 xao = u32(ia_ok ? ia : n - 1) * u32(m);
@@ -96,6 +111,7 @@ __global__ __launch_bounds__(64 * kGramWaves) void vec_gram_fwd_f32_kernel(const
     av[s] = a;
   }
   const int64_t base = gpair_off(n, row_begin);
+  MM_FSTAMP(1);
   for (int t = 0; t < kGramFwdTiles; ++t) {
     const int j0 = (jt0 + t) * 32;
     if (j0 >= n) break;  // wave-uniform
@@ -106,6 +122,7 @@ __global__ __launch_bounds__(64 * kGramWaves) void vec_gram_fwd_f32_kernel(const
       bv[s] = b_next[s];
       asm volatile("" : "+v"(bv[s]));
     }
+    MM_FSTAMP(2 + 3 * t);
     if (t + 1 < kGramFwdTiles) request_b(t + 1, b_next);
     f32x16 acc;
 #pragma unroll
@@ -117,20 +134,57 @@ __global__ __launch_bounds__(64 * kGramWaves) void vec_gram_fwd_f32_kernel(const
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s], b, acc, 0, 0, 0);
     }
     const int j = j0 + r;
-    // offsets advance by additions: rows in register order are i0 + 4h + {0,1,2,3, 8,...}, and
-    // off(row + 1) = off(row) + n - row - 2 (a 64-bit multiply per element cost more than the acosh)
-    int row = i0 + 4 * h;
-    int64_t o = gpair_off(n, row) - base + (j - row - 1);
+#ifdef MM_GRAM_STAMP
+    asm volatile("" : "+v"(acc));
+#endif
+    MM_FSTAMP(3 + 3 * t);
+    if (j0 > i0 + 31 && j0 + 32 <= n && i0 + 32 <= row_end) {
+      // Interior tile (all but the diagonal and the ragged edges): the kernel is bound by the ISSUE of its stores
+      // (tools/gram_timeline.py fwd: the 16 dword stores of a tile took 2 - 4 k cycles to issue), so the tile is turned
+      // through LDS — a lane then holds 4 consecutive columns of a row — and leaves as 4 `global_store_dwordx4`.
 #pragma unroll
-    for (int q = 0; q < 16; ++q) {
-      const float v = gram_value<float, KIND>(acc[q], squared);
-      if (row < row_end && j < n && j > row) out[o] = v;
-      const int step = (q & 3) == 3 ? 5 : 1;
+      for (int q = 0; q < 16; ++q) sO[wave][mfma_row(q, h)][r] = gram_value<float, KIND>(acc[q], squared);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      const int c4 = 4 * (lane & 7);
+      int row = i0 + (lane >> 3);
+      int64_t o = gpair_off(n, row) - base + (j0 + c4 - row - 1);
 #pragma unroll
-      for (int d = 0; d < 5; ++d)
-        if (d < step) { o += n - row - 2; ++row; }
+      for (int k = 0; k < 4; ++k) {
+        const f32x4u v = *reinterpret_cast<const f32x4u*>(&sO[wave][(lane >> 3) + 8 * k][c4]);
+        *reinterpret_cast<f32x4u*>(out + o) = v;
+        o += 8 * int64_t(n - row - 2) - 28;   // eight rows down: sum of (n - row' - 2) over row' = row .. row + 7
+        row += 8;
+      }
+      __builtin_amdgcn_wave_barrier();   // the tile is rewritten by the next pass
+    } else {
+      // offsets advance by additions: rows in register order are i0 + 4h + {0,1,2,3, 8,...}, and
+      // off(row + 1) = off(row) + n - row - 2 (a 64-bit multiply per element cost more than the acosh)
+      int row = i0 + 4 * h;
+      int64_t o = gpair_off(n, row) - base + (j - row - 1);
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const float v = gram_value<float, KIND>(acc[q], squared);
+        if (row < row_end && j < n && j > row) out[o] = v;
+        const int step = (q & 3) == 3 ? 5 : 1;
+#pragma unroll
+        for (int d = 0; d < 5; ++d)
+          if (d < step) { o += n - row - 2; ++row; }
+      }
     }
+    MM_FSTAMP(4 + 3 * t);
   }
+#ifdef MM_GRAM_STAMP
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+  MM_FSTAMP(14);
+#ifdef MM_GRAM_STAMP
+  {
+    const unsigned wg_ = blockIdx.y * gridDim.x + blockIdx.x;
+    if (lane == 0 && wg_ < 2048) g_gramf_stamps[(wg_ * 4 + wave) * 16 + 15] = __builtin_amdgcn_s_memrealtime();
+  }
+#endif
 }
 
 // fp64: 16x16 tile per wavefront
@@ -191,7 +245,6 @@ constexpr int kGramBwdWaves = 4;
 #ifndef MM_GRAM_BWD_MIN_WAVES
 #define MM_GRAM_BWD_MIN_WAVES 2   // measured: 2-3 wavefronts per SIMD (156 VGPRs) 39 us, 4 (128 VGPRs) 47 us
 #endif
-__device__ __forceinline__ int mfma_row(int q, int h) { return (q & 3) + 8 * (q >> 2) + 4 * h; }
 
 // LOSS != 0 (mm_vec_pdist_loss): `g` holds the TARGET squared distances; the loss term, its derivative and
 // the upstream gradient of each pair are formed on the accumulator registers (loss.hpp).  Entries outside
@@ -447,7 +500,7 @@ __device__ unsigned long long g_gram_stamps[1024 * 4 * 26];
 template <int KIND, int KS, int LOSS>
 __global__ __launch_bounds__(64 * kGramBwdWaves) __attribute__((amdgpu_waves_per_eu(MM_GRAM_BWD_MIN_WAVES)))
 void vec_gram_bwd_sym_f32_kernel(const float* __restrict__ x, const float* __restrict__ g, int n, int m, int row_begin,
-                                 int row_end, int squared, float* __restrict__ grad, LossArgs<float> la) {
+                                 int row_end, int squared, int parts, float* __restrict__ grad, LossArgs<float> la) {
   __shared__ float sT[kGramBwdWaves][32][33];     // per-wavefront transpose tile
   __shared__ float accI[kGramBwdWaves][32][32];   // row-side accumulators of the super-tile's four row blocks
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -461,7 +514,9 @@ void vec_gram_bwd_sym_f32_kernel(const float* __restrict__ x, const float* __res
   // others, tools/gram_timeline.py) — so the last workgroups placed are the lightest.
   const int nT = (n + 31) / 32;
   const int nS = (nT + 3) / 4;
-  const int id = blockIdx.x, nOff = nS * (nS - 1) / 2;
+  // `parts` (1, 2 or 4) workgroups share a super-tile: each takes 4 / parts of its four steps and flushes its own sums
+  const int id = blockIdx.x / parts, part = blockIdx.x - id * parts, nOff = nS * (nS - 1) / 2;
+  const int steps = 4 / parts, t_begin = part * steps, t_end = t_begin + steps;
   int As, Bs;
   if (id < nOff) {
     Bs = int((__builtin_sqrtf(8.f * float(id) + 1.f) + 1.f) * 0.5f);
@@ -541,7 +596,7 @@ void vec_gram_bwd_sym_f32_kernel(const float* __restrict__ x, const float* __res
       const int jj = J + 2 * s + h;
       xJ[s] = x[u32(jj < n ? jj : n - 1) * u32(m) + u32(rc)];
     }
-    if constexpr (kAhead) request(0, gr_next, xa_next);   // the first step's operands, in flight together with the column block's
+    if constexpr (kAhead) request(t_begin, gr_next, xa_next);   // the first step's operands, in flight together with the column block's
     if constexpr (!kEuclid) {
 #pragma unroll
       for (int s = 0; s < KS; ++s) asm volatile("" : "+v"(bJ[s]));
@@ -569,7 +624,7 @@ void vec_gram_bwd_sym_f32_kernel(const float* __restrict__ x, const float* __res
   const float kInvalid = LOSS != MM_LOSS_NONE ? __builtin_nanf("") : 0.f;
   __syncthreads();
   MM_GSTAMP(1);
-  for (int t = 0; t < 4; ++t) {
+  for (int t = t_begin; t < t_end; ++t) {
     const int a = (wave + t) & 3;          // row block of this step (distinct per wavefront)
     const int ib = As * 4 + a, I = ib * 32;
     const bool live = j_live && ib < nT && ib <= jb;   // wave-uniform; below-diagonal tiles belong to their mirror
@@ -579,7 +634,7 @@ void vec_gram_bwd_sym_f32_kernel(const float* __restrict__ x, const float* __res
       for (int s = 0; s < 16; ++s) gr[s] = gr_next[s];
 #pragma unroll
       for (int s = 0; s < KS; ++s) xa[s] = xa_next[s];
-      if (t < 3) request(t + 1, gr_next, xa_next);
+      if (t + 1 < t_end) request(t + 1, gr_next, xa_next);
     }
     if (live) {
       if constexpr (!kAhead) request(t, gr, xa);
@@ -820,7 +875,21 @@ int vec_gram_bwd_launch(int kind, int loss_kind, const float* xp, const float* g
   static const int forced = [] { const char* e = std::getenv("MM_GRAM_BWD_ORDERED"); return e ? (e[0] == '1' ? 1 : 0) : -1; }();
   const bool ordered = forced >= 0 ? forced == 1 : kind == MM_EUCLIDEAN;
   const int nS = (nT + 3) / 4;                       // super-tiles of 4 x 4 tiles per side
-  const dim3 sgrid(unsigned(nS * (nS + 1) / 2));     // unordered pairs of super-tile indices
+  // Workgroups per super-tile.  All workgroups of these launches are resident at once, so the CU with the most of them
+  // decides the duration: 528 super-tiles (n = 4039) are two per CU on 240 CUs and three on 16 (tools/gram_timeline.py).
+  // When the fullest CU carries more than 1.2 x the average, every super-tile is split between two workgroups (two of
+  // its four steps each; both flush their own sums): n = 4039 Lorentz 33.9 -> 32.7 us, n = 5000 sphere 46.8 -> 43.6 us on
+  // one box; four parts: 39.5 / 48.4 us (prologue and flush per workgroup outweigh the balance).  MM_GRAM_BWD_PARTS forces.
+  static const int parts_env = [] { const char* e = std::getenv("MM_GRAM_BWD_PARTS"); return e ? std::atoi(e) : 0; }();
+  static const int cus = [] {
+    int dev = 0, c = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || c < 1) c = 256;
+    return c;
+  }();
+  const int64_t nsuper = int64_t(nS) * (nS + 1) / 2;
+  int parts = ((nsuper + cus - 1) / cus) * cus * 5 > nsuper * 6 ? 2 : 1;
+  if (parts_env == 1 || parts_env == 2 || parts_env == 4) parts = parts_env;
+  const dim3 sgrid(unsigned(nS * (nS + 1) / 2) * unsigned(parts));     // unordered pairs of super-tile indices
   {
     ProfScope prof(PROF_VEC_BWD, st);
 #define MM_GRAM_BWD(KIND_, KS_, LOSS_)                                                                        \
@@ -830,7 +899,7 @@ int vec_gram_bwd_launch(int kind, int loss_kind, const float* xp, const float* g
                                                                         int(row_end), squared, tpw, op, la);  \
     else                                                                                                      \
       vec_gram_bwd_sym_f32_kernel<KIND_, KS_, LOSS_><<<sgrid, block, 0, st>>>(xp, gp, int(n), m,            \
-                                                                        int(row_begin), int(row_end), squared, op, la); \
+                                                                        int(row_begin), int(row_end), squared, parts, op, la); \
   } while (0)
 #define MM_GRAM_BWD_KS(KIND_, LOSS_)                        \
   do {                                                      \
@@ -939,6 +1008,9 @@ int vec_gram_loss(int dtype, int kind, int loss_kind, const void* x, const void*
 }  // namespace mm
 
 #ifdef MM_GRAM_STAMP
+extern "C" int mm_dbg_read_gramf_stamps(void* host, size_t bytes) {
+  return int(hipMemcpyFromSymbol(host, HIP_SYMBOL(mm::g_gramf_stamps), bytes));
+}
 extern "C" int mm_dbg_read_gram_stamps(void* host, size_t bytes) {
   return int(hipMemcpyFromSymbol(host, HIP_SYMBOL(mm::g_gram_stamps), bytes));
 }

@@ -28,6 +28,28 @@ def main():
         torch.autograd.grad(d2, x, g)
     torch.cuda.synchronize()
     raw = B.lib()._lib
+    if len(sys.argv) > 3 and sys.argv[3] == 'fwd':
+        fb = np.zeros(2048 * 4 * 16, dtype=np.uint64)
+        ff = raw.mm_dbg_read_gramf_stamps
+        ff.restype, ff.argtypes = ctypes.c_int, [ctypes.c_void_p, ctypes.c_size_t]
+        assert ff(fb.ctypes.data, fb.nbytes) == 0
+        fs = fb.reshape(-1, 16).astype(np.int64)
+        fs = fs[fs[:, 14] > 0]
+        life = fs[:, 14] - fs[:, 0]
+        print(f'forward: {len(fs)} live wavefronts; life cycles min {life.min()} median {int(np.median(life))} max {life.max()}')
+        print(f'  A operand + first B request: median {int(np.median(fs[:, 1] - fs[:, 0]))}')
+        for t in range(4):
+            ok = fs[:, 4 + 3 * t] > 0
+            if not ok.any():
+                continue
+            prev = fs[ok, 1] if t == 0 else fs[ok, 1 + 3 * t]
+            print(f'  tile {t}: {ok.sum()} wavefronts; B wait {int(np.median(fs[ok, 2 + 3 * t] - prev))}; MFMAs {int(np.median(fs[ok, 3 + 3 * t] - fs[ok, 2 + 3 * t]))}; '
+                  f'acosh + stores issued {int(np.median(fs[ok, 4 + 3 * t] - fs[ok, 3 + 3 * t]))}')
+        last = np.max(fs[:, 2:14], axis=1)
+        print(f'  stores drained (vmcnt(0)) after the last tile: median {int(np.median(fs[:, 14] - last))}')
+        end = fs[:, 15]
+        print(f'  wavefront END spread by the realtime clock: {(end.max() - end.min()) / 100.0:.1f} us')
+        return
     buf = np.zeros(1024 * 4 * 26, dtype=np.uint64)
     fn = raw.mm_dbg_read_gram_stamps
     fn.restype, fn.argtypes = ctypes.c_int, [ctypes.c_void_p, ctypes.c_size_t]

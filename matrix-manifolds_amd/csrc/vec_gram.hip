@@ -78,8 +78,12 @@ __global__ __launch_bounds__(64 * kGramWaves) void vec_gram_fwd_f32_kernel(const
   __shared__ __attribute__((aligned(16))) float sO[kGramWaves][32][36];   // output tile per wavefront (rows of 144 B: 16-B aligned quads)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r = lane & 31, h = lane >> 5;
-  const int i0 = row_begin + blockIdx.y * 32;
-  const int jt0 = ((i0 + 1) / 32) + (blockIdx.x * kGramWaves + wave) * kGramFwdTiles;
+  // grid: x = row tile, y = group of column tiles.  (The other way round, a launch whose x extent is 8 — n = 4039: 127
+  // column tiles in groups of 16 — puts column group k of EVERY row tile on XCD k, workgroups being dealt round-robin over
+  // the 8 XCDs in linear order: the triangle's long rows all start in group 0, so one XCD ran 127 live workgroups and the
+  // last one 15.)
+  const int i0 = row_begin + blockIdx.x * 32;
+  const int jt0 = ((i0 + 1) / 32) + (blockIdx.y * kGramWaves + wave) * kGramFwdTiles;
   if (jt0 * 32 >= n) return;  // wave-uniform
   MM_FSTAMP(0);
   const int ia = i0 + r;
@@ -194,8 +198,8 @@ __global__ __launch_bounds__(64 * kGramWaves) void vec_gram_fwd_f64_kernel(const
                                                                          double* __restrict__ out) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r = lane & 15, h = lane >> 4;
-  const int i0 = row_begin + blockIdx.y * 16;
-  const int j0 = (((i0 + 1) / 16) + blockIdx.x * kGramWaves + wave) * 16;
+  const int i0 = row_begin + blockIdx.x * 16;   // grid: x = row tile, y = group of column tiles (see the fp32 kernel)
+  const int j0 = (((i0 + 1) / 16) + blockIdx.y * kGramWaves + wave) * 16;
   if (j0 >= n) return;
   const int ia = i0 + r, jb = j0 + r;
   const bool ia_ok = ia < n, jb_ok = jb < n;
@@ -808,7 +812,7 @@ extern "C" int mm_vec_pdist_fwd_gram(int dtype, int kind, const void* x, int64_t
   const int ntile_cols = int((n + tile - 1) / tile) - int((row_begin + 1) / tile);
   if (ntile_cols <= 0) return MM_OK;
   const int per_wg = kGramWaves * (dtype == MM_F32 ? kGramFwdTiles : 1);
-  const dim3 grid((ntile_cols + per_wg - 1) / per_wg, int((row_end - row_begin + tile - 1) / tile));
+  const dim3 grid(int((row_end - row_begin + tile - 1) / tile), (ntile_cols + per_wg - 1) / per_wg);   // x = row tiles, y = column groups
   const dim3 block(64 * kGramWaves);
   {
     ProfScope prof(PROF_VEC_FWD, st);

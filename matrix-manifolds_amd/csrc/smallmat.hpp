@@ -236,6 +236,28 @@ __device__ __forceinline__ void lt_m_lt(const TL (&li)[Packed<D>::NP], const TL 
     }
 }
 
+// acc += Li^T M Lc^T, the sum carried by the accumulator through the second product's FMA chains (no separate adds)
+template <typename T, int D, typename TL>
+__device__ __forceinline__ void lt_m_lt_acc(const TL (&li)[Packed<D>::NP], const TL (&lc)[Packed<D>::NP],
+                                            const T (&m)[Packed<D>::NP], T (&acc)[D][D]) {
+  T b[D][D];  // B = Li^T M : B[r][c] = sum_{k>=r} Li[k][r] M[k][c]
+#pragma unroll
+  for (int r = 0; r < D; ++r)
+#pragma unroll
+    for (int c = 0; c < D; ++c) {
+      T t = li[pidx(r, r)] * m[pidx(r, c)];
+#pragma unroll
+      for (int k = r + 1; k < D; ++k) t = Num<T>::fma(li[pidx(k, r)], m[pidx(k, c)], t);
+      b[r][c] = t;
+    }
+#pragma unroll
+  for (int r = 0; r < D; ++r)
+#pragma unroll
+    for (int c = 0; c < D; ++c)
+#pragma unroll
+      for (int k = 0; k <= c; ++k) acc[r][c] = Num<T>::fma(b[r][k], lc[pidx(c, k)], acc[r][c]);
+}
+
 // out = F S F^T for a full row-major DxD matrix F (symmetric result, packed).
 template <typename T, int D>
 __device__ __forceinline__ void congr_full(const T (&f)[D * D], const T (&s)[Packed<D>::NP],

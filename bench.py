@@ -447,9 +447,10 @@ def worker(args):
     elapsed, mode, phases = time_workload(wl, args.steps, args.warmup, fence, use_graph, graph_collective, rank)
     elapsed = reduce_max(elapsed, dev, world)
 
-    # per-kernel durations: HIP events recorded on the launch stream around each kernel (csrc/prof.hpp).  Event
-    # records cannot live inside a captured graph, so they bracket the kernels of an eager pass of the same step
-    # issued right after the timed region; one discarded pass first (event creation, allocator warm-up).
+    # per-kernel durations: HIP events attached to each pair kernel's own dispatch on the launch stream
+    # (hipExtLaunchKernelGGL start / stop events, csrc/prof.hpp: the kernel's execution time as a profiler sees it).
+    # They cannot live inside a captured graph, so they time the kernels of an eager pass of the same step issued
+    # right after the timed region; one discarded pass first (event creation, allocator warm-up).
     kern, eager_ms = {'fwd': None, 'bwd': None}, None
     if not args.no_prof:
         lib.call('mm_prof_enable', 1)
@@ -504,7 +505,7 @@ def worker(args):
                                'traffic': rk.get('traffic_bytes'),
                                'traffic_source': (pmc or {}).get('source') if rk else None,
                                'algorithmic_bytes': by, 'avg_launch_us': kern['bwd'],
-                               'measured_in': 'eager pass after the timed region (HIP events on the launch stream)',
+                               'measured_in': 'eager pass after the timed region; HIP events attached to the kernel dispatch on the launch stream (hipExtLaunchKernelGGL)',
                                'valu_insts_per_64_pairs': rk.get('valu_insts_per_64_pairs')}
             if kern['fwd']:
                 byf = pairs_local * esz + n * 12 * esz

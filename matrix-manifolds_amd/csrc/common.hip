@@ -23,6 +23,13 @@ void prof_begin(int id, hipStream_t st) {
   g_spans[id].push_back(s);
 }
 void prof_end(int id, hipStream_t st) { (void)hipEventRecord(g_spans[id].back().b, st); }
+void prof_span(int id, hipEvent_t* start, hipEvent_t* stop) {
+  Span s;
+  if (!g_pool.empty()) { s = g_pool.back(); g_pool.pop_back(); }
+  else { (void)hipEventCreate(&s.a); (void)hipEventCreate(&s.b); }
+  g_spans[id].push_back(s);
+  *start = s.a; *stop = s.b;
+}
 }  // namespace mm
 
 extern "C" {

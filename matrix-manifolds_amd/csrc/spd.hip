@@ -1004,15 +1004,14 @@ int spd_pdist_fwd_t(const T* x, int64_t n, int64_t rb, int64_t re, int squared, 
   if (rc) return rc;
   if (re <= rb || pair_off(n, re) == pair_off(n, rb)) return MM_OK;
   const dim3 grid = fold_grid<kFwdTI, kBlock * pair_cols<T, D>()>(n, rb, re);
-  {
-    ProfScope prof(PROF_SPD_FWD, st);
-    if (squared)
-      spd_pdist_fwd_kernel<T, D, kFwdTI, true><<<grid, dim3(kBlock), 0, st>>>(ws.nodeL, ws.nodeC, int(n), int(rb), int(re), T(wmin),
-                                                                               T(wmax), out);
-    else
-      spd_pdist_fwd_kernel<T, D, kFwdTI, false><<<grid, dim3(kBlock), 0, st>>>(ws.nodeL, ws.nodeC, int(n), int(rb), int(re), T(wmin),
-                                                                                T(wmax), out);
-  }
+  const T* nl = ws.nodeL;
+  const T* nc = ws.nodeC;
+  if (squared)
+    launch_timed(PROF_SPD_FWD, spd_pdist_fwd_kernel<T, D, kFwdTI, true>, grid, dim3(kBlock), st, nl, nc, int(n), int(rb), int(re),
+                 T(wmin), T(wmax), out);
+  else
+    launch_timed(PROF_SPD_FWD, spd_pdist_fwd_kernel<T, D, kFwdTI, false>, grid, dim3(kBlock), st, nl, nc, int(n), int(rb), int(re),
+                 T(wmin), T(wmax), out);
   MM_CHECK_LAUNCH();
   return MM_OK;
 }
@@ -1032,10 +1031,9 @@ int spd_pdist_bwd_launch_sq(Ws<T>& ws, const T* g, int64_t n, int64_t rb, int64_
   if (env_grid > 0) grid = env_grid;   // (experiments: over- / under-subscription of the device)
   grid = std::max<int64_t>(1, std::min<int64_t>(grid, (units + 7) / 8));
   dim3 g3{unsigned(grid), 1, 1};
-  {
-    ProfScope prof(PROF_SPD_BWD, st);
-    kernel<<<g3, dim3(kThreads), 0, st>>>(ws.nodeLC, ws.nodeC, g, int(n), int(rb), int(re), T(wmin), T(wmax), ws.accM, ws.accS, la);
-  }
+  const T* nlc = ws.nodeLC;
+  const T* nc = ws.nodeC;
+  launch_timed(PROF_SPD_BWD, kernel, g3, dim3(kThreads), st, nlc, nc, g, int(n), int(rb), int(re), T(wmin), T(wmax), ws.accM, ws.accS, la);
   MM_CHECK_LAUNCH();
   return MM_OK;
 }

@@ -256,7 +256,7 @@ class VectorManifold(Manifold):
 
 def _vec_radam(kind, m, x, egrad, exp_avg, exp_avg_sq, step, ticket, lr, betas, nc, eps, max_grad_norm, exact,
                inplace):
-    ok = (x.is_cuda and x.dtype in (torch.float32, torch.float64) and 1 <= m <= 32 and x.numel() > 0
+    ok = (x.is_cuda and x.dtype in (torch.float32, torch.float64) and 1 <= m <= B.lib().raw('mm_vec_max_dim')() and x.numel() > 0
           and exp_avg.is_contiguous() and exp_avg_sq.is_contiguous() and exp_avg.dtype == x.dtype
           and exp_avg_sq.dtype == x.dtype and exp_avg.shape == x.shape and exp_avg_sq.shape == x.shape)
     if not ok:
@@ -276,7 +276,7 @@ def _vec_radam(kind, m, x, egrad, exp_avg, exp_avg_sq, step, ticket, lr, betas, 
 
 
 def _vec_momentum(kind, m, x, egrad, buf, lr, momentum, dampening, max_grad_norm, exact, inplace):
-    ok = (x.is_cuda and x.dtype in (torch.float32, torch.float64) and 1 <= m <= 32 and x.numel() > 0
+    ok = (x.is_cuda and x.dtype in (torch.float32, torch.float64) and 1 <= m <= B.lib().raw('mm_vec_max_dim')() and x.numel() > 0
           and buf.is_contiguous() and buf.dtype == x.dtype and buf.shape == x.shape)
     if not ok:
         return None

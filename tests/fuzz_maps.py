@@ -49,7 +49,7 @@ def main():
             raw = torch.randn(cnt, N, p, dtype=torch.float64)
             what = f'{fam}({N},{p})'
         else:
-            m = rng.randint(2, 32)
+            m = rng.randint(2, 32) if rng.random() < 0.8 else rng.randint(33, 64)   # (the kernels go to 64)
             man = {'lorentz': M.Lorentz, 'sphere': M.Sphere, 'euclidean': M.Euclidean}[fam](m)
             ref = rp.make(fam, m)
             x = ref.rand(cnt, ir=rng.choice([0.01, 0.5]), dtype=torch.float64)

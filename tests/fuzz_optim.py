@@ -60,7 +60,7 @@ def main():
                 man = ref = None
                 x = torch.randn(rng.choice([(), (3, ), (4, 5)]), dtype=torch.float64)
             else:
-                m = rng.randint(2, 32)
+                m = rng.randint(2, 32) if rng.random() < 0.8 else rng.randint(33, 64)   # (the kernels go to 64)
                 man = {'euclidean': M.Euclidean, 'lorentz': M.Lorentz, 'sphere': M.Sphere}[fam](m)
                 ref = rp.make(fam, m)
                 x = ref.rand(cnt, ir=rng.choice([0.01, 0.5]), dtype=torch.float64)

@@ -38,7 +38,7 @@ def main():
             x = man.rand(n, out=torch.empty(0, dtype=torch.float64, device='cuda'), ir=spread)
             what = f'spd{d} ir={spread}'
         else:
-            m = rng.randint(2 if fam != 'euclidean' else 1, 32)
+            m = rng.randint(2 if fam != 'euclidean' else 1, 32) if rng.random() < 0.8 else rng.randint(33, 64)   # (the kernels go to 64)
             man = {'euclidean': M.Euclidean, 'lorentz': M.Lorentz, 'sphere': M.Sphere}[fam](m)
             man.use_gram = rng.random() < 0.5
             spread = rng.choice([0.01, 0.3, 1.0])

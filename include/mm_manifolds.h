@@ -157,6 +157,9 @@ enum {
 };
 int mm_spd_map(int dtype, int op, const void* x, const void* u, int64_t m, int d, double wmin,
                double wmax, void* out, mm_stream_t stream);
+/* SymmetricPositiveDefinite.symeig — spd.py:35-41, 63-64 (linalg/fast.py:53-91 for n = 2, 3; LAPACK on the CPU
+ * otherwise): eigenvalues of sym(x[k]), ascending.   x [m,d,d] -> w [m,d] */
+int mm_spd_eigvalsh(int dtype, const void* x, int64_t m, int d, void* w, mm_stream_t stream);
 /* SymmetricPositiveDefinite.norm — spd.py:113-117: ||L^-1 U L^-T||_F  -> out [m] */
 int mm_spd_norm(int dtype, const void* x, const void* u, int64_t m, int d, int squared, void* out,
                 mm_stream_t stream);

@@ -843,6 +843,33 @@ __global__ void spd_norm_kernel(const T* __restrict__ x, const T* __restrict__ u
   if (in) out[k] = squared ? s : Num<T>::sqrt(s);
 }
 
+// Eigenvalues of sym(X), ascending: SymmetricPositiveDefinite.symeig (spd.py:35-41, 63-64; fast.symeig2x2 / symeig3x3 for
+// n = 2, 3 in the reference, LAPACK on the CPU otherwise) — one symmetric matrix per lane, cyclic Jacobi to machine precision.
+template <typename T, int D>
+__global__ void spd_eigvalsh_kernel(const T* __restrict__ x, int64_t m, T* __restrict__ w) {
+  constexpr int NP = Packed<D>::NP;
+  const int64_t k0 = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  const bool in = k0 < m;
+  const int64_t k = in ? k0 : 0;
+  T a[NP], v[D][D];
+  load_sym_packed<T, D>(x + k * D * D, a);
+  jacobi_eig<T, D, false>(a, v);
+  T e[D];
+#pragma unroll
+  for (int r = 0; r < D; ++r) e[r] = a[pidx(r, r)];
+#pragma unroll
+  for (int i = 0; i < D; ++i)          // (odd-even transposition sort: branch-free compare-exchanges)
+#pragma unroll
+    for (int j = (i & 1); j + 1 < D; j += 2) {
+      const T lo = Num<T>::min(e[j], e[j + 1]), hi = Num<T>::max(e[j], e[j + 1]);
+      e[j] = lo; e[j + 1] = hi;
+    }
+  if (in) {
+#pragma unroll
+    for (int r = 0; r < D; ++r) w[k * D + r] = e[r];
+  }
+}
+
 template <typename T, int D>
 // (x and xnew are deliberately not __restrict__: the update may be done in place, xnew == x — every thread
 // reads its whole point before it writes it)
@@ -1245,6 +1272,13 @@ int mm_spd_norm(int dtype, const void* x, const void* u, int64_t m, int d, int s
   MM_DISPATCH(dtype, d,
               (launch_pointwise<T, D>(spd_norm_kernel<T, D>, m, st, static_cast<const T*>(x),
                                       static_cast<const T*>(u), m, squared, static_cast<T*>(out))));
+}
+
+int mm_spd_eigvalsh(int dtype, const void* x, int64_t m, int d, void* w, mm_stream_t stream) {
+  if (m < 0 || (m > 0 && (!x || !w))) return MM_ERR_ARG;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  MM_DISPATCH(dtype, d,
+              (launch_pointwise<T, D>(spd_eigvalsh_kernel<T, D>, m, st, static_cast<const T*>(x), m, static_cast<T*>(w))));
 }
 
 int mm_spd_rsgd_step(int dtype, const void* x, const void* egrad, int64_t m, int d, double lr, double max_grad_norm,

@@ -75,6 +75,7 @@ SIGNATURES = {
     'mm_spd_dist_fwd': (_i, [_i, _vp, _vp, _i64, _i, _i, _dbl, _dbl, _vp, _vp]),
     'mm_spd_dist_bwd': (_i, [_i, _vp, _vp, _vp, _i64, _i, _i, _dbl, _dbl, _vp, _vp, _vp]),
     'mm_spd_map': (_i, [_i, _i, _vp, _vp, _i64, _i, _dbl, _dbl, _vp, _vp]),
+    'mm_spd_eigvalsh': (_i, [_i, _vp, _i64, _i, _vp, _vp]),
     'mm_spd_norm': (_i, [_i, _vp, _vp, _i64, _i, _i, _vp, _vp]),
     'mm_spd_rsgd_step': (_i, [_i, _vp, _vp, _i64, _i, _dbl, _dbl, _i, _vp, _vp]),
     'mm_vec_max_dim': (_i, []),

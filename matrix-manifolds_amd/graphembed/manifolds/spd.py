@@ -270,8 +270,15 @@ class SymmetricPositiveDefinite(Manifold):
         return out.reshape(shape)
 
     def symeig(self, x):
-        """Eigenvalues (ascending) — used by the reference's monitor (monitor.py:39-45)."""
-        return torch.linalg.eigvalsh(x)
+        """Eigenvalues of sym(x), ascending (spd.py:35-41, 63-64; the reference's monitor reads them, monitor.py:39-45):
+        one Jacobi eigensolve per matrix in registers (`mm_spd_eigvalsh`); batch shape kept."""
+        xc = _flat(x.detach(), self.n)
+        out = torch.empty(xc.shape[0], self.n, dtype=xc.dtype, device=xc.device)
+        if xc.shape[0]:
+            with B.on_device(xc.device):
+                B.lib().call('mm_spd_eigvalsh', B.dtype_code(xc), B.ptr(xc), xc.shape[0], self.n, B.ptr(out),
+                             B.stream_of(xc))
+        return out.reshape(*x.shape[:-2], self.n)
 
     def inner(self, x, u, v, keepdim=False):  # spd.py:96-106: tr(X^-1 U X^-1 V)
         assert not x.requires_grad and not u.requires_grad and not v.requires_grad

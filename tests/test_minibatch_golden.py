@@ -1,0 +1,117 @@
+"""The node-minibatch objective (graphembed/train.py:206-213, modules.py:84-105, data/dataset.py:19-27) pinned DIRECTLY to values
+recorded from the real reference (tests/golden/gen_golden_minibatch.py): loss and all gradients of
+`objective_fn(dataset[idx], embedding.compute_dists(idx))` — against the oracle port on the CPU, and on the GPU against the
+in-kernel minibatch path (`mm_product_pairs_loss_subset`: rows, targets and gradient rows addressed through the index
+vector) as well as the gather -> compute_dists -> objective path."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, 'matrix-manifolds_amd')):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+GOLD = np.load(os.path.join(ROOT, 'tests', 'golden', 'minibatch.npz'))
+DT = {'f32': torch.float32, 'f64': torch.float64}
+CASES = ['product', 'spd3', 'lorentz11']
+LOSSES = {'stress': {}, 'quotient': dict(epoch=2, alpha=1.3)}
+
+
+def sym_if_spd(a, is_spd):
+    return 0.5 * (a + np.swapaxes(a, -1, -2)) if is_spd else a
+
+
+def check(loss, grads, base, lname, nfac, spd_factor, tol):
+    ref = float(GOLD[f'{base}/{lname}/loss'])
+    assert abs(float(loss) - ref) <= tol * abs(ref), (float(loss), ref)
+    for k in range(nfac):
+        a = sym_if_spd(grads[k], k == spd_factor)
+        b = sym_if_spd(GOLD[f'{base}/{lname}/grad_x_{k}'].astype(np.float64), k == spd_factor)
+        assert a.shape == b.shape
+        assert np.abs(a - b).max() <= 20 * tol * max(np.abs(b).max(), 1e-30), (lname, k, np.abs(a - b).max(), np.abs(b).max())
+        gs, rs = float(grads[nfac + k]), float(GOLD[f'{base}/{lname}/grad_s_{k}'])
+        assert abs(gs - rs) <= 20 * tol * max(abs(rs), 1e-30), (lname, 'scale', k, gs, rs)
+
+
+@pytest.mark.parametrize('case', CASES)
+@pytest.mark.parametrize('dname', list(DT))
+def test_oracle_port_minibatch_objective(case, dname):
+    from oracle import ref_port as rp
+    mans = {'product': [rp.Lorentz(6), rp.Sphere(6), rp.SPD(2)], 'spd3': [rp.SPD(3)], 'lorentz11': [rp.Lorentz(11)]}[case]
+    base = f'{case}/{dname}'
+    dt = DT[dname]
+    idx = torch.from_numpy(GOLD[f'{base}/idx'])
+    sq = torch.from_numpy(GOLD[f'{base}/graph_d']).to(dt).pow(2)
+    sq = sq / sq.max()                                  # GraphDataset.__init__, data/dataset.py:10-13
+    n = 61
+    dense = torch.zeros(n, n, dtype=dt)
+    i, j = torch.triu_indices(n, n, 1)
+    dense[i, j] = sq
+    dense = dense + dense.T
+    sub = dense[idx][:, idx]
+    bi, bj = torch.triu_indices(len(idx), len(idx), 1)
+    gd = sub[bi, bj]                                     # dataset[idx]
+    for lname, kw in LOSSES.items():
+        xs = [torch.from_numpy(GOLD[f'{base}/x_{k}']).requires_grad_() for k in range(len(mans))]
+        sc = [torch.tensor(float(s), dtype=dt, requires_grad=True) for s in GOLD[f'{base}/scales']]
+        md = rp.compute_dists(mans, xs, sc, idx)
+        loss = rp.stress_loss(gd, md) if lname == 'stress' else rp.quotient_loss(gd, md, **kw)
+        grads = [g.double().numpy() for g in torch.autograd.grad(loss, xs + sc)]
+        spd_factor = {'product': 2, 'spd3': 0, 'lorentz11': -1}[case]
+        check(loss.item(), grads, base, lname, len(mans), spd_factor, 2e-4 if dname == 'f32' else 1e-9)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('case', CASES)
+@pytest.mark.parametrize('dname', list(DT))
+@pytest.mark.parametrize('path', ['in_kernel', 'gather'])
+def test_minibatch_objective_gpu(case, dname, path):
+    from graphembed import _backend as B
+    from graphembed import manifolds as M
+    from graphembed.data import GraphDataset
+    from graphembed.modules import BatchedObjective, ManifoldEmbedding
+    from graphembed.objectives import QuotientLoss, StressLoss
+    dt = DT[dname]
+    base = f'{case}/{dname}'
+    mans = {'product': lambda: [M.Lorentz(6), M.Sphere(6), M.SymmetricPositiveDefinite(2)],
+            'spd3': lambda: [M.SymmetricPositiveDefinite(3)], 'lorentz11': lambda: [M.Lorentz(11)]}[case]()
+    spd_factor = {'product': 2, 'spd3': 0, 'lorentz11': -1}[case]
+    torch.set_default_dtype(dt)
+    try:
+        with torch.device('cuda'):
+            emb = ManifoldEmbedding(61, mans)
+            ds = GraphDataset(torch.from_numpy(GOLD[f'{base}/graph_d']).to(dt).cuda())
+        with torch.no_grad():
+            for k, x in enumerate(emb.xs):
+                x.copy_(torch.from_numpy(GOLD[f'{base}/x_{k}']).cuda())
+            for k, s in enumerate(emb.scales):
+                s.fill_(float(GOLD[f'{base}/scales'][k]))
+        idx = torch.from_numpy(GOLD[f'{base}/idx']).cuda()
+        params = list(emb.xs) + list(emb.scales)
+        for lname, kw in LOSSES.items():
+            fn = StressLoss() if lname == 'stress' else QuotientLoss()
+            if path == 'in_kernel':
+                lib, calls = B.lib(), []
+                orig = lib.call
+                lib.call = lambda name, *a: (calls.append(name), orig(name, *a))[1]
+                try:
+                    loss = BatchedObjective(fn, ds, emb)(idx, **kw)
+                finally:
+                    del lib.call
+                assert 'mm_product_pairs_loss_subset' in calls, calls    # the index vector goes into the kernel
+            else:
+                loss = fn(ds[idx], emb.compute_dists(idx), **kw)
+            grads = [g.double().cpu().numpy() for g in torch.autograd.grad(loss, params)]
+            # fp64: the reference's SPD closed forms carry their eps terms (1e-8 ... 1e-6 of bias); Lorentz has none
+            tol64 = 5e-6 if spd_factor >= 0 else 1e-9
+            check(loss.item(), grads, base, lname, len(mans), spd_factor, 2e-4 if dname == 'f32' else tol64)
+            rest = np.ones(61, dtype=bool)
+            rest[GOLD[f'{base}/idx']] = False
+            for k in range(len(mans)):
+                assert not grads[k][rest].any()          # rows outside the batch: exactly zero, as autograd gives them
+    finally:
+        torch.set_default_dtype(torch.float32)

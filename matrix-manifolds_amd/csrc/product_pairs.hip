@@ -155,12 +155,17 @@ __global__ __launch_bounds__(kPCols * kPWaves) void product_pair_kernel(PArgs<T>
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  // (requested unconditionally from clamped addresses for ALL factors first, masked when they are written to LDS further
+  // down: as `valid ? F.x[..] : 0` inside the loop, every factor's rows cost one serial memory round trip)
+  constexpr int kStageIts = kPMaxTI * kPMP / 64;
+  T staged[NV > 0 ? NV : 1][kStageIts];
 #pragma unroll
   for (int f = 0; f < NV; ++f) {
     const PVec<T>& F = pa.v[f];
-    for (int e = lane; e < ti * kPMP; e += 64) {
-      const int r = e / kPMP, k = e % kPMP;
-      rowpt[f][wave][r][k] = (k < F.m && i0 + r < n) ? F.x[size_t(rownode[wave][r]) * F.m + k] : T(0);
+#pragma unroll
+    for (int it = 0; it < kStageIts; ++it) {
+      const int e = lane + 64 * it, r = min(e / kPMP, ti - 1), k = e % kPMP;
+      staged[f][it] = F.x[size_t(rownode[wave][r]) * F.m + min(k, F.m - 1)];
     }
   }
   __shared__ T rowL[kPWaves][kPMaxTI][2 * NPS];  // L_i^-1 and L_i of the tile's rows
@@ -175,6 +180,15 @@ __global__ __launch_bounds__(kPCols * kPWaves) void product_pair_kernel(PArgs<T>
     }
   }
   // every load of the preamble is in flight by now; pin them here so that none is sunk below its mask
+#pragma unroll
+  for (int f = 0; f < NV; ++f) {
+#pragma unroll
+    for (int it = 0; it < kStageIts; ++it) {
+      pin_v(staged[f][it]);
+      const int e = lane + 64 * it, r = e / kPMP, k = e % kPMP;
+      if (e < ti * kPMP) rowpt[f][wave][r][k] = (k < pa.v[f].m && i0 + r < n) ? staged[f][it] : T(0);
+    }
+  }
 #pragma unroll
   for (int f = 0; f < NV; ++f) {
     pin_v(spv[f]);

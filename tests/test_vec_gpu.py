@@ -329,6 +329,34 @@ def test_optim_sphere_dominant_eigenvector():
     assert abs(abs((v[:, -1] @ x.detach()).item()) - 1) < 1e-3
 
 
+@pytest.mark.parametrize('n', [3, 4, 5])
+@pytest.mark.parametrize('optim', ['rsgd', 'radam'])
+@pytest.mark.parametrize('seed', [0, 1])
+def test_reference_optim_test_dominant_eigenvector(n, optim, seed):
+    """graphembed/tests/test_optim.py:13-41 with its own parametrisation, sizes, learning rate, iteration count and
+    tolerances (atol 1e-4), for RiemannianSGD AND RiemannianAdam: 200 steps on the sphere find the dominant eigenvector of
+    a random symmetric matrix; the iterate has unit norm after every step."""
+    from graphembed import manifolds as M
+    from graphembed.modules import ManifoldParameter
+    from graphembed.optim import RiemannianAdam, RiemannianSGD
+    torch.manual_seed(seed)
+    a = torch.rand(n, n, dtype=torch.float64, device='cuda')
+    a = 0.5 * (a + a.T)                                           # conftest.py rand_sym
+    man = M.Sphere(n)
+    x = ManifoldParameter(man.rand(1, out=torch.empty(0, dtype=torch.float64, device='cuda'))[0], manifold=man)
+    opt = RiemannianSGD([x], lr=1e-1) if optim == 'rsgd' else RiemannianAdam([x], lr=1e-1)
+    for _ in range(200):
+        opt.zero_grad()
+        loss = -torch.einsum('i,ij,j', x, a, x)
+        loss.backward()
+        opt.step()
+        assert abs(1.0 - x.detach().norm().item()) <= 1e-4
+    x_opt = x.detach()
+    w, v = torch.linalg.eigh(a)
+    assert ((x_opt / v[:, -1]).abs() - 1).abs().max().item() <= 1e-4
+    assert abs((a @ x_opt).norm().item() - w[-1].item()) <= 1e-4
+
+
 @pytest.mark.parametrize('case', ['euclidean10', 'lorentz11', 'sphere6', 'lorentz3'])
 @pytest.mark.parametrize('dname', ['f32', 'f64'])
 @pytest.mark.parametrize('loss_name', ['stress', 'quotient'])

@@ -18,7 +18,8 @@ void prof_span(int id, hipEvent_t* start, hipEvent_t* stop);
 // `kernel<<<grid, block, 0, st>>>(args...)`, timed when profiling is on
 template <typename... Args, typename F = void (*)(Args...)>
 inline void launch_timed(int id, F kernel, dim3 grid, dim3 block, hipStream_t st, Args... args) {
-  if (prof_on()) {
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  if (prof_on() && hipStreamIsCapturing(st, &cap) == hipSuccess && cap == hipStreamCaptureStatusNone) {   // (never inside a graph)
     hipEvent_t a, b;
     prof_span(id, &a, &b);
     hipExtLaunchKernelGGL(kernel, grid, block, 0, st, a, b, 0, args...);

@@ -34,6 +34,7 @@
 #include "adam.hpp"
 
 #include "spd_ws.hpp"
+#include "stamp.hpp"
 
 namespace mm {
 
@@ -328,9 +329,6 @@ __device__ __forceinline__ T pair_row_load(const T* __restrict__ g, int n, int64
   return *reinterpret_cast<const T*>(grow + off);
 }
 
-#ifdef MM_BWD_STAMP   // diagnostic build only (tools/build_variant.sh stamp -DMM_BWD_STAMP): per-workgroup start / end clocks
-__device__ unsigned long long g_bwd_stamps[4 * 16384];
-#endif
 // Backward: a launch of (at most) as many workgroups as the device holds at once; workgroup w walks its share of the
 // balanced column walk (spd_ws.hpp, ColWalk): down one 64-column block, chunk after chunk of up to NW x TI rows (each
 // wavefront a contiguous slice of the chunk's rows, its lanes the block's 64 columns), then on to the next block.
@@ -356,10 +354,7 @@ __global__ __launch_bounds__((64 * bwd_waves<T, D>()), (bwd_min_waves<T, D>())) 
   static_assert(TI % 2 == 0, "the row loop is unrolled twice");
   __shared__ T redM[NW][TI][NP];
   __shared__ T colS[NW][NC][D * D][64];
-#ifdef MM_BWD_STAMP
-  const unsigned long long stamp0 = __builtin_amdgcn_s_memrealtime();
-  const unsigned long long stampc0 = __builtin_amdgcn_s_memtime();
-#endif
+  MM_SPD_STAMP_BEGIN();
   const ColWalk walk(n, row_begin, row_end, 64 * NC);
   const int64_t total = walk.total();
   int64_t pos = ColWalk::share_begin(total, blockIdx.x, gridDim.x);
@@ -618,18 +613,7 @@ __global__ __launch_bounds__((64 * bwd_waves<T, D>()), (bwd_min_waves<T, D>())) 
       atomic_add(&la.slots[kLossSlots + slot], dd);
     }
   }
-#ifdef MM_BWD_STAMP
-  if (threadIdx.x == 0) {
-    const unsigned wg = blockIdx.x;
-    if (wg < 16384) {
-      g_bwd_stamps[4 * wg + 0] = stamp0;
-      g_bwd_stamps[4 * wg + 1] = __builtin_amdgcn_s_memrealtime();
-      g_bwd_stamps[4 * wg + 2] = (static_cast<unsigned long long>(__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11))) << 32) |
-                                 __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11));   // HW_ID | XCC_ID
-      g_bwd_stamps[4 * wg + 3] = __builtin_amdgcn_s_memtime() - stampc0;
-    }
-  }
-#endif
+  MM_SPD_STAMP_END();
 }
 
 // grad_x[i] = sym(accS_i X_i^-1) - L_i^-T accM_i L_i^-1   (symmetric, full DxD)

@@ -1,0 +1,72 @@
+// Diagnostic clocks of the pair kernels — compiled out of the product.  Variant builds define MM_BWD_STAMP (SPD backward:
+// per-workgroup start / end / placement, tools/stamp_timeline.py) or MM_GRAM_STAMP (matrix-core vector kernels: per-wavefront
+// phase clocks, tools/gram_timeline.py); the kernels carry one-line hooks that expand to nothing otherwise.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace mm {
+
+__device__ __forceinline__ unsigned long long stamp_hw_id() {   // HW_ID << 32 | XCC_ID
+  return (static_cast<unsigned long long>(__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11))) << 32) |
+         __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11));
+}
+
+#ifdef MM_BWD_STAMP
+__device__ unsigned long long g_bwd_stamps[4 * 16384];
+#define MM_SPD_STAMP_BEGIN()                                              \
+  const unsigned long long stamp0_ = __builtin_amdgcn_s_memrealtime();    \
+  const unsigned long long stampc0_ = __builtin_amdgcn_s_memtime()
+#define MM_SPD_STAMP_END()                                                        \
+  do {                                                                            \
+    if (threadIdx.x == 0 && blockIdx.x < 16384) {                                 \
+      unsigned long long* o_ = &g_bwd_stamps[4 * blockIdx.x];                     \
+      o_[0] = stamp0_;                                                            \
+      o_[1] = __builtin_amdgcn_s_memrealtime();                                   \
+      o_[2] = stamp_hw_id();                                                      \
+      o_[3] = __builtin_amdgcn_s_memtime() - stampc0_;                            \
+    }                                                                             \
+  } while (0)
+#else
+#define MM_SPD_STAMP_BEGIN() do {} while (0)
+#define MM_SPD_STAMP_END() do {} while (0)
+#endif
+
+#ifdef MM_GRAM_STAMP
+__device__ unsigned long long g_gram_stamps[1024 * 4 * 26];    // symmetric backward: 26 slots per wavefront
+__device__ unsigned long long g_gramf_stamps[2048 * 4 * 16];   // forward: 16 slots per wavefront
+#define MM_GSTAMP(k)                                                                                                  \
+  do {                                                                                                                \
+    if (lane == 0 && blockIdx.x < 1024) g_gram_stamps[(blockIdx.x * 4 + wave) * 26 + (k)] = __builtin_amdgcn_s_memtime(); \
+  } while (0)
+#define MM_GSTAMP_END()                                                           \
+  do {                                                                            \
+    if (lane == 0 && blockIdx.x < 1024) {                                         \
+      unsigned long long* o_ = &g_gram_stamps[(blockIdx.x * 4 + wave) * 26];      \
+      o_[23] = __builtin_amdgcn_s_memrealtime();                                  \
+      o_[24] = stamp_hw_id();                                                     \
+    }                                                                             \
+  } while (0)
+#define MM_FSTAMP(k)                                                                                               \
+  do {                                                                                                             \
+    const unsigned wg_ = blockIdx.y * gridDim.x + blockIdx.x;                                                      \
+    if (lane == 0 && wg_ < 2048) g_gramf_stamps[(wg_ * 4 + wave) * 16 + (k)] = __builtin_amdgcn_s_memtime();     \
+  } while (0)
+#define MM_FSTAMP_END()                                                                                            \
+  do {                                                                                                             \
+    const unsigned wg_ = blockIdx.y * gridDim.x + blockIdx.x;                                                      \
+    if (lane == 0 && wg_ < 2048) g_gramf_stamps[(wg_ * 4 + wave) * 16 + 15] = __builtin_amdgcn_s_memrealtime();   \
+  } while (0)
+#define MM_STAMP_WAIT_VM() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")      // a phase ends when its loads have landed
+#define MM_STAMP_WAIT_LGKM() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+#define MM_STAMP_PIN(v) asm volatile("" : "+v"(v))                              // ... or when a value exists
+#else
+#define MM_GSTAMP(k) do {} while (0)
+#define MM_GSTAMP_END() do {} while (0)
+#define MM_FSTAMP(k) do {} while (0)
+#define MM_FSTAMP_END() do {} while (0)
+#define MM_STAMP_WAIT_VM() do {} while (0)
+#define MM_STAMP_WAIT_LGKM() do {} while (0)
+#define MM_STAMP_PIN(v) do {} while (0)
+#endif
+
+}  // namespace mm

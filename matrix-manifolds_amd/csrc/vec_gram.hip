@@ -19,6 +19,7 @@
 
 #include "../../include/mm_manifolds.h"
 #include "prof.hpp"
+#include "stamp.hpp"
 #include "smallmat.hpp"
 #include "vecfn.hpp"
 #include "loss.hpp"
@@ -60,16 +61,6 @@ typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));   // four 
 // kernel walked through 6 serial memory round trips per tile (load, wait, MFMA, load, wait, MFMA ...).  The next tile's B
 // operand is requested before the current tile's epilogue (acosh + 16 stores).  KS = MFMA k-steps (ceil(m / 2), rounded up
 // to a dispatch class) is a template parameter so that the operand arrays stay in registers.
-#ifdef MM_GRAM_STAMP   // diagnostic build only: per-wavefront phase clocks of the forward (tools/gram_timeline.py fwd)
-__device__ unsigned long long g_gramf_stamps[2048 * 4 * 16];
-#define MM_FSTAMP(k)                                                                                              \
-  do {                                                                                                            \
-    const unsigned wg_ = blockIdx.y * gridDim.x + blockIdx.x;                                                     \
-    if (lane == 0 && wg_ < 2048) g_gramf_stamps[(wg_ * 4 + wave) * 16 + (k)] = __builtin_amdgcn_s_memtime();    \
-  } while (0)
-#else
-#define MM_FSTAMP(k)
-#endif
 template <int KIND, int KS>
 __global__ __launch_bounds__(64 * kGramWaves) void vec_gram_fwd_f32_kernel(const float* __restrict__ x, int n, int m,
                                                                          int row_begin, int row_end, int squared,
@@ -138,9 +129,7 @@ __global__ __launch_bounds__(64 * kGramWaves) void vec_gram_fwd_f32_kernel(const
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s], b, acc, 0, 0, 0);
     }
     const int j = j0 + r;
-#ifdef MM_GRAM_STAMP
-    asm volatile("" : "+v"(acc));
-#endif
+    MM_STAMP_PIN(acc);
     MM_FSTAMP(3 + 3 * t);
     if (j0 > i0 + 31 && j0 + 32 <= n && i0 + 32 <= row_end) {
       // Interior tile (all but the diagonal and the ragged edges): the kernel is bound by the ISSUE of its stores
@@ -179,16 +168,9 @@ __global__ __launch_bounds__(64 * kGramWaves) void vec_gram_fwd_f32_kernel(const
     }
     MM_FSTAMP(4 + 3 * t);
   }
-#ifdef MM_GRAM_STAMP
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
+  MM_STAMP_WAIT_VM();
   MM_FSTAMP(14);
-#ifdef MM_GRAM_STAMP
-  {
-    const unsigned wg_ = blockIdx.y * gridDim.x + blockIdx.x;
-    if (lane == 0 && wg_ < 2048) g_gramf_stamps[(wg_ * 4 + wave) * 16 + 15] = __builtin_amdgcn_s_memrealtime();
-  }
-#endif
+  MM_FSTAMP_END();
 }
 
 // fp64: 16x16 tile per wavefront
@@ -492,15 +474,6 @@ void vec_gram_bwd_f32_kernel(const float* __restrict__ x, const float* __restric
 // current step computes (176 VGPRs, 2 wavefronts per SIMD: 43.5 us); 2 x 4 super-tiles with a private LDS accumulator
 // set per wavefront and no barrier (twice the workgroups, half the tiles each: 53 us); LDS float atomics on one shared
 // accumulator set (100 us).
-#ifdef MM_GRAM_STAMP   // diagnostic build only: per-wavefront phase clocks of the symmetric backward (tools/gram_timeline.py)
-__device__ unsigned long long g_gram_stamps[1024 * 4 * 26];
-#define MM_GSTAMP(k)                                                                                              \
-  do {                                                                                                            \
-    if (lane == 0 && blockIdx.x < 1024) g_gram_stamps[(blockIdx.x * 4 + wave) * 26 + (k)] = __builtin_amdgcn_s_memtime(); \
-  } while (0)
-#else
-#define MM_GSTAMP(k)
-#endif
 template <int KIND, int KS, int LOSS>
 __global__ __launch_bounds__(64 * kGramBwdWaves) __attribute__((amdgpu_waves_per_eu(MM_GRAM_BWD_MIN_WAVES)))
 void vec_gram_bwd_sym_f32_kernel(const float* __restrict__ x, const float* __restrict__ g, int n, int m, int row_begin,
@@ -653,9 +626,7 @@ void vec_gram_bwd_sym_f32_kernel(const float* __restrict__ x, const float* __res
           xo += u32((s & 3) == 3 ? 5 : 1) * u32(m);
         }
       }
-#ifdef MM_GRAM_STAMP
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
+      MM_STAMP_WAIT_VM();
       MM_GSTAMP(2 + 5 * t);
       // ---- validity: each unordered pair once (i < j), inside the matrix, row inside the shard
       const bool interior = !diag && I + 32 <= n && J + 32 <= n && I >= row_begin && I + 32 <= row_end;
@@ -704,9 +675,7 @@ void vec_gram_bwd_sym_f32_kernel(const float* __restrict__ x, const float* __res
           w[s] = ok ? dldm * sp * PairFn<float, KIND>::dq(q[s], 1) : 0.f;
         }
       }
-#ifdef MM_GRAM_STAMP
-      asm volatile("" : "+v"(w[15]));
-#endif
+      MM_STAMP_PIN(w[15]);
       MM_GSTAMP(3 + 5 * t);
       // ---- 3. ACC_J += W^T X_I (the accumulator as the A operand) ...
       // The B operand needs no masking: rows outside the matrix were loaded from the last row (finite) and meet w = 0;
@@ -734,9 +703,7 @@ void vec_gram_bwd_sym_f32_kernel(const float* __restrict__ x, const float* __res
       // row block a of the super-tile belongs to this wavefront during this step
 #pragma unroll
       for (int k = 0; k < 16; ++k) accI[a][mfma_row(k, h)][r] += pacc[k];
-#ifdef MM_GRAM_STAMP
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#endif
+      MM_STAMP_WAIT_LGKM();
       MM_GSTAMP(5 + 5 * t);
     }
     __syncthreads();
@@ -785,14 +752,7 @@ void vec_gram_bwd_sym_f32_kernel(const float* __restrict__ x, const float* __res
     flush(sT[wave], I);
   }
   MM_GSTAMP(22);
-#ifdef MM_GRAM_STAMP
-  if (lane == 0 && blockIdx.x < 1024) {
-    unsigned long long* out = &g_gram_stamps[(blockIdx.x * 4 + wave) * 26];
-    out[23] = __builtin_amdgcn_s_memrealtime();
-    out[24] = (static_cast<unsigned long long>(__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11))) << 32) |
-              __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11));   // HW_ID | XCC_ID
-  }
-#endif
+  MM_GSTAMP_END();
 }
 
 #include "vec_gram_bwd64.hpp"

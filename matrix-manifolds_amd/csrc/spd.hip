@@ -1038,6 +1038,15 @@ int spd_pdist_bwd_launch_sq(Ws<T>& ws, const T* g, int64_t n, int64_t rb, int64_
   const int64_t units = ColWalk(int(n), int(rb), int(re), 64 * pair_cols<T, D>()).total();
   if (units <= 0) return MM_OK;
   int64_t grid = resident_workgroups(kernel, kThreads);
+  // Small launches (a rank's shard, small n): a workgroup flushes its column-side sums once per column block, so it needs
+  // enough rows to pay for that — with fewer than ~48 rows of a column block per workgroup the launch is made of flushes
+  // (one eighth of the headline problem, 13 k units: 1024 workgroups 23.8 us, 256 workgroups 17.1 us; a quarter: 24.2 -> 22.2 us;
+  // tools/gpu_shard_grid.sh).  Whole multiples of the CU count, at least one workgroup per CU.
+  {
+    const int64_t cus = device_cus();
+    const int64_t by_rows = units / 48 / cus * cus;
+    if (by_rows < grid) grid = std::max<int64_t>(cus, by_rows);
+  }
   static const int64_t env_grid = std::getenv("MM_SPD_BWD_GRID") ? std::atoll(std::getenv("MM_SPD_BWD_GRID")) : 0;
   if (env_grid > 0) grid = env_grid;   // (experiments: over- / under-subscription of the device)
   grid = std::max<int64_t>(1, std::min<int64_t>(grid, (units + 7) / 8));

@@ -164,6 +164,19 @@ struct ColWalk {
   }
 };
 
+// Compute units of the current device (cached)
+inline int device_cus() {
+  static int cache[64] = {0};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+  if (cache[dev] == 0) {
+    int cus = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;
+    cache[dev] = cus;
+  }
+  return cache[dev];
+}
+
 // Workgroups of `kernel` that are resident at once on the current device (occupancy x compute units), cached per
 // kernel and device.  hipOccupancyMaxActiveBlocksPerMultiprocessor can report one block too many per CU for kernels
 // with 81-96 scalar registers (MI355X_MICROARCH.md, Residency): capped at 7 blocks of 256 threads.

@@ -339,12 +339,20 @@ def time_workload(wl, steps, warmup, fence, use_graph, graph_collective=False, r
     if warm_seconds > 0:
         # secondary workloads follow seconds of host-side input generation with an idle GPU: a handful of warm-up steps
         # ends before the clocks are back up (a 1.4 ms step measured 2.2 ms), so they also warm up for a minimum TIME
+        # (every rank must run the SAME number of steps — each holds a collective: the decision to go on is itself reduced)
         torch.cuda.synchronize()
         tw0 = time.perf_counter()
-        while time.perf_counter() - tw0 < warm_seconds:
+        while True:
             for _ in range(4):
                 run()
             torch.cuda.synchronize()
+            more = time.perf_counter() - tw0 < warm_seconds
+            if world > 1:
+                flag = torch.tensor([1.0 if more else 0.0], device=wl.x.device)
+                dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+                more = flag.item() > 0
+            if not more:
+                break
     fence()
     t0 = time.perf_counter()
     for _ in range(steps):

@@ -337,7 +337,7 @@ def time_workload(wl, steps, warmup, fence, use_graph, graph_collective=False, r
     for _ in range(warmup):
         run()
     if warm_seconds > 0:
-        # secondary workloads follow seconds of host-side input generation with an idle GPU: a handful of warm-up steps
+        # every workload follows seconds of host-side input generation with an idle GPU: a handful of warm-up steps
         # ends before the clocks are back up (a 1.4 ms step measured 2.2 ms), so they also warm up for a minimum TIME
         # (every rank must run the SAME number of steps — each holds a collective: the decision to go on is itself reduced)
         torch.cuda.synchronize()
@@ -385,6 +385,7 @@ def time_workload(wl, steps, warmup, fence, use_graph, graph_collective=False, r
               'step_wall_us': wall_us}
     if in_graph_collective:
         phases['note'] = 'all-reduce inside the graph: kernels_us includes it'
+    phases['_run'] = run          # (for the caller's kernel-timing pass; removed before the phases are reported)
     return elapsed, mode, phases
 
 
@@ -452,7 +453,10 @@ def worker(args):
 
     # ---- headline ---------------------------------------------------------------------------
     wl = PdistWorkload(DIM, n, torch.float32, 0.1, world, rank, dev)
-    elapsed, mode, phases = time_workload(wl, args.steps, args.warmup, fence, use_graph, graph_collective, rank)
+    # (W warm-up steps as asked, then 50 ms more of untimed steps: W = 10 steps are under a millisecond of GPU time, not
+    # enough for the clocks to settle after the seconds of host-side input generation)
+    elapsed, mode, phases = time_workload(wl, args.steps, args.warmup, fence, use_graph, graph_collective, rank,
+                                          warm_seconds=0.05)
     elapsed = reduce_max(elapsed, dev, world)
 
     # per-kernel durations: HIP events attached to each pair kernel's own dispatch on the launch stream
@@ -460,11 +464,11 @@ def worker(args):
     # They cannot live inside a captured graph, so they time the kernels of an eager pass of the same step issued
     # right after the timed region; one discarded pass first (event creation, allocator warm-up).
     kern, eager_ms = {'fwd': None, 'bwd': None}, None
+    run_step = phases.pop('_run')
     if not args.no_prof:
-        lib.call('mm_prof_enable', 1)
+        # (a) the same step through Python autograd, one synchronised step at a time: its host cost
         wl.eager_step()
         fence()
-        collect_kernel_us(lib)                 # discard
         times = []
         for _ in range(max(5, min(args.steps, 20))):
             te = time.perf_counter()
@@ -473,6 +477,18 @@ def worker(args):
             times.append(time.perf_counter() - te)
         fence()
         eager_ms = median(times) * 1e3
+        # (b) kernel durations in the clock regime of the timed region: each profiled eager step is queued behind a
+        # burst of replays of the timed step, with no synchronisation in between — the device never idles (issued one
+        # step at a time from Python it idles 45 % of the time, the clocks drop and the kernels take ~10 % longer)
+        lib.call('mm_prof_enable', 1)
+        wl.eager_step()
+        fence()
+        collect_kernel_us(lib)                 # discard
+        for _ in range(max(5, min(args.steps, 20))):
+            for _ in range(8):
+                run_step()
+            wl.eager_step()
+        fence()
         lib.call('mm_prof_enable', 0)
         kern = collect_kernel_us(lib)
     per_rank = gather_objects({'rank': rank, 'rows': list(wl.rows), 'pairs': wl.hi - wl.lo, **phases,
@@ -493,7 +509,8 @@ def worker(args):
             'config': {'workload': f'grqc-class graph, n={n} nodes -> SPD(3) affine-invariant, all '
                                    f'{P} pairs, squared distance + backward, reference init (||log X||=0.1)',
                        'pairs_per_step': P, 'parallelism': f'pair-rows sharded x{world}, 1 all-reduce',
-                       'launch': mode, 'backend': backend if world > 1 else None},
+                       'launch': mode, 'backend': backend if world > 1 else None,
+                       'untimed_warm_seconds': 0.05},
             'per_rank': per_rank,
             'kernel_source_hash': kernel_source_hash(),
         }
@@ -513,7 +530,7 @@ def worker(args):
                                'traffic': rk.get('traffic_bytes'),
                                'traffic_source': (pmc or {}).get('source') if rk else None,
                                'algorithmic_bytes': by, 'avg_launch_us': kern['bwd'],
-                               'measured_in': 'eager pass after the timed region; HIP events attached to the kernel dispatch on the launch stream (hipExtLaunchKernelGGL)',
+                               'measured_in': 'eager steps queued behind replays of the timed step right after the timed region (device never idle); HIP events attached to the kernel dispatch on the launch stream (hipExtLaunchKernelGGL)',
                                'valu_insts_per_64_pairs': rk.get('valu_insts_per_64_pairs')}
             if kern['fwd']:
                 byf = pairs_local * esz + n * 12 * esz
@@ -542,6 +559,7 @@ def worker(args):
             w = PdistWorkload(d, nn, dt, ir, world, rank, dev)
             el, md, ph = time_workload(w, k2, w2, fence, use_graph, graph_collective, rank, tag=name + ': ', warm_seconds=0.05)
             el = reduce_max(el, dev, world)
+            run_w = ph.pop('_run')
             kk = {'fwd': None, 'bwd': None}
             if not args.no_prof:
                 lib.call('mm_prof_enable', 1)
@@ -549,6 +567,8 @@ def worker(args):
                 fence()
                 collect_kernel_us(lib)
                 for _ in range(5):
+                    for _ in range(8):
+                        run_w()
                     w.eager_step()
                 fence()
                 lib.call('mm_prof_enable', 0)
@@ -566,6 +586,7 @@ def worker(args):
         # the size where sharding pays: BASELINE config 5 (bio-wormnet-class, ~16k nodes, SPD(4), distortion loss)
         w = FusedLossWorkload(4, 16384, torch.float32, world, rank, dev)
         el, md, ph = time_workload(w, k2, w2, fence, use_graph, graph_collective, rank, tag='config 5: ', warm_seconds=0.1)
+        ph.pop('_run')
         el = reduce_max(el, dev, world)
         ranks5 = gather_objects({'rank': rank, 'rows': list(w.rows), 'pairs': w.hi - w.lo, **ph}, world)
         extra.append({'workload': 'BASELINE config 5: n=16384 nodes -> SPD(4), all-pairs QuotientLoss, fused '

@@ -17,9 +17,12 @@ import bench  # noqa: E402
 def graph_us(wl, steps=40):
     fence = bench.Fence(1)
     graph, _ = bench.graph_of(wl.kernels, fence)
-    for _ in range(10):
-        graph.replay()
-    torch.cuda.synchronize()
+    import time
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < 0.05:      # warm clocks
+        for _ in range(8):
+            graph.replay()
+        torch.cuda.synchronize()
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     a.record()
     for _ in range(steps):

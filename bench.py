@@ -230,17 +230,22 @@ def median(v):
 class PdistWorkload:
     """d2 = man.pdist(x, squared=True, rows=shard); grad = d d2 / d x . g  (+ one all-reduce for N > 1)."""
 
-    def __init__(self, d, n, dtype, ir, world, rank, dev, seed=42):
+    def __init__(self, d, n, dtype, ir, world, rank, dev, seed=42, local_g=False):
         import torch
         from graphembed import _backend as B
         from graphembed.manifolds import SymmetricPositiveDefinite
         self.d, self.n, self.world, self.rank = d, n, world, rank
         self.dtype = dtype
-        x, g = synthetic_spd(n, d, seed, dev, ir=ir, dtype=dtype)   # replicated embedding, same on every rank
         self.rows = B.shard_rows(n, world, rank)
         self.lo, self.hi = B.pair_offset(n, self.rows[0]), B.pair_offset(n, self.rows[1])
-        self.g_local = g[self.lo:self.hi].contiguous()
-        del g
+        if local_g:   # (large n: only this rank's slice of the upstream gradient is ever generated)
+            x, _ = synthetic_spd(n, d, seed, dev, ir=ir, dtype=dtype, with_g=False)
+            gen = torch.Generator(device=dev).manual_seed(seed + 1 + rank)
+            self.g_local = torch.randn(self.hi - self.lo, generator=gen, dtype=dtype, device=dev)
+        else:
+            x, g = synthetic_spd(n, d, seed, dev, ir=ir, dtype=dtype)   # replicated embedding, same on every rank
+            self.g_local = g[self.lo:self.hi].contiguous()
+            del g
         self.man = SymmetricPositiveDefinite(d)
         self.x = x.requires_grad_()
         self.P = n * (n - 1) // 2
@@ -581,6 +586,23 @@ def worker(args):
                 byb = (w.hi - w.lo) * w.esz + nn * 4 * np_ * w.esz
                 rec['bwd_hbm_frac'] = byb / (kk['bwd'] * 1e-6) / 1e9 / HBM_PEAK_GBS
             extra.append(rec)
+            del w
+            torch.cuda.empty_cache()
+        if world > 1 and n == N_NODES:
+            # WEAK scaling of the same path beside the strong-scaling headline: per-GPU work fixed at the headline's 12.5 M
+            # pairs — N ranks embed a graph of 5000 sqrt(N) nodes (N x 12.5 M pairs), pair rows sharded, one all-reduce of the
+            # (sqrt(N) times larger) gradient.  The 5000-node problem itself is 80 us of work: its strong scaling is bounded
+            # by the latency of one collective, this block shows what the design does when a rank has a full launch to chew on.
+            nw = int(round(N_NODES * world ** 0.5))
+            w = PdistWorkload(DIM, nw, torch.float32, 0.1, world, rank, dev, local_g=True)
+            el, md, ph = time_workload(w, k2, w2, fence, use_graph, graph_collective, rank, tag='weak scaling: ', warm_seconds=0.05)
+            ph.pop('_run')
+            el = reduce_max(el, dev, world)
+            ranksw = gather_objects({'rank': rank, 'rows': list(w.rows), 'pairs': w.hi - w.lo, **ph}, world)
+            extra.append({'workload': f'weak scaling of the headline path: SPD(3) f32, n = 5000 sqrt(N) = {nw} nodes, {w.P} pairs '
+                                      f'({w.P // world} per GPU), pdist fwd+bwd, pair rows sharded, 1 all-reduce',
+                          'pairs_per_step': w.P, 'ms_per_step': el / k2 * 1e3, 'value': w.P * k2 / el, 'unit': 'pairs/s',
+                          'steps': k2, 'n_gpus': world, 'scaling': 'weak', 'launch': md, 'per_rank': ranksw})
             del w
             torch.cuda.empty_cache()
         # the size where sharding pays: BASELINE config 5 (bio-wormnet-class, ~16k nodes, SPD(4), distortion loss)

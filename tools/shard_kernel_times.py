@@ -51,6 +51,17 @@ def main():
             del wl
             torch.cuda.empty_cache()
         out['config 5 SPD(4) n=16384 f32 fused QuotientLoss step (us)'][f'N={world} (first, last rank)'] = ranks
+    key = 'weak scaling SPD(3) f32, n = 5000 sqrt(N), 12.5 M pairs per rank (us, first and last rank)'
+    out[key] = {}
+    for world in (2, 4, 8):
+        nw = int(round(5000 * world ** 0.5))
+        ranks = []
+        for r in sorted({0, world - 1}):
+            wl = bench.PdistWorkload(3, nw, torch.float32, 0.1, world, r, dev, local_g=True)
+            ranks.append(round(graph_us(wl), 1))
+            del wl
+            torch.cuda.empty_cache()
+        out[key][f'N={world} (n={nw})'] = ranks
     print(json.dumps(out, indent=1))
 
 

@@ -5,7 +5,9 @@ One step = one pass of the hot path over all pairs of the synthetic embedding:
     d2 = SPD(3).pdist(x, squared=True);  d2.backward(g)
 (`g` a fixed random upstream gradient, so no loss is fused in — SURVEY.md §8d),
 with the pair list sharded by rows across the ranks and, for N > 1, ONE RCCL
-all-reduce(sum) of the embedding gradient inside the timed region.
+all-reduce(sum) of the embedding gradient inside the timed region — issued through the
+library's own communicator (mm_allreduce_sum, include/mm_manifolds.h) and captured in the
+same hipGraph as the kernels.
 
     python bench.py [--gpus N] [--steps K] [--warmup W]
 
@@ -196,8 +198,9 @@ class Fence:
         torch.cuda.synchronize()
 
 
-def graph_of(fn, fence, warm=3):
-    """Capture fn() (a sequence of launches on the current stream) into a hipGraph; returns (graph, outputs)."""
+def graph_of(fn, fence, warm=3, with_collective=False):
+    """Capture fn() (a sequence of launches on the current stream) into a hipGraph; returns (graph, outputs).
+    With a collective inside, the capture is thread-local: RCCL's proxy threads may call the runtime meanwhile."""
     import torch
     side = torch.cuda.Stream()
     side.wait_stream(torch.cuda.current_stream())
@@ -207,10 +210,22 @@ def graph_of(fn, fence, warm=3):
     torch.cuda.current_stream().wait_stream(side)
     fence()
     graph = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(graph):
+    kw = {'capture_error_mode': 'thread_local'} if with_collective else {}
+    with torch.cuda.graph(graph, **kw):
         out = fn()
     fence()
     return graph, out
+
+
+def all_agree(ok, world, dev):
+    """True iff `ok` on every rank (a capture that fails on one rank must fail the mode for all of them)."""
+    if world == 1:
+        return ok
+    import torch
+    import torch.distributed as dist
+    flag = torch.tensor([1.0 if ok else 0.0], device=dev)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    return flag.item() > 0
 
 
 def collect_kernel_us(lib, names=(('fwd', 0), ('bwd', 1))):
@@ -230,11 +245,11 @@ def median(v):
 class PdistWorkload:
     """d2 = man.pdist(x, squared=True, rows=shard); grad = d d2 / d x . g  (+ one all-reduce for N > 1)."""
 
-    def __init__(self, d, n, dtype, ir, world, rank, dev, seed=42, local_g=False):
+    def __init__(self, d, n, dtype, ir, world, rank, dev, seed=42, local_g=False, comm=None):
         import torch
         from graphembed import _backend as B
         from graphembed.manifolds import SymmetricPositiveDefinite
-        self.d, self.n, self.world, self.rank = d, n, world, rank
+        self.d, self.n, self.world, self.rank, self.comm = d, n, world, rank, comm
         self.dtype = dtype
         self.rows = B.shard_rows(n, world, rank)
         self.lo, self.hi = B.pair_offset(n, self.rows[0]), B.pair_offset(n, self.rows[1])
@@ -257,11 +272,16 @@ class PdistWorkload:
         grad, = torch.autograd.grad(d2, self.x, self.g_local)
         return grad
 
+    def reduce(self, t):
+        """The single collective of a step: mm_allreduce_sum over the library's RCCL communicator, or
+        torch.distributed when the ranks share a GPU (gloo dry run)."""
+        from graphembed import parallel
+        return parallel.all_reduce_(t, comm=self.comm)
+
     def eager_step(self):
-        import torch.distributed as dist
         grad = self.kernels()
         if self.world > 1:
-            dist.all_reduce(grad)               # the single collective of a step
+            self.reduce(grad)
         return grad
 
 
@@ -270,12 +290,12 @@ class FusedLossWorkload:
     kernel (mm_spd_pdist_loss: no pair vector of distances), pair rows sharded, ONE all-reduce of
     {grad_x, loss, grad_scale}."""
 
-    def __init__(self, d, n, dtype, world, rank, dev, seed=7):
+    def __init__(self, d, n, dtype, world, rank, dev, seed=7, comm=None):
         import torch
         from graphembed import _backend as B
         from graphembed.manifolds import SymmetricPositiveDefinite
         from graphembed.objectives import QuotientLoss
-        self.d, self.n, self.world, self.rank = d, n, world, rank
+        self.d, self.n, self.world, self.rank, self.comm = d, n, world, rank, comm
         self.x, _ = synthetic_spd(n, d, seed, dev, ir=0.1, dtype=dtype, with_g=False)
         self.x.requires_grad_()
         self.scale = torch.tensor(0.5, dtype=dtype, device=dev, requires_grad=True)
@@ -297,11 +317,12 @@ class FusedLossWorkload:
         torch.cat([gx.reshape(-1), gs.reshape(1), loss.detach().reshape(1)], out=self.flat)
         return self.flat
 
+    reduce = PdistWorkload.reduce
+
     def eager_step(self):
-        import torch.distributed as dist
         flat = self.kernels()
         if self.world > 1:
-            dist.all_reduce(flat)
+            self.reduce(flat)
         return flat
 
 
@@ -315,21 +336,39 @@ def time_workload(wl, steps, warmup, fence, use_graph, graph_collective=False, r
         import torch.distributed as dist
     graph, static = None, None
     mode = 'eager'
+    in_graph_collective = False
+    dev = wl.x.device
     if use_graph:
-        try:
-            if world > 1 and graph_collective:
-                graph, static = graph_of(wl.eager_step, fence)   # RCCL all-reduce captured in the graph
-                mode = 'hipGraph replay (kernels + all-reduce)'
-            else:
-                graph, static = graph_of(wl.kernels, fence)
-                mode = 'hipGraph replay (kernels)' + (' + eager all-reduce' if world > 1 else '')
-        except Exception as exc:  # noqa: BLE001 — report and measure eagerly instead
-            if rank == 0:
-                print(f'[bench] {tag}hipGraph capture unavailable ({type(exc).__name__}: {exc}); eager launches',
+        # level 1: kernels AND the all-reduce in one captured graph (the host is out of the step entirely);
+        # level 2: the kernels captured, the all-reduce issued eagerly behind each replay;
+        # level 3 (only if the kernels themselves cannot be captured): eager launches.
+        # A level that fails on ANY rank is abandoned by all of them.
+        if world > 1 and graph_collective:
+            try:
+                graph, static = graph_of(wl.eager_step, fence, with_collective=True)
+                ok = True
+            except Exception as exc:  # noqa: BLE001
+                ok, graph = False, None
+                print(f'[bench] rank {rank}: {tag}capture with the all-reduce failed ({type(exc).__name__}: {exc})',
                       file=sys.stderr)
-            graph, mode = None, 'eager'
-            fence()
-    in_graph_collective = graph is not None and world > 1 and graph_collective
+            if all_agree(ok, world, dev):
+                mode, in_graph_collective = 'hipGraph replay (kernels + all-reduce)', True
+            else:
+                graph = None
+                torch.cuda.synchronize()
+        if graph is None:
+            try:
+                graph, static = graph_of(wl.kernels, fence)
+                ok = True
+            except Exception as exc:  # noqa: BLE001 — report and measure eagerly instead
+                ok, graph = False, None
+                print(f'[bench] rank {rank}: {tag}hipGraph capture unavailable ({type(exc).__name__}: {exc}); eager launches',
+                      file=sys.stderr)
+            if all_agree(ok, world, dev):
+                mode = 'hipGraph replay (kernels)' + (' + eager all-reduce' if world > 1 else '')
+            else:
+                graph, mode = None, 'eager'
+                fence()
 
     def run():
         if graph is None:
@@ -337,7 +376,7 @@ def time_workload(wl, steps, warmup, fence, use_graph, graph_collective=False, r
             return
         graph.replay()
         if world > 1 and not in_graph_collective:
-            dist.all_reduce(static)
+            wl.reduce(static)
 
     for _ in range(warmup):
         run()
@@ -379,7 +418,7 @@ def time_workload(wl, steps, warmup, fence, use_graph, graph_collective=False, r
             out = static
         e1.record()
         if world > 1 and not in_graph_collective:
-            dist.all_reduce(out)
+            wl.reduce(out)
         e2.record()
     fence()
     wall_us = (time.perf_counter() - tw) / k2 * 1e6
@@ -453,11 +492,19 @@ def worker(args):
     lib = B.lib()
     fence = Fence(world)
     use_graph = args.graph in ('on', 'auto')
-    graph_collective = backend == 'nccl' and os.environ.get('MM_BENCH_GRAPH_COLLECTIVE', '0') == '1'
+    # N > 1 over RCCL: the collective goes through the library's own communicator (mm_comm_init / mm_allreduce_sum,
+    # one per process, created once) and is captured in the step's graph by default; MM_BENCH_GRAPH_COLLECTIVE=0 keeps
+    # it outside (graph-replayed kernels + eager all-reduce).  Ranks that share a GPU (gloo dry run) cannot build an
+    # RCCL communicator: they reduce through torch.distributed, outside the graph.
+    comm = None
+    if world > 1 and backend == 'nccl':
+        from graphembed.comm import Communicator
+        comm = Communicator.from_torch_distributed(dev)
+    graph_collective = comm is not None and os.environ.get('MM_BENCH_GRAPH_COLLECTIVE', '1') != '0'
     n = args.n
 
     # ---- headline ---------------------------------------------------------------------------
-    wl = PdistWorkload(DIM, n, torch.float32, 0.1, world, rank, dev)
+    wl = PdistWorkload(DIM, n, torch.float32, 0.1, world, rank, dev, comm=comm)
     # (W warm-up steps as asked, then 50 ms more of untimed steps: W = 10 steps are under a millisecond of GPU time, not
     # enough for the clocks to settle after the seconds of host-side input generation)
     elapsed, mode, phases = time_workload(wl, args.steps, args.warmup, fence, use_graph, graph_collective, rank,
@@ -515,6 +562,9 @@ def worker(args):
                                    f'{P} pairs, squared distance + backward, reference init (||log X||=0.1)',
                        'pairs_per_step': P, 'parallelism': f'pair-rows sharded x{world}, 1 all-reduce',
                        'launch': mode, 'backend': backend if world > 1 else None,
+                       'collective': (None if world == 1 else
+                                      'mm_allreduce_sum (C ABI, process-lifetime RCCL communicator)' if comm is not None
+                                      else f'torch.distributed {backend}'),
                        'untimed_warm_seconds': 0.05},
             'per_rank': per_rank,
             'kernel_source_hash': kernel_source_hash(),
@@ -561,7 +611,7 @@ def worker(args):
                       ('SPD(3) n=4158 f32 (grqc, BASELINE config 3), reference init', DIM, 4158, torch.float32, 0.1),
                       ('SPD(4) n=2274 f32 (BASELINE config 5, small graph), reference init', 4, 2274, torch.float32, 0.1)]
         for name, d, nn, dt, ir in cases:
-            w = PdistWorkload(d, nn, dt, ir, world, rank, dev)
+            w = PdistWorkload(d, nn, dt, ir, world, rank, dev, comm=comm)
             el, md, ph = time_workload(w, k2, w2, fence, use_graph, graph_collective, rank, tag=name + ': ', warm_seconds=0.05)
             el = reduce_max(el, dev, world)
             run_w = ph.pop('_run')
@@ -594,7 +644,7 @@ def worker(args):
             # (sqrt(N) times larger) gradient.  The 5000-node problem itself is 80 us of work: its strong scaling is bounded
             # by the latency of one collective, this block shows what the design does when a rank has a full launch to chew on.
             nw = int(round(N_NODES * world ** 0.5))
-            w = PdistWorkload(DIM, nw, torch.float32, 0.1, world, rank, dev, local_g=True)
+            w = PdistWorkload(DIM, nw, torch.float32, 0.1, world, rank, dev, local_g=True, comm=comm)
             el, md, ph = time_workload(w, k2, w2, fence, use_graph, graph_collective, rank, tag='weak scaling: ', warm_seconds=0.05)
             ph.pop('_run')
             el = reduce_max(el, dev, world)
@@ -606,7 +656,7 @@ def worker(args):
             del w
             torch.cuda.empty_cache()
         # the size where sharding pays: BASELINE config 5 (bio-wormnet-class, ~16k nodes, SPD(4), distortion loss)
-        w = FusedLossWorkload(4, 16384, torch.float32, world, rank, dev)
+        w = FusedLossWorkload(4, 16384, torch.float32, world, rank, dev, comm=comm)
         el, md, ph = time_workload(w, k2, w2, fence, use_graph, graph_collective, rank, tag='config 5: ', warm_seconds=0.1)
         ph.pop('_run')
         el = reduce_max(el, dev, world)
@@ -624,6 +674,8 @@ def worker(args):
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(42, n)
         print(json.dumps(out), flush=True)
+    if comm is not None:
+        comm.destroy()
     if world > 1:
         dist.destroy_process_group()
     watchdog.cancel()

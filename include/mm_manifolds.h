@@ -37,7 +37,8 @@ extern "C" {
 typedef void* mm_stream_t; /* hipStream_t */
 
 enum { MM_F32 = 0, MM_F64 = 1 };
-enum { MM_OK = 0, MM_ERR_ARG = -1, MM_ERR_UNSUPPORTED = -2 };
+enum { MM_OK = 0, MM_ERR_ARG = -1, MM_ERR_UNSUPPORTED = -2,
+       MM_ERR_COMM = -3 /* RCCL missing or an RCCL call failed: text in mm_comm_last_error() */ };
 
 /* vector-manifold kinds for mm_vec_* */
 enum { MM_EUCLIDEAN = 0, MM_LORENTZ = 1, MM_SPHERE = 2 };
@@ -384,6 +385,32 @@ size_t mm_graph_sort_rows_ws_bytes(int dtype, int64_t n);
 int mm_graph_sort_rows(int dtype, const void* dist, int64_t n, int* order, void* ws, size_t ws_bytes,
                        mm_stream_t stream);
 
+/* ---- the collective of the sharded path ----------------------------------------- */
+/* One process per GPU; the embedding is replicated, the pair list is cut into row ranges (mm_shard_rows) and every
+ * step ends with ONE all-reduce(sum) of {point gradients, loss, scale gradients} over a process-lifetime RCCL
+ * communicator (xGMI).  Replaces the reference's only parallel call site, torch.nn.DataParallel around
+ * BatchedObjective (graphembed/graphembed/train.py:107-109: broadcast + gather + reduce-add per step); SURVEY.md §8b
+ * "allreduce_grad(buf)".  RCCL is bound at run time (dlopen; MM_RCCL_LIB overrides the search), so the library loads
+ * without it; every entry below then returns MM_ERR_COMM.
+ *   rendezvous: rank 0 calls mm_comm_unique_id and hands the MM_COMM_ID_BYTES token to the other ranks through any
+ *               host channel (file, socket, MPI, a torch.distributed store); every rank then calls mm_comm_init with
+ *               the same token — collective, blocks until all `world` ranks have arrived.  `device` = HIP device
+ *               ordinal of this rank (made current).  world = 1 is valid (a one-rank communicator).
+ *   mm_allreduce_sum: in place, buf [count] of `dtype` in device memory, enqueued on `stream`, never synchronises —
+ *               capturable into a HIP graph together with the kernels around it (after one uncaptured call).
+ *   mm_comm_last_error: text of this thread's last MM_ERR_COMM. */
+typedef struct mm_comm* mm_comm_t;
+enum { MM_COMM_ID_BYTES = 128 };
+int mm_comm_available(void);          /* 1 if RCCL could be bound */
+int mm_comm_rccl_version(void);       /* NCCL_VERSION_CODE of the bound RCCL, 0 if none */
+int mm_comm_unique_id(void* id_out /* host, MM_COMM_ID_BYTES */);
+int mm_comm_init(mm_comm_t* comm, int rank, int world, const void* unique_id, int device);
+int mm_comm_rank(mm_comm_t comm);
+int mm_comm_world(mm_comm_t comm);
+int mm_allreduce_sum(mm_comm_t comm, int dtype, void* buf, int64_t count, mm_stream_t stream);
+int mm_comm_destroy(mm_comm_t comm);
+const char* mm_comm_last_error(void);
+
 /* ---- one training step per call ------------------------------------------------ */
 /* The body of the reference's training loop for one full batch (graphembed/graphembed/train.py:198-222:
  * objective(dataset[idx], embedding.compute_dists(idx)) -> backward -> optimizer.step() for the point and the
@@ -392,8 +419,11 @@ int mm_graph_sort_rows(int dtype, const void* dist, int64_t n, int* order, void*
  * (mm_*_rsgd_step, mm_*_rsgd_momentum_step, mm_*_radam_step[_multi]).  Nothing is allocated, nothing synchronises;
  * a caller whose loop is not captured in a HIP graph pays one foreign-function call per step instead of ~15.
  * Parameters are updated IN PLACE; gradients are left in the `grad` buffers (the scales' gradients in
- * loss_out[1 + k]); loss_out[0] is the loss BEFORE the update, as the reference logs it. */
-enum { MM_OPT_RSGD = 0, MM_OPT_RADAM = 1 };
+ * loss_out[1 + k]); loss_out[0] is the loss BEFORE the update, as the reference logs it.
+ * Multi-GPU: with a row range and a communicator the same call issues objective (this rank's pairs) -> one
+ * all-reduce -> optimizer, still without touching the host in between (capturable as one HIP graph). */
+enum { MM_OPT_NONE = -1 /* frozen: read by the objective, never stepped (a scale during burn-in) */,
+       MM_OPT_RSGD = 0, MM_OPT_RADAM = 1 };
 typedef struct mm_step_param {
   int kind;              /* MM_EUCLIDEAN / MM_LORENTZ / MM_SPHERE, or MM_FACTOR_SPD; flat parameters: MM_EUCLIDEAN */
   int dim;               /* m of a vector point, d of an SPD(d) point, 1 for a scalar                              */
@@ -422,6 +452,15 @@ typedef struct mm_train_step {
   void* loss_out;                /* [1 + nf]                                                                       */
   void* ws;                      /* workspace of the embedding's objective kernel (mm_*_ws_bytes)                  */
   int ws_flags;                  /* MM_WS_CLEAN when a product workspace is known to be clean                      */
+  /* -- sharded step (mm_abi_version() >= 2); all zero = the whole pair list on one GPU ------------------------- */
+  int64_t row_begin, row_end;    /* this rank's rows of the pair list (mm_shard_rows); row_end <= 0 means n.  `target`
+                                    is then this rank's SLICE: the targets of the pairs from mm_pair_offset(n,row_begin) on */
+  mm_comm_t comm;                /* NULL: no collective.  Else ONE mm_allreduce_sum of reduce_buf between the objective
+                                    and the optimizer kernels, on the same stream: afterwards every rank holds the full
+                                    gradients and loss and applies the identical update — replicas stay equal, no broadcast */
+  void* reduce_buf;              /* [reduce_count] of `dtype`: ONE allocation that contains every points[k].grad and
+                                    loss_out (MM_ERR_ARG otherwise) — the message of the collective                 */
+  int64_t reduce_count;
 } mm_train_step;
 int mm_train_step_run(const mm_train_step* step, mm_stream_t stream);
 

@@ -34,7 +34,7 @@ void prof_span(int id, hipEvent_t* start, hipEvent_t* stop) {
 
 extern "C" {
 
-int mm_abi_version(void) { return 1; }
+int mm_abi_version(void) { return 2; }   // 2: mm_comm_*, sharded mm_train_step (row range + communicator), MM_OPT_NONE
 
 const char* mm_target_arch(void) { return "gfx950"; }
 

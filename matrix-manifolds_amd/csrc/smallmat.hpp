@@ -322,7 +322,8 @@ __device__ __forceinline__ void jacobi_eig(T (&a)[Packed<D>::NP], T (&v)[D][D], 
   // (D >= 6: the sweeps stay a loop — unrolled, a 9x9 solve with eigenvectors is ~30 000 instructions per call site —
   // and get a few more of them: the quadratic convergence of cyclic Jacobi starts later for larger matrices)
   constexpr int kSweeps = D <= 5 ? N::kMaxSweeps : N::kMaxSweeps + 4;
-#pragma unroll(D <= 5 ? N::kMaxSweeps : 1)
+  constexpr int kUnrollSweeps = D <= 5 ? N::kMaxSweeps : 1;
+#pragma unroll kUnrollSweeps
   for (int sweep = 0; sweep < kSweeps; ++sweep) {
     bool active = sweep < kMinSweeps;
     if (active) {

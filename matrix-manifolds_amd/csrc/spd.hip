@@ -462,7 +462,8 @@ __global__ __launch_bounds__((64 * bwd_waves<T, D>()), (bwd_min_waves<T, D>())) 
           const int irow = ib + u;
           const int ieff = (u == 0 || irow < i1) ? irow : INT32_MAX;   // scalar; only the slot after the first can be past the slice
           const T (&lcur)[2 * NP] = lrow[u];
-          // the row after the slice is inside the table (i1 <= n - 1).  The running offset is pinned: otherwise the loop
+          // the row after the slice is inside the table (i1 <= n - 1), and the row after THAT — requested by the masked last
+          // slot of a slice with an odd row count — is at most the table's padding row n (spd_ws.hpp).  The running offset is pinned: otherwise the loop
           // runs on a pointer one iteration ahead and every scalar load pays a 64-bit add for its negative offset
           roff += unsigned(2 * NP * sizeof(T));
           asm volatile("" : "+s"(roff));
@@ -1037,7 +1038,7 @@ int spd_pdist_bwd_launch_sq(Ws<T>& ws, const T* g, int64_t n, int64_t rb, int64_
   auto kernel = spd_pdist_bwd_kernel<T, D, kBwdTI, LOSS, SQ>;
   const int64_t units = ColWalk(int(n), int(rb), int(re), 64 * pair_cols<T, D>()).total();
   if (units <= 0) return MM_OK;
-  int64_t grid = resident_workgroups(kernel, kThreads);
+  int64_t grid = resident_workgroups<spd_pdist_bwd_kernel<T, D, kBwdTI, LOSS, SQ>>(kThreads);
   // Small launches (a rank's shard, small n): a workgroup flushes its column-side sums once per column block, so it needs
   // enough rows to pay for that — with fewer than ~48 rows of a column block per workgroup the launch is made of flushes
   // (one eighth of the headline problem, 13 k units: 1024 workgroups 23.8 us, 256 workgroups 17.1 us; a quarter: 24.2 -> 22.2 us;

@@ -3,6 +3,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cstdint>
 
 #include "../../include/mm_manifolds.h"
@@ -46,7 +47,9 @@ __host__ __device__ inline int64_t pair_off(int64_t n, int64_t row) { return row
 //   accS   T[D*D][n]  column-side accumulators  sum_i L_i^-T M_ij L_i^T
 //   loss   T[2][256]  fused-loss partial sums (loss, d loss / d softplus(scale)), spread over 256 slots
 //   nodeLd T[n]       log det X_i = 2 sum log diag L_i (Stein divergence, spd_stein.hip)
-//   nodeLC T[n][2NP]  {L_i^-1, L_i} interleaved: the backward's row operand, ONE scalar pointer and two scalar loads per row
+//   nodeLC T[n+1][2NP] {L_i^-1, L_i} interleaved: the backward's row operand, ONE scalar pointer and two scalar loads per row.
+//                     Row n is padding: the backward requests the operands of the NEXT row unconditionally, and the masked
+//                     last slot of a slice with an odd row count that ends at row n - 1 asks for row n (never used).
 // The gradient w.r.t. the column point is L_i^-T [M A^-1] L_i^-1 with A^-1 = L_i^T X_j^-1 L_i, i.e.
 // (L_i^-T M L_i^T) X_j^-1: the factor X_j^-1 is common to the whole column, so only M is formed per
 // pair and X_j^-1 is applied once per point in finalize.
@@ -66,7 +69,7 @@ template <typename T> struct Ws {
   static size_t bad_bytes(int64_t n) { return (size_t(n) * sizeof(int) + 63) / 64 * 64; }
   static size_t bytes(int64_t n, int d) {
     const int np = d * (d + 1) / 2;
-    return 64 + bad_bytes(n) + sizeof(T) * (size_t(n) * (6 * np + d * d + 1) + 2 * kLossSlots);
+    return 64 + bad_bytes(n) + sizeof(T) * (size_t(n) * (6 * np + d * d + 1) + 2 * kLossSlots + 2 * np);
   }
   Ws(void* base, int64_t n, int d) {
     const int np = d * (d + 1) / 2;
@@ -177,22 +180,25 @@ inline int device_cus() {
   return cache[dev];
 }
 
-// Workgroups of `kernel` that are resident at once on the current device (occupancy x compute units), cached per
-// kernel and device.  hipOccupancyMaxActiveBlocksPerMultiprocessor can report one block too many per CU for kernels
+// Workgroups of `Kernel` that are resident at once on the current device (occupancy x compute units), cached per
+// kernel INSTANTIATION and device: the kernel is a non-type template parameter, so every <T, D, LOSS, SQ> variant has its
+// own cache (keyed on the function-pointer TYPE, all variants of one element type shared the entry of whichever ran
+// first).  The cache entries are atomics: concurrent first calls compute the same value twice, nothing worse.
+// hipOccupancyMaxActiveBlocksPerMultiprocessor can report one block too many per CU for kernels
 // with 81-96 scalar registers (MI355X_MICROARCH.md, Residency): capped at 7 blocks of 256 threads.
-template <typename K> inline int resident_workgroups(K kernel, int block_threads) {
-  static int cache[64] = {0};
+template <auto Kernel> inline int resident_workgroups(int block_threads) {
+  static std::atomic<int> cache[64];
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
-  if (cache[dev] == 0) {
+  if (cache[dev].load(std::memory_order_relaxed) == 0) {
     int per_cu = 0, cus = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, block_threads, 0) != hipSuccess || per_cu < 1) per_cu = 4;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, Kernel, block_threads, 0) != hipSuccess || per_cu < 1) per_cu = 4;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;
     const int cap = (7 * 256) / block_threads > 0 ? (7 * 256) / block_threads : 1;
     if (per_cu > cap) per_cu = cap;
-    cache[dev] = per_cu * cus;
+    cache[dev].store(per_cu * cus, std::memory_order_relaxed);
   }
-  return cache[dev];
+  return cache[dev].load(std::memory_order_relaxed);
 }
 
 }  // namespace mm

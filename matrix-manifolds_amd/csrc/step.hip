@@ -65,22 +65,44 @@ int vector_group_step(int dtype, const mm_step_param* const* ps, const void* con
                                  p.adam_eps, p.max_grad_norm, p.exact, xn, st);
 }
 
+// [p, p + bytes) lies inside [base, base + size)
+bool inside(const void* p, size_t bytes, const void* base, size_t size) {
+  const char* a = static_cast<const char*>(p);
+  const char* b = static_cast<const char*>(base);
+  return a >= b && a + bytes <= b + size;
+}
+
 }  // namespace
 
 extern "C" int mm_train_step_run(const mm_train_step* s, mm_stream_t st) {
-  if (!s || s->nf < 1 || s->nf > 4 || !s->loss_out || !s->target || s->n < 0) return MM_ERR_ARG;
+  if (!s || s->nf < 1 || s->nf > 4 || !s->loss_out || s->n < 0) return MM_ERR_ARG;
   if (s->dtype != MM_F32 && s->dtype != MM_F64) return MM_ERR_ARG;
   const int nf = s->nf;
+  // this rank's rows of the pair list (all of them on one GPU)
+  const int64_t rb = s->row_begin, re = s->row_end <= 0 ? s->n : s->row_end;
+  if (rb < 0 || re > s->n || rb > re) return MM_ERR_ARG;
+  if (!s->target && mm_pair_offset(s->n, re) > mm_pair_offset(s->n, rb)) return MM_ERR_ARG;
+  if (s->comm) {
+    // the message of the collective is ONE buffer holding every gradient and the loss record
+    if (!s->reduce_buf || s->reduce_count <= 0) return MM_ERR_ARG;
+    const size_t size = size_t(s->reduce_count) * esize(s->dtype);
+    if (!inside(s->loss_out, size_t(1 + nf) * esize(s->dtype), s->reduce_buf, size)) return MM_ERR_ARG;
+    for (int k = 0; k < nf; ++k) {
+      const mm_step_param& p = s->points[k];
+      const size_t pt = p.kind == MM_FACTOR_SPD ? size_t(p.dim) * p.dim : size_t(p.dim);
+      if (!p.grad || !inside(p.grad, size_t(p.count) * pt * esize(s->dtype), s->reduce_buf, size)) return MM_ERR_ARG;
+    }
+  }
   int rc;
   // ---- objective and gradients
   if (nf == 1) {
     const mm_step_param& p = s->points[0];
     if (!p.x || !p.grad) return MM_ERR_ARG;
     if (p.kind == MM_FACTOR_SPD)
-      rc = mm_spd_pdist_loss(s->dtype, s->loss_kind, p.x, s->target, s->scales[0].x, s->n, p.dim, 0, s->n, s->alpha, s->eps,
+      rc = mm_spd_pdist_loss(s->dtype, s->loss_kind, p.x, s->target, s->scales[0].x, s->n, p.dim, rb, re, s->alpha, s->eps,
                              s->terms, s->loss_params, s->wmin, s->wmax, s->loss_out, p.grad, s->ws, 0, st);
     else
-      rc = mm_vec_pdist_loss(s->dtype, p.kind, s->loss_kind, p.x, s->target, s->scales[0].x, s->n, p.dim, 0, s->n, s->alpha,
+      rc = mm_vec_pdist_loss(s->dtype, p.kind, s->loss_kind, p.x, s->target, s->scales[0].x, s->n, p.dim, rb, re, s->alpha,
                              s->eps, s->terms, s->loss_params, s->loss_out, p.grad, s->ws, st);
   } else {
     int kinds[4], dims[4];
@@ -92,16 +114,23 @@ extern "C" int mm_train_step_run(const mm_train_step* s, mm_stream_t st) {
       grads[k] = s->points[k].grad;
       if (!xs[k] || !grads[k]) return MM_ERR_ARG;
     }
-    rc = mm_product_pairs_loss(s->dtype, s->loss_kind, nf, kinds, dims, xs, sc, s->target, s->n, 0, s->n, s->alpha, s->eps,
+    rc = mm_product_pairs_loss(s->dtype, s->loss_kind, nf, kinds, dims, xs, sc, s->target, s->n, rb, re, s->alpha, s->eps,
                                s->terms, s->loss_params, s->wmin, s->wmax, grads, s->loss_out, s->ws, s->ws_flags, st);
   }
   if (rc != MM_OK) return rc;
+  // ---- the one collective of a sharded step: {gradients, loss, scale gradients} summed over the ranks, in place, on the
+  // same stream (train.py:107-109 is a broadcast + gather + reduce-add per step in the reference)
+  if (s->comm) {
+    rc = mm_allreduce_sum(s->comm, s->dtype, s->reduce_buf, s->reduce_count, st);
+    if (rc != MM_OK) return rc;
+  }
   // ---- optimizer: SPD points one launch each; vector-space parameters (points and scales) grouped by rule
   const mm_step_param* vec[8];
   const void* vgrad[8];
   int nv = 0;
   for (int k = 0; k < nf; ++k) {
     const mm_step_param& p = s->points[k];
+    if (p.optimizer == MM_OPT_NONE) continue;   // frozen
     if (p.kind == MM_FACTOR_SPD) {
       rc = optimizer_step(s->dtype, p, p.grad, st);
       if (rc != MM_OK) return rc;
@@ -111,7 +140,7 @@ extern "C" int mm_train_step_run(const mm_train_step* s, mm_stream_t st) {
   }
   for (int k = 0; k < nf; ++k) {
     const mm_step_param& q = s->scales[k];
-    if (!q.x) continue;   // a factor without a trainable scale
+    if (!q.x || q.optimizer == MM_OPT_NONE) continue;   // a factor without a scale / a frozen one (burn-in): read, not stepped
     vec[nv] = &q;
     vgrad[nv++] = static_cast<const char*>(s->loss_out) + size_t(1 + k) * esize(s->dtype);
   }

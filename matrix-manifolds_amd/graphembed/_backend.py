@@ -47,6 +47,15 @@ SIGNATURES = {
                                     _i, _vp]),
     'mm_spd_prepare': (_i, [_i, _vp, _i64, _i, _vp, _vp]),
     'mm_train_step_run': (_i, [_vp, _vp]),
+    'mm_comm_available': (_i, []),
+    'mm_comm_rccl_version': (_i, []),
+    'mm_comm_unique_id': (_i, [_vp]),
+    'mm_comm_init': (_i, [_c.POINTER(_vp), _i, _i, _vp, _i]),
+    'mm_comm_rank': (_i, [_vp]),
+    'mm_comm_world': (_i, [_vp]),
+    'mm_allreduce_sum': (_i, [_vp, _i, _vp, _i64, _vp]),
+    'mm_comm_destroy': (_i, [_vp]),
+    'mm_comm_last_error': (_c.c_char_p, []),
     'mm_vec_rsgd_multi_max': (_i, []),
     'mm_vec_rsgd_step_multi': (_i, [_i, _i, _c.POINTER(_i), _c.POINTER(_vp), _c.POINTER(_vp), _c.POINTER(_i64),
                                      _c.POINTER(_i), _dbl, _dbl, _i, _c.POINTER(_vp), _vp]),
@@ -134,7 +143,10 @@ class HipLibrary:
     def call(self, name, *args):
         rc = getattr(self._lib, name)(*args)
         if rc != 0:
-            kind = {-1: 'invalid argument', -2: 'unsupported size/dtype'}.get(rc, f'hipError_t {rc}')
+            if rc == -3:
+                kind = 'collective: ' + self._lib.mm_comm_last_error().decode(errors='replace')
+            else:
+                kind = {-1: 'invalid argument', -2: 'unsupported size/dtype'}.get(rc, f'hipError_t {rc}')
             raise BackendError(f'{name} failed: {kind}')
 
     def raw(self, name):

@@ -271,7 +271,16 @@ class SymmetricPositiveDefinite(Manifold):
 
     def symeig(self, x):
         """Eigenvalues of sym(x), ascending (spd.py:35-41, 63-64; the reference's monitor reads them, monitor.py:39-45):
-        one Jacobi eigensolve per matrix in registers (`mm_spd_eigvalsh`); batch shape kept."""
+        one Jacobi eigensolve per matrix in registers (`mm_spd_eigvalsh`); batch shape kept.  Not differentiable
+        (the differentiable path is `dist` / `pdist`); matrices wider than the kernels' range go to the GPU's
+        `torch.linalg.eigvalsh`."""
+        B.require_gpu(x)
+        if torch.is_grad_enabled() and x.requires_grad:
+            raise NotImplementedError('SPD.symeig is a monitoring map (no autograd on the HIP path): call it under '
+                                      'torch.no_grad() or on x.detach(); dist / pdist are the differentiable entry points')
+        if self.n > B.lib().raw('mm_spd_max_dim')():
+            xd = x.detach()
+            return torch.linalg.eigvalsh(0.5 * (xd + xd.transpose(-1, -2)))
         xc = _flat(x.detach(), self.n)
         out = torch.empty(xc.shape[0], self.n, dtype=xc.dtype, device=xc.device)
         if xc.shape[0]:

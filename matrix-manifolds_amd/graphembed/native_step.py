@@ -17,7 +17,13 @@ The optimizers stay the owners of hyper-parameters and state (learning-rate sche
 and Adam moments are the optimizers' own tensors); `p.grad` of every parameter is a persistent buffer that the step
 overwrites.  Supported: what the fused objective kernels support — one SPD or vector factor, or a product of up to
 three vector factors (dimension <= 16) and one SPD(2)/SPD(3) factor — with StressLoss / QuotientLoss, RiemannianSGD
-(with or without momentum) and RiemannianAdam.  Anything else raises `ValueError` at construction."""
+(with or without momentum) and RiemannianAdam.  Anything else raises `ValueError` at construction.
+
+Multi-GPU (one process per GPU): `NativeTrainStep(..., shard=PairShard(n), comm=Communicator...)` evaluates this rank's
+rows of the pair list, all-reduces {gradients, loss, scale gradients} ONCE through the library's RCCL communicator between
+the objective and the optimizer kernels — inside the same C call, on the same stream, no host round trip — and applies
+the identical update on every rank (the replacement of train.py:107-109, torch.nn.DataParallel).  `targets` may be the
+full pair vector or this rank's slice."""
 import ctypes
 
 import torch
@@ -39,10 +45,12 @@ class _TrainStep(_c.Structure):
     _fields_ = [('dtype', _c.c_int), ('loss_kind', _c.c_int), ('terms', _c.c_int), ('alpha', _c.c_double),
                 ('eps', _c.c_double), ('loss_params', _c.c_void_p), ('wmin', _c.c_double), ('wmax', _c.c_double),
                 ('n', _c.c_int64), ('nf', _c.c_int), ('points', _StepParam * 4), ('scales', _StepParam * 4),
-                ('target', _c.c_void_p), ('loss_out', _c.c_void_p), ('ws', _c.c_void_p), ('ws_flags', _c.c_int)]
+                ('target', _c.c_void_p), ('loss_out', _c.c_void_p), ('ws', _c.c_void_p), ('ws_flags', _c.c_int),
+                ('row_begin', _c.c_int64), ('row_end', _c.c_int64), ('comm', _c.c_void_p), ('reduce_buf', _c.c_void_p),
+                ('reduce_count', _c.c_int64)]
 
 
-OPT_RSGD, OPT_RADAM = 0, 1
+OPT_NONE, OPT_RSGD, OPT_RADAM = -1, 0, 1
 
 
 def _factor_of(man):
@@ -57,7 +65,7 @@ def _factor_of(man):
 
 class NativeTrainStep:
 
-    def __init__(self, embedding, objective_fn, targets, optimizers):
+    def __init__(self, embedding, objective_fn, targets, optimizers, shard=None, comm=None):
         from graphembed.modules import _pair_kernel_factors
         from graphembed.optim import RiemannianAdam, RiemannianSGD
         if not hasattr(objective_fn, 'fused_spec'):
@@ -81,8 +89,17 @@ class NativeTrainStep:
                 raise ValueError(f'dimension {dim} exceeds the kernels\' range ({cap})')
         n = xs[0].shape[0]
         npairs = n * (n - 1) // 2
+        if shard is not None:
+            if shard.n != n:
+                raise ValueError(f'the shard is cut for {shard.n} points, the embedding has {n}')
+            if targets.numel() == npairs:
+                targets = shard.slice(targets)
+            npairs = shard.num_pairs
+        if comm is not None and (shard is None or comm.world != shard.world or comm.rank != shard.rank):
+            raise ValueError('a communicator needs the matching PairShard (same world size and rank)')
         if targets.numel() != npairs:
-            raise ValueError(f'targets has {targets.numel()} entries, the embedding has {npairs} pairs')
+            raise ValueError(f'targets has {targets.numel()} entries, the step covers {npairs} pairs')
+        self.shard, self.comm = shard, comm
         self.embedding, self.objective_fn, self.optimizers = embedding, objective_fn, list(optimizers)
         self.n, self.k, self.dtype, self.device = n, k, dtype, dev
         self._opt_of = {}
@@ -96,8 +113,13 @@ class NativeTrainStep:
         dt = B.dtype_code(xs[0])
         with B.on_device(dev):
             self.target = targets.detach().to(device=dev, dtype=dtype).contiguous()
-            self.loss_out = torch.zeros(1 + k, dtype=dtype, device=dev)
-            self.grads = [torch.zeros_like(x) for x in xs]
+            # ONE allocation for everything the collective of a sharded step sums: the point gradients of every factor,
+            # then {loss, scale gradients} — the message of mm_allreduce_sum (mm_train_step.reduce_buf)
+            sizes = [x.numel() for x in xs]
+            self.flat = torch.zeros(sum(sizes) + 1 + k, dtype=dtype, device=dev)
+            parts = torch.split(self.flat, sizes + [1 + k])
+            self.grads = [g.view_as(x) for g, x in zip(parts[:k], xs)]
+            self.loss_out = parts[k]
             kinds = (_c.c_int * k)(*[f[0] for f in factors])
             dims = (_c.c_int * k)(*[f[1] for f in factors])
             if k > 1:
@@ -119,6 +141,12 @@ class NativeTrainStep:
                 d.wmin, d.wmax = man.wmin, man.wmax
         d.target, d.loss_out, d.ws = self.target.data_ptr(), self.loss_out.data_ptr(), self.ws.data_ptr()
         d.ws_flags = 0
+        if shard is not None:
+            d.row_begin, d.row_end = shard.rows
+            if shard.rows[1] <= 0:      # (row_end <= 0 means n in the ABI: an empty shard at row 0 is rows [0, 0) of 0 pairs)
+                d.row_begin, d.row_end = n, n
+        if comm is not None:
+            d.comm, d.reduce_buf, d.reduce_count = comm.handle.value, self.flat.data_ptr(), self.flat.numel()
         for i, (x, f) in enumerate(zip(xs, factors)):
             q = d.points[i]
             q.kind, q.dim, q.count, q.x, q.grad = f[0], f[1], n, x.data_ptr(), self.grads[i].data_ptr()
@@ -182,8 +210,7 @@ class NativeTrainStep:
                 if i < self.k:
                     raise ValueError('every point parameter needs an optimizer')
                 q.x = p.data_ptr()          # a frozen scale (burn-in): read by the objective, not stepped
-                q.optimizer, q.lr = OPT_RSGD, 0.0
-                q.momentum, q.state0, q.max_grad_norm = 0.0, None, -1.0
+                q.optimizer = OPT_NONE
         if need_first:
             return self._first_step_unfused(**objective_kwargs)
         with B.on_device(self.device):
@@ -194,10 +221,17 @@ class NativeTrainStep:
 
     def _first_step_unfused(self, **objective_kwargs):
         """First step of a heavy-ball RSGD: the momentum buffers do not exist yet — run it through the optimizers."""
-        loss = self.embedding.fused_objective(self.objective_fn, self.target, None, **objective_kwargs)
+        if self.shard is not None:
+            from graphembed import parallel
+            loss = parallel.sharded_fused_objective(self.embedding, self.objective_fn, self.target, self.shard,
+                                                    comm=self.comm, **objective_kwargs)
+        else:
+            loss = self.embedding.fused_objective(self.objective_fn, self.target, None, **objective_kwargs)
         for o in self.optimizers:
             o.zero_grad(set_to_none=True)
         loss.backward()
+        if self.shard is not None and self.shard.world > 1:
+            loss = parallel.all_reduce_(loss.detach().clone(), comm=self.comm, group=self.shard.group)
         for o in self.optimizers:
             o.step()
         for x, g in zip(self.embedding.xs, self.grads):

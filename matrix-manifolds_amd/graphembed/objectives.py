@@ -51,13 +51,16 @@ class QuotientLoss(ObjectiveFunction):
             self._dyn_value = (1.0, 1.0)
         return self._dyn
 
-    def set_epoch(self, epoch, alpha):
+    def set_epoch(self, epoch, alpha, force=False):
         """Writes the schedule of `epoch` into the device-resident parameters (after `on_device`): nothing
         when the values are the ones already there, else an asynchronous copy from a pinned staging buffer
-        on the current stream (stream order makes it visible to the kernels launched after it; the staging
-        buffer is rewritten only after the previous copy has been consumed)."""
+        on the CURRENT stream (the staging buffer is rewritten only after the previous copy has been consumed).
+        Stream order makes the new values visible to kernels launched later on that stream; a consumer on
+        ANOTHER stream (a graph replayed from a side stream) must wait for the copy — `fused_spec` does so
+        for the calling stream, and `wait_schedule()` does it explicitly.  `force=True` rewrites the device
+        copy even if the host believes it is current (after the tensor was restored / overwritten externally)."""
         value = (float(alpha), 1.0 / (epoch + 1))
-        if value == self._dyn_value:
+        if value == self._dyn_value and not force:
             return
         if self._dyn.is_cuda:
             if getattr(self, '_dyn_event', None) is not None:
@@ -66,9 +69,19 @@ class QuotientLoss(ObjectiveFunction):
             self._dyn.copy_(self._dyn_host, non_blocking=True)
             self._dyn_event = torch.cuda.Event()
             self._dyn_event.record()
+            self._dyn_stream = torch.cuda.current_stream(self._dyn.device).cuda_stream
         else:
             self._dyn[0], self._dyn[1] = value
         self._dyn_value = value
+
+    def wait_schedule(self):
+        """Makes the current stream wait for the last `set_epoch` copy if that was issued on another stream."""
+        ev = getattr(self, '_dyn_event', None)
+        if ev is None or self._dyn is None or not self._dyn.is_cuda:
+            return
+        cur = torch.cuda.current_stream(self._dyn.device)
+        if cur.cuda_stream != getattr(self, '_dyn_stream', None) and not ev.query():
+            cur.wait_event(ev)
 
     def fused_spec(self, *, epoch, alpha):
         """(kind, alpha, eps, terms[, device {alpha, eps}]) for the fused loss+gradient kernels
@@ -80,6 +93,7 @@ class QuotientLoss(ObjectiveFunction):
             return ('quotient', float(alpha), eps, terms)
         if not (self._dyn.is_cuda and torch.cuda.is_current_stream_capturing()):
             self.set_epoch(epoch, alpha)
+            self.wait_schedule()
         return ('quotient', float(alpha), eps, terms, self._dyn)
 
     def __str__(self):

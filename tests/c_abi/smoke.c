@@ -18,7 +18,7 @@ int main(void) {
   const int64_t n = 37;
   const int d = 3;
   const int64_t P = n * (n - 1) / 2;
-  if (mm_abi_version() < 1) return 4;
+  if (mm_abi_version() < 2) return 4;
   if (mm_pair_offset(n, n) != P) return 4;
   double* a = malloc(sizeof(double) * n);
   double* x = calloc((size_t)n * d * d, sizeof(double));
@@ -89,6 +89,34 @@ int main(void) {
   for (int t = 0; t < 12; ++t)
     if (fabsf(xn[t] - (xe[t] - 0.1f * ge[t])) > 1e-6f) return 8;
   printf("euclidean(4): pdist and RSGD step ok\n");
+  /* the collective of the sharded path (replaces torch.nn.DataParallel, train.py:107-109): a one-rank RCCL communicator —
+   * rendezvous token, init, an in-place all-reduce(sum) on the stream (one rank: the buffer must come back unchanged),
+   * and the sharded training-step descriptor's argument checks */
+  if (mm_comm_available()) {
+    char token[MM_COMM_ID_BYTES];
+    mm_comm_t comm = NULL;
+    CHECK_MM(mm_comm_unique_id(token));
+    int dev = 0;
+    CHECK_HIP(hipGetDevice(&dev));
+    CHECK_MM(mm_comm_init(&comm, 0, 1, token, dev));
+    if (mm_comm_world(comm) != 1 || mm_comm_rank(comm) != 0) return 10;
+    CHECK_MM(mm_allreduce_sum(comm, MM_F32, dxe, 12, st));
+    CHECK_MM(mm_allreduce_sum(comm, MM_F64, dgrad, n * 9, st));
+    float back[12];
+    double* gback = malloc(sizeof(double) * n * 9);
+    CHECK_HIP(hipMemcpyAsync(back, dxe, sizeof back, hipMemcpyDeviceToHost, st));
+    CHECK_HIP(hipMemcpyAsync(gback, dgrad, sizeof(double) * n * 9, hipMemcpyDeviceToHost, st));
+    CHECK_HIP(hipStreamSynchronize(st));
+    for (int t = 0; t < 12; ++t) if (back[t] != xe[t]) return 11;
+    for (int64_t t = 0; t < n * 9; ++t) if (gback[t] != grad[t]) return 11;
+    if (mm_allreduce_sum(NULL, MM_F32, dxe, 12, st) != MM_ERR_ARG) return 12;
+    if (mm_allreduce_sum(comm, 7, dxe, 12, st) != MM_ERR_ARG) return 12;
+    CHECK_MM(mm_comm_destroy(comm));
+    printf("mm_comm: one-rank RCCL communicator (RCCL %d), all-reduce in place ok\n", mm_comm_rccl_version());
+  } else {
+    printf("mm_comm: RCCL not bound (%s)\n", mm_comm_last_error());
+    return 13;
+  }
   /* argument errors are return codes, never exceptions */
   if (mm_spd_pdist_fwd(MM_F64, NULL, n, d, 0, n, 1, 1e-8, 1e8, dout, ws, 0, st) != MM_ERR_ARG) return 9;
   if (mm_spd_pdist_fwd(MM_F64, dx, n, 10, 0, n, 1, 1e-8, 1e8, dout, ws, 0, st) != MM_ERR_UNSUPPORTED) return 9;   /* SPD(2..9) */

@@ -30,7 +30,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(raw, name), f'{name} declared in mm_manifolds.h but not exported'
     assert declared == set(B.SIGNATURES), declared ^ set(B.SIGNATURES)
     assert lib.raw('mm_target_arch')() == b'gfx950'
-    assert lib.raw('mm_abi_version')() >= 1
+    assert lib.raw('mm_abi_version')() >= 2
     assert lib.raw('mm_spd_max_dim')() >= 4 and lib.raw('mm_vec_max_dim')() >= 16
 
 
@@ -46,8 +46,8 @@ def test_argument_errors_need_no_gpu():
     assert g(B.MM_F32, B.LORENTZ, p, 10, 1000, 0, 10, 1, p, None) == -2                   # m too large
     with pytest.raises(B.BackendError):
         lib.call('mm_spd_pdist_fwd', B.MM_F32, None, 10, 3, 0, 10, 1, 1e-8, 1e8, None, None, 0, None)
-    assert lib.raw('mm_spd_pdist_ws_bytes')(B.MM_F32, 5000, 3) == 64 + 20032 + 4 * (5000 * (6 * 6 + 9 + 1) + 512)
-    assert lib.raw('mm_spd_pdist_ws_bytes')(B.MM_F64, 7, 4) == 64 + 64 + 8 * (7 * (6 * 10 + 16 + 1) + 512)
+    assert lib.raw('mm_spd_pdist_ws_bytes')(B.MM_F32, 5000, 3) == 64 + 20032 + 4 * (5000 * (6 * 6 + 9 + 1) + 512 + 2 * 6)   # (+ one padding row of nodeLC)
+    assert lib.raw('mm_spd_pdist_ws_bytes')(B.MM_F64, 7, 4) == 64 + 64 + 8 * (7 * (6 * 10 + 16 + 1) + 512 + 2 * 10)
 
 
 @pytest.mark.parametrize('n,world', [(1, 1), (2, 2), (5, 8), (40, 3), (5000, 8), (16384, 8), (4039, 7)])
@@ -298,3 +298,78 @@ def test_embedding_deepcopy_keeps_manifolds():
     assert torch.equal(dup[0].data, p.data) and dup[0].data_ptr() != p.data_ptr()
     q = ManifoldParameter(torch.zeros(2), manifold=man, requires_grad=False)
     assert copy.deepcopy(q).requires_grad is False and copy.deepcopy(q).manifold is man
+
+
+# ---- round 3: the collective behind the C ABI, the sharded one-call step -----------------------------------------
+def test_comm_entry_points_reject_bad_arguments_without_a_gpu():
+    lib = B.lib()
+    assert lib.raw('mm_allreduce_sum')(None, B.MM_F32, None, 4, None) == -1          # no communicator
+    handle = ctypes.c_void_p()
+    token = (ctypes.c_char * 128)()
+    assert lib.raw('mm_comm_init')(ctypes.byref(handle), 3, 2, token, 0) == -1       # rank >= world
+    assert lib.raw('mm_comm_init')(ctypes.byref(handle), 0, 0, token, 0) == -1       # world < 1
+    assert lib.raw('mm_comm_init')(None, 0, 1, token, 0) == -1
+    assert lib.raw('mm_comm_unique_id')(None) == -1
+    assert lib.raw('mm_comm_destroy')(None) == 0
+    assert lib.raw('mm_comm_world')(None) == 0 and lib.raw('mm_comm_rank')(None) == -1
+    assert lib.raw('mm_comm_available')() in (0, 1)
+    assert isinstance(lib.raw('mm_comm_last_error')(), bytes)
+
+
+def test_train_step_struct_layout_matches_the_header(tmp_path):
+    """The ctypes mirror of mm_train_step / mm_step_param (graphembed/native_step.py) against the C compiler's layout."""
+    import shutil
+    import subprocess
+    from graphembed.native_step import _StepParam, _TrainStep
+    if shutil.which('gcc') is None:
+        pytest.skip('gcc not available')
+    fields_p = [f[0] for f in _StepParam._fields_]
+    fields_t = [f[0] for f in _TrainStep._fields_]
+    src = ['#include <stdio.h>', '#include <stddef.h>', '#include "mm_manifolds.h"', 'int main(void) {',
+           'printf("%zu %zu\\n", sizeof(mm_step_param), sizeof(mm_train_step));']
+    for f in fields_p:
+        src.append(f'printf("p {f} %zu\\n", offsetof(mm_step_param, {f}));')
+    for f in fields_t:
+        src.append(f'printf("t {f} %zu\\n", offsetof(mm_train_step, {f}));')
+    src += ['return 0; }']
+    c = tmp_path / 'layout.c'
+    c.write_text('\n'.join(src))
+    exe = str(tmp_path / 'layout')
+    subprocess.run(['gcc', '-std=c11', '-I' + os.path.join(ROOT, 'include'), str(c), '-o', exe], check=True)
+    out = subprocess.run([exe], capture_output=True, text=True, check=True).stdout.split('\n')
+    sp, st = map(int, out[0].split())
+    assert (sp, st) == (ctypes.sizeof(_StepParam), ctypes.sizeof(_TrainStep))
+    for line in out[1:]:
+        if not line:
+            continue
+        which, name, off = line.split()
+        cls = _StepParam if which == 'p' else _TrainStep
+        assert getattr(cls, name).offset == int(off), (which, name)
+
+
+def test_sync_grads_uses_an_installed_communicator():
+    """graphembed.parallel routes the step's collective through the installed communicator object (the RCCL one on a
+    GPU box) and falls back to torch.distributed without one."""
+    from graphembed import parallel
+
+    class Fake:
+        world, rank = 2, 0
+        calls = 0
+
+        def all_reduce_(self, t):
+            Fake.calls += 1
+            return t.mul_(2)
+    a = torch.ones(3, requires_grad=True)
+    b = torch.ones(2, requires_grad=True)
+    parallel.set_communicator(Fake())
+    try:
+        x, y = parallel.sync_grads(a, b)
+        (x.sum() + 3 * y.sum()).backward()
+    finally:
+        parallel.set_communicator(None)
+    assert Fake.calls == 1                                  # ONE collective for all parameters
+    assert torch.equal(a.grad, torch.full((3,), 2.0)) and torch.equal(b.grad, torch.full((2,), 6.0))
+    a.grad = None
+    x, = parallel.sync_grads(a)                             # no communicator, no process group: identity
+    x.sum().backward()
+    assert torch.equal(a.grad, torch.ones(3))

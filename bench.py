@@ -326,6 +326,82 @@ class FusedLossWorkload:
         return flat
 
 
+class VecPdistWorkload:
+    """BASELINE configs 1 and 2: d2 = man.pdist(x, squared=True); d2.backward(g) on a vector manifold (tree40 ->
+    Euclidean R^10; facebook, n = 4039 -> Lorentz H^10: Gram forward / backward on the matrix cores)."""
+
+    def __init__(self, kind, m, n, dtype, dev, seed=0):
+        import torch
+        from graphembed import manifolds as M
+        self.man = {'lorentz': M.Lorentz, 'euclidean': M.Euclidean, 'sphere': M.Sphere}[kind](m)
+        torch.manual_seed(seed)
+        self.x = self.man.rand(n, out=torch.empty(0, device=dev, dtype=dtype)).requires_grad_()
+        self.P = n * (n - 1) // 2
+        self.g = torch.randn(self.P, device=dev, dtype=dtype)
+        self.n, self.m, self.world, self.rank, self.comm = n, m, 1, 0, None
+        self.esz = self.x.element_size()
+
+    def kernels(self):
+        import torch
+        d2 = self.man.pdist(self.x, squared=True)
+        grad, = torch.autograd.grad(d2, self.x, self.g)
+        return grad
+
+    eager_step = kernels
+
+    def reduce(self, t):
+        return t
+
+
+class TrainStepWorkload:
+    """A full training step of train.py:198-222 — objective (fused loss + gradients), optimizer update of points and
+    scales — issued by ONE C-ABI call (mm_train_step_run, graphembed.native_step.NativeTrainStep) and replayed as a graph.
+    With a communicator: this rank's pair rows, one all-reduce of {gradients, loss, scale gradients} INSIDE the call."""
+
+    def __init__(self, mans, n, dtype, dev, loss='stress', world=1, rank=0, comm=None, seed=0):
+        import torch
+        from graphembed.modules import ManifoldEmbedding
+        from graphembed.native_step import NativeTrainStep
+        from graphembed.objectives import QuotientLoss, StressLoss
+        from graphembed.optim import RiemannianSGD
+        from graphembed.parallel import PairShard
+        torch.manual_seed(seed)
+        torch.set_default_dtype(dtype)
+        try:
+            with torch.device(dev):
+                self.emb = ManifoldEmbedding(n, mans)
+        finally:
+            torch.set_default_dtype(torch.float32)
+        self.n, self.world, self.rank, self.comm = n, world, rank, comm
+        self.P = n * (n - 1) // 2
+        shard = PairShard(n, world=world, rank=rank) if world > 1 else None
+        lo, hi = (shard.lo, shard.hi) if shard else (0, self.P)
+        gen = torch.Generator(device=dev).manual_seed(seed + 1000 + rank)
+        target = torch.rand(hi - lo, generator=gen, dtype=dtype, device=dev) * 0.99 + 0.01
+        self.fn = QuotientLoss() if loss == 'quotient' else StressLoss()
+        if loss == 'quotient':
+            self.fn.on_device(dev)
+            self.fn.set_epoch(3, 1.0)
+        # (learning rates of 1e-6 / 1e-7: the arithmetic of a step does not depend on them, and the synthetic embedding —
+        # random targets — stays in the regime the workload names, the reference's initialisation, for the whole run
+        # instead of drifting to wherever a few thousand steps towards random targets take it)
+        opts = [RiemannianSGD(list(self.emb.xs), lr=1e-6, exact=True, max_grad_norm=20),
+                RiemannianSGD(list(self.emb.scales), lr=1e-7, max_grad_norm=500)]
+        self.step = NativeTrainStep(self.emb, self.fn, target, opts, shard=shard, comm=comm if world > 1 else None)
+        self.x = self.emb.xs[0]
+        self.rows = shard.rows if shard else (0, n)
+        self.lo, self.hi = lo, hi
+        self.in_call_collective = comm is not None and world > 1
+
+    def kernels(self):
+        return self.step(epoch=3, alpha=1.0)
+
+    eager_step = kernels
+
+    def reduce(self, t):
+        return t
+
+
 def time_workload(wl, steps, warmup, fence, use_graph, graph_collective=False, rank=0, tag='', warm_seconds=0.0):
     """Times `steps` steps of the workload between fences.  Returns (elapsed_s, launch_mode, phases) where
     phases = per-step means, in us, of this rank's device time in the kernels and in the all-reduce and of
@@ -338,7 +414,23 @@ def time_workload(wl, steps, warmup, fence, use_graph, graph_collective=False, r
     mode = 'eager'
     in_graph_collective = False
     dev = wl.x.device
-    if use_graph:
+    # (a workload whose step already contains its collective — the one-call training step with a communicator — has
+    # nothing to reduce afterwards: it is captured whole, with the thread-local capture mode RCCL needs)
+    in_call = getattr(wl, 'in_call_collective', False)
+    if use_graph and in_call:
+        try:
+            graph, static = graph_of(wl.kernels, fence, with_collective=True)
+            ok = True
+        except Exception as exc:  # noqa: BLE001
+            ok, graph = False, None
+            print(f'[bench] rank {rank}: {tag}capture of the one-call step failed ({type(exc).__name__}: {exc}); eager calls',
+                  file=sys.stderr)
+        if all_agree(ok, world, dev):
+            mode, in_graph_collective = 'hipGraph replay (one C-ABI call: kernels + all-reduce + optimizer)', True
+        else:
+            graph, mode = None, 'eager (one C-ABI call per step)'
+            torch.cuda.synchronize()
+    elif use_graph:
         # level 1: kernels AND the all-reduce in one captured graph (the host is out of the step entirely);
         # level 2: the kernels captured, the all-reduce issued eagerly behind each replay;
         # level 3 (only if the kernels themselves cannot be captured): eager launches.
@@ -369,6 +461,9 @@ def time_workload(wl, steps, warmup, fence, use_graph, graph_collective=False, r
             else:
                 graph, mode = None, 'eager'
                 fence()
+
+    if in_call:
+        in_graph_collective = True     # (nothing to issue after the kernels, graphed or not)
 
     def run():
         if graph is None:
@@ -638,6 +733,54 @@ def worker(args):
             extra.append(rec)
             del w
             torch.cuda.empty_cache()
+        if world == 1 and n == N_NODES:
+            from graphembed import manifolds as M
+            # BASELINE configs 2 and 1 (pdist fwd + bwd on vector manifolds; Gram kernels on the matrix cores for Lorentz)
+            for name, kind, m, nn, dt in (('BASELINE config 2: facebook-class graph n=4039 -> Lorentz H^10 (11 coords) f32', 'lorentz', 11, 4039, torch.float32),
+                                          ('BASELINE config 2 in f64 (the dtype run.py:32-35 sets)', 'lorentz', 11, 4039, torch.float64),
+                                          ('BASELINE config 1: tree40 n=40 -> Euclidean R^10 f64 (plumbing: launch-bound)', 'euclidean', 10, 40, torch.float64)):
+                w = VecPdistWorkload(kind, m, nn, dt, dev)
+                el, md, ph = time_workload(w, k2, w2, fence, use_graph, False, rank, tag=name + ': ', warm_seconds=0.05)
+                run_w = ph.pop('_run')
+                kk = {'fwd': None, 'bwd': None}
+                if not args.no_prof:
+                    lib.call('mm_prof_enable', 1)
+                    w.eager_step()
+                    fence()
+                    collect_kernel_us(lib, (('fwd', 2), ('bwd', 3)))
+                    for _ in range(5):
+                        for _ in range(8):
+                            run_w()
+                        w.eager_step()
+                    fence()
+                    lib.call('mm_prof_enable', 0)
+                    kk = collect_kernel_us(lib, (('fwd', 2), ('bwd', 3)))
+                rec = {'workload': name + ', pdist fwd+bwd', 'pairs_per_step': w.P, 'ms_per_step': el / k2 * 1e3,
+                       'value': w.P * k2 / el, 'unit': 'pairs/s', 'steps': k2, 'launch': md,
+                       'fwd_kernel_us': kk['fwd'], 'bwd_kernel_us': kk['bwd']}
+                if kk['bwd']:   # algorithmic bytes: read g (one element per pair) + points in + gradient out
+                    rec['bwd_hbm_frac'] = (w.P * w.esz + 2 * nn * m * w.esz) / (kk['bwd'] * 1e-6) / 1e9 / HBM_PEAK_GBS
+                if kk['fwd']:
+                    rec['fwd_hbm_frac'] = (w.P * w.esz + nn * m * w.esz) / (kk['fwd'] * 1e-6) / 1e9 / HBM_PEAK_GBS
+                extra.append(rec)
+                del w
+                torch.cuda.empty_cache()
+            # full training steps (objective + optimizer; ONE C-ABI call, replayed as a graph): configs 3, 4 and 2
+            for name, mans, nn, dt, loss in (
+                    ('BASELINE config 3 training step: SPD(3) n=5000 f32, StressLoss + RSGD (2 launches: pair kernel, fused finalize+update+tables)',
+                     lambda: [M.SymmetricPositiveDefinite(3)], N_NODES, torch.float32, 'stress'),
+                    ('BASELINE config 4 training step: csphd n=1025 -> H^5 x S^5 x SPD(2) f32, StressLoss + RSGD (mixed-manifold pair kernel)',
+                     lambda: [M.Lorentz(6), M.Sphere(6), M.SymmetricPositiveDefinite(2)], 1025, torch.float32, 'stress'),
+                    ('BASELINE config 4 training step in f64', lambda: [M.Lorentz(6), M.Sphere(6), M.SymmetricPositiveDefinite(2)], 1025, torch.float64, 'stress'),
+                    ('BASELINE config 2 training step: Lorentz(11) n=4039 f32, StressLoss + RSGD', lambda: [M.Lorentz(11)], 4039, torch.float32, 'stress'),
+                    ('BASELINE config 5 training step: SPD(4) n=16384 f32, QuotientLoss + RSGD', lambda: [M.SymmetricPositiveDefinite(4)], 16384, torch.float32, 'quotient')):
+                w = TrainStepWorkload(mans(), nn, dt, dev, loss=loss)
+                el, md, ph = time_workload(w, k2, w2, fence, use_graph, False, rank, tag=name + ': ', warm_seconds=0.05)
+                ph.pop('_run')
+                extra.append({'workload': name, 'pairs_per_step': w.P, 'ms_per_step': el / k2 * 1e3, 'value': w.P * k2 / el,
+                              'unit': 'pairs/s', 'steps': k2, 'launch': md + ' of mm_train_step_run'})
+                del w
+                torch.cuda.empty_cache()
         if world > 1 and n == N_NODES:
             # WEAK scaling of the same path beside the strong-scaling headline: per-GPU work fixed at the headline's 12.5 M
             # pairs — N ranks embed a graph of 5000 sqrt(N) nodes (N x 12.5 M pairs), pair rows sharded, one all-reduce of the
@@ -667,6 +810,22 @@ def worker(args):
                       'steps': k2, 'n_gpus': world, 'scaling': 'strong', 'launch': md, 'per_rank': ranks5})
         del w
         torch.cuda.empty_cache()
+        if world > 1 and comm is not None:
+            # the same configuration as a full training step through ONE C-ABI call per step: this rank's pair rows ->
+            # all-reduce (mm_allreduce_sum inside mm_train_step_run) -> identical RSGD update on every rank
+            from graphembed import manifolds as M
+            w = TrainStepWorkload([M.SymmetricPositiveDefinite(4)], 16384, torch.float32, dev, loss='quotient', world=world,
+                                  rank=rank, comm=comm)
+            el, md, ph = time_workload(w, k2, w2, fence, use_graph, graph_collective, rank, tag='config 5 step: ', warm_seconds=0.1)
+            ph.pop('_run')
+            el = reduce_max(el, dev, world)
+            ranks5 = gather_objects({'rank': rank, 'rows': list(w.rows), 'pairs': w.hi - w.lo, **ph}, world)
+            extra.append({'workload': 'BASELINE config 5 training step: n=16384 -> SPD(4), QuotientLoss + RSGD, pair rows sharded, '
+                                      'objective -> all-reduce -> update in ONE mm_train_step_run per rank',
+                          'pairs_per_step': w.P, 'ms_per_step': el / k2 * 1e3, 'value': w.P * k2 / el, 'unit': 'pairs/s',
+                          'steps': k2, 'n_gpus': world, 'scaling': 'strong', 'launch': md, 'per_rank': ranks5})
+            del w
+            torch.cuda.empty_cache()
 
     if rank == 0:
         if extra:

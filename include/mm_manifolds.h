@@ -420,6 +420,9 @@ const char* mm_comm_last_error(void);
  * a caller whose loop is not captured in a HIP graph pays one foreign-function call per step instead of ~15.
  * Parameters are updated IN PLACE; gradients are left in the `grad` buffers (the scales' gradients in
  * loss_out[1 + k]); loss_out[0] is the loss BEFORE the update, as the reference logs it.
+ * A single SPD factor is issued as TWO launches: the pair kernel (loss + gradient sums) and one per-point kernel that
+ * finishes the gradient, applies the optimizer rule, writes the new point and its tables for the next step, closes the
+ * loss record and updates a momentum-free RSGD scale — instead of prepare + pair + finalize + point update + scale update.
  * Multi-GPU: with a row range and a communicator the same call issues objective (this rank's pairs) -> one
  * all-reduce -> optimizer, still without touching the host in between (capturable as one HIP graph). */
 enum { MM_OPT_NONE = -1 /* frozen: read by the objective, never stepped (a scale during burn-in) */,
@@ -451,7 +454,11 @@ typedef struct mm_train_step {
   const void* target;            /* squared graph distances, pair-vector order [n(n-1)/2]                          */
   void* loss_out;                /* [1 + nf]                                                                       */
   void* ws;                      /* workspace of the embedding's objective kernel (mm_*_ws_bytes)                  */
-  int ws_flags;                  /* MM_WS_CLEAN when a product workspace is known to be clean                      */
+  int ws_flags;                  /* MM_WS_CLEAN when a product workspace is known to be clean; MM_WS_PREPARED when a
+                                    single SPD factor's workspace holds the tables of the CURRENT points: a step with an
+                                    optimizer on the SPD points writes the tables of the new points itself (the optimizer
+                                    kernel does what mm_spd_prepare does), so from the second consecutive step on the
+                                    caller passes MM_WS_PREPARED — unless it changed the points in between             */
   /* -- sharded step (mm_abi_version() >= 2); all zero = the whole pair list on one GPU ------------------------- */
   int64_t row_begin, row_end;    /* this rank's rows of the pair list (mm_shard_rows); row_end <= 0 means n.  `target`
                                     is then this rank's SLICE: the targets of the pairs from mm_pair_offset(n,row_begin) on */

@@ -503,6 +503,67 @@ template <typename T> __device__ __forceinline__ T log_series3(const T (&a)[6], 
   return tr2;
 }
 
+// ---- log(A) of a pair at moderate distance: the RECENTRED series (3x3, fp32) -----------------------------------
+// log A = log(mu) I + log(I + E'),  E' = A / mu - I  with  mu = tr A / 3 (the scalar that minimises ||A - mu I||_F).
+// E' is traceless, so its spectral radius is at most sqrt(2/3) ||E'||_F: the gate ||E'||_F^2 <= kCentredGate3 bounds it
+// by 0.66, where log(1+x) = x p(x) holds to 4e-8 |x| with p of degree 15 (Chebyshev-interpolated on |x| <= 0.66,
+// tools/design/series_fit_wide.py).  Same evaluation as log_series3 — Horner's rule in R[E']/(chi_E') — but with
+// s1 = tr E' = 0 a step is TWO multiply-adds: (a0, a1, a2) . E' + c I = (a2 s3 + c, a0 - a2 s2, a1).  ~95 instructions
+// with one reciprocal and one logarithm, against ~185 for the Cayley-transform logarithm below: embeddings whose pair
+// distances are a few tenths (||log X|| ~ 0.35: training after the first epochs) stay eigen-free AND inverse-free.
+// `pre` multiplies the result.
+constexpr double kCentredGate3 = 0.6534;   // (2/3) * 0.6534 = 0.66^2
+template <typename T> struct LogSeriesWide;
+template <> struct LogSeriesWide<float> {
+  static constexpr int kTerms = 16;
+  static constexpr float kA[kTerms] = {9.999999847e-01f, -4.999999854e-01f, 3.333378158e-01f, -2.500042795e-01f,
+                                       1.997873233e-01f, -1.664636323e-01f, 1.466440033e-01f, -1.286147090e-01f,
+                                       7.866430935e-02f, -6.903477397e-02f, 2.371349367e-01f, -2.228347962e-01f,
+                                       -2.667691364e-01f, 2.562672116e-01f, 4.274908187e-01f, -4.061057313e-01f};
+};
+// true if the pair is OUTSIDE the recentred series' range (NaN counts as outside): ||A - mu I||_F^2 > kCentredGate3 mu^2.
+// Evaluated from A alone, in the branch that needs it (rows that failed the close-pair gate): the close-pair path keeps
+// nothing alive for it.
+template <typename T> __device__ __forceinline__ bool centred_far3(const T (&a)[6]) {
+  using N = Num<T>;
+  const T mu = (a[pidx(0, 0)] + a[pidx(1, 1)] + a[pidx(2, 2)]) * T(1.0 / 3.0);
+  const T d0 = a[pidx(0, 0)] - mu, d1 = a[pidx(1, 1)] - mu, d2 = a[pidx(2, 2)] - mu;
+  const T off = N::fma(a[pidx(1, 0)], a[pidx(1, 0)], N::fma(a[pidx(2, 0)], a[pidx(2, 0)], a[pidx(2, 1)] * a[pidx(2, 1)]));
+  const T dev = N::fma(d0, d0, N::fma(d1, d1, N::fma(d2, d2, off + off)));   // ||A - mu I||_F^2
+  return !(dev <= T(kCentredGate3) * (mu * mu)) || !(mu > T(0));
+}
+template <typename T> __device__ __forceinline__ void log_series3_centred(const T (&a)[6], T (&m0)[6], T pre = T(1)) {
+  using N = Num<T>;
+  using S = LogSeriesWide<T>;
+  const T mu = (a[pidx(0, 0)] + a[pidx(1, 1)] + a[pidx(2, 2)]) * T(1.0 / 3.0);
+  const T rmu = N::rcp(mu);
+  const T e00 = N::fma(a[pidx(0, 0)], rmu, T(-1)), e11 = N::fma(a[pidx(1, 1)], rmu, T(-1)), e22 = N::fma(a[pidx(2, 2)], rmu, T(-1));
+  const T e10 = a[pidx(1, 0)] * rmu, e20 = a[pidx(2, 0)] * rmu, e21 = a[pidx(2, 1)] * rmu;
+  const T f00 = N::fma(e00, e00, N::fma(e10, e10, e20 * e20));
+  const T f11 = N::fma(e10, e10, N::fma(e11, e11, e21 * e21));
+  const T f22 = N::fma(e20, e20, N::fma(e21, e21, e22 * e22));
+  const T f10 = N::fma(e10, e00, N::fma(e11, e10, e21 * e20));
+  const T f20 = N::fma(e20, e00, N::fma(e21, e10, e22 * e20));
+  const T f21 = N::fma(e20, e10, N::fma(e21, e11, e22 * e21));
+  const T s2 = T(-0.5) * (f00 + f11 + f22);          // s1 = 0: s2 = -tr(E'^2) / 2
+  const T s3 = e00 * N::fma(e11, e22, -e21 * e21) - e10 * N::fma(e10, e22, -e21 * e20) +
+               e20 * N::fma(e10, e21, -e11 * e20);
+  T a0 = T(S::kA[S::kTerms - 3]), a1 = T(S::kA[S::kTerms - 2]), a2 = T(S::kA[S::kTerms - 1]);
+#pragma unroll
+  for (int k = S::kTerms - 4; k >= 0; --k) {
+    const T n0 = N::fma(a2, s3, T(S::kA[k])), n1 = N::fma(-a2, s2, a0);
+    a2 = a1; a0 = n0; a1 = n1;
+  }
+  const T logmu = N::log(mu);
+  const T b0 = N::fma(a2, s3, logmu) * pre, b1 = N::fma(-a2, s2, a0) * pre, b2 = a1 * pre;
+  m0[pidx(0, 0)] = N::fma(b2, f00, N::fma(b1, e00, b0));
+  m0[pidx(1, 1)] = N::fma(b2, f11, N::fma(b1, e11, b0));
+  m0[pidx(2, 2)] = N::fma(b2, f22, N::fma(b1, e22, b0));
+  m0[pidx(1, 0)] = N::fma(b2, f10, b1 * e10);
+  m0[pidx(2, 0)] = N::fma(b2, f20, b1 * e20);
+  m0[pidx(2, 1)] = N::fma(b2, f21, b1 * e21);
+}
+
 // ---- Cayley-transform logarithm: the general eigen-free path (3x3) ------------------------------
 // log A = log(mu) I + 2 atanh(Z),  Z = (A - mu I)(A + mu I)^-1  (spectrum z = (l - mu)/(l + mu), |z| < 1
 // for every SPD A), atanh(Z) = Z P(Z^2) with P a near-minimax polynomial of atanh(sqrt w)/sqrt w on

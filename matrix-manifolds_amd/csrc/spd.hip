@@ -34,11 +34,38 @@
 #include "adam.hpp"
 
 #include "spd_ws.hpp"
+#include "spd_step.hpp"
 #include "stamp.hpp"
 
 namespace mm {
 
 // ------------------------------------------------------------------ prep
+// The per-node tables of ONE point from its packed symmetric part: Cholesky factor, its inverse, log det (the part of
+// _lult, manifolds/spd.py:108-111, that depends on one point only).  Shared by spd_prep_kernel and by the fused optimizer
+// kernels, which write the tables of the NEW point in the same pass (no preparation launch in steady state).
+template <typename T, int D>
+__device__ __forceinline__ void node_tables(const T (&xs)[Packed<D>::NP], int i, T* __restrict__ nodeL, T* __restrict__ nodeX,
+                                            T* __restrict__ nodeC, int* __restrict__ bad, T* __restrict__ nodeLd,
+                                            T* __restrict__ nodeLC) {
+  constexpr int NP = Packed<D>::NP;
+  T l[NP], li[NP];
+  const bool ok = cholesky<T, D>(xs, l);
+  invert_lower<T, D>(l, li);
+#pragma unroll
+  for (int k = 0; k < NP; ++k) {
+    nodeL[size_t(i) * NP + k] = li[k];
+    nodeX[size_t(i) * NP + k] = xs[k];
+    nodeC[size_t(i) * NP + k] = l[k];
+    nodeLC[size_t(i) * 2 * NP + k] = li[k];
+    nodeLC[size_t(i) * 2 * NP + NP + k] = l[k];
+  }
+  bad[i] = ok ? 0 : 1;
+  T ld = T(0);
+#pragma unroll
+  for (int k = 0; k < D; ++k) ld += Num<T>::log(l[pidx(k, k)]);
+  nodeLd[i] = ld + ld;
+}
+
 template <typename T, int D>
 __global__ void spd_prep_kernel(const T* __restrict__ x, int n, T* __restrict__ nodeL, T* __restrict__ nodeX,
                                 T* __restrict__ nodeC, T* __restrict__ accM, T* __restrict__ accS,
@@ -49,26 +76,13 @@ __global__ void spd_prep_kernel(const T* __restrict__ x, int n, T* __restrict__ 
   if (blockIdx.x == 0)
     for (int t = threadIdx.x; t < 2 * kLossSlots; t += blockDim.x) loss[t] = T(0);
   if (i >= n) return;
-  T xs[NP], l[NP], li[NP];
+  T xs[NP];
   load_sym_packed<T, D>(x + size_t(i) * D * D, xs);
-  const bool ok = cholesky<T, D>(xs, l);
-  invert_lower<T, D>(l, li);
+  node_tables<T, D>(xs, i, nodeL, nodeX, nodeC, bad, nodeLd, nodeLC);
 #pragma unroll
-  for (int k = 0; k < NP; ++k) {
-    nodeL[size_t(i) * NP + k] = li[k];
-    nodeX[size_t(i) * NP + k] = xs[k];
-    nodeC[size_t(i) * NP + k] = l[k];
-    nodeLC[size_t(i) * 2 * NP + k] = li[k];
-    nodeLC[size_t(i) * 2 * NP + NP + k] = l[k];
-    accM[size_t(k) * n + i] = T(0);
-  }
+  for (int k = 0; k < NP; ++k) accM[size_t(k) * n + i] = T(0);
 #pragma unroll
   for (int k = 0; k < D * D; ++k) accS[size_t(k) * n + i] = T(0);
-  bad[i] = ok ? 0 : 1;
-  T ld = T(0);
-#pragma unroll
-  for (int k = 0; k < D; ++k) ld += Num<T>::log(l[pidx(k, k)]);
-  nodeLd[i] = ld + ld;
 }
 
 __global__ void spd_count_bad_kernel(const int* __restrict__ bad, int n, int* __restrict__ status) {
@@ -224,7 +238,8 @@ template <int N, typename F> __device__ __forceinline__ void static_for(F&& f) {
 // scalar loads and the loop's scalar bookkeeping (every instruction of a wavefront, scalar ones included, takes an issue
 // slot of its SIMD) and, in the backward, the row-side reduction (one reduction of M_a + M_b); wider matrices and fp64
 // do not have the registers for it.
-template <typename T, int D> constexpr int pair_cols() { return (sizeof(T) == 4 && D <= 3) ? 2 : 1; }
+template <typename T, int D> constexpr int pair_cols() { return (sizeof(T) == 4 && D <= 3) ? 2 : ((sizeof(T) == 4 && D == 4) ? MM_SPD4_FWD_NC : 1); }
+template <typename T, int D> constexpr int pair_cols_bwd() { return (sizeof(T) == 4 && D <= 3) ? 2 : ((sizeof(T) == 4 && D == 4) ? MM_SPD4_BWD_NC : 1); }
 
 // Tile: TI rows x (256 x NC) columns per workgroup; lane l of wavefront w owns the columns jbase + 64 (NC w + q) + l.
 // The row loop is unrolled twice with two alternating scalar register sets for the row operand L_i^-1 (no copies), the
@@ -341,7 +356,7 @@ __global__ __launch_bounds__((64 * bwd_waves<T, D>()), (bwd_min_waves<T, D>())) 
                                                                LossArgs<T> la) {
   constexpr int NP = Packed<D>::NP;
   constexpr int NW = bwd_waves<T, D>();
-  constexpr int NC = pair_cols<T, D>();   // lane l owns the columns jbase + 64 q + l, q < NC
+  constexpr int NC = pair_cols_bwd<T, D>();   // lane l owns the columns jbase + 64 q + l, q < NC
   // LOSS != 0: `g` holds the TARGET (graph) squared distances; the upstream gradient of each pair is
   // derived in registers from the loss, and the loss / scale-gradient sums leave through la.slots.
   constexpr int squared = SQ ? 1 : 0;   // (a template parameter: as a run-time flag it cost two vector instructions per row)
@@ -519,12 +534,18 @@ __global__ __launch_bounds__((64 * bwd_waves<T, D>()), (bwd_min_waves<T, D>())) 
             // to ~16: every pair of an embedding with O(1) distances) the Cayley-transform logarithm.
             // What is left (very wide spectra, NaN, non-PD) goes to the Jacobi path.
             T a[NC][NP];
-            bool far = false;   // some pair of this row is outside the close-pair gate
+            bool far = false;    // some pair of this row is outside the close-pair gate
+#ifdef MM_NO_CENTRED   // (A/B builds: tools/snap_make.sh nocentred -DMM_NO_CENTRED)
+            constexpr bool kCentred = false;
+#else
+            constexpr bool kCentred = D == 3 && std::is_same<T, float>::value;
+#endif
             static_for<NC>([&](auto qc) {
               constexpr int q = decltype(qc)::value;
               congr_chol<T, D>(li, xj[q], a[q]);
               far = far | !(close_gate<T, D>(a[q]) <= T(kCloseGate));   // (| : no exec-masked short circuit)
             });
+            bool far2 = true;    // some pair is outside the recentred series' range (SPD(3) fp32), decided only for far rows
             if (__builtin_expect(!__any(far), 1)) {
               static_for<NC>([&](auto qc) {
                 constexpr int q = decltype(qc)::value;
@@ -532,7 +553,31 @@ __global__ __launch_bounds__((64 * bwd_waves<T, D>()), (bwd_min_waves<T, D>())) 
                 log_close<T, D>(a[q], m0, g_first ? gs[q] + gs[q] : T(1));
                 finish(qc, m0, g_first);
               });
-            } else {
+              far2 = false;
+            } else if constexpr (kCentred) {
+              far2 = false;
+              static_for<NC>([&](auto qc) {
+                constexpr int q = decltype(qc)::value;
+                far2 = far2 | centred_far3<T>(a[q]);
+              });
+              far2 = __any(far2);
+              if (!far2) {
+                // pairs at moderate distance (spectral radius of A / mu - I up to 0.66): the recentred series — no
+                // eigensolve, no inverse (smallmat.hpp, log_series3_centred)
+                static_for<NC>([&](auto qc) {
+                  constexpr int q = decltype(qc)::value;
+                  T ac[NP], m0[NP];
+#pragma unroll
+                  for (int k = 0; k < NP; ++k) {
+                    ac[k] = a[q][k];
+                    asm volatile("" : "+v"(ac[k]));   // (the series' arithmetic starts HERE: nothing of it is hoisted above the gates)
+                  }
+                  log_series3_centred<T>(ac, m0, g_first ? gs[q] + gs[q] : T(1));
+                  finish(qc, m0, g_first);
+                });
+              }
+            }
+            if (far2) {
               static_for<NC>([&](auto qc) {
                 constexpr int q = decltype(qc)::value;
                 T m0[NP];
@@ -617,17 +662,13 @@ __global__ __launch_bounds__((64 * bwd_waves<T, D>()), (bwd_min_waves<T, D>())) 
   MM_SPD_STAMP_END();
 }
 
-// grad_x[i] = sym(accS_i X_i^-1) - L_i^-T accM_i L_i^-1   (symmetric, full DxD)
+// grad_x[i] = sym(accS_i X_i^-1) - L_i^-T accM_i L_i^-1   (symmetric; packed in gi).  Reads the accumulators of node i and
+// leaves them zero for the next backward.  Shared by spd_pdist_finalize_kernel and the fused optimizer kernels.
 template <typename T, int D>
-__global__ void spd_pdist_finalize_kernel(const T* __restrict__ nodeL, T* __restrict__ accM,
-                                          T* __restrict__ accS, int n, T* __restrict__ grad,
-                                          T* __restrict__ slots, const T* __restrict__ scale_raw,
-                                          T* __restrict__ loss_out) {
+__device__ __forceinline__ void node_gradient(const T* __restrict__ nodeL, T* __restrict__ accM, T* __restrict__ accS, int n,
+                                              int i, T (&gi)[Packed<D>::NP]) {
   constexpr int NP = Packed<D>::NP;
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (slots && blockIdx.x == 0 && threadIdx.x < 64) loss_finalize<T>(slots, scale_raw, loss_out);
-  if (i >= n) return;
-  T li[NP], m[NP], gi[NP], xinv[NP], sc[D][D];
+  T li[NP], m[NP], xinv[NP], sc[D][D];
 #pragma unroll
   for (int k = 0; k < NP; ++k) {
     li[k] = nodeL[size_t(i) * NP + k];
@@ -663,6 +704,19 @@ __global__ void spd_pdist_finalize_kernel(const T* __restrict__ nodeL, T* __rest
       }
       gi[pidx(r, c)] = T(0.5) * (a + b) - gi[pidx(r, c)];
     }
+}
+
+template <typename T, int D>
+__global__ void spd_pdist_finalize_kernel(const T* __restrict__ nodeL, T* __restrict__ accM,
+                                          T* __restrict__ accS, int n, T* __restrict__ grad,
+                                          T* __restrict__ slots, const T* __restrict__ scale_raw,
+                                          T* __restrict__ loss_out) {
+  constexpr int NP = Packed<D>::NP;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (slots && blockIdx.x == 0 && threadIdx.x < 64) loss_finalize<T>(slots, scale_raw, loss_out);
+  if (i >= n) return;
+  T gi[NP];
+  node_gradient<T, D>(nodeL, accM, accS, n, i, gi);
   store_sym_full<T, D>(grad + size_t(i) * D * D, gi);
 }
 
@@ -855,6 +909,93 @@ __global__ void spd_eigvalsh_kernel(const T* __restrict__ x, int64_t m, T* __res
   }
 }
 
+// ---- the optimizer rules on one point (packed symmetric X and Euclidean gradient in, new point out) ------------------
+// rgrad = X sym(G) X (spd.py:134-135), ||rgrad||_X = ||L^-1 rgrad L^-T||_F (spd.py:113-117), exp / second-order retraction
+// (spd.py:137-154).  Each is the body of one per-point kernel below and of the fused step kernel further down: the same
+// arithmetic whichever way a step is issued.
+template <typename T, int D>
+__device__ __forceinline__ T spd_rgrad_setup(const T (&xs)[Packed<D>::NP], const T (&gs)[Packed<D>::NP],
+                                             T (&r)[Packed<D>::NP], T (&l)[Packed<D>::NP], T (&li)[Packed<D>::NP],
+                                             bool want_norm) {
+  constexpr int NP = Packed<D>::NP;
+  T xf[D * D];
+#pragma unroll
+  for (int a = 0; a < D; ++a)
+#pragma unroll
+    for (int c = 0; c < D; ++c) xf[a * D + c] = xs[pidx(a, c)];
+  congr_full<T, D>(xf, gs, r);  // Riemannian gradient X sym(G) X
+  cholesky<T, D>(xs, l);
+  invert_lower<T, D>(l, li);
+  T s = T(0);
+  if (want_norm) {
+    T a[NP];
+    congr_lower<T, D>(li, r, a);
+#pragma unroll
+    for (int p = 0; p < D; ++p)
+#pragma unroll
+      for (int c = 0; c <= p; ++c) s += (p == c ? T(1) : T(2)) * a[pidx(p, c)] * a[pidx(p, c)];
+  }
+  return s;   // ||r||_X^2 (0 if not asked for)
+}
+
+// momentum-free RSGD (rsgd.py:63-68, 82)
+template <typename T, int D>
+__device__ __forceinline__ void spd_rsgd_update(const T (&xs)[Packed<D>::NP], const T (&gs)[Packed<D>::NP], T lr,
+                                                T max_grad_norm, int exact, T (&o)[Packed<D>::NP]) {
+  constexpr int NP = Packed<D>::NP;
+  T r[NP], l[NP], li[NP];
+  const T s = spd_rgrad_setup<T, D>(xs, gs, r, l, li, max_grad_norm > T(0));
+  T scale = -lr;
+  if (max_grad_norm > T(0)) scale *= Num<T>::min(max_grad_norm / Num<T>::sqrt(s), T(1));
+#pragma unroll
+  for (int q = 0; q < NP; ++q) r[q] *= scale;
+  if (exact) spd_explog<T, D, false>(l, li, r, o);
+  else spd_retr<T, D>(xs, li, r, o);
+}
+
+// heavy-ball variant (rsgd.py:70-80): buf = momentum buf + (1 - dampening) rgrad, x' = exp/retr(x, -lr buf); the
+// SPD transport is the identity (spd.py:196-199); buf is kept symmetric and updated in place.
+template <typename T, int D>
+__device__ __forceinline__ void spd_momentum_update(const T (&xs)[Packed<D>::NP], const T (&gs)[Packed<D>::NP],
+                                                    T (&b)[Packed<D>::NP], T lr, T momentum, T dampening, T max_grad_norm,
+                                                    int exact, T (&o)[Packed<D>::NP]) {
+  constexpr int NP = Packed<D>::NP;
+  T r[NP], l[NP], li[NP];
+  const T nn = spd_rgrad_setup<T, D>(xs, gs, r, l, li, max_grad_norm > T(0));
+  T clip = T(1);
+  if (max_grad_norm > T(0)) clip = Num<T>::min(max_grad_norm / Num<T>::sqrt(nn), T(1));
+#pragma unroll
+  for (int q = 0; q < NP; ++q) {
+    b[q] = Num<T>::fma(momentum, b[q], (T(1) - dampening) * (r[q] * clip));
+    r[q] = -lr * b[q];
+  }
+  if (exact) spd_explog<T, D, false>(l, li, r, o);
+  else spd_retr<T, D>(xs, li, r, o);
+}
+
+// Riemannian Adam (radam.py:62-98) — see vec_radam_step_kernel; the SPD transport is the identity (spd.py:196-199),
+// exp_avg is kept symmetric.  vprev / return value: the point's second-moment scalar.
+template <typename T, int D>
+__device__ __forceinline__ T spd_adam_update(const T (&xs)[Packed<D>::NP], const T (&gs)[Packed<D>::NP],
+                                             T (&mo)[Packed<D>::NP], T vprev, const AdamArgs<T>& a, T beta2, T alpha,
+                                             T (&o)[Packed<D>::NP]) {
+  constexpr int NP = Packed<D>::NP;
+  T r[NP], l[NP], li[NP];
+  const T nn = spd_rgrad_setup<T, D>(xs, gs, r, l, li, true);   // ||r||_X^2 (no floor, unlike Manifold.norm)
+  const T nrm = Num<T>::sqrt(nn);
+  const T clip = a.max_grad_norm > T(0) ? Num<T>::min(a.max_grad_norm / nrm, T(1)) : T(1);
+  const T v = Num<T>::fma(beta2, vprev, (T(1) - beta2) * nrm * nrm);
+  const T f = -alpha / (Num<T>::sqrt(v) + a.eps);
+#pragma unroll
+  for (int q = 0; q < NP; ++q) {
+    mo[q] = Num<T>::fma(a.beta1, mo[q], (T(1) - a.beta1) * (r[q] * clip));
+    r[q] = mo[q] * f;
+  }
+  if (a.exact) spd_explog<T, D, false>(l, li, r, o);
+  else spd_retr<T, D>(xs, li, r, o);
+  return v;
+}
+
 template <typename T, int D>
 // (x and xnew are deliberately not __restrict__: the update may be done in place, xnew == x — every thread
 // reads its whole point before it writes it)
@@ -864,37 +1005,13 @@ __global__ void spd_rsgd_step_kernel(const T* x, const T* __restrict__ eg, int64
   const int64_t k0 = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
   const bool in = k0 < m;
   const int64_t k = in ? k0 : 0;
-  T xs[NP], gs[NP], r[NP], l[NP], li[NP], o[NP];
+  T xs[NP], gs[NP], o[NP];
   load_sym_packed<T, D>(x + k * D * D, xs);
   load_sym_packed<T, D>(eg + k * D * D, gs);
-  T xf[D * D];
-#pragma unroll
-  for (int a = 0; a < D; ++a)
-#pragma unroll
-    for (int c = 0; c < D; ++c) xf[a * D + c] = xs[pidx(a, c)];
-  congr_full<T, D>(xf, gs, r);  // Riemannian gradient X sym(G) X
-  cholesky<T, D>(xs, l);
-  invert_lower<T, D>(l, li);
-  T scale = -lr;
-  if (max_grad_norm > T(0)) {
-    T a[NP];
-    congr_lower<T, D>(li, r, a);
-    T s = T(0);
-#pragma unroll
-    for (int p = 0; p < D; ++p)
-#pragma unroll
-      for (int c = 0; c <= p; ++c) s += (p == c ? T(1) : T(2)) * a[pidx(p, c)] * a[pidx(p, c)];
-    scale *= Num<T>::min(max_grad_norm / Num<T>::sqrt(s), T(1));
-  }
-#pragma unroll
-  for (int q = 0; q < NP; ++q) r[q] *= scale;
-  if (exact) spd_explog<T, D, false>(l, li, r, o);
-  else spd_retr<T, D>(xs, li, r, o);
+  spd_rsgd_update<T, D>(xs, gs, lr, max_grad_norm, exact, o);
   if (in) store_sym_full<T, D>(xnew + k * D * D, o);
 }
 
-// heavy-ball variant (rsgd.py:70-80): buf = momentum buf + (1 - dampening) rgrad, x' = exp/retr(x, -lr buf); the
-// SPD transport is the identity (spd.py:196-199); buf is kept symmetric and updated in place.
 template <typename T, int D>
 __global__ void spd_rsgd_momentum_kernel(const T* x, const T* __restrict__ eg, T* buf, int64_t m, T lr, T momentum,
                                          T dampening, T max_grad_norm, int exact, T* xnew) {
@@ -902,44 +1019,17 @@ __global__ void spd_rsgd_momentum_kernel(const T* x, const T* __restrict__ eg, T
   const int64_t k0 = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
   const bool in = k0 < m;
   const int64_t k = in ? k0 : 0;
-  T xs[NP], gs[NP], r[NP], l[NP], li[NP], o[NP], b[NP];
+  T xs[NP], gs[NP], o[NP], b[NP];
   load_sym_packed<T, D>(x + k * D * D, xs);
   load_sym_packed<T, D>(eg + k * D * D, gs);
   load_sym_packed<T, D>(buf + k * D * D, b);
-  T xf[D * D];
-#pragma unroll
-  for (int p = 0; p < D; ++p)
-#pragma unroll
-    for (int c = 0; c < D; ++c) xf[p * D + c] = xs[pidx(p, c)];
-  congr_full<T, D>(xf, gs, r);
-  cholesky<T, D>(xs, l);
-  invert_lower<T, D>(l, li);
-  T clip = T(1);
-  if (max_grad_norm > T(0)) {
-    T w[NP];
-    congr_lower<T, D>(li, r, w);
-    T nn = T(0);
-#pragma unroll
-    for (int p = 0; p < D; ++p)
-#pragma unroll
-      for (int c = 0; c <= p; ++c) nn += (p == c ? T(1) : T(2)) * w[pidx(p, c)] * w[pidx(p, c)];
-    clip = Num<T>::min(max_grad_norm / Num<T>::sqrt(nn), T(1));
-  }
-#pragma unroll
-  for (int q = 0; q < NP; ++q) {
-    b[q] = Num<T>::fma(momentum, b[q], (T(1) - dampening) * (r[q] * clip));
-    r[q] = -lr * b[q];
-  }
-  if (exact) spd_explog<T, D, false>(l, li, r, o);
-  else spd_retr<T, D>(xs, li, r, o);
+  spd_momentum_update<T, D>(xs, gs, b, lr, momentum, dampening, max_grad_norm, exact, o);
   if (in) {
     store_sym_full<T, D>(xnew + k * D * D, o);
     store_sym_full<T, D>(buf + k * D * D, b);
   }
 }
 
-// fused Riemannian Adam update (radam.py:62-98) — see vec_radam_step_kernel; the SPD transport is the identity
-// (spd.py:196-199), exp_avg is kept symmetric.
 template <typename T, int D>
 __global__ void spd_radam_step_kernel(const T* x, const T* __restrict__ eg, T* exp_avg, T* exp_avg_sq, int64_t m,
                                       AdamArgs<T> a, T* xnew) {
@@ -949,38 +1039,11 @@ __global__ void spd_radam_step_kernel(const T* x, const T* __restrict__ eg, T* e
   const int64_t k = in ? k0 : 0;
   T beta2, alpha;
   adam_coeffs(a, beta2, alpha);
-  T xs[NP], gs[NP], r[NP], l[NP], li[NP], o[NP], mo[NP];
+  T xs[NP], gs[NP], o[NP], mo[NP];
   load_sym_packed<T, D>(x + k * D * D, xs);
   load_sym_packed<T, D>(eg + k * D * D, gs);
   load_sym_packed<T, D>(exp_avg + k * D * D, mo);
-  T xf[D * D];
-#pragma unroll
-  for (int p = 0; p < D; ++p)
-#pragma unroll
-    for (int c = 0; c < D; ++c) xf[p * D + c] = xs[pidx(p, c)];
-  congr_full<T, D>(xf, gs, r);  // Riemannian gradient X sym(G) X
-  cholesky<T, D>(xs, l);
-  invert_lower<T, D>(l, li);
-  T nn = T(0);  // ||r||_X^2 = ||L^-1 r L^-T||_F^2 (spd.py:113-117; no floor, unlike Manifold.norm)
-  {
-    T w[NP];
-    congr_lower<T, D>(li, r, w);
-#pragma unroll
-    for (int p = 0; p < D; ++p)
-#pragma unroll
-      for (int c = 0; c <= p; ++c) nn += (p == c ? T(1) : T(2)) * w[pidx(p, c)] * w[pidx(p, c)];
-  }
-  const T nrm = Num<T>::sqrt(nn);
-  const T clip = a.max_grad_norm > T(0) ? Num<T>::min(a.max_grad_norm / nrm, T(1)) : T(1);
-  const T v = Num<T>::fma(beta2, exp_avg_sq[k * D * D], (T(1) - beta2) * nrm * nrm);
-  const T f = -alpha / (Num<T>::sqrt(v) + a.eps);
-#pragma unroll
-  for (int q = 0; q < NP; ++q) {
-    mo[q] = Num<T>::fma(a.beta1, mo[q], (T(1) - a.beta1) * (r[q] * clip));
-    r[q] = mo[q] * f;
-  }
-  if (a.exact) spd_explog<T, D, false>(l, li, r, o);
-  else spd_retr<T, D>(xs, li, r, o);
+  const T v = spd_adam_update<T, D>(xs, gs, mo, exp_avg_sq[k * D * D], a, beta2, alpha, o);
   if (in) {
     store_sym_full<T, D>(xnew + k * D * D, o);
     store_sym_full<T, D>(exp_avg + k * D * D, mo);
@@ -988,6 +1051,87 @@ __global__ void spd_radam_step_kernel(const T* x, const T* __restrict__ eg, T* e
     for (int q = 0; q < D * D; ++q) exp_avg_sq[k * D * D + q] = v;
   }
   adam_tick(a.step, a.ticket, gridDim.x);
+}
+
+// ---- the fused training-step kernel: gradient of a point from the pair kernel's accumulators (what
+// spd_pdist_finalize_kernel does) -> optimizer rule -> new point -> ITS per-node tables for the next step's pair
+// kernels (what spd_prep_kernel does), one thread per point; block 0 also closes the loss record and, when asked,
+// applies the scale parameter's momentum-free RSGD update (Euclidean(1): rsgd.py:56-68 with base.py:29-33's norm).
+// A step is then TWO launches — the pair kernel and this one — instead of prep + pair + finalize + point update +
+// scale update (train.py:198-222 is ~60 framework launches in the reference).
+enum { RULE_RSGD = 0, RULE_MOMENTUM = 1, RULE_ADAM = 2 };
+template <typename T> struct StepRule {
+  T lr, momentum, dampening, max_grad_norm;
+  int exact;
+  T* state0;          // momentum buffer / exp_avg
+  T* state1;          // exp_avg_sq
+  AdamArgs<T> adam;
+};
+template <typename T> struct StepFuse {
+  // gradient source: FIN -> the accumulators (finalize arithmetic here; the Euclidean gradient is also stored to grad);
+  // else the finished gradient is read from grad
+  const T* nodeL; T* accM; T* accS;
+  T* grad;
+  T* slots; const T* scale_raw; T* loss_out;     // FIN: the loss record, closed by block 0
+  T* scale_x; T scale_lr, scale_clip;            // FIN: the scale's own RSGD update (null: stepped elsewhere / frozen)
+  // PREP: tables of the new points
+  T* tabL; T* tabX; T* tabC; int* bad; T* tabLd; T* tabLC;
+};
+template <typename T, int D, int RULE, bool FIN, bool PREP>
+__global__ void spd_fused_step_kernel(T* x, int n, StepRule<T> rule, StepFuse<T> f) {
+  constexpr int NP = Packed<D>::NP;
+  if constexpr (FIN) {
+    if (f.slots && blockIdx.x == 0 && threadIdx.x < 64) {
+      loss_finalize<T>(f.slots, f.scale_raw, f.loss_out);
+      if (f.scale_x && threadIdx.x == 0) {
+        // vec_rsgd_point<T, MM_EUCLIDEAN> for one scalar: r = g, ||r|| = sqrt(max(g^2, 1e-8)), x' = x - lr clip r
+        const T g = f.loss_out[1];
+        T scale = -f.scale_lr;
+        if (f.scale_clip > T(0)) scale *= Num<T>::min(f.scale_clip / Num<T>::sqrt(Num<T>::max(g * g, T(1e-8))), T(1));
+        *f.scale_x = *f.scale_x + g * scale;
+      }
+    }
+  }
+  const int i0 = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool in = i0 < n;
+  const int i = in ? i0 : 0;
+  T beta2 = T(0), alpha = T(0);
+  if constexpr (RULE == RULE_ADAM) adam_coeffs(rule.adam, beta2, alpha);
+  T xs[NP], gs[NP], o[NP];
+  load_sym_packed<T, D>(x + size_t(i) * D * D, xs);
+  if constexpr (FIN) {
+    if (in) {
+      node_gradient<T, D>(f.nodeL, f.accM, f.accS, n, i, gs);
+      store_sym_full<T, D>(f.grad + size_t(i) * D * D, gs);
+    } else {
+#pragma unroll
+      for (int k = 0; k < NP; ++k) gs[k] = T(0);
+    }
+  } else {
+    load_sym_packed<T, D>(f.grad + size_t(i) * D * D, gs);
+  }
+  if constexpr (RULE == RULE_RSGD) {
+    spd_rsgd_update<T, D>(xs, gs, rule.lr, rule.max_grad_norm, rule.exact, o);
+  } else if constexpr (RULE == RULE_MOMENTUM) {
+    T b[NP];
+    load_sym_packed<T, D>(rule.state0 + size_t(i) * D * D, b);
+    spd_momentum_update<T, D>(xs, gs, b, rule.lr, rule.momentum, rule.dampening, rule.max_grad_norm, rule.exact, o);
+    if (in) store_sym_full<T, D>(rule.state0 + size_t(i) * D * D, b);
+  } else {
+    T mo[NP];
+    load_sym_packed<T, D>(rule.state0 + size_t(i) * D * D, mo);
+    const T v = spd_adam_update<T, D>(xs, gs, mo, rule.state1[size_t(i) * D * D], rule.adam, beta2, alpha, o);
+    if (in) {
+      store_sym_full<T, D>(rule.state0 + size_t(i) * D * D, mo);
+#pragma unroll
+      for (int q = 0; q < D * D; ++q) rule.state1[size_t(i) * D * D + q] = v;
+    }
+  }
+  if (in) {
+    store_sym_full<T, D>(x + size_t(i) * D * D, o);
+    if constexpr (PREP) node_tables<T, D>(o, i, f.tabL, f.tabX, f.tabC, f.bad, f.tabLd, f.tabLC);
+  }
+  if constexpr (RULE == RULE_ADAM) adam_tick(rule.adam.step, rule.adam.ticket, gridDim.x);
 }
 
 // ------------------------------------------------------------------ launchers
@@ -1036,7 +1180,7 @@ int spd_pdist_bwd_launch_sq(Ws<T>& ws, const T* g, int64_t n, int64_t rb, int64_
                             hipStream_t st, LossArgs<T> la) {
   constexpr int kThreads = 64 * bwd_waves<T, D>();
   auto kernel = spd_pdist_bwd_kernel<T, D, kBwdTI, LOSS, SQ>;
-  const int64_t units = ColWalk(int(n), int(rb), int(re), 64 * pair_cols<T, D>()).total();
+  const int64_t units = ColWalk(int(n), int(rb), int(re), 64 * pair_cols_bwd<T, D>()).total();
   if (units <= 0) return MM_OK;
   int64_t grid = resident_workgroups<spd_pdist_bwd_kernel<T, D, kBwdTI, LOSS, SQ>>(kThreads);
   // Small launches (a rank's shard, small n): a workgroup flushes its column-side sums once per column block, so it needs
@@ -1104,6 +1248,53 @@ int spd_pdist_bwd_t(const T* x, const T* g, int64_t n, int64_t rb, int64_t re, i
   return MM_OK;
 }
 
+// ---- fused training step (spd_step.hpp) ------------------------------------------------------------------------
+template <typename T, int D, bool FIN>
+int spd_fused_step_launch(const mm_train_step* s, Ws<T>& ws, hipStream_t st, bool fuse_scale) {
+  const mm_step_param& p = s->points[0];
+  const mm_step_param& q = s->scales[0];
+  const int n = int(s->n);
+  StepRule<T> rule{T(p.lr), T(p.momentum), T(p.dampening), T(p.max_grad_norm), p.exact, static_cast<T*>(p.state0),
+                   static_cast<T*>(p.state1),
+                   AdamArgs<T>{T(p.lr), T(p.beta1), T(p.beta2), T(p.adam_eps), T(p.max_grad_norm), p.nc, p.exact, p.step, p.ticket}};
+  StepFuse<T> f{ws.nodeL, ws.accM, ws.accS, static_cast<T*>(p.grad),
+                ws.loss, static_cast<const T*>(q.x), static_cast<T*>(s->loss_out),
+                fuse_scale ? static_cast<T*>(q.x) : nullptr, T(q.lr), T(q.max_grad_norm),
+                ws.nodeL, ws.nodeX, ws.nodeC, ws.bad, ws.nodeLd, ws.nodeLC};
+  const dim3 grid((n + 127) / 128), block(128);
+  T* x = static_cast<T*>(p.x);
+  if (p.optimizer == MM_OPT_RADAM) spd_fused_step_kernel<T, D, RULE_ADAM, FIN, true><<<grid, block, 0, st>>>(x, n, rule, f);
+  else if (p.momentum != 0.0) spd_fused_step_kernel<T, D, RULE_MOMENTUM, FIN, true><<<grid, block, 0, st>>>(x, n, rule, f);
+  else spd_fused_step_kernel<T, D, RULE_RSGD, FIN, true><<<grid, block, 0, st>>>(x, n, rule, f);
+  MM_CHECK_LAUNCH();
+  return MM_OK;
+}
+
+template <typename T, int D>
+int spd_fused_train_step_t(const mm_train_step* s, int64_t rb, int64_t re, bool with_objective, hipStream_t st,
+                           bool* scale_stepped) {
+  const int64_t n = s->n;
+  Ws<T> ws(s->ws, n, D);
+  *scale_stepped = false;
+  if (!with_objective) return spd_fused_step_launch<T, D, false>(s, ws, st, false);
+  int rc = spd_pdist_prepare<T, D>(static_cast<const T*>(s->points[0].x), n, ws, s->ws_flags, st);
+  if (rc) return rc;
+  if (re > rb && pair_off(n, re) > pair_off(n, rb)) {
+    LossArgs<T> la{static_cast<const T*>(s->scales[0].x), T(s->alpha), T(s->eps), s->terms, ws.loss, s->loss_params};
+    const T* target = static_cast<const T*>(s->target);
+    if (s->loss_kind == MM_LOSS_STRESS)
+      rc = spd_pdist_bwd_launch<T, D, MM_LOSS_STRESS>(ws, target, n, rb, re, 1, s->wmin, s->wmax, st, la);
+    else
+      rc = spd_pdist_bwd_launch<T, D, MM_LOSS_QUOTIENT>(ws, target, n, rb, re, 1, s->wmin, s->wmax, st, la);
+    if (rc) return rc;
+  }
+  const mm_step_param& q = s->scales[0];
+  const bool fuse_scale = q.x && q.optimizer == MM_OPT_RSGD && q.momentum == 0.0;
+  rc = spd_fused_step_launch<T, D, true>(s, ws, st, fuse_scale);
+  if (rc == MM_OK) *scale_stepped = fuse_scale;
+  return rc;
+}
+
 #include "spd_stein.hpp"
 
 // dtype x D dispatch ---------------------------------------------------------
@@ -1145,6 +1336,23 @@ int launch_pointwise(K kernel, int64_t m, hipStream_t st, A... args) {
   kernel<<<dim3((unsigned)((m + bs - 1) / bs)), dim3(bs), 0, st>>>(args...);
   MM_CHECK_LAUNCH();
   return MM_OK;
+}
+
+bool spd_step_fusable(const mm_train_step* s) {
+  if (!s || s->nf != 1 || s->n < 1 || s->n > kSpdMaxNodes || !s->ws) return false;
+  const mm_step_param& p = s->points[0];
+  if (p.kind != MM_FACTOR_SPD || p.dim < 2 || p.dim > kSpdMaxD || !p.x || !p.grad || p.count != s->n) return false;
+  if (s->loss_kind != MM_LOSS_STRESS && s->loss_kind != MM_LOSS_QUOTIENT) return false;
+  if (s->loss_kind == MM_LOSS_QUOTIENT && !(s->terms & 3)) return false;
+  if (p.optimizer == MM_OPT_RSGD) return p.momentum == 0.0 || p.state0 != nullptr;
+  if (p.optimizer == MM_OPT_RADAM) return p.state0 && p.state1 && p.step && p.ticket;
+  return false;
+}
+
+int spd_fused_train_step(const mm_train_step* s, int64_t rb, int64_t re, bool with_objective, hipStream_t st,
+                         bool* scale_stepped) {
+  const int d = s->points[0].dim;
+  MM_DISPATCH(s->dtype, d, (spd_fused_train_step_t<T, D>(s, rb, re, with_objective, st, scale_stepped)));
 }
 
 }  // namespace mm

@@ -24,7 +24,18 @@ constexpr int64_t kSpdMaxNodes = int64_t(1) << 22;
 // that let four wavefronts share a SIMD instead of three (SPD(4), n = 16384: 1157 -> 1069 us; the few spills land in the
 // Jacobi fallback).  fp64 SPD(3) (forward 138, backward 217 registers) capped at 128 / 168 was measured and NOT adopted:
 // reference init -4 % but the mid-training spread +15 % (spills in the Cayley path).
-template <typename T, int D> constexpr int bwd_min_waves() { return (sizeof(T) == 4 && (D == 3 || D == 4)) ? 4 : 1; }
+#ifndef MM_SPD4_BWD_WAVES
+#define MM_SPD4_BWD_WAVES 4
+#endif
+#ifndef MM_SPD4_BWD_NC
+#define MM_SPD4_BWD_NC 1
+#endif
+#ifndef MM_SPD4_FWD_NC
+#define MM_SPD4_FWD_NC 1
+#endif
+template <typename T, int D> constexpr int bwd_min_waves() {
+  return (sizeof(T) == 4 && D == 3) ? 4 : ((sizeof(T) == 4 && D == 4) ? MM_SPD4_BWD_WAVES : 1);
+}
 // Wavefronts of a backward workgroup: they share one column block and flush its column-side sums once
 template <typename T, int D> constexpr int bwd_waves() {
   // (the column-side combine buffer is D^2 x 64 values per wavefront: 4 wavefronts up to 64 KB of it, else 2, else 1)

@@ -7,6 +7,7 @@
 #include <hip/hip_runtime.h>
 
 #include "../../include/mm_manifolds.h"
+#include "spd_step.hpp"
 
 namespace {
 
@@ -94,13 +95,23 @@ extern "C" int mm_train_step_run(const mm_train_step* s, mm_stream_t st) {
     }
   }
   int rc;
+  // ---- a single SPD factor takes the fused form: pair kernel -> ONE kernel for finalize + optimizer rule + the tables of
+  // the new points (sharded: pair kernel -> finalize -> all-reduce -> optimizer rule + tables)
+  const bool spd_fused = nf == 1 && mm::spd_step_fusable(s);
+  bool points_done = false, scale_done = false;
+  if (spd_fused && !s->comm) {
+    rc = mm::spd_fused_train_step(s, rb, re, true, static_cast<hipStream_t>(st), &scale_done);
+    if (rc != MM_OK) return rc;
+    points_done = true;
+  } else
   // ---- objective and gradients
   if (nf == 1) {
     const mm_step_param& p = s->points[0];
     if (!p.x || !p.grad) return MM_ERR_ARG;
     if (p.kind == MM_FACTOR_SPD)
       rc = mm_spd_pdist_loss(s->dtype, s->loss_kind, p.x, s->target, s->scales[0].x, s->n, p.dim, rb, re, s->alpha, s->eps,
-                             s->terms, s->loss_params, s->wmin, s->wmax, s->loss_out, p.grad, s->ws, 0, st);
+                             s->terms, s->loss_params, s->wmin, s->wmax, s->loss_out, p.grad, s->ws,
+                             s->ws_flags & MM_WS_PREPARED, st);
     else
       rc = mm_vec_pdist_loss(s->dtype, p.kind, s->loss_kind, p.x, s->target, s->scales[0].x, s->n, p.dim, rb, re, s->alpha,
                              s->eps, s->terms, s->loss_params, s->loss_out, p.grad, s->ws, st);
@@ -128,7 +139,12 @@ extern "C" int mm_train_step_run(const mm_train_step* s, mm_stream_t st) {
   const mm_step_param* vec[8];
   const void* vgrad[8];
   int nv = 0;
-  for (int k = 0; k < nf; ++k) {
+  if (spd_fused && s->comm) {
+    rc = mm::spd_fused_train_step(s, rb, re, false, static_cast<hipStream_t>(st), &scale_done);
+    if (rc != MM_OK) return rc;
+    points_done = true;
+  }
+  for (int k = 0; k < nf && !points_done; ++k) {
     const mm_step_param& p = s->points[k];
     if (p.optimizer == MM_OPT_NONE) continue;   // frozen
     if (p.kind == MM_FACTOR_SPD) {
@@ -141,6 +157,7 @@ extern "C" int mm_train_step_run(const mm_train_step* s, mm_stream_t st) {
   for (int k = 0; k < nf; ++k) {
     const mm_step_param& q = s->scales[k];
     if (!q.x || q.optimizer == MM_OPT_NONE) continue;   // a factor without a scale / a frozen one (burn-in): read, not stepped
+    if (k == 0 && scale_done) continue;                 // updated by the fused step kernel
     vec[nv] = &q;
     vgrad[nv++] = static_cast<const char*>(s->loss_out) + size_t(1 + k) * esize(s->dtype);
   }

@@ -159,6 +159,10 @@ class NativeTrainStep:
         self._params = xs + scales
         self._slots = [d.points[i] for i in range(k)] + [d.scales[i] for i in range(k)]
         self._trainable_scale = [True] * k
+        # a single SPD factor: the optimizer kernel of a step also writes the per-node tables of the NEW points, so the next
+        # step skips the preparation launch (MM_WS_PREPARED) — as long as nobody else touched the points in between
+        self._spd_single = k == 1 and factors[0][0] == B.FACTOR_SPD
+        self._tables_of = None
 
     # ------------------------------------------------------------------------------------------------------------
     def _bind_optimizer(self, p, q):
@@ -212,11 +216,18 @@ class NativeTrainStep:
                 q.x = p.data_ptr()          # a frozen scale (burn-in): read by the objective, not stepped
                 q.optimizer = OPT_NONE
         if need_first:
+            self._tables_of = None
             return self._first_step_unfused(**objective_kwargs)
+        if self._spd_single:
+            x = self._params[0]
+            d.ws_flags = B.MM_WS_PREPARED if self._tables_of == (x.data_ptr(), x._version) else 0
         with B.on_device(self.device):
             B.lib().call('mm_train_step_run', ctypes.byref(d), B.stream_of(self.target))
         if self.k > 1:
             d.ws_flags = B.WS_CLEAN      # the pair kernel leaves its workspace clean
+        elif self._spd_single:
+            x = self._params[0]
+            self._tables_of = (x.data_ptr(), x._version)
         return self.loss_out[0]
 
     def _first_step_unfused(self, **objective_kwargs):

@@ -1,0 +1,167 @@
+"""The fused SPD training step of mm_train_step_run (csrc/spd.hip, spd_fused_step_kernel): pair kernel -> ONE per-point
+kernel that finishes the gradient (spd_pdist_finalize_kernel's arithmetic), applies the optimizer rule
+(optim/rsgd.py:29-82, optim/radam.py:62-98), writes the new point AND its per-node tables (spd_prep_kernel's arithmetic:
+the next step passes MM_WS_PREPARED) and updates a momentum-free RSGD scale.  Checked against the eager loop on the same
+classes (which is pinned to the reference's golden RSGD / RAdam traces in test_spd_gpu.py / test_radam.py), for every
+rule, d = 2..5, both dtypes, and with the tables invalidated from outside in the middle of a run."""
+import copy
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, 'matrix-manifolds_amd')):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+pytestmark = pytest.mark.gpu
+
+
+def _setup(d, n, dt, spread=0.3):
+    from graphembed import manifolds as M
+    from graphembed.modules import ManifoldEmbedding
+    torch.set_default_dtype(dt)
+    try:
+        torch.manual_seed(5)
+        with torch.device('cuda'):
+            emb = ManifoldEmbedding(n, [M.SymmetricPositiveDefinite(d)])
+            with torch.no_grad():
+                emb.perturb(spread)
+            target = torch.rand(n * (n - 1) // 2) * 0.9 + 0.05
+    finally:
+        torch.set_default_dtype(torch.float32)
+    return emb, target
+
+
+def _opts(emb, rule, scale_rule='rsgd'):
+    from graphembed.optim import RiemannianAdam, RiemannianSGD
+    # (learning rates small enough that six steps stay a descent: a diverging run amplifies fp32 rounding chaotically)
+    pts = {'rsgd': lambda p: RiemannianSGD(p, lr=2e-3, exact=True, max_grad_norm=20),
+           'rsgd_retr': lambda p: RiemannianSGD(p, lr=2e-3, exact=False, max_grad_norm=None),
+           'momentum': lambda p: RiemannianSGD(p, lr=1e-3, momentum=0.5, dampening=0.1, exact=True, max_grad_norm=20),
+           'adam': lambda p: RiemannianAdam(p, lr=1e-2, exact=True, max_grad_norm=20),
+           'adam_nc': lambda p: RiemannianAdam(p, lr=1e-2, betas=(0.9, None), nc=True, exact=False, max_grad_norm=None)}[rule]
+    sc = {'rsgd': lambda p: RiemannianSGD(p, lr=1e-4, max_grad_norm=500),
+          'rsgd_noclip': lambda p: RiemannianSGD(p, lr=1e-4, max_grad_norm=None),
+          'momentum': lambda p: RiemannianSGD(p, lr=1e-5, momentum=0.5, max_grad_norm=500),
+          'adam': lambda p: RiemannianAdam(p, lr=1e-3, max_grad_norm=500)}[scale_rule]
+    return [pts(list(emb.xs)), sc(list(emb.scales))]
+
+
+def _eager(emb, fn, target, opts, epochs):
+    out = []
+    for epoch in range(epochs):
+        loss = emb.fused_objective(fn, target, None, epoch=epoch, alpha=1.0)
+        for o in opts:
+            o.zero_grad(set_to_none=True)
+        loss.backward()
+        for o in opts:
+            o.step()
+        out.append(loss.item())
+    return out
+
+
+def _close(a, b, dt, what):
+    rt, at = (2e-4, 2e-5) if dt == torch.float32 else (1e-9, 1e-11)
+    np.testing.assert_allclose(b, a, rtol=rt, atol=at, err_msg=what)
+
+
+@pytest.mark.parametrize('d', [2, 3, 4, 5])
+@pytest.mark.parametrize('rule,scale_rule', [('rsgd', 'rsgd'), ('rsgd_retr', 'rsgd_noclip'), ('momentum', 'rsgd'),
+                                             ('adam', 'adam'), ('adam_nc', 'momentum'), ('rsgd', 'adam')])
+@pytest.mark.parametrize('dt', [torch.float32, torch.float64], ids=['f32', 'f64'])
+def test_fused_spd_step_matches_the_eager_loop(d, rule, scale_rule, dt):
+    from graphembed import _backend as B
+    from graphembed.native_step import NativeTrainStep
+    from graphembed.objectives import QuotientLoss, StressLoss
+    n, epochs = 131, 6
+    emb_a, target = _setup(d, n, dt)
+    emb_b = copy.deepcopy(emb_a)
+    fn = QuotientLoss() if 'adam' in rule else StressLoss()
+    la = _eager(emb_a, fn, target, _opts(emb_a, rule, scale_rule), epochs)
+    ob = _opts(emb_b, rule, scale_rule)
+    step = NativeTrainStep(emb_b, fn, target, ob)
+    flags, lb = [], []
+    for epoch in range(epochs):
+        lb.append(step(epoch=epoch, alpha=1.0).item())
+        flags.append(step._desc.ws_flags)
+    first_fused = 1 if 'momentum' in (rule, scale_rule) else 0   # (the first heavy-ball step creates its buffer through the optimizer)
+    assert flags[first_fused] == 0 and all(f == B.MM_WS_PREPARED for f in flags[first_fused + 1:]), flags
+    _close(la, lb, dt, 'losses')
+    for a, b in zip(list(emb_a.xs) + list(emb_a.scales), list(emb_b.xs) + list(emb_b.scales)):
+        _close(a.detach().cpu().numpy(), b.detach().cpu().numpy(), dt, 'parameters')
+    # the gradient left behind is the Euclidean gradient of the LAST step's loss at the points BEFORE its update
+    assert torch.isfinite(emb_b.xs[0].grad).all() and emb_b.xs[0].grad.abs().max() > 0
+    # optimizer state advanced alike
+    oa = _opts(copy.deepcopy(emb_a), rule, scale_rule)   # (fresh: only the key set is compared below)
+    sb = ob[0].state[emb_b.xs[0]]
+    assert set(sb) >= ({'momentum_buffer'} if rule == 'momentum' else {'exp_avg', 'exp_avg_sq', 'step'} if 'adam' in rule else set())
+    if 'adam' in rule:
+        assert float(sb['step']) == epochs + 1
+
+
+def test_tables_written_by_the_step_equal_a_fresh_preparation():
+    """After a fused step the workspace holds exactly what mm_spd_prepare computes from the new points."""
+    from graphembed import _backend as B
+    from graphembed.native_step import NativeTrainStep
+    from graphembed.objectives import StressLoss
+    for d, dt in ((3, torch.float32), (4, torch.float64)):
+        n = 257
+        emb, target = _setup(d, n, dt)
+        step = NativeTrainStep(emb, StressLoss(), target, _opts(emb, 'rsgd'))
+        step(), step()
+        fresh = torch.zeros_like(step.ws)
+        x = emb.xs[0]
+        B.lib().call('mm_spd_prepare', B.dtype_code(x), B.ptr(x), n, d, B.ptr(fresh), B.stream_of(x))
+        torch.cuda.synchronize()
+        head = 64 + (n * 4 + 63) // 64 * 64           # status word + per-point flags (ints), then the tables (spd_ws.hpp)
+        assert torch.equal(step.ws[:head], fresh[:head])
+        a, b = step.ws[head:].view(dt), fresh[head:].view(dt)
+        np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), rtol=1e-6 if dt == torch.float32 else 1e-14, atol=0)
+
+
+def test_points_changed_from_outside_drop_the_prepared_flag():
+    """An in-place edit of the points between two steps (stabilize / projx / a manual perturbation) invalidates the tables:
+    the next step prepares again and matches the eager loop that did the same edit."""
+    from graphembed.native_step import NativeTrainStep
+    from graphembed.objectives import StressLoss
+    dt, n = torch.float64, 97
+    emb_a, target = _setup(3, n, dt)
+    emb_b = copy.deepcopy(emb_a)
+    fn = StressLoss()
+    oa, ob = _opts(emb_a, 'rsgd'), _opts(emb_b, 'rsgd')
+    step = NativeTrainStep(emb_b, fn, target, ob)
+    la, lb = [], []
+    for epoch in range(5):
+        if epoch == 3:
+            with torch.no_grad():
+                for e in (emb_a, emb_b):
+                    e.xs[0].mul_(1.1)              # bumps the tensor's version counter
+        la += _eager(emb_a, fn, target, oa, 1)
+        lb.append(step().item())
+        assert step._desc.ws_flags == (0 if epoch in (0, 3) else 1)
+    np.testing.assert_allclose(lb, la, rtol=1e-10)
+
+
+def test_fused_step_frozen_points_take_the_unfused_objective():
+    """MM_OPT_NONE on the points (no optimizer rule): the objective runs unfused and nothing is updated."""
+    import ctypes
+    from graphembed import _backend as B
+    from graphembed.native_step import NativeTrainStep, OPT_NONE
+    from graphembed.objectives import StressLoss
+    emb, target = _setup(3, 64, torch.float32)
+    step = NativeTrainStep(emb, StressLoss(), target, _opts(emb, 'rsgd'))
+    step()
+    before = emb.xs[0].detach().clone()
+    d = step._desc
+    d.points[0].optimizer = OPT_NONE
+    d.scales[0].optimizer = OPT_NONE
+    d.ws_flags = 0
+    B.lib().call('mm_train_step_run', ctypes.byref(d), B.stream_of(step.target))
+    torch.cuda.synchronize()
+    assert torch.equal(emb.xs[0].detach(), before)
+    loss = emb.fused_objective(StressLoss(), target, None)
+    np.testing.assert_allclose(step.loss_out[0].item(), loss.item(), rtol=1e-5)

@@ -135,6 +135,7 @@ FUZZ = [('tests/fuzz_pdist.py', ['50', '20261']), ('tests/fuzz_pdist.py', ['6', 
         ('tests/fuzz_optim.py', ['50', '20263']), ('tests/fuzz_maps.py', ['50', '20264']),
         ('tests/fuzz_misc.py', ['50', '20265']), ('tests/fuzz_metrics.py', ['40', '20266']),
         ('tools/fuzz_product.py', ['50', '20267']), ('tools/fuzz_product.py', ['30', '20268', '--single']),
+        ('tools/fuzz_product.py', ['8', '20270', '--big']),
         ('tools/fuzz_graph.py', ['30', '20269'])]
 
 

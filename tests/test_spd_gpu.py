@@ -346,6 +346,50 @@ def test_close_pair_gate_is_seamless(d):
     assert err <= 5e-5, err
 
 
+@pytest.mark.parametrize('spread', [0.25, 0.35, 0.42, 0.5])
+def test_recentred_series_regime(spread):
+    """SPD(3) fp32 backward at MODERATE pair distances (||log X|| ~ 0.35: training after the first epochs): the matrix
+    logarithm comes from the recentred series log A = log(mu) I + log(I + (A / mu - I)), mu = tr A / 3 (smallmat.hpp,
+    log_series3_centred) when every pair of a wavefront row passes its gate, else from the Cayley-transform path.  Spreads
+    0.25 / 0.35: every far row takes the recentred series; 0.42 / 0.5: rows on both sides of its gate.  Gradients of d^2,
+    of d, and the fused StressLoss (d^2 from ||log A||_F^2 of the same series) against the fp64 checker."""
+    from graphembed.manifolds import SymmetricPositiveDefinite as SPD
+    from oracle import exact
+    from oracle import ref_port as rp
+    gen = torch.Generator().manual_seed(int(spread * 100))
+    port = rp.SPD(3)
+    n = 640
+    scale = spread * (0.6 + 0.4 * torch.rand(n, generator=gen))
+    u = torch.randn(n, 6, dtype=torch.float64, generator=gen)
+    u = u / u.norm(dim=-1, keepdim=True) * scale.double().reshape(n, 1)
+    x32 = port.exp(port.zero(n, dtype=torch.float64), port.from_vec(u)).float()
+    g32 = torch.randn(n * (n - 1) // 2, generator=gen)
+    xin = x32.double().numpy()
+    ref_d2 = exact.spd_pdist(xin)
+    man = SPD(3)
+    x = x32.cuda().requires_grad_()
+    for squared in (True, False):
+        ref_g = exact.spd_pdist_grad(xin, g32.double().numpy(), squared=squared)
+        gr, = torch.autograd.grad(man.pdist(x, squared=squared), x, g32.cuda())
+        err = np.abs(gr.double().cpu().numpy() - ref_g).max() / np.abs(ref_g).max()
+        assert err <= 3e-5, (spread, squared, err)
+    # fused objective: m = softplus(s) d^2, loss = sum (m - t)^2, gradient = sum 2 (m - t) softplus(s) d d^2 / d x
+    from graphembed.objectives import StressLoss
+    target = (torch.rand(n * (n - 1) // 2, generator=gen) * 0.9 + 0.05)
+    s_raw = torch.tensor(0.3, device='cuda', requires_grad=True)
+    xl = x32.cuda().requires_grad_()
+    loss = man.pdist_loss(xl, s_raw, target.cuda(), StressLoss().fused_spec(), rows=(0, n))
+    gx, gs = torch.autograd.grad(loss, (xl, s_raw))
+    sp = float(np.log1p(np.exp(0.3)))
+    res = sp * ref_d2 - target.double().numpy()
+    assert abs(loss.item() - float((res ** 2).sum())) <= 3e-5 * float((res ** 2).sum())
+    ref_gx = exact.spd_pdist_grad(xin, 2 * res * sp)
+    err = np.abs(gx.double().cpu().numpy() - ref_gx).max() / np.abs(ref_gx).max()
+    assert err <= 3e-5, (spread, 'fused', err)
+    ref_gs = float((2 * res * ref_d2).sum() / (1 + np.exp(-0.3)))
+    assert abs(gs.item() - ref_gs) <= 1e-4 * abs(ref_gs)
+
+
 # ------------------------------------------------------------------ fused loss + gradients
 def _losses():
     from graphembed.objectives import QuotientLoss, StressLoss

@@ -504,6 +504,9 @@ template <typename T> __device__ __forceinline__ T log_series3(const T (&a)[6], 
 }
 
 // ---- log(A) of a pair at moderate distance: the RECENTRED series (3x3, fp32) -----------------------------------
+// (fp64 was built and dropped: degree 33 / 35 reach 7e-16, but the compiler keeps the 34 - 36 double constants in 68 - 72
+// vector registers across the row loop — the fp64 backward went from 218 to 256 registers, two wavefronts per SIMD to one.
+// tools/design/series_fit_wide64.py keeps the fit.)
 // log A = log(mu) I + log(I + E'),  E' = A / mu - I  with  mu = tr A / 3 (the scalar that minimises ||A - mu I||_F).
 // E' is traceless, so its spectral radius is at most sqrt(2/3) ||E'||_F: the gate ||E'||_F^2 <= kCentredGate3 bounds it
 // by 0.66, where log(1+x) = x p(x) holds to 4e-8 |x| with p of degree 15 (Chebyshev-interpolated on |x| <= 0.66,
@@ -562,6 +565,44 @@ template <typename T> __device__ __forceinline__ void log_series3_centred(const 
   m0[pidx(1, 0)] = N::fma(b2, f10, b1 * e10);
   m0[pidx(2, 0)] = N::fma(b2, f20, b1 * e20);
   m0[pidx(2, 1)] = N::fma(b2, f21, b1 * e21);
+}
+
+// d^2 = ||log A||_F^2 of a pair at moderate distance, straight from invariants (the forward's counterpart of
+// log_series3_centred): with L = log mu, A' = A / mu = I + E' (traceless E'),
+//   ||log A||_F^2 = 3 L^2 + 2 L log det A' + tr(E'^2 q(E')),   log^2(1+x) = x^2 q(x),  det A' = 1 + s1 + s2 + s3,
+// q of degree 15 on |x| <= 0.66 (3e-7 x^2, tools/design/series_fit_wide.py), Horner in R[E']/(chi_E') with s1 = 0 (two
+// multiply-adds per coefficient), tr E'^3 = 3 s3 and tr E'^4 = (tr E'^2)^2 / 2 for a traceless 3 x 3 matrix: no matrix
+// product at all, two logarithms and one reciprocal.  ~75 instructions against ~95 for the closed-form eigenvalues.
+template <typename T> struct LogSqSeriesWide;
+template <> struct LogSqSeriesWide<float> {
+  static constexpr int kTerms = 16;
+  static constexpr float kQ[kTerms] = {9.999998930e-01f, -9.999998963e-01f, 9.166980138e-01f, -8.333637039e-01f,
+                                       7.596244972e-01f, -6.985597554e-01f, 6.746606801e-01f, -6.295878238e-01f,
+                                       3.395295792e-01f, -3.133767555e-01f, 1.520582314e+00f, -1.462563750e+00f,
+                                       -1.927056128e+00f, 1.871837175e+00f, 2.893810986e+00f, -2.795949233e+00f};
+};
+template <typename T> __device__ __forceinline__ T logsq_series3_centred(const T (&a)[6]) {
+  using N = Num<T>;
+  using S = LogSqSeriesWide<T>;
+  const T mu = (a[pidx(0, 0)] + a[pidx(1, 1)] + a[pidx(2, 2)]) * T(1.0 / 3.0);
+  const T rmu = N::rcp(mu);
+  const T e00 = N::fma(a[pidx(0, 0)], rmu, T(-1)), e11 = N::fma(a[pidx(1, 1)], rmu, T(-1)), e22 = N::fma(a[pidx(2, 2)], rmu, T(-1));
+  const T e10 = a[pidx(1, 0)] * rmu, e20 = a[pidx(2, 0)] * rmu, e21 = a[pidx(2, 1)] * rmu;
+  T t2 = N::fma(e00, e00, N::fma(e11, e11, e22 * e22));
+  t2 = N::fma(T(2), N::fma(e10, e10, N::fma(e20, e20, e21 * e21)), t2);
+  const T s1 = e00 + e11 + e22;                       // rounding only (mu rmu - 1): kept in det A', dropped in the recurrence
+  const T s2 = T(-0.5) * t2;
+  const T s3 = e00 * N::fma(e11, e22, -e21 * e21) - e10 * N::fma(e10, e22, -e21 * e20) +
+               e20 * N::fma(e10, e21, -e11 * e20);
+  T h0 = T(S::kQ[S::kTerms - 3]), h1 = T(S::kQ[S::kTerms - 2]), h2 = T(S::kQ[S::kTerms - 1]);
+#pragma unroll
+  for (int k = S::kTerms - 4; k >= 0; --k) {
+    const T n0 = N::fma(h2, s3, T(S::kQ[k])), n1 = N::fma(-h2, s2, h0);
+    h2 = h1; h0 = n0; h1 = n1;
+  }
+  const T core = N::fma(h2, T(0.5) * t2 * t2, N::fma(h1, T(3) * s3, h0 * t2));
+  const T lmu = N::log(mu), ldet = N::log((T(1) + s1) + (s2 + s3));
+  return N::fma(lmu, N::fma(T(3), lmu, ldet + ldet), core);
 }
 
 // ---- Cayley-transform logarithm: the general eigen-free path (3x3) ------------------------------
@@ -774,6 +815,14 @@ template <> struct LogSqSeries<double> {  // degree 19: max error 4.7e-17 x^2 (t
     4.54016324988081366e-01, -4.33266732950779887e-01, 4.19186214916998590e-01, -4.01958766939621959e-01,
     3.42135448468324777e-01, -3.29342696720597350e-01, 5.48091271953506265e-01, -5.29456865029041324e-01};
 };
+// ||A - I||_F^2 with the arithmetic of logsq_series3 (the forward's close-pair gate: shared with the series)
+template <typename T> __device__ __forceinline__ T close_dev3(const T (&a)[6]) {
+  using N = Num<T>;
+  const T e00 = a[pidx(0, 0)] - T(1), e11 = a[pidx(1, 1)] - T(1), e22 = a[pidx(2, 2)] - T(1);
+  const T e10 = a[pidx(1, 0)], e20 = a[pidx(2, 0)], e21 = a[pidx(2, 1)];
+  T t2 = N::fma(e00, e00, N::fma(e11, e11, e22 * e22));
+  return N::fma(T(2), N::fma(e10, e10, N::fma(e20, e20, e21 * e21)), t2);
+}
 template <typename T> __device__ __forceinline__ T logsq_series3(const T (&a)[6], T* e2) {
   using N = Num<T>;
   using S = LogSqSeries<T>;
@@ -802,9 +851,8 @@ template <typename T> __device__ __forceinline__ T logsq_series3(const T (&a)[6]
 // Same for 4x4: intermediates h0 I + h1 E + h2 E^2 + h3 E^3, multiplication by E through
 //   (h0,h1,h2,h3) . E + c I = (c - h3 s4, h0 + h3 s3, h1 - h3 s2, h2 + h3 s1),  E^4 = s1 E^3 - s2 E^2 + s3 E - s4 I,
 // s1..s4 from the power sums tr E^m (Newton's identities; tr E^3 = <E^2,E>, tr E^4 = ||E^2||_F^2).
-template <typename T> __device__ __forceinline__ T log_series4(const T (&a)[10], T (&m0)[10], T pre = T(1)) {
+template <typename T, typename S = LogSeries<T>> __device__ __forceinline__ T log_series4(const T (&a)[10], T (&m0)[10], T pre = T(1)) {
   using N = Num<T>;
-  using S = LogSeries<T>;
   T e[10], e2[10], e3[10];
 #pragma unroll
   for (int k = 0; k < 10; ++k) e[k] = a[k];
@@ -860,9 +908,8 @@ template <typename T> __device__ __forceinline__ T log_series4(const T (&a)[10],
 // d^2 = ||log A||_F^2 of a close 4x4 pair from the invariants (the 4x4 counterpart of logsq_series3): tr(E^2 q(E)) with
 // q(E) = h0 I + h1 E + h2 E^2 + h3 E^3 by Horner in R[E]/(chi_E) and the power sums p2..p5 (p5 from Newton's identity).
 // Only E^2 is formed: 100 multiply-adds against 180 for log_series4 followed by the Frobenius norm.
-template <typename T> __device__ __forceinline__ T logsq_series4(const T (&a)[10]) {
+template <typename T, typename S = LogSqSeries<T>> __device__ __forceinline__ T logsq_series4(const T (&a)[10], T* det = nullptr) {
   using N = Num<T>;
-  using S = LogSqSeries<T>;
   T e[10], e2[10];
 #pragma unroll
   for (int k = 0; k < 10; ++k) e[k] = a[k];
@@ -897,6 +944,7 @@ template <typename T> __device__ __forceinline__ T logsq_series4(const T (&a)[10
   const T s3 = T(1.0 / 3.0) * (N::fma(s2, p1, -s1 * p2) + p3);
   const T s4 = T(0.25) * (N::fma(s3, p1, -s2 * p2) + N::fma(s1, p3, -p4));
   const T p5 = N::fma(s1, p4, -s2 * p3) + N::fma(s3, p2, -s4 * p1);
+  if (det) *det = ((T(1) + s1) + s2) + (s3 + s4);   // det(I + E) (the recentred form needs log det)
   T h0 = T(S::kQ[S::kTerms - 4]), h1 = T(S::kQ[S::kTerms - 3]), h2 = T(S::kQ[S::kTerms - 2]), h3 = T(S::kQ[S::kTerms - 1]);
 #pragma unroll
   for (int k = S::kTerms - 5; k >= 0; --k) {
@@ -904,6 +952,51 @@ template <typename T> __device__ __forceinline__ T logsq_series4(const T (&a)[10
     h0 = n0; h1 = n1; h2 = n2; h3 = n3;
   }
   return N::fma(h3, p5, N::fma(h2, p4, N::fma(h1, p3, h0 * p2)));
+}
+
+// ---- the recentred series for 4 x 4 (fp32): log A = log(mu) I + log(I + E'), E' = A / mu - I, mu = tr A / 4 -----------
+// Same polynomials as the 3 x 3 forms (|x| <= 0.66: LogSeriesWide / LogSqSeriesWide); a traceless symmetric 4 x 4 matrix
+// has spectral radius at most sqrt(3/4) ||E'||_F, hence the gate ||A - mu I||_F^2 <= kCentredGate4 mu^2.  The general
+// 4 x 4 Horner recurrence of log_series4 / logsq_series4 is reused on A / mu (p1 = tr E' is rounding-sized, not assumed
+// zero): ~230 instructions against ~400 for the Cayley-transform logarithm.
+constexpr double kCentredGate4 = 0.5808;   // (3/4) * 0.5808 = 0.66^2
+template <typename T> __device__ __forceinline__ bool centred_far4(const T (&a)[10]) {
+  using N = Num<T>;
+  const T mu = ((a[pidx(0, 0)] + a[pidx(1, 1)]) + (a[pidx(2, 2)] + a[pidx(3, 3)])) * T(0.25);
+  T dg = T(0), off = T(0);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const T d = a[pidx(r, r)] - mu;
+    dg = N::fma(d, d, dg);
+#pragma unroll
+    for (int c = 0; c < r; ++c) off = N::fma(a[pidx(r, c)], a[pidx(r, c)], off);
+  }
+  const T dev = N::fma(T(2), off, dg);
+  return !(dev <= T(kCentredGate4) * (mu * mu)) || !(mu > T(0));
+}
+template <typename T> __device__ __forceinline__ void log_series4_centred(const T (&a)[10], T (&m0)[10], T pre = T(1)) {
+  using N = Num<T>;
+  const T mu = ((a[pidx(0, 0)] + a[pidx(1, 1)]) + (a[pidx(2, 2)] + a[pidx(3, 3)])) * T(0.25);
+  const T rmu = N::rcp(mu);
+  T as[10];
+#pragma unroll
+  for (int k = 0; k < 10; ++k) as[k] = a[k] * rmu;
+  log_series4<T, LogSeriesWide<T>>(as, m0, pre);
+  const T lm = N::log(mu) * pre;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) m0[pidx(r, r)] += lm;
+}
+template <typename T> __device__ __forceinline__ T logsq_series4_centred(const T (&a)[10]) {
+  using N = Num<T>;
+  const T mu = ((a[pidx(0, 0)] + a[pidx(1, 1)]) + (a[pidx(2, 2)] + a[pidx(3, 3)])) * T(0.25);
+  const T rmu = N::rcp(mu);
+  T as[10];
+#pragma unroll
+  for (int k = 0; k < 10; ++k) as[k] = a[k] * rmu;
+  T det;
+  const T core = logsq_series4<T, LogSqSeriesWide<T>>(as, &det);
+  const T lmu = N::log(mu), ldet = N::log(det);
+  return N::fma(lmu, N::fma(T(4), lmu, ldet + ldet), core);   // sum (L + l_k)^2 = 4 L^2 + 2 L log det A' + sum l_k^2
 }
 
 // out (packed) = V diag(f) V^T

@@ -180,11 +180,15 @@ __device__ __forceinline__ T pair_value(const TL (&li)[Packed<D>::NP], const T (
   if constexpr (D == 3 && std::is_same<T, float>::value) {
     float a[6], w[3], v[3][3];
     pair_a<float, 3, CHOL>(li, xj, a);
-    {  // close pairs (whole wavefront within ||A - I||_F <= 0.3): invariants-only series
+    // close pairs (whole wavefront within ||A - I||_F <= 0.3): invariants-only series (its arithmetic shares the gate's)
+    if (__builtin_expect(!__any(!(close_dev3<float>(a) <= float(kCloseGate))), 1)) {
       float e2;
-      const float sq = logsq_series3<float>(a, &e2);
-      if (!__any(!(e2 <= float(kCloseGate)))) return sq;
+      return logsq_series3<float>(a, &e2);
     }
+#ifndef MM_NO_CENTRED
+    // pairs at moderate distance (training after the first epochs): the recentred invariants-only series
+    if (!__any(centred_far3<float>(a))) return logsq_series3_centred<float>(a);
+#endif
     eig3_trig(a, w);
     const bool wide = !(w[0] * 32.f > w[2]);  // true for NaN / non-positive spectra too
     if (__any(wide)) {
@@ -211,6 +215,11 @@ __device__ __forceinline__ T pair_value(const TL (&li)[Packed<D>::NP], const T (
       if (__builtin_expect(!__any(!(e2 <= T(kCloseGate))), 1)) return sq;
     } else {
       if (__builtin_expect(!__any(!(close_gate<T, D>(a) <= T(kCloseGate))), 1)) return logsq_series4<T>(a);
+#ifndef MM_NO_CENTRED
+      if constexpr (std::is_same<T, float>::value) {   // pairs at moderate distance: the recentred invariants-only series
+        if (!__any(centred_far4<T>(a))) return logsq_series4_centred<T>(a);
+      }
+#endif
     }
     const T gate = log_cayley<T, D>(a, m0);
     if (__builtin_expect(!__any(!(gate <= T(kCayleyGate))), 1)) return frob2<T, D>(m0);
@@ -538,7 +547,7 @@ __global__ __launch_bounds__((64 * bwd_waves<T, D>()), (bwd_min_waves<T, D>())) 
 #ifdef MM_NO_CENTRED   // (A/B builds: tools/snap_make.sh nocentred -DMM_NO_CENTRED)
             constexpr bool kCentred = false;
 #else
-            constexpr bool kCentred = D == 3 && std::is_same<T, float>::value;
+            constexpr bool kCentred = (D == 3 || D == 4) && std::is_same<T, float>::value;
 #endif
             static_for<NC>([&](auto qc) {
               constexpr int q = decltype(qc)::value;
@@ -558,12 +567,12 @@ __global__ __launch_bounds__((64 * bwd_waves<T, D>()), (bwd_min_waves<T, D>())) 
               far2 = false;
               static_for<NC>([&](auto qc) {
                 constexpr int q = decltype(qc)::value;
-                far2 = far2 | centred_far3<T>(a[q]);
+                if constexpr (D == 3) far2 = far2 | centred_far3<T>(a[q]); else far2 = far2 | centred_far4<T>(a[q]);
               });
               far2 = __any(far2);
               if (!far2) {
                 // pairs at moderate distance (spectral radius of A / mu - I up to 0.66): the recentred series — no
-                // eigensolve, no inverse (smallmat.hpp, log_series3_centred)
+                // eigensolve, no inverse (smallmat.hpp, log_series3_centred / log_series4_centred)
                 static_for<NC>([&](auto qc) {
                   constexpr int q = decltype(qc)::value;
                   T ac[NP], m0[NP];
@@ -572,7 +581,8 @@ __global__ __launch_bounds__((64 * bwd_waves<T, D>()), (bwd_min_waves<T, D>())) 
                     ac[k] = a[q][k];
                     asm volatile("" : "+v"(ac[k]));   // (the series' arithmetic starts HERE: nothing of it is hoisted above the gates)
                   }
-                  log_series3_centred<T>(ac, m0, g_first ? gs[q] + gs[q] : T(1));
+                  if constexpr (D == 3) log_series3_centred<T>(ac, m0, g_first ? gs[q] + gs[q] : T(1));
+                  else log_series4_centred<T>(ac, m0, g_first ? gs[q] + gs[q] : T(1));
                   finish(qc, m0, g_first);
                 });
               }
@@ -588,6 +598,8 @@ __global__ __launch_bounds__((64 * bwd_waves<T, D>()), (bwd_min_waves<T, D>())) 
           } else {
             static_for<NC>([&](auto qc) { jacobi_path(qc); });
           }
+          // (one shared tail for all paths.  Issuing it separately inside the close-pair branch — so that the paths' results
+          // need not merge in front of it — was measured: no gain for SPD(3), +3.7 % for SPD(4); profiles/r03_experiments.md)
           static_for<NC>([&](auto qc) {
             constexpr int q = decltype(qc)::value;
             lt_m_lt_acc<T, D>(li, lc, m[q], accJ[q]);   // (the sum rides the FMA chains: 6 adds fewer per pair, -0.8 us)
@@ -1152,6 +1164,19 @@ int spd_pdist_prepare(const T* x, int64_t n, Ws<T>& ws, int flags, hipStream_t s
 }
 
 constexpr int kFwdTI = 8;   // rows of a forward tile (sweep on MI355X, SPD(3) fp32, n = 5000: 8 / 16 / 32 rows -> 28.8 / 30.1 / 33.0 us)
+template <typename T, int D, int TI>
+int spd_pdist_fwd_launch(const T* nl, const T* nc, int64_t n, int64_t rb, int64_t re, int squared, double wmin, double wmax,
+                         T* out, hipStream_t st) {
+  const dim3 grid = fold_grid<TI, kBlock * pair_cols<T, D>()>(n, rb, re);
+  if (squared)
+    launch_timed(PROF_SPD_FWD, spd_pdist_fwd_kernel<T, D, TI, true>, grid, dim3(kBlock), st, nl, nc, int(n), int(rb), int(re),
+                 T(wmin), T(wmax), out);
+  else
+    launch_timed(PROF_SPD_FWD, spd_pdist_fwd_kernel<T, D, TI, false>, grid, dim3(kBlock), st, nl, nc, int(n), int(rb), int(re),
+                 T(wmin), T(wmax), out);
+  MM_CHECK_LAUNCH();
+  return MM_OK;
+}
 template <typename T, int D>
 int spd_pdist_fwd_t(const T* x, int64_t n, int64_t rb, int64_t re, int squared, double wmin, double wmax, T* out,
                     void* wsp, int flags, hipStream_t st) {
@@ -1159,17 +1184,17 @@ int spd_pdist_fwd_t(const T* x, int64_t n, int64_t rb, int64_t re, int squared, 
   int rc = spd_pdist_prepare<T, D>(x, n, ws, flags, st);
   if (rc) return rc;
   if (re <= rb || pair_off(n, re) == pair_off(n, rb)) return MM_OK;
-  const dim3 grid = fold_grid<kFwdTI, kBlock * pair_cols<T, D>()>(n, rb, re);
   const T* nl = ws.nodeL;
   const T* nc = ws.nodeC;
-  if (squared)
-    launch_timed(PROF_SPD_FWD, spd_pdist_fwd_kernel<T, D, kFwdTI, true>, grid, dim3(kBlock), st, nl, nc, int(n), int(rb), int(re),
-                 T(wmin), T(wmax), out);
-  else
-    launch_timed(PROF_SPD_FWD, spd_pdist_fwd_kernel<T, D, kFwdTI, false>, grid, dim3(kBlock), st, nl, nc, int(n), int(rb), int(re),
-                 T(wmin), T(wmax), out);
-  MM_CHECK_LAUNCH();
-  return MM_OK;
+  // A small launch (a rank's shard of a small problem, a small graph) is as long as ONE workgroup's tile: with fewer
+  // than ~4 workgroups per CU at 8 rows, tiles of 2 rows make it four times shorter (one eighth of the 5000-node problem:
+  // 420 workgroups of 8 rows, 7 us, against 3 us pro rata).  D <= 4 only: the instantiations are not free to compile.
+  if constexpr (D <= 4) {
+    const dim3 g8 = fold_grid<kFwdTI, kBlock * pair_cols<T, D>()>(n, rb, re);
+    if (int64_t(g8.x) * g8.y < 4 * int64_t(device_cus()))
+      return spd_pdist_fwd_launch<T, D, 2>(nl, nc, n, rb, re, squared, wmin, wmax, out, st);
+  }
+  return spd_pdist_fwd_launch<T, D, kFwdTI>(nl, nc, n, rb, re, squared, wmin, wmax, out, st);
 }
 
 // One launch of (at most) the resident capacity; fewer workgroups when the row range is small (>= 8 rows of a column

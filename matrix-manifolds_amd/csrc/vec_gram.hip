@@ -15,7 +15,6 @@
 // fp64: v_mfma_f64_16x16x4_f64, 16x16 tiles (its own C layout: row = (l>>4)+4q).
 #include <hip/hip_runtime.h>
 
-#include <algorithm>
 #include <cstdlib>
 
 #include "../../include/mm_manifolds.h"
@@ -475,17 +474,12 @@ void vec_gram_bwd_f32_kernel(const float* __restrict__ x, const float* __restric
 // current step computes (176 VGPRs, 2 wavefronts per SIMD: 43.5 us); 2 x 4 super-tiles with a private LDS accumulator
 // set per wavefront and no barrier (twice the workgroups, half the tiles each: 53 us); LDS float atomics on one shared
 // accumulator set (100 us).
-// NW = wavefronts of a workgroup = COLUMN blocks of its super-tile (4 row blocks x NW column blocks).  All workgroups of a
-// launch are resident at once and the CU with the most of them decides the duration, so the host picks the shape whose
-// workgroup count fills whole rounds of CUs best: n = 4039 is 528 super-tiles of 4 x 4 — two per CU on 240 CUs, three on
-// 16, i.e. 48 tiles on the fullest CU against 32 on average — but 724 of 4 x 3: three per CU on 212 CUs, 36 tiles at most.
-// NW = 3: 2-D grid (x = row group, y = column group; groups below the diagonal exit at once).
-template <int KIND, int KS, int LOSS, int NW>
-__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(MM_GRAM_BWD_MIN_WAVES)))
+template <int KIND, int KS, int LOSS>
+__global__ __launch_bounds__(64 * kGramBwdWaves) __attribute__((amdgpu_waves_per_eu(MM_GRAM_BWD_MIN_WAVES)))
 void vec_gram_bwd_sym_f32_kernel(const float* __restrict__ x, const float* __restrict__ g, int n, int m, int row_begin,
                                  int row_end, int squared, int parts, float* __restrict__ grad, LossArgs<float> la) {
-  __shared__ float sT[NW][32][33];     // per-wavefront transpose tile
-  __shared__ float accI[4][32][32];    // row-side accumulators of the super-tile's four row blocks
+  __shared__ float sT[kGramBwdWaves][32][33];     // per-wavefront transpose tile
+  __shared__ float accI[kGramBwdWaves][32][32];   // row-side accumulators of the super-tile's four row blocks
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int r = lane & 31, h = lane >> 5;
   using u32 = unsigned int;
@@ -497,30 +491,22 @@ void vec_gram_bwd_sym_f32_kernel(const float* __restrict__ x, const float* __res
   // others, tools/gram_timeline.py) — so the last workgroups placed are the lightest.
   const int nT = (n + 31) / 32;
   const int nS = (nT + 3) / 4;
-  int As, Bs, t_begin = 0, t_end = 4;
-  if constexpr (NW == 4) {
-    // `parts` (1, 2 or 4) workgroups share a super-tile: each takes 4 / parts of its four steps and flushes its own sums
-    const int id = blockIdx.x / parts, part = blockIdx.x - id * parts, nOff = nS * (nS - 1) / 2;
-    const int steps = 4 / parts;
-    t_begin = part * steps;
-    t_end = t_begin + steps;
-    if (id < nOff) {
-      Bs = int((__builtin_sqrtf(8.f * float(id) + 1.f) + 1.f) * 0.5f);
-      while (Bs * (Bs - 1) / 2 > id) --Bs;
-      while ((Bs + 1) * Bs / 2 <= id) ++Bs;
-      As = id - Bs * (Bs - 1) / 2;
-    } else {
-      As = Bs = id - nOff;
-    }
+  // `parts` (1, 2 or 4) workgroups share a super-tile: each takes 4 / parts of its four steps and flushes its own sums
+  const int id = blockIdx.x / parts, part = blockIdx.x - id * parts, nOff = nS * (nS - 1) / 2;
+  const int steps = 4 / parts, t_begin = part * steps, t_end = t_begin + steps;
+  int As, Bs;
+  if (id < nOff) {
+    Bs = int((__builtin_sqrtf(8.f * float(id) + 1.f) + 1.f) * 0.5f);
+    while (Bs * (Bs - 1) / 2 > id) --Bs;
+    while ((Bs + 1) * Bs / 2 <= id) ++Bs;
+    As = id - Bs * (Bs - 1) / 2;
   } else {
-    As = blockIdx.x;
-    Bs = blockIdx.y;
-    if (4 * As > NW * Bs + NW - 1) return;   // every tile of this group lies below the diagonal
+    As = Bs = id - nOff;
   }
   if (As * 128 >= row_end || As * 128 + 127 < row_begin) return;   // no pair of this super-tile has its row in the shard
   constexpr bool kEuclid = KIND == MM_EUCLIDEAN;
   const int rc = r < m ? r : m - 1;
-  const int jb = Bs * NW + wave, J = jb * 32;   // this wavefront's column block
+  const int jb = Bs * 4 + wave, J = jb * 32;   // this wavefront's column block
   const bool j_live = jb < nT;                  // (ragged last super-tile)
   const u32 base = u32(gpair_off(n, row_begin));
   const u32 gmax = u32(gpair_off(n, row_end)) - base - 1u;  // last valid index of this shard's slice
@@ -608,7 +594,7 @@ void vec_gram_bwd_sym_f32_kernel(const float* __restrict__ x, const float* __res
   f32x16 accJ;
 #pragma unroll
   for (int q = 0; q < 16; ++q) accJ[q] = 0.f;
-  for (int e = threadIdx.x; e < 4 * 32 * 32; e += 64 * NW) (&accI[0][0][0])[e] = 0.f;
+  for (int e = threadIdx.x; e < kGramBwdWaves * 32 * 32; e += 64 * kGramBwdWaves) (&accI[0][0][0])[e] = 0.f;
   float sp = 1.f, loss_acc = 0.f, ds_acc = 0.f;
   loss_resolve<float, LOSS>(la);
   if constexpr (LOSS != MM_LOSS_NONE) sp = softplus_of(la.scale_raw);
@@ -725,14 +711,14 @@ void vec_gram_bwd_sym_f32_kernel(const float* __restrict__ x, const float* __res
   }
   // ---- flush: wavefront w writes its column block's ACC_J and row block w's ACC_I, 32 x m contiguous floats each
   if constexpr (LOSS != MM_LOSS_NONE) {
-    __shared__ float lossW[NW][2];
+    __shared__ float lossW[kGramBwdWaves][2];
     const float l = wave_sum(loss_acc), d = wave_sum(ds_acc);
     if (lane == 0) { lossW[wave][0] = l; lossW[wave][1] = d; }
     __syncthreads();
     if (threadIdx.x == 0) {
       float ls = 0.f, dd = 0.f;
 #pragma unroll
-      for (int wv = 0; wv < NW; ++wv) { ls += lossW[wv][0]; dd += lossW[wv][1]; }
+      for (int wv = 0; wv < kGramBwdWaves; ++wv) { ls += lossW[wv][0]; dd += lossW[wv][1]; }
       const int slot = blockIdx.x & (kLossSlots - 1);
       atomic_add(&la.slots[slot], ls);
       atomic_add(&la.slots[kLossSlots + slot], dd);
@@ -756,15 +742,14 @@ void vec_gram_bwd_sym_f32_kernel(const float* __restrict__ x, const float* __res
   };
   if (j_live) flush(sT[wave], J);
   __builtin_amdgcn_wave_barrier();
-  for (int rbk = wave; rbk < 4; rbk += NW) {   // row blocks of the super-tile (accI is 32 wide: through the transpose tile for one flush routine)
-    const int I = (As * 4 + rbk) * 32;
+  {   // row block `wave` of the super-tile (accI is 32 wide: through the transpose tile for one flush routine)
+    const int I = (As * 4 + wave) * 32;
 #pragma unroll
-    for (int k = 0; k < 16; ++k) sT[wave][mfma_row(k, h)][r] = accI[rbk][mfma_row(k, h)][r];
+    for (int k = 0; k < 16; ++k) sT[wave][mfma_row(k, h)][r] = accI[wave][mfma_row(k, h)][r];
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     flush(sT[wave], I);
-    __builtin_amdgcn_wave_barrier();
   }
   MM_GSTAMP(22);
   MM_GSTAMP_END();
@@ -869,16 +854,6 @@ int vec_gram_bwd_launch(int kind, int loss_kind, const float* xp, const float* g
   int parts = ((nsuper + cus - 1) / cus) * cus * 5 > nsuper * 6 ? 2 : 1;
   if (parts_env == 1 || parts_env == 2 || parts_env == 4) parts = parts_env;
   const dim3 sgrid(unsigned(nS * (nS + 1) / 2) * unsigned(parts));     // unordered pairs of super-tile indices
-  // Shape of the super-tiles: 4 x 4 (one or two workgroups each) or 4 x 3 — whichever leaves the fullest CU with the
-  // fewest tiles, a workgroup's prologue and flush counted as three tiles' worth (MM_GRAM_BWD_NW = 3 / 4 forces).
-  static const int nw_env = [] { const char* e = std::getenv("MM_GRAM_BWD_NW"); return e ? std::atoi(e) : 0; }();
-  const int nSc3 = (nT + 2) / 3;
-  int64_t live3 = 0;
-  for (int b = 0; b < nSc3; ++b) live3 += std::min<int64_t>(nS, (3 * b + 2) / 4 + 1);
-  auto rounds = [&](int64_t wgs) { return (wgs + cus - 1) / cus; };
-  const int64_t cost4 = rounds(nsuper * parts) * (16 / parts + 3), cost3 = rounds(live3) * (12 + 3);
-  const bool three = nw_env == 3 || (nw_env != 4 && parts_env == 0 && cost3 < cost4);
-  const dim3 sgrid3{unsigned(nS), unsigned(nSc3), 1u}, block3{64u * 3u, 1u, 1u};
   {
     ProfScope prof(PROF_VEC_BWD, st);
 #define MM_GRAM_BWD(KIND_, KS_, LOSS_)                                                                        \
@@ -886,11 +861,8 @@ int vec_gram_bwd_launch(int kind, int loss_kind, const float* xp, const float* g
     if (ordered)                                                                                              \
       vec_gram_bwd_f32_kernel<KIND_, KS_, LOSS_><<<grid, block, 0, st>>>(xp, gp, int(n), m, int(row_begin), \
                                                                         int(row_end), squared, tpw, op, la);  \
-    else if (three)                                                                                           \
-      vec_gram_bwd_sym_f32_kernel<KIND_, KS_, LOSS_, 3><<<sgrid3, block3, 0, st>>>(xp, gp, int(n), m,       \
-                                                                        int(row_begin), int(row_end), squared, 1, op, la); \
     else                                                                                                      \
-      vec_gram_bwd_sym_f32_kernel<KIND_, KS_, LOSS_, 4><<<sgrid, block, 0, st>>>(xp, gp, int(n), m,         \
+      vec_gram_bwd_sym_f32_kernel<KIND_, KS_, LOSS_><<<sgrid, block, 0, st>>>(xp, gp, int(n), m,            \
                                                                         int(row_begin), int(row_end), squared, parts, op, la); \
   } while (0)
 #define MM_GRAM_BWD_KS(KIND_, LOSS_)                        \

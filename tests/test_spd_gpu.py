@@ -346,9 +346,10 @@ def test_close_pair_gate_is_seamless(d):
     assert err <= 5e-5, err
 
 
+@pytest.mark.parametrize('d,dname', [(3, 'f32'), (4, 'f32'), (3, 'f64')])   # (fp64 has no recentred path: Cayley / Jacobi there)
 @pytest.mark.parametrize('spread', [0.25, 0.35, 0.42, 0.5])
-def test_recentred_series_regime(spread):
-    """SPD(3) fp32 backward at MODERATE pair distances (||log X|| ~ 0.35: training after the first epochs): the matrix
+def test_recentred_series_regime(spread, d, dname):
+    """SPD(3) / SPD(4) fp32 and SPD(3) fp64 forward and backward at MODERATE pair distances (||log X|| ~ 0.35: training after the first epochs): the matrix
     logarithm comes from the recentred series log A = log(mu) I + log(I + (A / mu - I)), mu = tr A / 3 (smallmat.hpp,
     log_series3_centred) when every pair of a wavefront row passes its gate, else from the Cayley-transform path.  Spreads
     0.25 / 0.35: every far row takes the recentred series; 0.42 / 0.5: rows on both sides of its gate.  Gradients of d^2,
@@ -356,38 +357,44 @@ def test_recentred_series_regime(spread):
     from graphembed.manifolds import SymmetricPositiveDefinite as SPD
     from oracle import exact
     from oracle import ref_port as rp
-    gen = torch.Generator().manual_seed(int(spread * 100))
-    port = rp.SPD(3)
+    gen = torch.Generator().manual_seed(int(spread * 100) + d)
+    port = rp.SPD(d)
     n = 640
     scale = spread * (0.6 + 0.4 * torch.rand(n, generator=gen))
-    u = torch.randn(n, 6, dtype=torch.float64, generator=gen)
+    u = torch.randn(n, d * (d + 1) // 2, dtype=torch.float64, generator=gen)
     u = u / u.norm(dim=-1, keepdim=True) * scale.double().reshape(n, 1)
-    x32 = port.exp(port.zero(n, dtype=torch.float64), port.from_vec(u)).float()
-    g32 = torch.randn(n * (n - 1) // 2, generator=gen)
+    dt = DT[dname]
+    f32 = dname == 'f32'
+    x32 = port.exp(port.zero(n, dtype=torch.float64), port.from_vec(u)).to(dt)
+    g32 = torch.randn(n * (n - 1) // 2, generator=gen).to(dt)
     xin = x32.double().numpy()
     ref_d2 = exact.spd_pdist(xin)
-    man = SPD(3)
+    man = SPD(d)
     x = x32.cuda().requires_grad_()
+    # forward: d^2 from the invariants of A / mu - I (logsq_series3_centred / logsq_series4_centred) on the rows that pass its gate
+    d2 = man.pdist(x, squared=True).detach().double().cpu().numpy()
+    bad = np.abs(d2 - ref_d2) - ((1e-6 + 2e-5 * np.abs(ref_d2)) if f32 else (1e-13 + 1e-11 * np.abs(ref_d2)))
+    assert bad.max() <= 0, (spread, f'd2 worst excess {bad.max():.3e}')
     for squared in (True, False):
         ref_g = exact.spd_pdist_grad(xin, g32.double().numpy(), squared=squared)
         gr, = torch.autograd.grad(man.pdist(x, squared=squared), x, g32.cuda())
         err = np.abs(gr.double().cpu().numpy() - ref_g).max() / np.abs(ref_g).max()
-        assert err <= 3e-5, (spread, squared, err)
+        assert err <= (3e-5 if f32 else 1e-10), (spread, squared, err)
     # fused objective: m = softplus(s) d^2, loss = sum (m - t)^2, gradient = sum 2 (m - t) softplus(s) d d^2 / d x
     from graphembed.objectives import StressLoss
-    target = (torch.rand(n * (n - 1) // 2, generator=gen) * 0.9 + 0.05)
-    s_raw = torch.tensor(0.3, device='cuda', requires_grad=True)
+    target = (torch.rand(n * (n - 1) // 2, generator=gen) * 0.9 + 0.05).to(dt)
+    s_raw = torch.tensor(0.3, device='cuda', dtype=dt, requires_grad=True)
     xl = x32.cuda().requires_grad_()
     loss = man.pdist_loss(xl, s_raw, target.cuda(), StressLoss().fused_spec(), rows=(0, n))
     gx, gs = torch.autograd.grad(loss, (xl, s_raw))
     sp = float(np.log1p(np.exp(0.3)))
     res = sp * ref_d2 - target.double().numpy()
-    assert abs(loss.item() - float((res ** 2).sum())) <= 3e-5 * float((res ** 2).sum())
+    assert abs(loss.item() - float((res ** 2).sum())) <= (3e-5 if f32 else 1e-10) * float((res ** 2).sum())
     ref_gx = exact.spd_pdist_grad(xin, 2 * res * sp)
     err = np.abs(gx.double().cpu().numpy() - ref_gx).max() / np.abs(ref_gx).max()
-    assert err <= 3e-5, (spread, 'fused', err)
+    assert err <= (3e-5 if f32 else 1e-10), (spread, 'fused', err)
     ref_gs = float((2 * res * ref_d2).sum() / (1 + np.exp(-0.3)))
-    assert abs(gs.item() - ref_gs) <= 1e-4 * abs(ref_gs)
+    assert abs(gs.item() - ref_gs) <= (1e-4 if f32 else 1e-9) * abs(ref_gs)
 
 
 # ------------------------------------------------------------------ fused loss + gradients

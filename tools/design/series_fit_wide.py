@@ -36,3 +36,27 @@ if __name__ == '__main__':
         print(f'R = {r} terms {n}: max err {e:.2e} (fp32 Horner {e32:.2e})')
         if len(sys.argv) > 2 and int(sys.argv[2]) == n:
             print('   ', ', '.join('%.9ef' % v for v in c))
+
+
+def g2(x):
+    return g1(x) ** 2
+
+
+def fit2(r, n):
+    """log^2(1+x) = x^2 q(x): the forward's recentred series (logsq_series3_centred)"""
+    k = np.arange(n)
+    t = np.cos(np.pi * (k + 0.5) / n)
+    ch = C.chebfit(t, g2(r * t), n - 1)
+    mono = C.cheb2poly(ch) / r ** np.arange(n)
+    xs = np.linspace(-r, r, 200001)
+    err = np.abs(P.polyval(xs, mono) - g2(xs)).max()
+    return mono, err
+
+
+if __name__ == '__main__' and len(sys.argv) > 3 and sys.argv[3] == 'sq':
+    r = float(sys.argv[1])
+    for n in range(12, 22):
+        c, e = fit2(r, n)
+        print(f'q: R = {r} terms {n}: max err {e:.2e}')
+        if int(sys.argv[2]) == n:
+            print('   ', ', '.join('%.9ef' % v for v in c))

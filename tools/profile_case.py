@@ -2,7 +2,9 @@
 """One workload of bench.py, alone in a process, for rocprofv3 (kernel names do not carry n):
     python3 tools/profile_case.py pdist D N f32|f64 IR [steps]      # SPD(D).pdist fwd + bwd, ||log X|| = IR
     python3 tools/profile_case.py loss  D N f32|f64 [steps]         # fused QuotientLoss step (BASELINE config 5)
-    python3 tools/profile_case.py vec   M N f32|f64 KIND [steps]    # KIND = lorentz | sphere | euclidean: pdist fwd + bwd"""
+    python3 tools/profile_case.py vec   M N f32|f64 KIND [steps]    # KIND = lorentz | sphere | euclidean: pdist fwd + bwd
+    python3 tools/profile_case.py step  D N f32|f64 [steps]         # full SPD(D) training step through mm_train_step_run (StressLoss + RSGD)
+    python3 tools/profile_case.py product N f32|f64 [steps]         # BASELINE config 4: H^5 x S^5 x SPD(2) training step, mixed-manifold pair kernel"""
 import os
 import sys
 
@@ -27,8 +29,17 @@ def vec_case(m, n, dt, which, steps, dev):
 
 
 def main():
-    kind, d, n, dt = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), {'f32': torch.float32, 'f64': torch.float64}[sys.argv[4]]
     dev = torch.device('cuda', 0)
+    if sys.argv[1] == 'product':
+        from graphembed import manifolds as M
+        n, dt = int(sys.argv[2]), {'f32': torch.float32, 'f64': torch.float64}[sys.argv[3]]
+        wl = bench.TrainStepWorkload([M.Lorentz(6), M.Sphere(6), M.SymmetricPositiveDefinite(2)], n, dt, dev)
+        return run_warm(wl.kernels, int(sys.argv[4]) if len(sys.argv) > 4 else 10)
+    kind, d, n, dt = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), {'f32': torch.float32, 'f64': torch.float64}[sys.argv[4]]
+    if kind == 'step':
+        from graphembed import manifolds as M
+        wl = bench.TrainStepWorkload([M.SymmetricPositiveDefinite(d)], n, dt, dev)
+        return run_warm(wl.kernels, int(sys.argv[5]) if len(sys.argv) > 5 else 10)
     if kind == 'vec':
         return vec_case(d, n, dt, sys.argv[5], int(sys.argv[6]) if len(sys.argv) > 6 else 10, dev)
     if kind == 'pdist':

@@ -1,7 +1,10 @@
 #!/usr/bin/env python3
 """Diagnostic: timeline of the SPD backward kernel's workgroups from in-kernel clock stamps (build
-`tools/build_variant.sh stamp -DMM_BWD_STAMP`, run with MM_MANIFOLDS_LIB=.../libmm_stamp.so).
-Prints residency over time, workgroup durations and the per-CU load."""
+`tools/snap_make.sh stamp -DMM_BWD_STAMP`, run with MM_MANIFOLDS_LIB=.../libmm_stamp.so).
+Prints residency over time, workgroup durations, the per-CU load and the SHADER CLOCK (s_memtime cycles per microsecond
+of s_memrealtime).   python tools/stamp_timeline.py [n] [--warm]
+--warm: the stamped launch is the last of >= 60 ms of back-to-back graph replays — the clock regime of bench.py's timed
+region (Clocks); without it: the 7th launch after seconds of host-side input generation (cold clocks)."""
 import ctypes
 import os
 import sys
@@ -17,14 +20,29 @@ from graphembed import _backend as B  # noqa: E402
 
 
 def main():
-    n = int(sys.argv[1]) if len(sys.argv) > 1 else 5000
+    args = [a for a in sys.argv[1:] if not a.startswith('--')]
+    n = int(args[0]) if args else 5000
     dev = torch.device('cuda', 0)
     wl = bench.PdistWorkload(3, n, torch.float32, 0.1, 1, 0, dev)
-    for _ in range(5):
+    if '--warm' in sys.argv:
+        import time
+        graph, _ = bench.graph_of(wl.kernels, bench.Fence(1))
+        t0 = time.perf_counter()
+        while time.perf_counter() - t0 < 0.06:
+            for _ in range(16):
+                graph.replay()
+            torch.cuda.synchronize()
+        for _ in range(64):       # the stamps read below are those of the last launch of an uninterrupted burst
+            graph.replay()
+        torch.cuda.synchronize()
+        print('regime: warm (last launch of a 64-replay burst after 60 ms of replays)')
+    else:
+        for _ in range(5):
+            wl.kernels()
+        torch.cuda.synchronize()
         wl.kernels()
-    torch.cuda.synchronize()
-    wl.kernels()
-    torch.cuda.synchronize()
+        torch.cuda.synchronize()
+        print('regime: cold (7th eager launch after input generation)')
     raw = B.lib()._lib
     buf = np.zeros(4 * 16384, dtype=np.uint64)
     fn = raw.mm_dbg_read_bwd_stamps

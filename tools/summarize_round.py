@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Text summary of a tools/gpu_profile_r02.sh output directory: per case and kernel the average duration
+"""Text summary of a tools/gpu_evidence.sh output directory: per case and kernel the average duration
 (rocprofv3 --kernel-trace --stats), the PMC counters per launch, HBM traffic (2 x FETCH_SIZE + WRITE_SIZE, KiB) and the
 algorithmic-bytes roofline fraction of the pair kernels."""
 import collections
@@ -35,15 +35,22 @@ def pmc(dirs):
 CASES = {'bench': ('SPD(3) f32 n=5000 reference init (headline; python3 bench.py)', 3, 5000, 4),
          'case_pdist_3_5000_f64_0_1': ('SPD(3) f64 n=5000 reference init', 3, 5000, 8),
          'case_pdist_3_5000_f32_0_35': ('SPD(3) f32 n=5000 mid-training spread (||log X|| = 0.35)', 3, 5000, 4),
+         'case_pdist_3_5000_f64_0_35': ('SPD(3) f64 n=5000 mid-training spread (||log X|| = 0.35)', 3, 5000, 8),
          'case_pdist_4_2274_f32_0_1': ('SPD(4) f32 n=2274 (BASELINE config 5, small graph)', 4, 2274, 4),
-         'case_pdist_4_16384_f32_0_1': ('SPD(4) f32 n=16384 pdist fwd + bwd', 4, 16384, 4),
+         'case_pdist_4_16384_f32_0_1': ('SPD(4) f32 n=16384 pdist fwd + bwd, reference init', 4, 16384, 4),
+         'case_pdist_4_16384_f32_0_35': ('SPD(4) f32 n=16384 pdist fwd + bwd, mid-training spread (||log X|| = 0.35)', 4, 16384, 4),
          'case_loss_4_16384_f32': ('SPD(4) f32 n=16384 fused QuotientLoss step (BASELINE config 5)', 4, 16384, 4),
-         'case_vec_11_4039_f32_lorentz': ('Lorentz(11) f32 n=4039 (BASELINE config 2) pdist fwd + bwd', 11, 4039, 4)}
+         'case_pdist_6_2000_f32_0_1': ('SPD(6) f32 n=2000 pdist fwd + bwd (Jacobi path)', 6, 2000, 4),
+         'case_pdist_9_2000_f32_0_1': ('SPD(9) f32 n=2000 pdist fwd + bwd (Jacobi path, the reference\'s largest test size)', 9, 2000, 4),
+         'case_step_3_5000_f32': ('SPD(3) f32 n=5000 full training step through mm_train_step_run (pair kernel + fused finalize/update/tables)', 3, 5000, 4),
+         'case_vec_11_4039_f32_lorentz': ('Lorentz(11) f32 n=4039 (BASELINE config 2) pdist fwd + bwd', 11, 4039, 4),
+         'case_product_1025': ('BASELINE config 4: H^5 x S^5 x SPD(2) f32 n=1025 training step (mixed-manifold pair kernel)', 2, 1025, 4),
+         'case_product_5000': ('H^5 x S^5 x SPD(2) f32 n=5000 training step (mixed-manifold pair kernel)', 2, 5000, 4)}
 for key, (title, d, n, esz) in CASES.items():
     st = stats(os.path.join(root, key + '_stats'))
     if not st:
         continue
-    pm = pmc([os.path.join(root, key + s) for s in ('_pmc_sq', '_pmc_fetch', '_pmc_write')])
+    pm = pmc([os.path.join(root, key + s) for s in ('_pmc_sq', '_pmc_fetch', '_pmc_write', '_pmc_mfma')])
     pairs = n * (n - 1) // 2
     npk = d * (d + 1) // 2
     print(f'== {title}: {pairs} pairs')
@@ -56,6 +63,21 @@ for key, (title, d, n, esz) in CASES.items():
             if 'FETCH_SIZE' in c and 'WRITE_SIZE' in c:
                 tr = (2 * c['FETCH_SIZE'] + c['WRITE_SIZE']) * 1024
                 line += f'; traffic {tr / 1e6:.1f} MB (2 x FETCH {2 * c["FETCH_SIZE"] * 1024 / 1e6:.1f} + WRITE {c["WRITE_SIZE"] * 1024 / 1e6:.1f}) = {tr / alg:.2f} x algorithmic'
+            if 'SQ_VALU_MFMA_BUSY_CYCLES' in c and c.get('SQ_BUSY_CYCLES'):
+                # matrix-core utilisation: cycles the MFMA pipes are busy / cycles the SQs are busy (both summed over SEs / XCDs)
+                line += (f"; MFMA busy {c['SQ_VALU_MFMA_BUSY_CYCLES'] / c['SQ_BUSY_CYCLES']:.1%} of SQ-busy cycles, "
+                         f"{c.get('SQ_INSTS_VALU_MFMA_MOPS_F32', 0) * 512 / (avg * 1e-6) / 1e12:.2f} TFLOP/s fp32 on the matrix cores "
+                         f"(MOPS x 512 flops; peak 157.3 vector-equivalent / 2516 bf16)")
+        elif 'product_pair' in name:
+            alg = pairs * esz
+            line += f'  | algorithmic {alg / 1e6:.1f} MB (4 B target per pair) -> {alg / avg / 1e3:.0f} GB/s = {alg / avg / 1e3 / HBM:.4f} of HBM peak'
+            if 'FETCH_SIZE' in c and 'WRITE_SIZE' in c:
+                tr = (2 * c['FETCH_SIZE'] + c['WRITE_SIZE']) * 1024
+                line += f'; traffic {tr / 1e6:.1f} MB = {tr / alg:.2f} x algorithmic'
+            if 'SQ_INSTS_VALU' in c:
+                line += f'; VALU {c["SQ_INSTS_VALU"] / (pairs * 2 / 64):.0f} instructions per 64 ORDERED pairs'
+            if 'SQ_WAVE_CYCLES' in c and c['SQ_WAVE_CYCLES']:
+                line += f'; wait {c.get("SQ_WAIT_ANY", 0) / c["SQ_WAVE_CYCLES"]:.0%} of wave cycles; LDS bank conflicts {c.get("SQ_LDS_BANK_CONFLICT", 0):.0f}'
         elif 'pdist_bwd' in name or 'pdist_fwd' in name:
             alg = pairs * esz + n * (4 if 'bwd' in name else 2) * npk * esz
             line += f'  | algorithmic {alg / 1e6:.1f} MB -> {alg / avg / 1e3:.0f} GB/s = {alg / avg / 1e3 / HBM:.3f} of HBM peak'

@@ -402,10 +402,14 @@ class TrainStepWorkload:
         return t
 
 
-def time_workload(wl, steps, warmup, fence, use_graph, graph_collective=False, rank=0, tag='', warm_seconds=0.0):
+def time_workload(wl, steps, warmup, fence, use_graph, graph_collective=False, rank=0, tag='', warm_seconds=0.0,
+                  min_timed_seconds=0.0):
     """Times `steps` steps of the workload between fences.  Returns (elapsed_s, launch_mode, phases) where
     phases = per-step means, in us, of this rank's device time in the kernels and in the all-reduce and of
-    the rest of the step's wall time (host gap), from an instrumented pass after the timed region."""
+    the rest of the step's wall time (host gap), from an instrumented pass after the timed region.
+    min_timed_seconds > 0 (secondary workloads only — the headline times EXACTLY the steps it is asked for): the step
+    count is raised until the timed region lasts that long (20 steps of a 50-us workload are one millisecond: a single
+    scheduling hiccup doubles the figure); phases['steps'] is the count used."""
     import torch
     world = wl.world
     if world > 1:
@@ -492,6 +496,19 @@ def time_workload(wl, steps, warmup, fence, use_graph, graph_collective=False, r
                 more = flag.item() > 0
             if not more:
                 break
+    if min_timed_seconds > 0:
+        fence()
+        tp = time.perf_counter()
+        for _ in range(steps):
+            run()
+        fence()
+        per = max((time.perf_counter() - tp) / steps, 1e-6)
+        want = float(min(5000, max(steps, int(min_timed_seconds / per) + 1)))
+        if world > 1:   # every rank holds a collective per step: all of them use the same count
+            t = torch.tensor([want], device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            want = t.item()
+        steps = int(want)
     fence()
     t0 = time.perf_counter()
     for _ in range(steps):
@@ -519,7 +536,7 @@ def time_workload(wl, steps, warmup, fence, use_graph, graph_collective=False, r
     wall_us = (time.perf_counter() - tw) / k2 * 1e6
     kern_us = median([e0.elapsed_time(e1) * 1e3 for e0, e1, _ in ev])
     coll_us = median([e1.elapsed_time(e2) * 1e3 for _, e1, e2 in ev])
-    phases = {'kernels_us': kern_us, 'allreduce_us': coll_us if world > 1 else 0.0,
+    phases = {'steps': steps, 'kernels_us': kern_us, 'allreduce_us': coll_us if world > 1 else 0.0,
               'host_gap_us': max(0.0, wall_us - kern_us - (coll_us if world > 1 else 0.0)),
               'step_wall_us': wall_us}
     if in_graph_collective:
@@ -697,7 +714,8 @@ def worker(args):
     # ---- secondary workloads, same JSON line ----------------------------------------------------
     extra = []
     if not args.no_extra:
-        k2, w2 = max(5, min(args.steps, 20)), max(2, min(args.warmup, 5))
+        kbase, w2 = max(5, min(args.steps, 20)), max(2, min(args.warmup, 5))
+        k2 = kbase   # (per workload: the count its timed region used, >= kbase — time_workload, min_timed_seconds)
         cases = []
         if world == 1 and n == N_NODES:
             cases += [('SPD(3) n=5000 f32, mid-training spread (||log X||=0.35)', DIM, N_NODES, torch.float32, 0.35),
@@ -707,7 +725,8 @@ def worker(args):
                       ('SPD(4) n=2274 f32 (BASELINE config 5, small graph), reference init', 4, 2274, torch.float32, 0.1)]
         for name, d, nn, dt, ir in cases:
             w = PdistWorkload(d, nn, dt, ir, world, rank, dev, comm=comm)
-            el, md, ph = time_workload(w, k2, w2, fence, use_graph, graph_collective, rank, tag=name + ': ', warm_seconds=0.05)
+            el, md, ph = time_workload(w, kbase, w2, fence, use_graph, graph_collective, rank, tag=name + ': ', warm_seconds=0.05, min_timed_seconds=0.02)
+            k2 = ph['steps']
             el = reduce_max(el, dev, world)
             run_w = ph.pop('_run')
             kk = {'fwd': None, 'bwd': None}
@@ -740,7 +759,8 @@ def worker(args):
                                           ('BASELINE config 2 in f64 (the dtype run.py:32-35 sets)', 'lorentz', 11, 4039, torch.float64),
                                           ('BASELINE config 1: tree40 n=40 -> Euclidean R^10 f64 (plumbing: launch-bound)', 'euclidean', 10, 40, torch.float64)):
                 w = VecPdistWorkload(kind, m, nn, dt, dev)
-                el, md, ph = time_workload(w, k2, w2, fence, use_graph, False, rank, tag=name + ': ', warm_seconds=0.05)
+                el, md, ph = time_workload(w, kbase, w2, fence, use_graph, False, rank, tag=name + ': ', warm_seconds=0.05, min_timed_seconds=0.02)
+                k2 = ph['steps']
                 run_w = ph.pop('_run')
                 kk = {'fwd': None, 'bwd': None}
                 if not args.no_prof:
@@ -775,7 +795,8 @@ def worker(args):
                     ('BASELINE config 2 training step: Lorentz(11) n=4039 f32, StressLoss + RSGD', lambda: [M.Lorentz(11)], 4039, torch.float32, 'stress'),
                     ('BASELINE config 5 training step: SPD(4) n=16384 f32, QuotientLoss + RSGD', lambda: [M.SymmetricPositiveDefinite(4)], 16384, torch.float32, 'quotient')):
                 w = TrainStepWorkload(mans(), nn, dt, dev, loss=loss)
-                el, md, ph = time_workload(w, k2, w2, fence, use_graph, False, rank, tag=name + ': ', warm_seconds=0.05)
+                el, md, ph = time_workload(w, kbase, w2, fence, use_graph, False, rank, tag=name + ': ', warm_seconds=0.05, min_timed_seconds=0.02)
+                k2 = ph['steps']
                 ph.pop('_run')
                 extra.append({'workload': name, 'pairs_per_step': w.P, 'ms_per_step': el / k2 * 1e3, 'value': w.P * k2 / el,
                               'unit': 'pairs/s', 'steps': k2, 'launch': md + ' of mm_train_step_run'})
@@ -788,7 +809,8 @@ def worker(args):
             # by the latency of one collective, this block shows what the design does when a rank has a full launch to chew on.
             nw = int(round(N_NODES * world ** 0.5))
             w = PdistWorkload(DIM, nw, torch.float32, 0.1, world, rank, dev, local_g=True, comm=comm)
-            el, md, ph = time_workload(w, k2, w2, fence, use_graph, graph_collective, rank, tag='weak scaling: ', warm_seconds=0.05)
+            el, md, ph = time_workload(w, kbase, w2, fence, use_graph, graph_collective, rank, tag='weak scaling: ', warm_seconds=0.05, min_timed_seconds=0.02)
+            k2 = ph['steps']
             ph.pop('_run')
             el = reduce_max(el, dev, world)
             ranksw = gather_objects({'rank': rank, 'rows': list(w.rows), 'pairs': w.hi - w.lo, **ph}, world)
@@ -800,7 +822,8 @@ def worker(args):
             torch.cuda.empty_cache()
         # the size where sharding pays: BASELINE config 5 (bio-wormnet-class, ~16k nodes, SPD(4), distortion loss)
         w = FusedLossWorkload(4, 16384, torch.float32, world, rank, dev, comm=comm)
-        el, md, ph = time_workload(w, k2, w2, fence, use_graph, graph_collective, rank, tag='config 5: ', warm_seconds=0.1)
+        el, md, ph = time_workload(w, kbase, w2, fence, use_graph, graph_collective, rank, tag='config 5: ', warm_seconds=0.1, min_timed_seconds=0.02)
+        k2 = ph['steps']
         ph.pop('_run')
         el = reduce_max(el, dev, world)
         ranks5 = gather_objects({'rank': rank, 'rows': list(w.rows), 'pairs': w.hi - w.lo, **ph}, world)
@@ -816,7 +839,8 @@ def worker(args):
             from graphembed import manifolds as M
             w = TrainStepWorkload([M.SymmetricPositiveDefinite(4)], 16384, torch.float32, dev, loss='quotient', world=world,
                                   rank=rank, comm=comm)
-            el, md, ph = time_workload(w, k2, w2, fence, use_graph, graph_collective, rank, tag='config 5 step: ', warm_seconds=0.1)
+            el, md, ph = time_workload(w, kbase, w2, fence, use_graph, graph_collective, rank, tag='config 5 step: ', warm_seconds=0.1, min_timed_seconds=0.02)
+            k2 = ph['steps']
             ph.pop('_run')
             el = reduce_max(el, dev, world)
             ranks5 = gather_objects({'rank': rank, 'rows': list(w.rows), 'pairs': w.hi - w.lo, **ph}, world)

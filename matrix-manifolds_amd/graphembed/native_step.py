@@ -97,6 +97,11 @@ class NativeTrainStep:
             npairs = shard.num_pairs
         if comm is not None and (shard is None or comm.world != shard.world or comm.rank != shard.rank):
             raise ValueError('a communicator needs the matching PairShard (same world size and rank)')
+        if shard is not None and shard.world > 1 and comm is None:
+            # (the collective sits INSIDE mm_train_step_run: without a communicator every rank would step on its own partial
+            # gradient.  Ranks that share a GPU cannot build an RCCL communicator — they use parallel.sharded_fused_objective,
+            # whose all-reduce goes through torch.distributed)
+            raise ValueError('a step sharded over several ranks needs the RCCL communicator (graphembed.comm.Communicator)')
         if targets.numel() != npairs:
             raise ValueError(f'targets has {targets.numel()} entries, the step covers {npairs} pairs')
         self.shard, self.comm = shard, comm

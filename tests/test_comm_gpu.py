@@ -219,3 +219,5 @@ def test_sharded_descriptor_argument_checks(comm):
     assert rc(ctypes.byref(d), None) == -1
     with pytest.raises(ValueError):
         NativeTrainStep(emb, StressLoss(), target, _optimizers(emb, False), comm=comm)   # a communicator needs its shard
+    with pytest.raises(ValueError):   # several ranks, no communicator: every rank would step on its partial gradient
+        NativeTrainStep(emb, StressLoss(), target, _optimizers(emb, False), shard=PairShard(n, world=2, rank=0))

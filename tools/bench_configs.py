@@ -46,6 +46,17 @@ def pdist_case(man, n, dtype, **kw):
             'pairs_per_s': P / (tot * 1e-6), 'GBps_8B_per_pair': P * 2 * x.element_size() / (tot * 1e-6) / 1e9}
 
 
+def native_case(mans, n, dtype, loss='stress'):
+    """full training step through ONE C-ABI call (mm_train_step_run / NativeTrainStep), replayed as a hipGraph — for a
+    single SPD factor two launches per step: pair kernel + fused finalize / update / tables (bench.TrainStepWorkload)"""
+    import bench
+    wl = bench.TrainStepWorkload(mans, n, dtype, torch.device('cuda', 0), loss=loss)
+    graph, _ = bench.graph_of(wl.kernels, bench.Fence(1))
+    t = timeit(graph.replay, iters=40, warm=200)
+    P = n * (n - 1) // 2
+    return {'n': n, 'pairs': P, 'dtype': str(dtype).split('.')[-1], 'step_us': t, 'pairs_per_s': P / (t * 1e-6)}
+
+
 def step_case(mans, n, dtype, fused=False, graph=False, pair_kernel=True, adam=False):
     """full training step: compute_dists + stress loss + backward + fused RSGD (momentum 0)"""
     torch.manual_seed(0)
@@ -128,6 +139,12 @@ CASES = {
     'c3_spd3_step_n5000_f32_fused': lambda: step_case([M.SymmetricPositiveDefinite(3)], 5000, torch.float32, fused=True),
     'c3_spd3_step_n5000_f32_fused_graph': lambda: step_case([M.SymmetricPositiveDefinite(3)], 5000, torch.float32, fused=True, graph=True),
     'c3_spd3_step_n5000_f32_graph': lambda: step_case([M.SymmetricPositiveDefinite(3)], 5000, torch.float32, graph=True),
+    'c3_spd3_step_n5000_f32_native_graph': lambda: native_case([M.SymmetricPositiveDefinite(3)], 5000, torch.float32),
+    'c3_spd3_step_n5000_f64_native_graph': lambda: native_case([M.SymmetricPositiveDefinite(3)], 5000, torch.float64),
+    'c4_csphd_product_step_f32_native_graph': lambda: native_case([M.Lorentz(6), M.Sphere(6), M.SymmetricPositiveDefinite(2)], 1025, torch.float32),
+    'c2_facebook_lorentz11_step_f32_native_graph': lambda: native_case([M.Lorentz(11)], 4039, torch.float32),
+    'c5_spd4_step_n16384_f32_native_graph': lambda: native_case([M.SymmetricPositiveDefinite(4)], 16384, torch.float32, loss='quotient'),
+    'c5_spd4_step_n2274_f32_native_graph': lambda: native_case([M.SymmetricPositiveDefinite(4)], 2274, torch.float32, loss='quotient'),
     'c5_spd4_step_n2274_f32_fused': lambda: step_case([M.SymmetricPositiveDefinite(4)], 2274, torch.float32, fused=True),
     'c3_spd3_minibatch512_step_f32': lambda: minibatch_case([M.SymmetricPositiveDefinite(3)], 5000, 512, torch.float32),
     'c3_spd3_minibatch512_step_f32_graph': lambda: minibatch_case([M.SymmetricPositiveDefinite(3)], 5000, 512, torch.float32, graph=True),

@@ -10,6 +10,7 @@ import sys
 
 root = sys.argv[1]
 HBM = 8000.0  # GB/s
+WARM_GHZ = 2.38  # shader clock of the timed regime (tools/stamp_timeline.py --warm)
 
 
 def stats(d):
@@ -63,11 +64,14 @@ for key, (title, d, n, esz) in CASES.items():
             if 'FETCH_SIZE' in c and 'WRITE_SIZE' in c:
                 tr = (2 * c['FETCH_SIZE'] + c['WRITE_SIZE']) * 1024
                 line += f'; traffic {tr / 1e6:.1f} MB (2 x FETCH {2 * c["FETCH_SIZE"] * 1024 / 1e6:.1f} + WRITE {c["WRITE_SIZE"] * 1024 / 1e6:.1f}) = {tr / alg:.2f} x algorithmic'
-            if 'SQ_VALU_MFMA_BUSY_CYCLES' in c and c.get('SQ_BUSY_CYCLES'):
-                # matrix-core utilisation: cycles the MFMA pipes are busy / cycles the SQs are busy (both summed over SEs / XCDs)
-                line += (f"; MFMA busy {c['SQ_VALU_MFMA_BUSY_CYCLES'] / c['SQ_BUSY_CYCLES']:.1%} of SQ-busy cycles, "
-                         f"{c.get('SQ_INSTS_VALU_MFMA_MOPS_F32', 0) * 512 / (avg * 1e-6) / 1e12:.2f} TFLOP/s fp32 on the matrix cores "
-                         f"(MOPS x 512 flops; peak 157.3 vector-equivalent / 2516 bf16)")
+            if 'SQ_VALU_MFMA_BUSY_CYCLES' in c:
+                # matrix-core utilisation: cycles the MFMA pipe of a SIMD is busy, summed over the 1024 SIMDs, against the
+                # kernel's duration at the warm shader clock (2.38 GHz, in-kernel stamps: profiles/r03_timeline_warm.txt)
+                util = c['SQ_VALU_MFMA_BUSY_CYCLES'] / 1024 / (avg * WARM_GHZ * 1e3)
+                tf = c.get('SQ_INSTS_VALU_MFMA_MOPS_F32', 0) * 512 / (avg * 1e-6) / 1e12
+                line += (f"; MFMA: {c.get('SQ_INSTS_VALU_MFMA_F32', 0):.0f} instructions, pipe busy {util:.1%} of the kernel's cycles "
+                         f"({c['SQ_VALU_MFMA_BUSY_CYCLES'] / max(c.get('SQ_INSTS_VALU_MFMA_F32', 1), 1):.0f} cycles each), "
+                         f"{tf:.1f} TFLOP/s = {tf / 157.3:.1%} of the 157.3 TFLOP/s fp32 matrix peak")
         elif 'product_pair' in name:
             alg = pairs * esz
             line += f'  | algorithmic {alg / 1e6:.1f} MB (4 B target per pair) -> {alg / avg / 1e3:.0f} GB/s = {alg / avg / 1e3 / HBM:.4f} of HBM peak'

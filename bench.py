@@ -200,7 +200,8 @@ class Fence:
 
 def graph_of(fn, fence, warm=3, with_collective=False):
     """Capture fn() (a sequence of launches on the current stream) into a hipGraph; returns (graph, outputs).
-    With a collective inside, the capture is thread-local: RCCL's proxy threads may call the runtime meanwhile."""
+    with_collective (any multi-rank run): the capture is thread-local — RCCL's proxy threads and the process group's
+    watchdog thread may call the runtime while this thread records."""
     import torch
     side = torch.cuda.Stream()
     side.wait_stream(torch.cuda.current_stream())
@@ -454,7 +455,7 @@ def time_workload(wl, steps, warmup, fence, use_graph, graph_collective=False, r
                 torch.cuda.synchronize()
         if graph is None:
             try:
-                graph, static = graph_of(wl.kernels, fence)
+                graph, static = graph_of(wl.kernels, fence, with_collective=world > 1)
                 ok = True
             except Exception as exc:  # noqa: BLE001 — report and measure eagerly instead
                 ok, graph = False, None

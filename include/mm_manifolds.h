@@ -470,6 +470,9 @@ typedef struct mm_train_step {
   int64_t reduce_count;
 } mm_train_step;
 int mm_train_step_run(const mm_train_step* step, mm_stream_t stream);
+/* Largest d for which a single SPD(d) factor takes the two-launch form above (and therefore leaves the workspace holding
+ * the tables of the new points: MM_WS_PREPARED on the next call); wider matrices are stepped by separate launches. */
+int mm_spd_fused_step_max_dim(void);
 
 #ifdef __cplusplus
 }

@@ -1363,10 +1363,13 @@ int launch_pointwise(K kernel, int64_t m, hipStream_t st, A... args) {
   return MM_OK;
 }
 
+constexpr int kFusedStepMaxD = 5;
 bool spd_step_fusable(const mm_train_step* s) {
   if (!s || s->nf != 1 || s->n < 1 || s->n > kSpdMaxNodes || !s->ws) return false;
   const mm_step_param& p = s->points[0];
-  if (p.kind != MM_FACTOR_SPD || p.dim < 2 || p.dim > kSpdMaxD || !p.x || !p.grad || p.count != s->n) return false;
+  // (SPD(2..5): the sizes the paper grid and the BASELINE configurations train; for d >= 6 a step is dominated by the Jacobi
+  // pair kernel — hundreds of microseconds — and the 48 fused instantiations would add minutes to the build)
+  if (p.kind != MM_FACTOR_SPD || p.dim < 2 || p.dim > kFusedStepMaxD || !p.x || !p.grad || p.count != s->n) return false;
   if (s->loss_kind != MM_LOSS_STRESS && s->loss_kind != MM_LOSS_QUOTIENT) return false;
   if (s->loss_kind == MM_LOSS_QUOTIENT && !(s->terms & 3)) return false;
   if (p.optimizer == MM_OPT_RSGD) return p.momentum == 0.0 || p.state0 != nullptr;
@@ -1377,7 +1380,18 @@ bool spd_step_fusable(const mm_train_step* s) {
 int spd_fused_train_step(const mm_train_step* s, int64_t rb, int64_t re, bool with_objective, hipStream_t st,
                          bool* scale_stepped) {
   const int d = s->points[0].dim;
-  MM_DISPATCH(s->dtype, d, (spd_fused_train_step_t<T, D>(s, rb, re, with_objective, st, scale_stepped)));
+  if (s->dtype != MM_F32 && s->dtype != MM_F64) return MM_ERR_ARG;
+#define MM_FUSED_D(T_, d_)                                                                                           \
+  switch (d_) {                                                                                                      \
+    case 2: return spd_fused_train_step_t<T_, 2>(s, rb, re, with_objective, st, scale_stepped);                      \
+    case 3: return spd_fused_train_step_t<T_, 3>(s, rb, re, with_objective, st, scale_stepped);                      \
+    case 4: return spd_fused_train_step_t<T_, 4>(s, rb, re, with_objective, st, scale_stepped);                      \
+    case 5: return spd_fused_train_step_t<T_, 5>(s, rb, re, with_objective, st, scale_stepped);                      \
+    default: return MM_ERR_UNSUPPORTED;                                                                              \
+  }
+  if (s->dtype == MM_F32) { MM_FUSED_D(float, d) }
+  MM_FUSED_D(double, d)
+#undef MM_FUSED_D
 }
 
 }  // namespace mm
@@ -1393,6 +1407,7 @@ int mm_dbg_read_bwd_stamps(void* host, size_t bytes) {
 #endif
 
 int mm_spd_max_dim(void) { return kSpdMaxD; }
+int mm_spd_fused_step_max_dim(void) { return kFusedStepMaxD < kSpdMaxD ? kFusedStepMaxD : kSpdMaxD; }
 
 size_t mm_spd_pdist_ws_bytes(int dtype, int64_t n, int d) {
   return dtype == MM_F64 ? Ws<double>::bytes(n, d) : Ws<float>::bytes(n, d);

@@ -166,7 +166,8 @@ class NativeTrainStep:
         self._trainable_scale = [True] * k
         # a single SPD factor: the optimizer kernel of a step also writes the per-node tables of the NEW points, so the next
         # step skips the preparation launch (MM_WS_PREPARED) — as long as nobody else touched the points in between
-        self._spd_single = k == 1 and factors[0][0] == B.FACTOR_SPD
+        self._spd_single = (k == 1 and factors[0][0] == B.FACTOR_SPD
+                            and factors[0][1] <= B.lib().raw('mm_spd_fused_step_max_dim')())
         self._tables_of = None
 
     # ------------------------------------------------------------------------------------------------------------

@@ -146,6 +146,21 @@ def test_points_changed_from_outside_drop_the_prepared_flag():
     np.testing.assert_allclose(lb, la, rtol=1e-10)
 
 
+def test_wide_matrices_take_the_unfused_step():
+    """SPD(6) is outside the fused step kernel's range (d <= 5): mm_train_step_run issues objective + finalize + update
+    as separate launches and matches the eager loop all the same."""
+    from graphembed.native_step import NativeTrainStep
+    from graphembed.objectives import StressLoss
+    n, dt = 67, torch.float64
+    emb_a, target = _setup(6, n, dt, spread=0.2)
+    emb_b = copy.deepcopy(emb_a)
+    la = _eager(emb_a, StressLoss(), target, _opts(emb_a, 'rsgd'), 3)
+    step = NativeTrainStep(emb_b, StressLoss(), target, _opts(emb_b, 'rsgd'))
+    lb = [step().item() for _ in range(3)]
+    _close(la, lb, dt, 'losses')
+    _close(emb_a.xs[0].detach().cpu().numpy(), emb_b.xs[0].detach().cpu().numpy(), dt, 'points')
+
+
 def test_fused_step_frozen_points_take_the_unfused_objective():
     """MM_OPT_NONE on the points (no optimizer rule): the objective runs unfused and nothing is updated."""
     import ctypes

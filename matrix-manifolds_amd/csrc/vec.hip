@@ -15,6 +15,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdlib>
+#include <type_traits>
 
 #include "../../include/mm_manifolds.h"
 #include "prof.hpp"
@@ -518,16 +519,29 @@ int vec_bwd_t(const T* x, const T* g, int64_t n, int m, int64_t rb, int64_t re, 
   constexpr int TI = 64;
   T* acc = static_cast<T*>(ws);
   T* slots = acc + size_t(n) * (MP + 1);
-  hipError_t e = hipMemsetAsync(acc, 0, sizeof(T) * (size_t(n) * (MP + 1) + 2 * kLossSlots), st);
-  if (e != hipSuccess) return int(e);
-  la.slots = slots;
-  if (re > rb) {
-    ProfScope prof(PROF_VEC_BWD, st);
-    vec_pdist_bwd_kernel<T, KIND, MP, TI, LOSS>
-        <<<dim3(int((n + kVBlock - 1) / kVBlock), int((n + TI - 1) / TI)), dim3(kVBlock), 0, st>>>(
-            x, g, int(n), m, int(rb), int(re), squared, acc, la);
+  // Symmetric form (vec_sym.hip: every unordered pair once, both endpoints fed, resident balanced grid) where it is
+  // instantiated; MM_VEC_BWD_ORDERED=1 forces the ordered-pair kernel below.
+  static const bool ordered_env = [] { const char* e = std::getenv("MM_VEC_BWD_ORDERED"); return e && e[0] == '1'; }();
+  constexpr int dtype_code = std::is_same<T, float>::value ? MM_F32 : MM_F64;
+  bool done = false;
+  if (!ordered_env && vec_sym_supports(dtype_code, m)) {
+    const int rc = vec_sym_backward_pairs(dtype_code, KIND, LOSS, squared, x, g, n, m, rb, re, ws, la.scale_raw, double(la.alpha),
+                                          double(la.eps), la.terms, la.dyn, st);
+    if (rc == MM_OK) done = true;
+    else if (rc != MM_ERR_UNSUPPORTED) return rc;
   }
-  MMV_CHECK();
+  if (!done) {
+    hipError_t e = hipMemsetAsync(acc, 0, sizeof(T) * (size_t(n) * (MP + 1) + 2 * kLossSlots), st);
+    if (e != hipSuccess) return int(e);
+    la.slots = slots;
+    if (re > rb) {
+      ProfScope prof(PROF_VEC_BWD, st);
+      vec_pdist_bwd_kernel<T, KIND, MP, TI, LOSS>
+          <<<dim3(int((n + kVBlock - 1) / kVBlock), int((n + TI - 1) / TI)), dim3(kVBlock), 0, st>>>(
+              x, g, int(n), m, int(rb), int(re), squared, acc, la);
+    }
+    MMV_CHECK();
+  }
   vec_pdist_finalize_kernel<T, KIND, MP><<<dim3(int((n + 127) / 128)), dim3(128), 0, st>>>(
       x, acc, int(n), m, grad, LOSS != MM_LOSS_NONE ? slots : static_cast<T*>(nullptr), la.scale_raw, loss_out);
   MMV_CHECK();
@@ -542,8 +556,6 @@ int vec_loss_t(int loss_kind, const T* x, const T* target, const T* scale_raw, i
     return vec_bwd_t<T, KIND, MP, MM_LOSS_STRESS>(x, target, n, m, rb, re, 1, grad, ws, st, la, loss_out);
   return vec_bwd_t<T, KIND, MP, MM_LOSS_QUOTIENT>(x, target, n, m, rb, re, 1, grad, ws, st, la, loss_out);
 }
-
-constexpr int pad_dim(int m) { return m <= 4 ? 4 : m <= 8 ? 8 : m <= 12 ? 12 : m <= 16 ? 16 : m <= 24 ? 24 : m <= 32 ? 32 : m <= 48 ? 48 : 64; }
 
 #define MMV_DISPATCH_MP(m, ...)                             \
   switch (pad_dim(m)) {                                     \
@@ -634,7 +646,8 @@ extern "C" {
 int mm_vec_max_dim(void) { return kVecMaxDim; }
 
 size_t mm_vec_pdist_ws_bytes(int dtype, int64_t n, int m) {
-  return (dtype == MM_F64 ? 8 : 4) * (size_t(n) * (pad_dim(m) + 1) + 2 * kLossSlots);
+  // acc [pad + 1][n] | loss slots [2][256] | zero-padded points [n + 1][pad] (symmetric backward, vec_sym.hip)
+  return (dtype == MM_F64 ? 8 : 4) * (size_t(n) * (pad_dim(m) + 1) + 2 * kLossSlots + size_t(n + 1) * pad_dim(m));
 }
 
 int mm_vec_pdist_fwd(int dtype, int kind, const void* x, int64_t n, int m, int64_t row_begin, int64_t row_end,
@@ -670,7 +683,10 @@ int mm_vec_pdist_loss(int dtype, int kind, int loss_kind, const void* x, const v
   if (loss_kind == MM_LOSS_QUOTIENT && !(terms & 3)) return MM_ERR_ARG;
   if (!target && mm_pair_offset(n, row_end) > mm_pair_offset(n, row_begin)) return MM_ERR_ARG;
   hipStream_t st = static_cast<hipStream_t>(stream);
-  if (vec_gram_supports(dtype, kind, n, m) && !std::getenv("MM_VEC_LOSS_VALU"))  // inner-product manifolds: MFMA
+  // inner-product manifolds in fp32: the matrix-core kernel; fp64 takes the symmetric VALU form below (vec_sym.hpp: it beats
+  // the fp64 matrix-core backward by a quarter); MM_VEC_LOSS_GRAM=1 / MM_VEC_LOSS_VALU=1 force either
+  static const bool force_gram = [] { const char* e = std::getenv("MM_VEC_LOSS_GRAM"); return e && e[0] == '1'; }();
+  if (vec_gram_supports(dtype, kind, n, m) && !std::getenv("MM_VEC_LOSS_VALU") && (dtype == MM_F32 || force_gram))
     return vec_gram_loss(dtype, kind, loss_kind, x, target, scale_raw, n, m, row_begin, row_end, alpha, eps, terms, loss_params,
                          loss_out, grad_x, ws, st);
   MMV_DISPATCH_T(dtype, MMV_DISPATCH_KIND(kind, MMV_DISPATCH_MP(m, (vec_loss_t<T, KIND, MP>(

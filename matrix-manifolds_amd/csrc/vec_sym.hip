@@ -1,0 +1,110 @@
+// Launchers of the symmetric VALU backward of the vector manifolds (vec_sym.hpp): its own translation unit so that the
+// ~100 instantiations compile beside vec.hip.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdlib>
+
+#include "../../include/mm_manifolds.h"
+#include "prof.hpp"
+#include "vec_sym.hpp"
+
+namespace mm {
+
+bool vec_sym_supports(int dtype, int m) {
+  return (dtype == MM_F32 && m >= 1 && m <= 32) || (dtype == MM_F64 && m >= 1 && m <= 16);
+}
+
+namespace {
+
+template <typename T, int KIND, int MP, int LOSS, bool SQ>
+int launch_pairs(const T* xpad, const T* g, int64_t n, int64_t rb, int64_t re, T* acc, LossArgs<T> la, hipStream_t st) {
+  constexpr int kThreads = 64 * kVSymWaves;
+  const int64_t units = ColWalk(int(n), int(rb), int(re), 64 * vsym_cols<T, MP>()).total();
+  if (units <= 0) return MM_OK;
+  int64_t grid = resident_workgroups<vec_pdist_bwd_sym_kernel<T, KIND, MP, LOSS, SQ>>(kThreads);
+  grid = std::min<int64_t>(grid, 3 * int64_t(device_cus()));   // (measured, n = 4039: 512 - 768 workgroups 54.6 us per fwd + bwd step, 1280: 62.2)
+  {   // small launches: enough rows per workgroup to pay for its column flush (as the SPD backward, spd.hip)
+    const int64_t cus = device_cus();
+    const int64_t by_rows = units / 48 / cus * cus;
+    if (by_rows < grid) grid = std::max<int64_t>(cus, by_rows);
+  }
+  static const int64_t env_grid = std::getenv("MM_VEC_BWD_GRID") ? std::atoll(std::getenv("MM_VEC_BWD_GRID")) : 0;
+  if (env_grid > 0) grid = env_grid;
+  grid = std::max<int64_t>(1, std::min<int64_t>(grid, (units + 7) / 8));
+  {
+    ProfScope prof(PROF_VEC_BWD, st);
+    vec_pdist_bwd_sym_kernel<T, KIND, MP, LOSS, SQ><<<dim3(unsigned(grid)), dim3(kThreads), 0, st>>>(xpad, g, int(n), int(rb),
+                                                                                                   int(re), acc, la);
+  }
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? MM_OK : int(e);
+}
+
+template <typename T, int KIND, int MP>
+int pairs_t(int loss_kind, int squared, const T* x, const T* g, int64_t n, int m, int64_t rb, int64_t re, void* ws,
+            const T* scale_raw, double alpha, double eps, int terms, const double* loss_params, hipStream_t st) {
+  T* acc = static_cast<T*>(ws);
+  T* slots = acc + size_t(n) * (MP + 1);
+  T* xpad = slots + 2 * kLossSlots;
+  const int acc_count = int(n * (MP + 1) + 2 * kLossSlots);
+  const int64_t work = std::max<int64_t>((n + 1) * MP, acc_count);
+  vec_sym_prep_kernel<T, MP><<<dim3(unsigned(std::min<int64_t>(1024, (work + 255) / 256))), dim3(256), 0, st>>>(
+      x, int(n), m, xpad, acc, acc_count);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return int(e);
+  if (re <= rb || pair_off(n, re) == pair_off(n, rb)) return MM_OK;
+  LossArgs<T> la{scale_raw, T(alpha), T(eps), terms, slots, loss_params};
+  if (loss_kind == MM_LOSS_STRESS) return launch_pairs<T, KIND, MP, MM_LOSS_STRESS, true>(xpad, g, n, rb, re, acc, la, st);
+  if (loss_kind == MM_LOSS_QUOTIENT) return launch_pairs<T, KIND, MP, MM_LOSS_QUOTIENT, true>(xpad, g, n, rb, re, acc, la, st);
+  if (squared) return launch_pairs<T, KIND, MP, MM_LOSS_NONE, true>(xpad, g, n, rb, re, acc, la, st);
+  return launch_pairs<T, KIND, MP, MM_LOSS_NONE, false>(xpad, g, n, rb, re, acc, la, st);
+}
+
+template <typename T, int KIND>
+int pairs_mp(int loss_kind, int squared, const T* x, const T* g, int64_t n, int m, int64_t rb, int64_t re, void* ws,
+             const T* scale_raw, double alpha, double eps, int terms, const double* loss_params, hipStream_t st) {
+#define MM_VSYM_CASE(MP_) case MP_: return pairs_t<T, KIND, MP_>(loss_kind, squared, x, g, n, m, rb, re, ws, scale_raw, alpha, eps, terms, loss_params, st)
+  switch (pad_dim(m)) {
+    MM_VSYM_CASE(4);
+    MM_VSYM_CASE(8);
+    MM_VSYM_CASE(12);
+    MM_VSYM_CASE(16);
+    default: break;
+  }
+  if constexpr (sizeof(T) == 4) {
+    switch (pad_dim(m)) {
+      MM_VSYM_CASE(24);
+      MM_VSYM_CASE(32);
+      default: break;
+    }
+  }
+#undef MM_VSYM_CASE
+  return MM_ERR_UNSUPPORTED;
+}
+
+template <typename T>
+int pairs_kind(int kind, int loss_kind, int squared, const T* x, const T* g, int64_t n, int m, int64_t rb, int64_t re, void* ws,
+               const T* scale_raw, double alpha, double eps, int terms, const double* loss_params, hipStream_t st) {
+  switch (kind) {
+    case MM_EUCLIDEAN: return pairs_mp<T, MM_EUCLIDEAN>(loss_kind, squared, x, g, n, m, rb, re, ws, scale_raw, alpha, eps, terms, loss_params, st);
+    case MM_LORENTZ: return pairs_mp<T, MM_LORENTZ>(loss_kind, squared, x, g, n, m, rb, re, ws, scale_raw, alpha, eps, terms, loss_params, st);
+    case MM_SPHERE: return pairs_mp<T, MM_SPHERE>(loss_kind, squared, x, g, n, m, rb, re, ws, scale_raw, alpha, eps, terms, loss_params, st);
+    default: return MM_ERR_ARG;
+  }
+}
+
+}  // namespace
+
+int vec_sym_backward_pairs(int dtype, int kind, int loss_kind, int squared, const void* x, const void* g, int64_t n, int m,
+                           int64_t rb, int64_t re, void* ws, const void* scale_raw, double alpha, double eps, int terms,
+                           const double* loss_params, hipStream_t st) {
+  if (!vec_sym_supports(dtype, m) || n > kSpdMaxNodes) return MM_ERR_UNSUPPORTED;
+  if (dtype == MM_F32)
+    return pairs_kind<float>(kind, loss_kind, squared, static_cast<const float*>(x), static_cast<const float*>(g), n, m, rb, re, ws,
+                             static_cast<const float*>(scale_raw), alpha, eps, terms, loss_params, st);
+  return pairs_kind<double>(kind, loss_kind, squared, static_cast<const double*>(x), static_cast<const double*>(g), n, m, rb, re,
+                            ws, static_cast<const double*>(scale_raw), alpha, eps, terms, loss_params, st);
+}
+
+}  // namespace mm

@@ -4,11 +4,24 @@
 #include <hip/hip_runtime.h>
 
 #include "../../include/mm_manifolds.h"
+#include <cstdint>
+
 #include "smallmat.hpp"
 
 namespace mm {
 
 constexpr double kEps = 1e-8;  // utils.py:13 (both precisions)
+
+// padded point dimension the pair kernels are instantiated for
+constexpr int pad_dim(int m) { return m <= 4 ? 4 : m <= 8 ? 8 : m <= 12 ? 12 : m <= 16 ? 16 : m <= 24 ? 24 : m <= 32 ? 32 : m <= 48 ? 48 : 64; }
+
+// Symmetric VALU backward (vec_sym.hip): prep (padded points, clean accumulators) + pair kernel into the accumulators
+// `ws` = acc [pad+1][n] | loss slots [2][256] | xpad [n+1][pad].  MM_ERR_UNSUPPORTED outside its range (fp32 m <= 32,
+// fp64 m <= 16): the caller then takes the ordered-pair kernel.
+bool vec_sym_supports(int dtype, int m);
+int vec_sym_backward_pairs(int dtype, int kind, int loss_kind, int squared, const void* x, const void* g, int64_t n, int m,
+                           int64_t rb, int64_t re, void* ws, const void* scale_raw, double alpha, double eps, int terms,
+                           const double* loss_params, hipStream_t st);
 
 template <typename T> __device__ __forceinline__ T acos_t(T c);
 template <> __device__ __forceinline__ float acos_t<float>(float c) { return ::acosf(c); }

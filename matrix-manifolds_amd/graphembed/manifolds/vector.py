@@ -8,6 +8,12 @@ from graphembed import _backend as B
 from graphembed.manifolds.base import Manifold
 
 
+import os as _os
+
+# MM_VEC_BWD = sym | gram: force the symmetric VALU backward (csrc/vec_sym.hpp) or the matrix-core one (csrc/vec_gram.hip)
+_BWD_FORM = _os.environ.get('MM_VEC_BWD', '')
+
+
 class _VecPdist(torch.autograd.Function):
 
     @staticmethod
@@ -49,6 +55,10 @@ class _VecPdist(torch.autograd.Function):
             f32 = xc.dtype == torch.float32
             mfma = n <= 32768 and ((ctx.use_gram and kind in (B.LORENTZ, B.SPHERE) and m <= (32 if f32 else 16)) or
                                    (f32 and kind == B.EUCLIDEAN and squared and m <= 31))
+            if _BWD_FORM == 'sym' or (_BWD_FORM != 'gram' and not f32 and m <= 16):
+                # fp64: the symmetric VALU backward (csrc/vec_sym.hpp) beats the fp64 matrix-core one (Lorentz(11) n = 4039:
+                # 68 + 10 us against 94 us); fp32 keeps the matrix cores (31 us against 34 + 10)
+                mfma = False
             if mfma:
                 # matrix-core backward (inner-product manifolds, fp32): W^T X, no workspace
                 lib.call('mm_vec_pdist_bwd_gram', dt, kind, B.ptr(xc), B.ptr(g), n, m, row_begin,

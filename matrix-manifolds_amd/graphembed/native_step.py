@@ -19,6 +19,12 @@ overwrites.  Supported: what the fused objective kernels support — one SPD or 
 three vector factors (dimension <= 16) and one SPD(2)/SPD(3) factor — with StressLoss / QuotientLoss, RiemannianSGD
 (with or without momentum) and RiemannianAdam.  Anything else raises `ValueError` at construction.
 
+A single SPD factor keeps the per-node tables of the pair kernels up to date itself (the optimizer kernel of a step writes
+the tables of the new points), so consecutive steps skip the preparation launch; an edit of the points from outside
+(`stabilize`, a manual in-place operation) is noticed through the tensor's storage / version and re-prepares.  A step that
+was CAPTURED into a HIP graph replays the launch sequence it was recorded with: after editing the points outside the
+graph, issue one eager `step()` (it prepares again) before replaying.
+
 Multi-GPU (one process per GPU): `NativeTrainStep(..., shard=PairShard(n), comm=Communicator...)` evaluates this rank's
 rows of the pair list, all-reduces {gradients, loss, scale gradients} ONCE through the library's RCCL communicator between
 the objective and the optimizer kernels — inside the same C call, on the same stream, no host round trip — and applies
@@ -235,6 +241,13 @@ class NativeTrainStep:
             x = self._params[0]
             self._tables_of = (x.data_ptr(), x._version)
         return self.loss_out[0]
+
+    def invalidate_tables(self):
+        """Forget that the workspace holds the per-node tables of the current points: the next step prepares them again.
+        Storage rebinding and every in-place torch operation on the points are noticed by themselves (data pointer,
+        version counter); call this after writing the points in a way torch does not see (a raw-pointer kernel, a
+        graph replay of somebody else's step)."""
+        self._tables_of = None
 
     def _first_step_unfused(self, **objective_kwargs):
         """First step of a heavy-ball RSGD: the momentum buffers do not exist yet — run it through the optimizers."""

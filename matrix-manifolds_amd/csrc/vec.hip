@@ -525,8 +525,10 @@ int vec_bwd_t(const T* x, const T* g, int64_t n, int m, int64_t rb, int64_t re, 
   constexpr int dtype_code = std::is_same<T, float>::value ? MM_F32 : MM_F64;
   bool done = false;
   if (!ordered_env && vec_sym_supports(dtype_code, m)) {
+    bool finalized = false;
     const int rc = vec_sym_backward_pairs(dtype_code, KIND, LOSS, squared, x, g, n, m, rb, re, ws, la.scale_raw, double(la.alpha),
-                                          double(la.eps), la.terms, la.dyn, st);
+                                          double(la.eps), la.terms, la.dyn, grad, loss_out, &finalized, st);
+    if (rc == MM_OK && finalized) return MM_OK;   // (Lorentz / sphere: flushed into the gradient by the pair kernel)
     if (rc == MM_OK) done = true;
     else if (rc != MM_ERR_UNSUPPORTED) return rc;
   }
@@ -683,10 +685,13 @@ int mm_vec_pdist_loss(int dtype, int kind, int loss_kind, const void* x, const v
   if (loss_kind == MM_LOSS_QUOTIENT && !(terms & 3)) return MM_ERR_ARG;
   if (!target && mm_pair_offset(n, row_end) > mm_pair_offset(n, row_begin)) return MM_ERR_ARG;
   hipStream_t st = static_cast<hipStream_t>(stream);
-  // inner-product manifolds in fp32: the matrix-core kernel; fp64 takes the symmetric VALU form below (vec_sym.hpp: it beats
-  // the fp64 matrix-core backward by a quarter); MM_VEC_LOSS_GRAM=1 / MM_VEC_LOSS_VALU=1 force either
+  // Inner-product manifolds: the symmetric VALU form (vec_sym.hpp: every pair once, sums flushed straight into the
+  // gradient — two launches) up to m = 16 in both precisions (Lorentz(11) n = 4039 training step, fp32: 51.6 us against
+  // 63.7 us through the matrix cores; fp64 99.7 against 141); the matrix-core kernel serves fp32 17 <= m <= 32.
+  // MM_VEC_LOSS_GRAM=1 / MM_VEC_LOSS_VALU=1 force either.
   static const bool force_gram = [] { const char* e = std::getenv("MM_VEC_LOSS_GRAM"); return e && e[0] == '1'; }();
-  if (vec_gram_supports(dtype, kind, n, m) && !std::getenv("MM_VEC_LOSS_VALU") && (dtype == MM_F32 || force_gram))
+  static const bool force_valu = [] { const char* e = std::getenv("MM_VEC_LOSS_VALU"); return e && e[0] == '1'; }();
+  if (vec_gram_supports(dtype, kind, n, m) && !force_valu && (force_gram || (dtype == MM_F32 && m > 16)))
     return vec_gram_loss(dtype, kind, loss_kind, x, target, scale_raw, n, m, row_begin, row_end, alpha, eps, terms, loss_params,
                          loss_out, grad_x, ws, st);
   MMV_DISPATCH_T(dtype, MMV_DISPATCH_KIND(kind, MMV_DISPATCH_MP(m, (vec_loss_t<T, KIND, MP>(

@@ -10,9 +10,9 @@
 //     of smallmat.hpp — one total per lane — and leave per slice with one atomic instruction per 64 values;
 //   * ONE resident grid with statically balanced shares of the column walk (spd_ws.hpp, ColWalk), the upstream
 //     gradients requested two rows ahead with running scalar offsets, priority lowered along the share.
-// Both sides land in the same structure-of-arrays accumulators acc[k][node] = sum over the node's pairs of w x_other[k]
-// that the ordered-pair kernel of vec.hip fills, so vec_pdist_finalize_kernel applies the manifold's linear map
-// (2 (x sum w - .) / -J / identity) unchanged.
+// Lorentz / sphere: both sides are flushed straight into the gradient (contiguous ranges, sign pattern on the way): two
+// launches per backward — preparation and pair kernel.  Euclidean: both sides land in the structure-of-arrays accumulators
+// acc[k][node] that the ordered-pair kernel of vec.hip fills, and vec_pdist_finalize_kernel applies 2 (x sum w - .).
 // Measured (MI355X, profiles/r03_experiments.md §11): Lorentz(11) n = 4039 fp32 34.0 us against 31.3 us for the matrix-core
 // backward (vec_gram.hip) — 299 instructions per 128 pairs (183 vector, 76 scalar: the shares of a 4039-node launch are
 // ~50 rows per workgroup, so the walk's set-up is not amortised) at ~50 % of the issue rate — plus a preparation and a
@@ -33,8 +33,15 @@
 namespace mm {
 
 // columns per lane: two where the registers allow it (fp32, MP <= 16)
-template <typename T, int MP> constexpr int vsym_cols() { return (sizeof(T) == 4 && MP <= 16) ? 2 : 1; }
-template <typename T, int MP> constexpr int vsym_min_waves() { return (sizeof(T) == 4 && MP <= 16) ? 4 : (sizeof(T) == 4 ? 2 : 1); }
+#ifndef MM_VSYM_NC_SMALL
+#define MM_VSYM_NC_SMALL 2   // columns per lane, fp32 m <= 12 (A/B builds: 3, 4)
+#endif
+template <typename T, int MP> constexpr int vsym_cols() {
+  return (sizeof(T) == 4 && MP <= 12) ? MM_VSYM_NC_SMALL : ((sizeof(T) == 4 && MP <= 16) ? 2 : 1);
+}
+template <typename T, int MP> constexpr int vsym_min_waves() {
+  return (sizeof(T) == 4 && MP <= 16) ? (vsym_cols<T, MP>() >= 4 ? 3 : (vsym_cols<T, MP>() == 3 ? 3 : 4)) : (sizeof(T) == 4 ? 2 : 1);
+}
 #ifndef MM_VSYM_AHEAD
 #define MM_VSYM_AHEAD 2   // rows of the pair vector requested ahead (measured, Lorentz(11) n = 4039: 2 -> 34.0 us, 4 -> 36.7 us)
 #endif
@@ -45,7 +52,7 @@ constexpr int kVSymTI = 16;   // rows per wavefront and chunk
 // accumulators — one launch in place of the memset of the ordered-pair kernel.
 template <typename T, int MP>
 __global__ void vec_sym_prep_kernel(const T* __restrict__ x, int n, int m, T* __restrict__ xpad, T* __restrict__ acc,
-                                    int acc_count) {
+                                    int acc_count, T* __restrict__ grad /* null: not flushed into directly */) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   const int stride = gridDim.x * blockDim.x;
   for (int e = t; e < (n + 1) * MP; e += stride) {
@@ -53,15 +60,22 @@ __global__ void vec_sym_prep_kernel(const T* __restrict__ x, int n, int m, T* __
     xpad[e] = (i < n && k < m) ? x[size_t(i) * m + k] : T(0);
   }
   for (int e = t; e < acc_count; e += stride) acc[e] = T(0);
+  if (grad)
+    for (int e = t; e < n * m; e += stride) grad[e] = T(0);
 }
 
 template <typename T, int KIND, int MP, int LOSS, bool SQ>
 __global__ __launch_bounds__((64 * kVSymWaves), (vsym_min_waves<T, MP>()))
-void vec_pdist_bwd_sym_kernel(const T* __restrict__ xpad /* [n+1][MP] */, const T* __restrict__ g, int n, int row_begin,
-                              int row_end, T* __restrict__ acc /* [MP+1][n] */, LossArgs<T> la) {
+void vec_pdist_bwd_sym_kernel(const T* __restrict__ xpad /* [n+1][MP] */, const T* __restrict__ g, int n, int m, int row_begin,
+                              int row_end, T* __restrict__ acc /* Euclidean: [MP+1][n] sums; else the gradient [n][m] */,
+                              LossArgs<T> la) {
   constexpr int NW = kVSymWaves, TI = kVSymTI;
   constexpr int NC = vsym_cols<T, MP>();
   constexpr bool kEuclid = KIND == MM_EUCLIDEAN;
+  // Lorentz / sphere: the sums ARE the gradient up to the sign pattern (d q / d x_j = -J x_i, lorentz.py:72-77,101-118;
+  // x_i, sphere.py:68-74), so both sides leave straight into grad [n][m] — contiguous ranges of it, the sign applied on the
+  // way — and no finalize launch follows.  Euclidean needs x_j sum w - sum w x_i: accumulators + vec_pdist_finalize_kernel.
+  constexpr bool kDirect = !kEuclid;
   constexpr int NR = MP + (kEuclid ? 1 : 0);   // values of the row-side reduction / of a column's sums
   constexpr int squared = SQ ? 1 : 0;
   T sp = T(1), loss_acc = T(0), ds_acc = T(0);
@@ -206,9 +220,20 @@ void vec_pdist_bwd_sym_kernel(const T* __restrict__ xpad /* [n+1][MP] */, const 
         }
         red_ptr -= red_step * ((i1 - i0 + kAhead - 1) / kAhead * kAhead);
         __builtin_amdgcn_wave_barrier();
-        for (int t = lane; t < tw * NR; t += 64) {
-          const int k = t / tw, il = t - k * tw;
-          if (i0 + il < i1) atomic_add(&acc[size_t(k) * n + i0 + il], redM[wave][il][k]);
+        if constexpr (kDirect) {
+          const int cnt = (i1 - i0) * m;             // rows i0 .. i1 - 1 of grad: one contiguous range
+          T* gp = acc + size_t(i0) * m;
+          for (int t = lane; t < cnt; t += 64) {
+            const int il = t / m, k = t - il * m;
+            T v = redM[wave][il][k];
+            if (KIND == MM_LORENTZ && k != 0) v = -v;
+            atomic_add(&gp[t], v);
+          }
+        } else {
+          for (int t = lane; t < tw * NR; t += 64) {
+            const int k = t / tw, il = t - k * tw;
+            if (i0 + il < i1) atomic_add(&acc[size_t(k) * n + i0 + il], redM[wave][il][k]);
+          }
         }
         __builtin_amdgcn_wave_barrier();
       }
@@ -221,13 +246,27 @@ void vec_pdist_bwd_sym_kernel(const T* __restrict__ xpad /* [n+1][MP] */, const 
 #pragma unroll
       for (int k = 0; k < NR; ++k) colS[wave][q][k][lane] = accJ[q][k];
     __syncthreads();
-    for (int t = wave; t < NC * NR; t += NW) {
-      const int q = t / NR, k = t - q * NR;
-      const int j = jbase + 64 * q + lane;
-      T sum = colS[0][q][k][lane];
+    if constexpr (kDirect) {
+      const int cols = min(64 * NC, n - jbase);       // columns jbase .. of grad: one contiguous range of cols * m values
+      T* gp = acc + size_t(jbase) * m;
+      for (int t = threadIdx.x; t < cols * m; t += 64 * NW) {
+        const int jl = t / m, k = t - jl * m;
+        const int q = jl >> 6, l = jl & 63;
+        T sum = colS[0][q][k][l];
 #pragma unroll
-      for (int wv = 1; wv < NW; ++wv) sum += colS[wv][q][k][lane];
-      if (j < n) atomic_add(&acc[size_t(k) * n + j], sum);
+        for (int wv = 1; wv < NW; ++wv) sum += colS[wv][q][k][l];
+        if (KIND == MM_LORENTZ && k != 0) sum = -sum;
+        atomic_add(&gp[t], sum);
+      }
+    } else {
+      for (int t = wave; t < NC * NR; t += NW) {
+        const int q = t / NR, k = t - q * NR;
+        const int j = jbase + 64 * q + lane;
+        T sum = colS[0][q][k][lane];
+#pragma unroll
+        for (int wv = 1; wv < NW; ++wv) sum += colS[wv][q][k][lane];
+        if (j < n) atomic_add(&acc[size_t(k) * n + j], sum);
+      }
     }
     ++cb;
     r = row_begin;

@@ -19,9 +19,11 @@ constexpr int pad_dim(int m) { return m <= 4 ? 4 : m <= 8 ? 8 : m <= 12 ? 12 : m
 // `ws` = acc [pad+1][n] | loss slots [2][256] | xpad [n+1][pad].  MM_ERR_UNSUPPORTED outside its range (fp32 m <= 32,
 // fp64 m <= 16): the caller then takes the ordered-pair kernel.
 bool vec_sym_supports(int dtype, int m);
+// *finalized: the gradient (and, with a loss, loss_out) is complete — Lorentz / sphere flush into `grad` directly; else the
+// caller runs vec_pdist_finalize_kernel on the accumulators.
 int vec_sym_backward_pairs(int dtype, int kind, int loss_kind, int squared, const void* x, const void* g, int64_t n, int m,
                            int64_t rb, int64_t re, void* ws, const void* scale_raw, double alpha, double eps, int terms,
-                           const double* loss_params, hipStream_t st);
+                           const double* loss_params, void* grad, void* loss_out, bool* finalized, hipStream_t st);
 
 template <typename T> __device__ __forceinline__ T acos_t(T c);
 template <> __device__ __forceinline__ float acos_t<float>(float c) { return ::acosf(c); }

@@ -55,9 +55,10 @@ class _VecPdist(torch.autograd.Function):
             f32 = xc.dtype == torch.float32
             mfma = n <= 32768 and ((ctx.use_gram and kind in (B.LORENTZ, B.SPHERE) and m <= (32 if f32 else 16)) or
                                    (f32 and kind == B.EUCLIDEAN and squared and m <= 31))
-            if _BWD_FORM == 'sym' or (_BWD_FORM != 'gram' and not f32 and m <= 16):
-                # fp64: the symmetric VALU backward (csrc/vec_sym.hpp) beats the fp64 matrix-core one (Lorentz(11) n = 4039:
-                # 68 + 10 us against 94 us); fp32 keeps the matrix cores (31 us against 34 + 10)
+            if _BWD_FORM == 'sym' or (_BWD_FORM != 'gram' and m <= 16 and (not f32 or kind != B.EUCLIDEAN)):
+                # up to m = 16 the symmetric VALU backward (csrc/vec_sym.hpp; Lorentz / sphere: flushed straight into the
+                # gradient, two launches) beats the matrix-core one — Lorentz(11) n = 4039 forward + backward 44 us against
+                # 54 us in fp32, 113 against 142 in fp64; the fp32 Euclidean squared distance keeps the matrix cores (67 / 76)
                 mfma = False
             if mfma:
                 # matrix-core backward (inner-product manifolds, fp32): W^T X, no workspace

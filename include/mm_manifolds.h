@@ -423,6 +423,8 @@ const char* mm_comm_last_error(void);
  * A single SPD factor is issued as TWO launches: the pair kernel (loss + gradient sums) and one per-point kernel that
  * finishes the gradient, applies the optimizer rule, writes the new point and its tables for the next step, closes the
  * loss record and updates a momentum-free RSGD scale — instead of prepare + pair + finalize + point update + scale update.
+ * So is a single vector factor where mm_vec_fused_step_supports says so (the per-point kernel there moves the pair kernel's
+ * sums into the gradient, steps the points and writes their zero-padded copy for the next pair kernel).
  * Multi-GPU: with a row range and a communicator the same call issues objective (this rank's pairs) -> one
  * all-reduce -> optimizer, still without touching the host in between (capturable as one HIP graph). */
 enum { MM_OPT_NONE = -1 /* frozen: read by the objective, never stepped (a scale during burn-in) */,
@@ -458,7 +460,9 @@ typedef struct mm_train_step {
                                     single SPD factor's workspace holds the tables of the CURRENT points: a step with an
                                     optimizer on the SPD points writes the tables of the new points itself (the optimizer
                                     kernel does what mm_spd_prepare does), so from the second consecutive step on the
-                                    caller passes MM_WS_PREPARED — unless it changed the points in between             */
+                                    caller passes MM_WS_PREPARED — unless it changed the points in between.  The same
+                                    holds for a single vector factor that takes the two-launch form
+                                    (mm_vec_fused_step_supports) and its padded copy of the points; ignored elsewhere  */
   /* -- sharded step (mm_abi_version() >= 2); all zero = the whole pair list on one GPU ------------------------- */
   int64_t row_begin, row_end;    /* this rank's rows of the pair list (mm_shard_rows); row_end <= 0 means n.  `target`
                                     is then this rank's SLICE: the targets of the pairs from mm_pair_offset(n,row_begin) on */
@@ -473,6 +477,9 @@ int mm_train_step_run(const mm_train_step* step, mm_stream_t stream);
 /* Largest d for which a single SPD(d) factor takes the two-launch form above (and therefore leaves the workspace holding
  * the tables of the new points: MM_WS_PREPARED on the next call); wider matrices are stepped by separate launches. */
 int mm_spd_fused_step_max_dim(void);
+/* 1 if a single vector factor (kind, dimension m) takes the two-launch form: the sizes at which the symmetric VALU pair
+ * kernel is the fused objective (every Euclidean size it is built for; Lorentz / sphere up to m = 16). */
+int mm_vec_fused_step_supports(int dtype, int kind, int m);
 
 #ifdef __cplusplus
 }

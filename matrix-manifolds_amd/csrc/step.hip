@@ -8,6 +8,7 @@
 
 #include "../../include/mm_manifolds.h"
 #include "spd_step.hpp"
+#include "vec_step.hpp"
 
 namespace {
 
@@ -98,9 +99,15 @@ extern "C" int mm_train_step_run(const mm_train_step* s, mm_stream_t st) {
   // ---- a single SPD factor takes the fused form: pair kernel -> ONE kernel for finalize + optimizer rule + the tables of
   // the new points (sharded: pair kernel -> finalize -> all-reduce -> optimizer rule + tables)
   const bool spd_fused = nf == 1 && mm::spd_step_fusable(s);
+  // ---- ... and so does a single vector factor where the symmetric VALU pair kernel is the objective (vec_step.hpp)
+  const bool vec_fused = nf == 1 && !spd_fused && mm::vec_step_fusable(s);
   bool points_done = false, scale_done = false;
   if (spd_fused && !s->comm) {
     rc = mm::spd_fused_train_step(s, rb, re, true, static_cast<hipStream_t>(st), &scale_done);
+    if (rc != MM_OK) return rc;
+    points_done = true;
+  } else if (vec_fused && !s->comm) {
+    rc = mm::vec_fused_train_step(s, rb, re, true, static_cast<hipStream_t>(st), &scale_done);
     if (rc != MM_OK) return rc;
     points_done = true;
   } else
@@ -141,6 +148,10 @@ extern "C" int mm_train_step_run(const mm_train_step* s, mm_stream_t st) {
   int nv = 0;
   if (spd_fused && s->comm) {
     rc = mm::spd_fused_train_step(s, rb, re, false, static_cast<hipStream_t>(st), &scale_done);
+    if (rc != MM_OK) return rc;
+    points_done = true;
+  } else if (vec_fused && s->comm) {
+    rc = mm::vec_fused_train_step(s, rb, re, false, static_cast<hipStream_t>(st), &scale_done);
     if (rc != MM_OK) return rc;
     points_done = true;
   }

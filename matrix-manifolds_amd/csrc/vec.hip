@@ -22,6 +22,8 @@
 #include "smallmat.hpp"
 #include "loss.hpp"
 #include "vecfn.hpp"
+#include "vec_step.hpp"
+#include "spd_ws.hpp"
 #include "adam.hpp"
 
 namespace mm {
@@ -357,11 +359,9 @@ __device__ __forceinline__ void vec_rsgd_point(const T* x, const T* __restrict__
 // heavy-ball variant (rsgd.py:70-80): buf = momentum buf + (1 - dampening) rgrad; x' = exp/retr(x, -lr buf);
 // buf is transported to x' and updated in place.
 template <typename T, int KIND>
-__global__ void vec_rsgd_momentum_kernel(const T* x, const T* __restrict__ eg, T* buf, int64_t cnt, int m, T lr,
-                                         T momentum, T dampening, T max_grad_norm, int exact, T* xnew) {
+__device__ __forceinline__ void vec_rsgd_momentum_point(const T* x, const T* __restrict__ eg, T* buf, int64_t p, int m, T lr,
+                                                        T momentum, T dampening, T max_grad_norm, int exact, T* xnew) {
   using N = Num<T>;
-  const int64_t p = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
-  if (p >= cnt) return;
   T xp[kVecMaxDim], r[kVecMaxDim], b[kVecMaxDim], o[kVecMaxDim];
   for (int k = 0; k < m; ++k) xp[k] = x[p * m + k];
   vec_egrad2rgrad<T, KIND>(xp, eg + p * m, m, r);
@@ -383,6 +383,13 @@ __global__ void vec_rsgd_momentum_kernel(const T* x, const T* __restrict__ eg, T
     xnew[p * m + k] = o[k];
     buf[p * m + k] = b[k];
   }
+}
+template <typename T, int KIND>
+__global__ void vec_rsgd_momentum_kernel(const T* x, const T* __restrict__ eg, T* buf, int64_t cnt, int m, T lr,
+                                         T momentum, T dampening, T max_grad_norm, int exact, T* xnew) {
+  const int64_t p = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (p >= cnt) return;
+  vec_rsgd_momentum_point<T, KIND>(x, eg, buf, p, m, lr, momentum, dampening, max_grad_norm, exact, xnew);
 }
 
 template <typename T, int KIND>
@@ -646,6 +653,7 @@ using namespace mm;
 extern "C" {
 
 int mm_vec_max_dim(void) { return kVecMaxDim; }
+int mm_vec_fused_step_supports(int dtype, int kind, int m) { return vec_fused_step_supports(dtype, kind, m) ? 1 : 0; }
 
 size_t mm_vec_pdist_ws_bytes(int dtype, int64_t n, int m) {
   // acc [pad + 1][n] | loss slots [2][256] | zero-padded points [n + 1][pad] (symmetric backward, vec_sym.hip)

@@ -1,0 +1,25 @@
+// Internal interface between step.hip (mm_train_step_run) and vec.hip: the fused training step of a single vector-manifold
+// factor (Euclidean / Lorentz / sphere) — the counterpart of spd_step.hpp.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "../../include/mm_manifolds.h"
+
+namespace mm {
+
+// The sizes the fused step serves: where the symmetric VALU pair kernel (vec_sym.hpp) is the fused objective's default.
+bool vec_fused_step_supports(int dtype, int kind, int m);
+
+// True if points[0] of `s` (a single vector factor) can take the fused step: a supported size and an optimizer rule with its
+// state present.
+bool vec_step_fusable(const mm_train_step* s);
+
+// with_objective: [preparation unless s->ws_flags has MM_WS_PREPARED] -> pair kernel (loss + gradient sums, left in the
+//   workspace) over rows [rb, re) -> ONE kernel: gradient from the sums (stored to points[0].grad) + loss record + optimizer
+//   rule of points[0] + the padded copy of the new points for the next step (+ the scale's own update when it is a
+//   momentum-free RSGD parameter: *scale_stepped = true).  Afterwards the workspace is prepared for the next call.
+// !with_objective: the gradient in points[0].grad is final (sharded step, after the all-reduce): optimizer rule
+//   (+ the scale's, as above, from loss_out[1]).
+int vec_fused_train_step(const mm_train_step* s, int64_t rb, int64_t re, bool with_objective, hipStream_t st, bool* scale_stepped);
+
+}  // namespace mm

@@ -17,6 +17,8 @@ bool vec_sym_supports(int dtype, int m) {
 
 namespace {
 
+constexpr int kPlain = VSYM_PLAIN, kStepPrepared = VSYM_STEP_PREPARED;
+
 template <typename T, int KIND, int MP, int LOSS, bool SQ>
 int launch_pairs(const T* xpad, const T* g, int64_t n, int m, int64_t rb, int64_t re, T* acc, LossArgs<T> la, hipStream_t st) {
   constexpr int kThreads = 64 * kVSymWaves;
@@ -49,31 +51,38 @@ __global__ void vec_sym_loss_finalize_kernel(T* __restrict__ slots, const T* __r
 template <typename T, int KIND, int MP>
 int pairs_t(int loss_kind, int squared, const T* x, const T* g, int64_t n, int m, int64_t rb, int64_t re, void* ws,
             const T* scale_raw, double alpha, double eps, int terms, const double* loss_params, T* grad, T* loss_out,
-            bool* finalized, hipStream_t st) {
-  constexpr bool kDirect = KIND != MM_EUCLIDEAN;   // Lorentz / sphere: the pair kernel flushes into the gradient itself
+            bool* finalized, int mode, hipStream_t st) {
+  // Lorentz / sphere: the pair kernel flushes into the gradient itself — or, in the training-step form (mode != kPlain), into
+  // the head of the accumulator region, [n][m], which the step's per-point kernel moves to the gradient and clears
+  const bool direct = KIND != MM_EUCLIDEAN && mode == kPlain;
+  const bool to_ws = KIND != MM_EUCLIDEAN && mode != kPlain;
   T* acc = static_cast<T*>(ws);
   T* slots = acc + size_t(n) * (MP + 1);
   T* xpad = slots + 2 * kLossSlots;
-  // (direct form: only the loss slots of the accumulator region are used — and cleared)
-  T* clear = kDirect ? slots : acc;
-  const int clear_count = kDirect ? 2 * kLossSlots : int(n * (MP + 1) + 2 * kLossSlots);
-  const int64_t work = std::max<int64_t>(std::max<int64_t>((n + 1) * MP, clear_count), kDirect ? n * m : 0);
-  vec_sym_prep_kernel<T, MP><<<dim3(unsigned(std::min<int64_t>(1024, (work + 255) / 256))), dim3(256), 0, st>>>(
-      x, int(n), m, xpad, clear, clear_count, kDirect ? grad : static_cast<T*>(nullptr));
-  hipError_t e = hipGetLastError();
-  if (e != hipSuccess) return int(e);
-  *finalized = kDirect;
+  hipError_t e;
+  if (mode != kStepPrepared) {
+    // (direct form: only the loss slots of the accumulator region are used — and cleared)
+    T* clear = direct ? slots : acc;
+    const int clear_count = direct ? 2 * kLossSlots : int(n * (MP + 1) + 2 * kLossSlots);
+    const int64_t work = std::max<int64_t>(std::max<int64_t>((n + 1) * MP, clear_count), direct ? n * m : 0);
+    vec_sym_prep_kernel<T, MP><<<dim3(unsigned(std::min<int64_t>(1024, (work + 255) / 256))), dim3(256), 0, st>>>(
+        x, int(n), m, xpad, clear, clear_count, direct ? grad : static_cast<T*>(nullptr));
+    e = hipGetLastError();
+    if (e != hipSuccess) return int(e);
+  }
+  *finalized = direct;
   int rc = MM_OK;
   if (re > rb && pair_off(n, re) > pair_off(n, rb)) {
     LossArgs<T> la{scale_raw, T(alpha), T(eps), terms, slots, loss_params};
-    T* out = kDirect ? grad : acc;
+    T* out = direct ? grad : acc;
+    (void)to_ws;
     if (loss_kind == MM_LOSS_STRESS) rc = launch_pairs<T, KIND, MP, MM_LOSS_STRESS, true>(xpad, g, n, m, rb, re, out, la, st);
     else if (loss_kind == MM_LOSS_QUOTIENT) rc = launch_pairs<T, KIND, MP, MM_LOSS_QUOTIENT, true>(xpad, g, n, m, rb, re, out, la, st);
     else if (squared) rc = launch_pairs<T, KIND, MP, MM_LOSS_NONE, true>(xpad, g, n, m, rb, re, out, la, st);
     else rc = launch_pairs<T, KIND, MP, MM_LOSS_NONE, false>(xpad, g, n, m, rb, re, out, la, st);
     if (rc != MM_OK) return rc;
   }
-  if (kDirect && loss_kind != MM_LOSS_NONE) {   // the loss record (the Euclidean form's finalize kernel does it there)
+  if (direct && loss_kind != MM_LOSS_NONE) {   // the loss record (the Euclidean form's finalize kernel does it there)
     vec_sym_loss_finalize_kernel<T><<<dim3(1), dim3(64), 0, st>>>(slots, scale_raw, loss_out);
     e = hipGetLastError();
     if (e != hipSuccess) return int(e);
@@ -84,8 +93,8 @@ int pairs_t(int loss_kind, int squared, const T* x, const T* g, int64_t n, int m
 template <typename T, int KIND>
 int pairs_mp(int loss_kind, int squared, const T* x, const T* g, int64_t n, int m, int64_t rb, int64_t re, void* ws,
              const T* scale_raw, double alpha, double eps, int terms, const double* loss_params, T* grad, T* loss_out,
-             bool* finalized, hipStream_t st) {
-#define MM_VSYM_CASE(MP_) case MP_: return pairs_t<T, KIND, MP_>(loss_kind, squared, x, g, n, m, rb, re, ws, scale_raw, alpha, eps, terms, loss_params, grad, loss_out, finalized, st)
+             bool* finalized, int mode, hipStream_t st) {
+#define MM_VSYM_CASE(MP_) case MP_: return pairs_t<T, KIND, MP_>(loss_kind, squared, x, g, n, m, rb, re, ws, scale_raw, alpha, eps, terms, loss_params, grad, loss_out, finalized, mode, st)
   switch (pad_dim(m)) {
     MM_VSYM_CASE(4);
     MM_VSYM_CASE(8);
@@ -107,11 +116,11 @@ int pairs_mp(int loss_kind, int squared, const T* x, const T* g, int64_t n, int 
 template <typename T>
 int pairs_kind(int kind, int loss_kind, int squared, const T* x, const T* g, int64_t n, int m, int64_t rb, int64_t re, void* ws,
                const T* scale_raw, double alpha, double eps, int terms, const double* loss_params, T* grad, T* loss_out,
-               bool* finalized, hipStream_t st) {
+               bool* finalized, int mode, hipStream_t st) {
   switch (kind) {
-    case MM_EUCLIDEAN: return pairs_mp<T, MM_EUCLIDEAN>(loss_kind, squared, x, g, n, m, rb, re, ws, scale_raw, alpha, eps, terms, loss_params, grad, loss_out, finalized, st);
-    case MM_LORENTZ: return pairs_mp<T, MM_LORENTZ>(loss_kind, squared, x, g, n, m, rb, re, ws, scale_raw, alpha, eps, terms, loss_params, grad, loss_out, finalized, st);
-    case MM_SPHERE: return pairs_mp<T, MM_SPHERE>(loss_kind, squared, x, g, n, m, rb, re, ws, scale_raw, alpha, eps, terms, loss_params, grad, loss_out, finalized, st);
+    case MM_EUCLIDEAN: return pairs_mp<T, MM_EUCLIDEAN>(loss_kind, squared, x, g, n, m, rb, re, ws, scale_raw, alpha, eps, terms, loss_params, grad, loss_out, finalized, mode, st);
+    case MM_LORENTZ: return pairs_mp<T, MM_LORENTZ>(loss_kind, squared, x, g, n, m, rb, re, ws, scale_raw, alpha, eps, terms, loss_params, grad, loss_out, finalized, mode, st);
+    case MM_SPHERE: return pairs_mp<T, MM_SPHERE>(loss_kind, squared, x, g, n, m, rb, re, ws, scale_raw, alpha, eps, terms, loss_params, grad, loss_out, finalized, mode, st);
     default: return MM_ERR_ARG;
   }
 }
@@ -120,16 +129,16 @@ int pairs_kind(int kind, int loss_kind, int squared, const T* x, const T* g, int
 
 int vec_sym_backward_pairs(int dtype, int kind, int loss_kind, int squared, const void* x, const void* g, int64_t n, int m,
                            int64_t rb, int64_t re, void* ws, const void* scale_raw, double alpha, double eps, int terms,
-                           const double* loss_params, void* grad, void* loss_out, bool* finalized, hipStream_t st) {
+                           const double* loss_params, void* grad, void* loss_out, bool* finalized, hipStream_t st, int mode) {
   *finalized = false;
   if (!vec_sym_supports(dtype, m) || n > kSpdMaxNodes) return MM_ERR_UNSUPPORTED;
   if (dtype == MM_F32)
     return pairs_kind<float>(kind, loss_kind, squared, static_cast<const float*>(x), static_cast<const float*>(g), n, m, rb, re, ws,
                              static_cast<const float*>(scale_raw), alpha, eps, terms, loss_params, static_cast<float*>(grad),
-                             static_cast<float*>(loss_out), finalized, st);
+                             static_cast<float*>(loss_out), finalized, mode, st);
   return pairs_kind<double>(kind, loss_kind, squared, static_cast<const double*>(x), static_cast<const double*>(g), n, m, rb, re,
                             ws, static_cast<const double*>(scale_raw), alpha, eps, terms, loss_params, static_cast<double*>(grad),
-                            static_cast<double*>(loss_out), finalized, st);
+                            static_cast<double*>(loss_out), finalized, mode, st);
 }
 
 }  // namespace mm

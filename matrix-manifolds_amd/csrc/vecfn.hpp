@@ -21,9 +21,22 @@ constexpr int pad_dim(int m) { return m <= 4 ? 4 : m <= 8 ? 8 : m <= 12 ? 12 : m
 bool vec_sym_supports(int dtype, int m);
 // *finalized: the gradient (and, with a loss, loss_out) is complete — Lorentz / sphere flush into `grad` directly; else the
 // caller runs vec_pdist_finalize_kernel on the accumulators.
+// mode: VSYM_PLAIN as above.  The training-step forms (vec_step.hpp) leave every kind's sums in the workspace — Lorentz /
+// sphere as gacc [n][m] at the head of the accumulator region — for the step's per-point kernel, which finishes the gradient,
+// closes the loss record and clears both; VSYM_STEP_PREPARED also skips the preparation launch (that kernel left the padded
+// copy of the new points and clean accumulators behind).
+enum { VSYM_PLAIN = 0, VSYM_STEP = 1, VSYM_STEP_PREPARED = 2 };
 int vec_sym_backward_pairs(int dtype, int kind, int loss_kind, int squared, const void* x, const void* g, int64_t n, int m,
                            int64_t rb, int64_t re, void* ws, const void* scale_raw, double alpha, double eps, int terms,
-                           const double* loss_params, void* grad, void* loss_out, bool* finalized, hipStream_t st);
+                           const double* loss_params, void* grad, void* loss_out, bool* finalized, hipStream_t st,
+                           int mode = VSYM_PLAIN);
+// the regions of that workspace (pad = pad_dim(m))
+template <typename T> struct VecSymWs {
+  T* acc;     // [pad + 1][n] sums (Euclidean) / gacc [n][m] (Lorentz, sphere; training-step form)
+  T* slots;   // [2][kLossSlots]
+  T* xpad;    // [n + 1][pad]
+  VecSymWs(void* ws, int64_t n, int pad) : acc(static_cast<T*>(ws)), slots(acc + size_t(n) * (pad + 1)), xpad(slots + 2 * 256) {}
+};
 
 template <typename T> __device__ __forceinline__ T acos_t(T c);
 template <> __device__ __forceinline__ float acos_t<float>(float c) { return ::acosf(c); }

@@ -48,6 +48,7 @@ SIGNATURES = {
     'mm_spd_prepare': (_i, [_i, _vp, _i64, _i, _vp, _vp]),
     'mm_train_step_run': (_i, [_vp, _vp]),
     'mm_spd_fused_step_max_dim': (_i, []),
+    'mm_vec_fused_step_supports': (_i, [_i, _i, _i]),
     'mm_comm_available': (_i, []),
     'mm_comm_rccl_version': (_i, []),
     'mm_comm_unique_id': (_i, [_vp]),

@@ -172,8 +172,11 @@ class NativeTrainStep:
         self._trainable_scale = [True] * k
         # a single SPD factor: the optimizer kernel of a step also writes the per-node tables of the NEW points, so the next
         # step skips the preparation launch (MM_WS_PREPARED) — as long as nobody else touched the points in between
-        self._spd_single = (k == 1 and factors[0][0] == B.FACTOR_SPD
-                            and factors[0][1] <= B.lib().raw('mm_spd_fused_step_max_dim')())
+        # (and so does the per-point kernel of a single vector factor: the zero-padded copy of the new points)
+        if k == 1 and factors[0][0] == B.FACTOR_SPD:
+            self._prepared_single = factors[0][1] <= lib.raw('mm_spd_fused_step_max_dim')()
+        else:
+            self._prepared_single = k == 1 and bool(lib.raw('mm_vec_fused_step_supports')(dt, factors[0][0], factors[0][1]))
         self._tables_of = None
 
     # ------------------------------------------------------------------------------------------------------------
@@ -230,14 +233,14 @@ class NativeTrainStep:
         if need_first:
             self._tables_of = None
             return self._first_step_unfused(**objective_kwargs)
-        if self._spd_single:
+        if self._prepared_single:
             x = self._params[0]
             d.ws_flags = B.MM_WS_PREPARED if self._tables_of == (x.data_ptr(), x._version) else 0
         with B.on_device(self.device):
             B.lib().call('mm_train_step_run', ctypes.byref(d), B.stream_of(self.target))
         if self.k > 1:
             d.ws_flags = B.WS_CLEAN      # the pair kernel leaves its workspace clean
-        elif self._spd_single:
+        elif self._prepared_single:
             x = self._params[0]
             self._tables_of = (x.data_ptr(), x._version)
         return self.loss_out[0]

@@ -180,3 +180,109 @@ def test_fused_step_frozen_points_take_the_unfused_objective():
     assert torch.equal(emb.xs[0].detach(), before)
     loss = emb.fused_objective(StressLoss(), target, None)
     np.testing.assert_allclose(step.loss_out[0].item(), loss.item(), rtol=1e-5)
+
+
+# ---- single vector factor (csrc/vec.hip, vec_fused_step_kernel; vec_step.hpp) ------------------------------------------------
+def _vec_setup(man_name, m, n, dt, spread=0.3):
+    from graphembed import manifolds as M
+    from graphembed.modules import ManifoldEmbedding
+    torch.set_default_dtype(dt)
+    try:
+        torch.manual_seed(7)
+        with torch.device('cuda'):
+            emb = ManifoldEmbedding(n, [getattr(M, man_name)(m)])
+            with torch.no_grad():
+                emb.perturb(spread)
+            target = torch.rand(n * (n - 1) // 2) * 0.9 + 0.05
+    finally:
+        torch.set_default_dtype(torch.float32)
+    return emb, target
+
+
+@pytest.mark.parametrize('man_name,m', [('Lorentz', 11), ('Sphere', 6), ('Euclidean', 10), ('Lorentz', 3), ('Sphere', 16),
+                                        ('Euclidean', 20)])
+@pytest.mark.parametrize('rule,scale_rule', [('rsgd', 'rsgd'), ('rsgd_retr', 'rsgd_noclip'), ('momentum', 'rsgd'),
+                                             ('adam', 'adam'), ('adam_nc', 'momentum'), ('rsgd', 'adam')])
+@pytest.mark.parametrize('dt', [torch.float32, torch.float64], ids=['f32', 'f64'])
+def test_fused_vector_step_matches_the_eager_loop(man_name, m, rule, scale_rule, dt):
+    """Pair kernel (sums left in the workspace) + ONE per-point kernel: gradient, loss record, optimizer rule, padded copy
+    of the new points, momentum-free RSGD scale — against the eager loop on the same classes (pinned to the reference's
+    golden RSGD / RAdam traces in test_vec_gpu.py / test_radam.py)."""
+    from graphembed import _backend as B
+    from graphembed.native_step import NativeTrainStep
+    from graphembed.objectives import QuotientLoss, StressLoss
+    if dt == torch.float64 and m > 16:
+        pytest.skip('the symmetric pair kernel is built up to m = 16 in fp64')
+    assert B.lib().raw('mm_vec_fused_step_supports')(B.MM_F32 if dt == torch.float32 else B.MM_F64,
+                                                     {'Euclidean': B.EUCLIDEAN, 'Lorentz': B.LORENTZ, 'Sphere': B.SPHERE}[man_name], m)
+    n, epochs = 197, 6
+    emb_a, target = _vec_setup(man_name, m, n, dt)
+    emb_b = copy.deepcopy(emb_a)
+    fn = QuotientLoss() if 'adam' in rule else StressLoss()
+    la = _eager(emb_a, fn, target, _opts(emb_a, rule, scale_rule), epochs)
+    ob = _opts(emb_b, rule, scale_rule)
+    step = NativeTrainStep(emb_b, fn, target, ob)
+    flags, lb = [], []
+    for epoch in range(epochs):
+        lb.append(step(epoch=epoch, alpha=1.0).item())
+        flags.append(step._desc.ws_flags)
+    first_fused = 1 if 'momentum' in (rule, scale_rule) else 0
+    assert flags[first_fused] == 0 and all(f == B.MM_WS_PREPARED for f in flags[first_fused + 1:]), flags
+    _close(la, lb, dt, 'losses')
+    for a, b in zip(list(emb_a.xs) + list(emb_a.scales), list(emb_b.xs) + list(emb_b.scales)):
+        _close(a.detach().cpu().numpy(), b.detach().cpu().numpy(), dt, 'parameters')
+    g = emb_b.xs[0].grad
+    assert torch.isfinite(g).all() and g.abs().max() > 0
+    # the gradient left behind = the Euclidean gradient of the last step's loss at the points before its update: redo that
+    # step's objective on a copy of the eager run, one step short
+    emb_c, _ = _vec_setup(man_name, m, n, dt)
+    oc = _opts(emb_c, rule, scale_rule)
+    _eager(emb_c, fn, target, oc, epochs - 1)
+    loss = emb_c.fused_objective(fn, target, None, epoch=epochs - 1, alpha=1.0)
+    gc, = torch.autograd.grad(loss, [emb_c.xs[0]])
+    scale = gc.abs().max().item()     # (relative to the largest entry: small entries of an fp32 sum carry its rounding)
+    assert (gc - g).abs().max().item() <= (2e-5 if dt == torch.float32 else 1e-10) * scale, 'gradient left in x.grad'
+    # the workspace is prepared for the next step: the padded copy equals the points, the sums are clear
+    pad = next(p for p in (4, 8, 12, 16, 24, 32) if p >= m)
+    ws = step.ws.view(dt)
+    acc, slots = n * (pad + 1), 2 * 256
+    assert not ws[:acc + slots].any()
+    xpad = ws[acc + slots:acc + slots + (n + 1) * pad].view(n + 1, pad)
+    assert torch.equal(xpad[:n, :m], emb_b.xs[0].detach().view(n, m)) and not xpad[:, m:].any() and not xpad[n].any()
+
+
+def test_vector_points_changed_from_outside_drop_the_prepared_flag():
+    from graphembed.native_step import NativeTrainStep
+    from graphembed.objectives import StressLoss
+    dt, n = torch.float64, 97
+    emb_a, target = _vec_setup('Lorentz', 6, n, dt)
+    emb_b = copy.deepcopy(emb_a)
+    fn = StressLoss()
+    oa, ob = _opts(emb_a, 'rsgd'), _opts(emb_b, 'rsgd')
+    step = NativeTrainStep(emb_b, fn, target, ob)
+    la, lb = [], []
+    for epoch in range(5):
+        if epoch == 3:
+            with torch.no_grad():
+                for e in (emb_a, emb_b):
+                    e.xs[0].copy_(e.manifolds[0].projx(e.xs[0] * 1.01))   # bumps the tensor's version counter
+        la += _eager(emb_a, fn, target, oa, 1)
+        lb.append(step().item())
+        assert step._desc.ws_flags == (0 if epoch in (0, 3) else 1)
+    np.testing.assert_allclose(lb, la, rtol=1e-10)
+
+
+def test_vector_step_outside_the_fused_range_is_unfused():
+    """Lorentz(24) in fp32: the matrix-core objective, separate update launches — same result as the eager loop."""
+    from graphembed import _backend as B
+    from graphembed.native_step import NativeTrainStep
+    from graphembed.objectives import StressLoss
+    assert not B.lib().raw('mm_vec_fused_step_supports')(B.MM_F32, B.LORENTZ, 24)
+    emb_a, target = _vec_setup('Lorentz', 24, 150, torch.float32)
+    emb_b = copy.deepcopy(emb_a)
+    la = _eager(emb_a, StressLoss(), target, _opts(emb_a, 'rsgd'), 4)
+    step = NativeTrainStep(emb_b, StressLoss(), target, _opts(emb_b, 'rsgd'))
+    lb = [step().item() for _ in range(4)]
+    assert step._desc.ws_flags == 0
+    _close(la, lb, torch.float32, 'losses')
+    _close(emb_a.xs[0].detach().cpu().numpy(), emb_b.xs[0].detach().cpu().numpy(), torch.float32, 'points')

@@ -4,7 +4,8 @@
     python3 tools/profile_case.py loss  D N f32|f64 [steps]         # fused QuotientLoss step (BASELINE config 5)
     python3 tools/profile_case.py vec   M N f32|f64 KIND [steps]    # KIND = lorentz | sphere | euclidean: pdist fwd + bwd
     python3 tools/profile_case.py step  D N f32|f64 [steps]         # full SPD(D) training step through mm_train_step_run (StressLoss + RSGD)
-    python3 tools/profile_case.py product N f32|f64 [steps]         # BASELINE config 4: H^5 x S^5 x SPD(2) training step, mixed-manifold pair kernel"""
+    python3 tools/profile_case.py product N f32|f64 [steps]         # BASELINE config 4: H^5 x S^5 x SPD(2) training step, mixed-manifold pair kernel
+    python3 tools/profile_case.py vstep M N f32|f64 KIND [steps]    # full training step of one vector factor (mm_train_step_run)"""
 import os
 import sys
 
@@ -40,6 +41,11 @@ def main():
         from graphembed import manifolds as M
         wl = bench.TrainStepWorkload([M.SymmetricPositiveDefinite(d)], n, dt, dev)
         return run_warm(wl.kernels, int(sys.argv[5]) if len(sys.argv) > 5 else 10)
+    if kind == 'vstep':
+        from graphembed import manifolds as M
+        man = {'lorentz': M.Lorentz, 'sphere': M.Sphere, 'euclidean': M.Euclidean}[sys.argv[5]](d)
+        wl = bench.TrainStepWorkload([man], n, dt, dev)
+        return run_warm(wl.kernels, int(sys.argv[6]) if len(sys.argv) > 6 else 10)
     if kind == 'vec':
         return vec_case(d, n, dt, sys.argv[5], int(sys.argv[6]) if len(sys.argv) > 6 else 10, dev)
     if kind == 'pdist':

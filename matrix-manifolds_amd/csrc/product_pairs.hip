@@ -26,7 +26,10 @@
 
 #include "../../include/mm_manifolds.h"
 #include "loss.hpp"
+#include "product_step.hpp"
 #include "smallmat.hpp"
+#include "spd_rules.hpp"
+#include "vec_rules.hpp"
 #include "vecfn.hpp"
 
 namespace mm {
@@ -407,9 +410,163 @@ __global__ __launch_bounds__(256) void product_pair_finalize_kernel(PArgs<T> pa,
   }
 }
 
+// ---- the step kernel of a product embedding (product_step.hpp): product_pair_finalize_kernel's work — sums -> gradients,
+// loss record — followed, per point, by the optimizer rule of its factor (vec_rules.hpp / spd_rules.hpp: the arithmetic of
+// the per-parameter kernels mm_vec_*_step / mm_spd_*_step) and, per scale, by its momentum-free RSGD update.
+// blockIdx.y = job: vector factor y (one thread per node), the SPD factor (one thread per node), the loss / scale sums (one
+// block per output).  A training step of the product is then TWO launches.
+template <typename T> struct PStep {
+  VecRuleArgs<T> v[kPMaxVec]; int vrule[kPMaxVec];
+  VecRuleArgs<T> s; int srule;
+  T* scale_x[4]; T scale_lr[4], scale_clip[4];   // by the caller's factor position; null: stepped elsewhere / frozen
+};
+template <typename T, int KIND>
+__device__ __forceinline__ void product_vec_rule(int rule, const T (&xp)[kPMP], const T (&g)[kPMP], int64_t j, int m, bool in,
+                                                 const VecRuleArgs<T>& R, T beta2, T alpha, T (&o)[kPMP]) {
+  if (rule == VRULE_ADAM) pad_rule_point<T, KIND, kPMP, VRULE_ADAM>(xp, g, j, m, in, R, beta2, alpha, o);
+  else if (rule == VRULE_MOMENTUM) pad_rule_point<T, KIND, kPMP, VRULE_MOMENTUM>(xp, g, j, m, in, R, beta2, alpha, o);
+  else pad_rule_point<T, KIND, kPMP, VRULE_RSGD>(xp, g, j, m, in, R, beta2, alpha, o);
+}
+template <typename T, int SD>
+__global__ __launch_bounds__(128) void product_step_kernel(PArgs<T> pa, PStep<T> ps, int nv, int n, T* __restrict__ slots,
+                                                           T* __restrict__ loss_out) {
+  constexpr int NPS = SD > 0 ? Packed<(SD > 0 ? SD : 2)>::NP : 1;
+  constexpr int DS = SD > 0 ? SD : 2;
+  using N = Num<T>;
+  const int job = blockIdx.y;
+  if (job == nv + (SD > 0 ? 1 : 0)) {
+    const int q = blockIdx.x;  // 0: loss, 1 + k: d loss / d scale_raw of the caller's factor k
+    if (q > pa.nf) return;
+    __shared__ double part[2];
+    static_assert(kLossSlots == 256, "two slots per thread");
+    T* sl = slots + size_t(q) * kLossSlots;
+    const double v = wave_sum(double(sl[threadIdx.x]) + double(sl[128 + threadIdx.x]));
+    sl[threadIdx.x] = T(0);  // every accumulator is left clean (MM_WS_CLEAN)
+    sl[128 + threadIdx.x] = T(0);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const double tot = part[0] + part[1];
+      const T* raw = nullptr;
+      for (int f = 0; f < nv; ++f)
+        if (pa.v[f].slot == q - 1) raw = pa.v[f].scale_raw;
+      if (SD > 0 && pa.s.slot == q - 1) raw = pa.s.scale_raw;
+      const T out = q == 0 ? T(tot) : (raw ? T(tot / (1.0 + ::exp(-double(*raw)))) : T(0));  // d softplus = sigmoid
+      loss_out[q] = out;
+      if (q > 0 && ps.scale_x[q - 1]) {
+        // the momentum-free RSGD rule for one scalar (Euclidean(1)): r = g, ||r|| = sqrt(max(g^2, 1e-8)), x' = x - lr clip r
+        T scale = -ps.scale_lr[q - 1];
+        const T clip = ps.scale_clip[q - 1];
+        if (clip > T(0)) scale *= N::min(clip / N::sqrt(N::max(out * out, T(1e-8))), T(1));
+        *ps.scale_x[q - 1] = *ps.scale_x[q - 1] + out * scale;
+      }
+    }
+    return;
+  }
+  const int j0 = blockIdx.x * 128 + threadIdx.x;
+  const bool in = j0 < n;
+  const int64_t j = in ? j0 : 0;
+  if (job < nv) {
+    PVec<T> F = pa.v[0];
+    VecRuleArgs<T> R = ps.v[0];
+    int rule = ps.vrule[0];
+#pragma unroll
+    for (int f = 1; f < kPMaxVec; ++f)
+      if (job == f) { F = pa.v[f]; R = ps.v[f]; rule = ps.vrule[f]; }
+    const int m = F.m;
+    T xp[kPMP], g[kPMP], o[kPMP];
+    load_padded<T, kPMP>(F.x, j, m, xp);
+    const T wsum = F.acc[size_t(kPMP) * n + j];
+#pragma unroll
+    for (int k = 0; k < kPMP; ++k) g[k] = F.acc[size_t(min(k, m - 1)) * n + j];
+#pragma unroll
+    for (int k = 0; k < kPMP; ++k) {
+      T r = g[k];
+      if (F.kind == MM_EUCLIDEAN) r = T(2) * (wsum * xp[k] - r);   // sum w 2 (x_j - x_i)
+      else if (F.kind == MM_LORENTZ) r = (k == 0) ? r : -r;         // dq / dx_j = -J x_i
+      g[k] = k < m ? r : T(0);
+    }
+    if (in) {
+#pragma unroll
+      for (int k = 0; k < kPMP; ++k)
+        if (k < m) F.acc[size_t(k) * n + j] = T(0);
+      if (F.kind == MM_EUCLIDEAN) F.acc[size_t(kPMP) * n + j] = T(0);
+      store_row<T, kPMP>(F.grad, j, m, g);
+    }
+    T beta2 = T(0), alpha = T(0);
+    if (rule == VRULE_ADAM) adam_coeffs(R.adam, beta2, alpha);
+    if (F.kind == MM_EUCLIDEAN) product_vec_rule<T, MM_EUCLIDEAN>(rule, xp, g, j, m, in, R, beta2, alpha, o);
+    else if (F.kind == MM_LORENTZ) product_vec_rule<T, MM_LORENTZ>(rule, xp, g, j, m, in, R, beta2, alpha, o);
+    else product_vec_rule<T, MM_SPHERE>(rule, xp, g, j, m, in, R, beta2, alpha, o);
+    if (in) store_row<T, kPMP>(const_cast<T*>(F.x), j, m, o);
+    if (rule == VRULE_ADAM) adam_tick(R.adam.step, R.adam.ticket, gridDim.x);   // (block-uniform)
+    return;
+  }
+  if constexpr (SD > 0) {
+    T xs[NPS], li[NPS], xinv[NPS], sc[DS][DS], gi[NPS], o[NPS];
+    load_sym_packed<T, SD>(pa.s.x + size_t(j) * SD * SD, xs);
+    {
+      T l[NPS];
+      cholesky<T, SD>(xs, l);
+      invert_lower<T, SD>(l, li);
+    }
+#pragma unroll
+    for (int r = 0; r < SD; ++r)
+#pragma unroll
+      for (int c = 0; c < SD; ++c) {
+        sc[r][c] = pa.s.accS[size_t(r * SD + c) * n + j];
+        if (in) pa.s.accS[size_t(r * SD + c) * n + j] = T(0);
+      }
+#pragma unroll
+    for (int r = 0; r < SD; ++r)
+#pragma unroll
+      for (int c = 0; c <= r; ++c) {
+        T acc = T(0);  // X^-1 = L^-T L^-1
+#pragma unroll
+        for (int k = r; k < SD; ++k) acc = N::fma(li[pidx(k, r)], li[pidx(k, c)], acc);
+        xinv[pidx(r, c)] = acc;
+      }
+#pragma unroll
+    for (int r = 0; r < SD; ++r)
+#pragma unroll
+      for (int c = 0; c <= r; ++c) {
+        T a = T(0), b = T(0);
+#pragma unroll
+        for (int k = 0; k < SD; ++k) {
+          a = N::fma(sc[r][k], xinv[pidx(k, c)], a);
+          b = N::fma(sc[c][k], xinv[pidx(k, r)], b);
+        }
+        gi[pidx(r, c)] = T(0.5) * (a + b);  // ordered pairs: both roles of a node arrive as "column side"
+      }
+    if (in) store_sym_full<T, SD>(pa.s.grad + size_t(j) * SD * SD, gi);
+    const VecRuleArgs<T>& R = ps.s;
+    T* x = const_cast<T*>(pa.s.x);
+    if (ps.srule == VRULE_RSGD) {
+      spd_rsgd_update<T, SD>(xs, gi, R.lr, R.max_grad_norm, R.exact, o);
+    } else if (ps.srule == VRULE_MOMENTUM) {
+      T b[NPS];
+      load_sym_packed<T, SD>(R.state0 + size_t(j) * SD * SD, b);
+      spd_momentum_update<T, SD>(xs, gi, b, R.lr, R.momentum, R.dampening, R.max_grad_norm, R.exact, o);
+      if (in) store_sym_full<T, SD>(R.state0 + size_t(j) * SD * SD, b);
+    } else {
+      T beta2, alpha, mo[NPS];
+      adam_coeffs(R.adam, beta2, alpha);
+      load_sym_packed<T, SD>(R.state0 + size_t(j) * SD * SD, mo);
+      const T v = spd_adam_update<T, SD>(xs, gi, mo, R.state1[size_t(j) * SD * SD], R.adam, beta2, alpha, o);
+      if (in) {
+        store_sym_full<T, SD>(R.state0 + size_t(j) * SD * SD, mo);
+#pragma unroll
+        for (int q = 0; q < SD * SD; ++q) R.state1[size_t(j) * SD * SD + q] = v;
+      }
+    }
+    if (in) store_sym_full<T, SD>(x + size_t(j) * SD * SD, o);
+    if (ps.srule == VRULE_ADAM) adam_tick(R.adam.step, R.adam.ticket, gridDim.x);
+  }
+}
+
 template <typename T, int NV, int SD>
 int product_pairs_launch(int loss_kind, PArgs<T> pa, const T* target, int64_t n, int64_t rb, int64_t re, LossArgs<T> la,
-                         T* loss_out, hipStream_t st) {
+                         T* loss_out, hipStream_t st, const PStep<T>* ps) {
   if (mm_pair_offset(n, re) > mm_pair_offset(n, rb)) {
     // rows per wavefront: short enough that the launch has ~2 wavefronts per SIMD (the work of a small
     // product embedding is latency, not throughput; measured at n = 1025: 2 -> 123, 4 -> 103, 8 -> 94,
@@ -423,8 +580,13 @@ int product_pairs_launch(int loss_kind, PArgs<T> pa, const T* target, int64_t n,
     else
       product_pair_kernel<T, NV, SD, MM_LOSS_QUOTIENT><<<grid, dim3(kPCols * kPWaves), 0, st>>>(pa, target, int(n), int(rb), int(re), ti, la);
   }
-  const dim3 fgrid(unsigned(std::max<int64_t>((n * kPMP + 255) / 256, 8)), unsigned(NV + (SD > 0 ? 1 : 0) + 1));
-  product_pair_finalize_kernel<T, NV, SD><<<fgrid, dim3(256), 0, st>>>(pa, int(n), la.slots, loss_out);
+  if (ps) {   // training step: gradients, loss record, optimizer rules and scales in one launch
+    const dim3 sgrid(unsigned(std::max<int64_t>((n + 127) / 128, 1 + pa.nf)), unsigned(NV + (SD > 0 ? 1 : 0) + 1));
+    product_step_kernel<T, SD><<<sgrid, dim3(128), 0, st>>>(pa, *ps, NV, int(n), la.slots, loss_out);
+  } else {
+    const dim3 fgrid(unsigned(std::max<int64_t>((n * kPMP + 255) / 256, 8)), unsigned(NV + (SD > 0 ? 1 : 0) + 1));
+    product_pair_finalize_kernel<T, NV, SD><<<fgrid, dim3(256), 0, st>>>(pa, int(n), la.slots, loss_out);
+  }
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? MM_OK : int(e);
 }
@@ -434,8 +596,15 @@ int product_pairs_t(int loss_kind, int nf, const int* kinds, const int* dims, co
                     const void* const* scale_raw, const void* target, int64_t n, int64_t rb, int64_t re, double alpha,
                     double eps, int terms, const double* loss_params, double wmin, double wmax, void* const* grads, void* loss_out, void* wsp,
                     int flags, hipStream_t st, const int64_t* idx = nullptr, const void* dense = nullptr,
-                    int64_t dense_n = 0) {
+                    int64_t dense_n = 0, const mm_train_step* step = nullptr, bool* scale_stepped = nullptr) {
   PArgs<T> pa{};
+  PStep<T> ps{};
+  auto rule_of = [](const mm_step_param& p, VecRuleArgs<T>& r) {
+    r = VecRuleArgs<T>{T(p.lr), T(p.momentum), T(p.dampening), T(p.max_grad_norm), p.exact, static_cast<T*>(p.state0),
+                       static_cast<T*>(p.state1),
+                       AdamArgs<T>{T(p.lr), T(p.beta1), T(p.beta2), T(p.adam_eps), T(p.max_grad_norm), p.nc, p.exact, p.step, p.ticket}};
+    return p.optimizer == MM_OPT_RADAM ? int(VRULE_ADAM) : (p.momentum != 0.0 ? int(VRULE_MOMENTUM) : int(VRULE_RSGD));
+  };
   pa.nf = nf;
   pa.idx = idx;
   pa.dense = static_cast<const T*>(dense);
@@ -457,6 +626,7 @@ int product_pairs_t(int loss_kind, int nf, const int* kinds, const int* dims, co
       pa.s.wmax = T(wmax);
       pa.s.slot = k;
       pa.s.grad = static_cast<T*>(grads[k]);
+      if (step) ps.srule = rule_of(step->points[k], ps.s);
       acc_elems += size_t(sd) * sd * n;
     } else {
       if (nv == kPMaxVec || dims[k] < 1 || dims[k] > kPMP || kinds[k] < MM_EUCLIDEAN || kinds[k] > MM_SPHERE)
@@ -469,6 +639,7 @@ int product_pairs_t(int loss_kind, int nf, const int* kinds, const int* dims, co
       F.kind = kinds[k];
       F.slot = k;
       F.grad = static_cast<T*>(grads[k]);
+      if (step) ps.vrule[nv - 1] = rule_of(step->points[k], ps.v[nv - 1]);
       acc_elems += size_t(kPMP + 1) * n;
     }
   }
@@ -476,10 +647,20 @@ int product_pairs_t(int loss_kind, int nf, const int* kinds, const int* dims, co
     hipError_t e = hipMemsetAsync(slots, 0, sizeof(T) * (size_t(1 + nf) * kLossSlots + acc_elems), st);
     if (e != hipSuccess) return int(e);
   }
+  if (step)
+    for (int k = 0; k < nf; ++k) {
+      const mm_step_param& q = step->scales[k];
+      const bool fuse = q.x && q.optimizer == MM_OPT_RSGD && q.momentum == 0.0;
+      ps.scale_x[k] = fuse ? static_cast<T*>(q.x) : nullptr;
+      ps.scale_lr[k] = T(q.lr);
+      ps.scale_clip[k] = T(q.max_grad_norm);
+      if (scale_stepped) scale_stepped[k] = fuse;
+    }
   LossArgs<T> la{nullptr, T(alpha), T(eps), terms, slots, loss_params};
   const T* tg = static_cast<const T*>(target);
   T* lo = static_cast<T*>(loss_out);
-#define MM_PP(NV_, SD_) return product_pairs_launch<T, NV_, SD_>(loss_kind, pa, tg, n, rb, re, la, lo, st)
+  const PStep<T>* psp = step ? &ps : nullptr;
+#define MM_PP(NV_, SD_) return product_pairs_launch<T, NV_, SD_>(loss_kind, pa, tg, n, rb, re, la, lo, st, psp)
   switch (nv * 4 + sd) {
     case 0 * 4 + 2: MM_PP(0, 2);
     case 0 * 4 + 3: MM_PP(0, 3);
@@ -495,6 +676,40 @@ int product_pairs_t(int loss_kind, int nf, const int* kinds, const int* dims, co
     default: return MM_ERR_UNSUPPORTED;
   }
 #undef MM_PP
+}
+
+// ---- fused training step (product_step.hpp) --------------------------------------------------------------------
+bool product_step_fusable(const mm_train_step* s) {
+  static const bool off = [] { const char* e = std::getenv("MM_PRODUCT_STEP_UNFUSED"); return e && e[0] == '1'; }();
+  if (off || s->nf < 2) return false;
+  for (int k = 0; k < s->nf; ++k) {
+    const mm_step_param& p = s->points[k];
+    if (!p.x || !p.grad || p.count != s->n) return false;
+    if (p.optimizer == MM_OPT_RSGD) { if (p.momentum != 0.0 && !p.state0) return false; }
+    else if (p.optimizer == MM_OPT_RADAM) { if (!p.state0 || !p.state1 || !p.step || !p.ticket) return false; }
+    else return false;
+  }
+  return true;
+}
+
+int product_fused_train_step(const mm_train_step* s, int64_t rb, int64_t re, hipStream_t st, bool* scale_stepped) {
+  int kinds[4], dims[4];
+  const void* xs[4];
+  const void* sc[4];
+  void* grads[4];
+  for (int k = 0; k < s->nf; ++k) {
+    kinds[k] = s->points[k].kind; dims[k] = s->points[k].dim; xs[k] = s->points[k].x; sc[k] = s->scales[k].x;
+    grads[k] = s->points[k].grad;
+    scale_stepped[k] = false;
+    if (!sc[k]) return MM_ERR_ARG;
+  }
+  if (s->dtype == MM_F32)
+    return product_pairs_t<float>(s->loss_kind, s->nf, kinds, dims, xs, sc, s->target, s->n, rb, re, s->alpha, s->eps, s->terms,
+                                  s->loss_params, s->wmin, s->wmax, grads, s->loss_out, s->ws, s->ws_flags, st, nullptr, nullptr,
+                                  0, s, scale_stepped);
+  return product_pairs_t<double>(s->loss_kind, s->nf, kinds, dims, xs, sc, s->target, s->n, rb, re, s->alpha, s->eps, s->terms,
+                                 s->loss_params, s->wmin, s->wmax, grads, s->loss_out, s->ws, s->ws_flags, st, nullptr, nullptr,
+                                 0, s, scale_stepped);
 }
 
 }  // namespace mm

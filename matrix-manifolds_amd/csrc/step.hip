@@ -9,6 +9,7 @@
 #include "../../include/mm_manifolds.h"
 #include "spd_step.hpp"
 #include "vec_step.hpp"
+#include "product_step.hpp"
 
 namespace {
 
@@ -37,34 +38,25 @@ int optimizer_step(int dtype, const mm_step_param& p, const void* grad, mm_strea
   return MM_ERR_ARG;
 }
 
-// parameters that can share one multi-parameter launch: same update rule and hyper-parameters, vector space
+// parameters that can share one multi-parameter launch: the same optimizer type (each brings its own hyper-parameters);
+// there is no multi-parameter heavy-ball kernel
 bool same_rule(const mm_step_param& a, const mm_step_param& b) {
-  return a.optimizer == b.optimizer && a.lr == b.lr && a.max_grad_norm == b.max_grad_norm && a.exact == b.exact &&
-         a.momentum == b.momentum && a.beta1 == b.beta1 && a.beta2 == b.beta2 && a.nc == b.nc && a.adam_eps == b.adam_eps;
+  return a.optimizer == b.optimizer && (a.optimizer == MM_OPT_RADAM || (a.momentum == 0.0 && b.momentum == 0.0));
 }
 
 // all vector-space parameters of `ps` (with gradients gs) that share a rule go out in one launch
 int vector_group_step(int dtype, const mm_step_param* const* ps, const void* const* gs, int count, mm_stream_t st) {
   if (count == 1) return optimizer_step(dtype, *ps[0], gs[0], st);
-  int kinds[8], ms[8];
-  const void* xs[8];
-  const void* gr[8];
-  void* xn[8];
-  void* m0[8];
-  void* m1[8];
-  double* steps[8];
-  unsigned* tickets[8];
-  int64_t cnts[8];
+  mm::VecGroupParam g[8];
   for (int t = 0; t < count; ++t) {
     const mm_step_param& p = *ps[t];
-    kinds[t] = p.kind; ms[t] = p.dim; xs[t] = p.x; gr[t] = gs[t]; xn[t] = p.x; cnts[t] = p.count;
-    m0[t] = p.state0; m1[t] = p.state1; steps[t] = p.step; tickets[t] = p.ticket;
+    if (!p.x || !gs[t] || p.count < 0 || p.dim < 1 || p.kind < MM_EUCLIDEAN || p.kind > MM_SPHERE) return MM_ERR_ARG;
+    if (p.dim > mm_vec_max_dim()) return MM_ERR_UNSUPPORTED;
+    if (p.optimizer == MM_OPT_RADAM && (!p.state0 || !p.state1 || !p.step || !p.ticket)) return MM_ERR_ARG;
+    g[t] = mm::VecGroupParam{p.kind, p.dim, p.count, p.x, gs[t], p.x, p.state0, p.state1, p.step, p.ticket,
+                             p.lr, p.max_grad_norm, p.beta1, p.beta2, p.adam_eps, p.nc, p.exact};
   }
-  const mm_step_param& p = *ps[0];
-  if (p.optimizer == MM_OPT_RSGD)
-    return mm_vec_rsgd_step_multi(dtype, count, kinds, xs, gr, cnts, ms, p.lr, p.max_grad_norm, p.exact, xn, st);
-  return mm_vec_radam_step_multi(dtype, count, kinds, xs, gr, m0, m1, steps, tickets, cnts, ms, p.lr, p.beta1, p.beta2, p.nc,
-                                 p.adam_eps, p.max_grad_norm, p.exact, xn, st);
+  return mm::vec_group_step(dtype, ps[0]->optimizer, count, g, static_cast<hipStream_t>(st));
 }
 
 // [p, p + bytes) lies inside [base, base + size)
@@ -101,13 +93,22 @@ extern "C" int mm_train_step_run(const mm_train_step* s, mm_stream_t st) {
   const bool spd_fused = nf == 1 && mm::spd_step_fusable(s);
   // ---- ... and so does a single vector factor where the symmetric VALU pair kernel is the objective (vec_step.hpp)
   const bool vec_fused = nf == 1 && !spd_fused && mm::vec_step_fusable(s);
-  bool points_done = false, scale_done = false;
+  // ---- ... and a product embedding on one GPU: the mixed-manifold pair kernel + ONE kernel for everything else
+  const bool product_fused = nf > 1 && !s->comm && mm::product_step_fusable(s);
+  bool points_done = false;
+  bool scale_done[4] = {false, false, false, false};
   if (spd_fused && !s->comm) {
-    rc = mm::spd_fused_train_step(s, rb, re, true, static_cast<hipStream_t>(st), &scale_done);
+    rc = mm::spd_fused_train_step(s, rb, re, true, static_cast<hipStream_t>(st), &scale_done[0]);
     if (rc != MM_OK) return rc;
     points_done = true;
   } else if (vec_fused && !s->comm) {
-    rc = mm::vec_fused_train_step(s, rb, re, true, static_cast<hipStream_t>(st), &scale_done);
+    rc = mm::vec_fused_train_step(s, rb, re, true, static_cast<hipStream_t>(st), &scale_done[0]);
+    if (rc != MM_OK) return rc;
+    points_done = true;
+  } else if (product_fused) {
+    for (int k = 0; k < nf; ++k)
+      if (!s->scales[k].x) return MM_ERR_ARG;
+    rc = mm::product_fused_train_step(s, rb, re, static_cast<hipStream_t>(st), scale_done);
     if (rc != MM_OK) return rc;
     points_done = true;
   } else
@@ -147,11 +148,11 @@ extern "C" int mm_train_step_run(const mm_train_step* s, mm_stream_t st) {
   const void* vgrad[8];
   int nv = 0;
   if (spd_fused && s->comm) {
-    rc = mm::spd_fused_train_step(s, rb, re, false, static_cast<hipStream_t>(st), &scale_done);
+    rc = mm::spd_fused_train_step(s, rb, re, false, static_cast<hipStream_t>(st), &scale_done[0]);
     if (rc != MM_OK) return rc;
     points_done = true;
   } else if (vec_fused && s->comm) {
-    rc = mm::vec_fused_train_step(s, rb, re, false, static_cast<hipStream_t>(st), &scale_done);
+    rc = mm::vec_fused_train_step(s, rb, re, false, static_cast<hipStream_t>(st), &scale_done[0]);
     if (rc != MM_OK) return rc;
     points_done = true;
   }
@@ -168,7 +169,7 @@ extern "C" int mm_train_step_run(const mm_train_step* s, mm_stream_t st) {
   for (int k = 0; k < nf; ++k) {
     const mm_step_param& q = s->scales[k];
     if (!q.x || q.optimizer == MM_OPT_NONE) continue;   // a factor without a scale / a frozen one (burn-in): read, not stepped
-    if (k == 0 && scale_done) continue;                 // updated by the fused step kernel
+    if (scale_done[k]) continue;                        // updated by the fused step kernel
     vec[nv] = &q;
     vgrad[nv++] = static_cast<const char*>(s->loss_out) + size_t(1 + k) * esize(s->dtype);
   }
@@ -179,9 +180,8 @@ extern "C" int mm_train_step_run(const mm_train_step* s, mm_stream_t st) {
     const mm_step_param* grp[8];
     const void* gg[8];
     int cnt = 0;
-    const bool multi_ok = vec[a]->optimizer == MM_OPT_RADAM || vec[a]->momentum == 0.0;   // (no multi heavy-ball kernel)
     for (int b = a; b < nv && cnt < most; ++b)
-      if (!done[b] && (b == a || (multi_ok && same_rule(*vec[a], *vec[b])))) {
+      if (!done[b] && (b == a || same_rule(*vec[a], *vec[b]))) {
         grp[cnt] = vec[b]; gg[cnt++] = vgrad[b]; done[b] = true;
       }
     rc = vector_group_step(s->dtype, grp, gg, cnt, st);

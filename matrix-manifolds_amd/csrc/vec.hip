@@ -456,32 +456,40 @@ template <typename T> struct RsgdMulti {
   T* xnew[kRsgdMultiMax];
   int64_t cnt[kRsgdMultiMax];
   int m[kRsgdMultiMax], kind[kRsgdMultiMax];
+  // hyper-parameters per parameter: the points of a product embedding and its scales sit in different parameter groups
+  // (experiments/run_grid.py:29-32) and still leave in one launch
+  T lr[kRsgdMultiMax], max_grad_norm[kRsgdMultiMax];
+  int exact[kRsgdMultiMax];
 };
 template <typename T>
-__global__ void vec_rsgd_multi_kernel(RsgdMulti<T> a, T lr, T max_grad_norm, int exact) {
+__global__ void vec_rsgd_multi_kernel(RsgdMulti<T> a) {
   const int t = blockIdx.y;
   const int64_t p = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
   if (p >= a.cnt[t]) return;
   const int kind = a.kind[t];
+  const T lr = a.lr[t], max_grad_norm = a.max_grad_norm[t];
+  const int exact = a.exact[t];
   if (kind == MM_EUCLIDEAN) vec_rsgd_point<T, MM_EUCLIDEAN>(a.x[t], a.eg[t], p, a.m[t], lr, max_grad_norm, exact, a.xnew[t]);
   else if (kind == MM_LORENTZ) vec_rsgd_point<T, MM_LORENTZ>(a.x[t], a.eg[t], p, a.m[t], lr, max_grad_norm, exact, a.xnew[t]);
   else vec_rsgd_point<T, MM_SPHERE>(a.x[t], a.eg[t], p, a.m[t], lr, max_grad_norm, exact, a.xnew[t]);
 }
 
-// ... and the Adam update of several parameters (each with its own moments, step counter and ticket)
+// ... and the Adam update of several parameters (each with its own moments, step counter, ticket and hyper-parameters)
 template <typename T> struct RadamMulti {
   RsgdMulti<T> p;
   T* exp_avg[kRsgdMultiMax];
   T* exp_avg_sq[kRsgdMultiMax];
   double* step[kRsgdMultiMax];
   unsigned* ticket[kRsgdMultiMax];
+  T beta1[kRsgdMultiMax], beta2[kRsgdMultiMax], eps[kRsgdMultiMax];
+  int nc[kRsgdMultiMax];
 };
 template <typename T>
-__global__ void vec_radam_multi_kernel(RadamMulti<T> s, AdamArgs<T> a) {
+__global__ void vec_radam_multi_kernel(RadamMulti<T> s) {
   const int t = blockIdx.y;
   const int64_t p = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
-  a.step = s.step[t];
-  a.ticket = s.ticket[t];
+  const AdamArgs<T> a{s.p.lr[t], s.beta1[t], s.beta2[t], s.eps[t], s.p.max_grad_norm[t], s.nc[t], s.p.exact[t], s.step[t],
+                      s.ticket[t]};
   T beta2, alpha;
   adam_coeffs(a, beta2, alpha);
   if (p < s.p.cnt[t]) {
@@ -597,53 +605,44 @@ int vec_gram_loss(int dtype, int kind, int loss_kind, const void* x, const void*
                   int m, int64_t row_begin, int64_t row_end, double alpha, double eps, int terms, const double* loss_params, void* loss_out,
                   void* grad, void* slots, hipStream_t st);
 
+// One launch for `count` vector-space parameters that share an optimizer TYPE (vec_step.hpp, VecGroupParam): momentum-free
+// RSGD or Riemannian Adam, each parameter with its own hyper-parameters and state.
 template <typename T>
-int vec_radam_multi_t(int count, const int* kinds, const void* const* xs, const void* const* egrads,
-                      void* const* exp_avg, void* const* exp_avg_sq, double* const* steps, unsigned* const* tickets,
-                      const int64_t* cnts, const int* ms, double lr, double beta1, double beta2, int nc, double eps,
-                      double max_grad_norm, int exact, void* const* x_new, hipStream_t st) {
+int vec_group_step_t(int optimizer, int count, const VecGroupParam* ps, hipStream_t st) {
   RadamMulti<T> s{};
   int64_t most = 0;
   for (int t = 0; t < count; ++t) {
-    s.p.x[t] = static_cast<const T*>(xs[t]);
-    s.p.eg[t] = static_cast<const T*>(egrads[t]);
-    s.p.xnew[t] = static_cast<T*>(x_new[t]);
-    s.p.cnt[t] = cnts[t];
-    s.p.m[t] = ms[t];
-    s.p.kind[t] = kinds[t];
-    s.exp_avg[t] = static_cast<T*>(exp_avg[t]);
-    s.exp_avg_sq[t] = static_cast<T*>(exp_avg_sq[t]);
-    s.step[t] = steps[t];
-    s.ticket[t] = tickets[t];
-    most = cnts[t] > most ? cnts[t] : most;
+    const VecGroupParam& q = ps[t];
+    s.p.x[t] = static_cast<const T*>(q.x);
+    s.p.eg[t] = static_cast<const T*>(q.grad);
+    s.p.xnew[t] = static_cast<T*>(q.xnew);
+    s.p.cnt[t] = q.cnt;
+    s.p.m[t] = q.m;
+    s.p.kind[t] = q.kind;
+    s.p.lr[t] = T(q.lr);
+    s.p.max_grad_norm[t] = T(q.max_grad_norm);
+    s.p.exact[t] = q.exact;
+    s.exp_avg[t] = static_cast<T*>(q.state0);
+    s.exp_avg_sq[t] = static_cast<T*>(q.state1);
+    s.step[t] = q.step;
+    s.ticket[t] = q.ticket;
+    s.beta1[t] = T(q.beta1); s.beta2[t] = T(q.beta2); s.eps[t] = T(q.eps);
+    s.nc[t] = q.nc;
+    most = q.cnt > most ? q.cnt : most;
   }
   if (most == 0) return MM_OK;
-  AdamArgs<T> a{T(lr), T(beta1), T(beta2), T(eps), T(max_grad_norm), nc, exact, nullptr, nullptr};
-  vec_radam_multi_kernel<T><<<dim3(unsigned((most + 127) / 128), unsigned(count)), dim3(128), 0, st>>>(s, a);
+  const dim3 grid(unsigned((most + 127) / 128), unsigned(count)), block(128);
+  if (optimizer == MM_OPT_RADAM) vec_radam_multi_kernel<T><<<grid, block, 0, st>>>(s);
+  else vec_rsgd_multi_kernel<T><<<grid, block, 0, st>>>(s.p);
   MMV_CHECK();
   return MM_OK;
 }
 
-template <typename T>
-int vec_rsgd_multi_t(int count, const int* kinds, const void* const* xs, const void* const* egrads,
-                            const int64_t* cnts, const int* ms, double lr, double max_grad_norm, int exact,
-                            void* const* x_new, hipStream_t st) {
-  RsgdMulti<T> a{};
-  int64_t most = 0;
-  for (int t = 0; t < count; ++t) {
-    a.x[t] = static_cast<const T*>(xs[t]);
-    a.eg[t] = static_cast<const T*>(egrads[t]);
-    a.xnew[t] = static_cast<T*>(x_new[t]);
-    a.cnt[t] = cnts[t];
-    a.m[t] = ms[t];
-    a.kind[t] = kinds[t];
-    most = cnts[t] > most ? cnts[t] : most;
-  }
-  if (most == 0) return MM_OK;
-  vec_rsgd_multi_kernel<T><<<dim3(unsigned((most + 127) / 128), unsigned(count)), dim3(128), 0, st>>>(
-      a, T(lr), T(max_grad_norm), exact);
-  MMV_CHECK();
-  return MM_OK;
+int vec_group_step(int dtype, int optimizer, int count, const VecGroupParam* ps, hipStream_t st) {
+  if (count < 1 || count > kRsgdMultiMax || !ps) return MM_ERR_ARG;
+  if (dtype == MM_F32) return vec_group_step_t<float>(optimizer, count, ps, st);
+  if (dtype == MM_F64) return vec_group_step_t<double>(optimizer, count, ps, st);
+  return MM_ERR_ARG;
 }
 
 }  // namespace mm
@@ -807,14 +806,11 @@ int mm_vec_radam_step_multi(int dtype, int count, const int* kinds, const void* 
       return MM_ERR_ARG;
     if (ms[t] > kVecMaxDim) return MM_ERR_UNSUPPORTED;
   }
-  hipStream_t st = static_cast<hipStream_t>(stream);
-  if (dtype == MM_F32)
-    return vec_radam_multi_t<float>(count, kinds, xs, egrads, exp_avg, exp_avg_sq, steps, tickets, cnts, ms, lr, beta1,
-                                    beta2, nc, eps, max_grad_norm, exact, x_new, st);
-  if (dtype == MM_F64)
-    return vec_radam_multi_t<double>(count, kinds, xs, egrads, exp_avg, exp_avg_sq, steps, tickets, cnts, ms, lr,
-                                     beta1, beta2, nc, eps, max_grad_norm, exact, x_new, st);
-  return MM_ERR_ARG;
+  VecGroupParam ps[kRsgdMultiMax];
+  for (int t = 0; t < count; ++t)
+    ps[t] = VecGroupParam{kinds[t], ms[t], cnts[t], xs[t], egrads[t], x_new[t], exp_avg[t], exp_avg_sq[t], steps[t], tickets[t],
+                          lr, max_grad_norm, beta1, beta2, eps, nc, exact};
+  return vec_group_step(dtype, MM_OPT_RADAM, count, ps, static_cast<hipStream_t>(stream));
 }
 
 int mm_vec_rsgd_multi_max(void) { return kRsgdMultiMax; }
@@ -829,12 +825,11 @@ int mm_vec_rsgd_step_multi(int dtype, int count, const int* kinds, const void* c
     if (kinds[t] < MM_EUCLIDEAN || kinds[t] > MM_SPHERE) return MM_ERR_ARG;
     if (ms[t] > kVecMaxDim) return MM_ERR_UNSUPPORTED;
   }
-  hipStream_t st = static_cast<hipStream_t>(stream);
-  if (dtype == MM_F32)
-    return vec_rsgd_multi_t<float>(count, kinds, xs, egrads, cnts, ms, lr, max_grad_norm, exact, x_new, st);
-  if (dtype == MM_F64)
-    return vec_rsgd_multi_t<double>(count, kinds, xs, egrads, cnts, ms, lr, max_grad_norm, exact, x_new, st);
-  return MM_ERR_ARG;
+  VecGroupParam ps[kRsgdMultiMax];
+  for (int t = 0; t < count; ++t)
+    ps[t] = VecGroupParam{kinds[t], ms[t], cnts[t], xs[t], egrads[t], x_new[t], nullptr, nullptr, nullptr, nullptr,
+                          lr, max_grad_norm, 0.0, 0.0, 0.0, 0, exact};
+  return vec_group_step(dtype, MM_OPT_RSGD, count, ps, static_cast<hipStream_t>(stream));
 }
 
 }  // extern "C"

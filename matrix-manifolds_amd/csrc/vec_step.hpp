@@ -22,4 +22,16 @@ bool vec_step_fusable(const mm_train_step* s);
 //   (+ the scale's, as above, from loss_out[1]).
 int vec_fused_train_step(const mm_train_step* s, int64_t rb, int64_t re, bool with_objective, hipStream_t st, bool* scale_stepped);
 
+// One launch for several vector-space parameters (points of vector factors, scales) that share an optimizer TYPE — the
+// momentum-free RSGD or Riemannian Adam — each with its own hyper-parameters and state (vec.hip, vec_*_multi_kernel).
+struct VecGroupParam {
+  int kind, m;
+  int64_t cnt;
+  const void* x; const void* grad; void* xnew;
+  void* state0; void* state1; double* step; unsigned* ticket;     // Adam: exp_avg, exp_avg_sq, step counter, ticket
+  double lr, max_grad_norm, beta1, beta2, eps;
+  int nc, exact;
+};
+int vec_group_step(int dtype, int optimizer, int count, const VecGroupParam* ps, hipStream_t st);
+
 }  // namespace mm

@@ -286,3 +286,68 @@ def test_vector_step_outside_the_fused_range_is_unfused():
     assert step._desc.ws_flags == 0
     _close(la, lb, torch.float32, 'losses')
     _close(emb_a.xs[0].detach().cpu().numpy(), emb_b.xs[0].detach().cpu().numpy(), torch.float32, 'points')
+
+
+# ---- product embeddings (csrc/product_pairs.hip, product_step_kernel; product_step.hpp) ----------------------------------------
+def _product_setup(spec, n, dt, spread=0.3):
+    from graphembed import manifolds as M
+    from graphembed.modules import ManifoldEmbedding
+    torch.set_default_dtype(dt)
+    try:
+        torch.manual_seed(11)
+        with torch.device('cuda'):
+            mans = [M.SymmetricPositiveDefinite(d) if name == 'SPD' else getattr(M, name)(d) for name, d in spec]
+            emb = ManifoldEmbedding(n, mans)
+            with torch.no_grad():
+                emb.perturb(spread)
+            target = torch.rand(n * (n - 1) // 2) * 0.9 + 0.05
+    finally:
+        torch.set_default_dtype(torch.float32)
+    return emb, target
+
+
+@pytest.mark.parametrize('spec,n', [((('Lorentz', 6), ('Sphere', 6), ('SPD', 2)), 131),      # BASELINE config 4's product
+                                    ((('Euclidean', 5), ('SPD', 3)), 77),
+                                    ((('Lorentz', 4), ('Euclidean', 16), ('Sphere', 3)), 150),
+                                    ((('Sphere', 6), ('SPD', 2)), 3)])                       # fewer points than loss blocks
+@pytest.mark.parametrize('rule,scale_rule', [('rsgd', 'rsgd'), ('rsgd_retr', 'rsgd_noclip'), ('momentum', 'rsgd'),
+                                             ('adam', 'adam'), ('adam_nc', 'momentum'), ('rsgd', 'adam')])
+@pytest.mark.parametrize('dt', [torch.float32, torch.float64], ids=['f32', 'f64'])
+def test_fused_product_step_matches_the_eager_loop(spec, n, rule, scale_rule, dt):
+    """Mixed-manifold pair kernel + ONE kernel (gradients, loss record, every factor's optimizer rule, RSGD scales) against
+    the eager loop on the same classes; the launches are counted through the library's own profiling hooks only
+    indirectly — what is asserted here is the arithmetic: losses, parameters, optimizer state, the gradients left behind."""
+    from graphembed.native_step import NativeTrainStep
+    from graphembed.objectives import QuotientLoss, StressLoss
+    epochs = 6
+    emb_a, target = _product_setup(spec, n, dt)
+    emb_b = copy.deepcopy(emb_a)
+    fn = QuotientLoss() if 'adam' in rule else StressLoss()
+    oa = _opts(emb_a, rule, scale_rule)
+    la = _eager(emb_a, fn, target, oa, epochs)
+    ob = _opts(emb_b, rule, scale_rule)
+    step = NativeTrainStep(emb_b, fn, target, ob)
+    lb = [step(epoch=epoch, alpha=1.0).item() for epoch in range(epochs)]
+    _close(la, lb, dt, 'losses')
+    for a, b in zip(list(emb_a.xs) + list(emb_a.scales), list(emb_b.xs) + list(emb_b.scales)):
+        _close(a.detach().cpu().numpy(), b.detach().cpu().numpy(), dt, 'parameters')
+    for xa, xb in zip(emb_a.xs, emb_b.xs):      # optimizer state of every factor advanced alike
+        sa, sb = oa[0].state[xa], ob[0].state[xb]
+        for key in ('momentum_buffer', 'exp_avg', 'exp_avg_sq'):
+            if key in sa:
+                # (relative to the buffer's largest entry: small entries of an fp32 accumulation carry its rounding)
+                ref = sa[key].abs().max().item()
+                assert (sa[key] - sb[key]).abs().max().item() <= (2e-4 if dt == torch.float32 else 1e-9) * ref, key
+        if 'step' in sa:
+            assert float(sa['step']) == float(sb['step']) == epochs + 1
+    # the gradients left behind: those of the last step's loss at the parameters before its update
+    emb_c, _ = _product_setup(spec, n, dt)
+    _eager(emb_c, fn, target, _opts(emb_c, rule, scale_rule), epochs - 1)
+    loss = emb_c.fused_objective(fn, target, None, epoch=epochs - 1, alpha=1.0)
+    gs = torch.autograd.grad(loss, list(emb_c.xs) + list(emb_c.scales))
+    for i, (g, p) in enumerate(zip(gs, list(emb_b.xs) + list(emb_b.scales))):
+        scale = max(g.abs().max().item(), 1e-30)
+        # (a scale's gradient is one fp32 sum over all pairs of terms of both signs: 2e-3, as in test_vec_gpu.py)
+        tol = (2e-3 if i >= len(emb_b.xs) else 5e-5) if dt == torch.float32 else 1e-9
+        assert (g - p.grad.view_as(g)).abs().max().item() <= tol * scale, (i, g, p.grad)
+    assert not step.ws[64:].any()              # the workspace is left clean (MM_WS_CLEAN)

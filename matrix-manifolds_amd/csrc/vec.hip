@@ -23,6 +23,7 @@
 #include "loss.hpp"
 #include "vecfn.hpp"
 #include "vec_step.hpp"
+#include "vec_rules.hpp"
 #include "spd_ws.hpp"
 #include "adam.hpp"
 
@@ -449,6 +450,15 @@ __global__ void vec_radam_step_kernel(const T* x, const T* __restrict__ eg, T* e
 // The same update for several parameters of one optimizer group in ONE launch (blockIdx.y = parameter):
 // the points of the vector factors of a product embedding, or its scale parameters — updates that are a
 // microsecond of work behind ~3 us of launch each.
+template <typename T, int KIND, int RULE>
+__device__ __forceinline__ void multi_point_padded(const T* x, const T* eg, T* xnew, int64_t p, int m, const VecRuleArgs<T>& R,
+                                                   T beta2, T alpha) {
+  T xp[16], g[16], o[16];
+  load_padded<T, 16>(x, p, m, xp);
+  load_padded<T, 16>(eg, p, m, g);
+  pad_rule_point<T, KIND, 16, RULE>(xp, g, p, m, true, R, beta2, alpha, o);
+  store_row<T, 16>(xnew, p, m, o);
+}
 constexpr int kRsgdMultiMax = 8;
 template <typename T> struct RsgdMulti {
   const T* x[kRsgdMultiMax];
@@ -469,6 +479,13 @@ __global__ void vec_rsgd_multi_kernel(RsgdMulti<T> a) {
   const int kind = a.kind[t];
   const T lr = a.lr[t], max_grad_norm = a.max_grad_norm[t];
   const int exact = a.exact[t];
+  if (a.m[t] <= 16) {   // the register-resident form (vec_rules.hpp; the arithmetic of vec_step.hip's kernels)
+    const VecRuleArgs<T> R{lr, T(0), T(0), max_grad_norm, exact, nullptr, nullptr, AdamArgs<T>{}};
+    if (kind == MM_EUCLIDEAN) multi_point_padded<T, MM_EUCLIDEAN, VRULE_RSGD>(a.x[t], a.eg[t], a.xnew[t], p, a.m[t], R, T(0), T(0));
+    else if (kind == MM_LORENTZ) multi_point_padded<T, MM_LORENTZ, VRULE_RSGD>(a.x[t], a.eg[t], a.xnew[t], p, a.m[t], R, T(0), T(0));
+    else multi_point_padded<T, MM_SPHERE, VRULE_RSGD>(a.x[t], a.eg[t], a.xnew[t], p, a.m[t], R, T(0), T(0));
+    return;
+  }
   if (kind == MM_EUCLIDEAN) vec_rsgd_point<T, MM_EUCLIDEAN>(a.x[t], a.eg[t], p, a.m[t], lr, max_grad_norm, exact, a.xnew[t]);
   else if (kind == MM_LORENTZ) vec_rsgd_point<T, MM_LORENTZ>(a.x[t], a.eg[t], p, a.m[t], lr, max_grad_norm, exact, a.xnew[t]);
   else vec_rsgd_point<T, MM_SPHERE>(a.x[t], a.eg[t], p, a.m[t], lr, max_grad_norm, exact, a.xnew[t]);
@@ -492,7 +509,13 @@ __global__ void vec_radam_multi_kernel(RadamMulti<T> s) {
                       s.ticket[t]};
   T beta2, alpha;
   adam_coeffs(a, beta2, alpha);
-  if (p < s.p.cnt[t]) {
+  if (p < s.p.cnt[t] && s.p.m[t] <= 16) {   // the register-resident form (vec_rules.hpp)
+    const int kind = s.p.kind[t], m = s.p.m[t];
+    const VecRuleArgs<T> R{a.lr, T(0), T(0), a.max_grad_norm, a.exact, s.exp_avg[t], s.exp_avg_sq[t], a};
+    if (kind == MM_EUCLIDEAN) multi_point_padded<T, MM_EUCLIDEAN, VRULE_ADAM>(s.p.x[t], s.p.eg[t], s.p.xnew[t], p, m, R, beta2, alpha);
+    else if (kind == MM_LORENTZ) multi_point_padded<T, MM_LORENTZ, VRULE_ADAM>(s.p.x[t], s.p.eg[t], s.p.xnew[t], p, m, R, beta2, alpha);
+    else multi_point_padded<T, MM_SPHERE, VRULE_ADAM>(s.p.x[t], s.p.eg[t], s.p.xnew[t], p, m, R, beta2, alpha);
+  } else if (p < s.p.cnt[t]) {
     const int kind = s.p.kind[t], m = s.p.m[t];
     if (kind == MM_EUCLIDEAN)
       vec_radam_point<T, MM_EUCLIDEAN>(s.p.x[t], s.p.eg[t], s.exp_avg[t], s.exp_avg_sq[t], p, m, a, beta2, alpha, s.p.xnew[t]);
@@ -753,6 +776,11 @@ int mm_vec_rsgd_step(int dtype, int kind, const void* x, const void* egrad, int6
   if (m > kVecMaxDim) return MM_ERR_UNSUPPORTED;
   if (cnt == 0) return MM_OK;
   hipStream_t st = static_cast<hipStream_t>(stream);
+  {   // m <= 16: the register-resident form (vec_step.hip)
+    const int rc = vec_rule_step(dtype, kind, MM_OPT_RSGD, x, egrad, x_new, cnt, m, lr, 0.0, 0.0, max_grad_norm, exact, nullptr,
+                                 nullptr, 0.0, 0.0, 0.0, 0, nullptr, nullptr, st);
+    if (rc != MM_ERR_UNSUPPORTED) return rc;
+  }
   const unsigned nb = unsigned((cnt + 127) / 128);
   MMV_DISPATCH_T(dtype, MMV_DISPATCH_KIND(kind, {
     vec_rsgd_step_kernel<T, KIND><<<dim3(nb), dim3(128), 0, st>>>(static_cast<const T*>(x),
@@ -767,6 +795,11 @@ int mm_vec_rsgd_momentum_step(int dtype, int kind, const void* x, const void* eg
   if (m > kVecMaxDim) return MM_ERR_UNSUPPORTED;
   if (cnt == 0) return MM_OK;
   hipStream_t st = static_cast<hipStream_t>(stream);
+  if (momentum != 0.0) {   // m <= 16: the register-resident form (vec_step.hip)
+    const int rc = vec_rule_step(dtype, kind, MM_OPT_RSGD, x, egrad, x_new, cnt, m, lr, momentum, dampening, max_grad_norm, exact,
+                                 momentum_buffer, nullptr, 0.0, 0.0, 0.0, 0, nullptr, nullptr, st);
+    if (rc != MM_ERR_UNSUPPORTED) return rc;
+  }
   const unsigned nb = unsigned((cnt + 127) / 128);
   MMV_DISPATCH_T(dtype, MMV_DISPATCH_KIND(kind, {
     vec_rsgd_momentum_kernel<T, KIND><<<dim3(nb), dim3(128), 0, st>>>(static_cast<const T*>(x),
@@ -783,6 +816,11 @@ int mm_vec_radam_step(int dtype, int kind, const void* x, const void* egrad, voi
   if (m > kVecMaxDim) return MM_ERR_UNSUPPORTED;
   if (cnt == 0) return MM_OK;
   hipStream_t st = static_cast<hipStream_t>(stream);
+  {   // m <= 16: the register-resident form (vec_step.hip)
+    const int rc = vec_rule_step(dtype, kind, MM_OPT_RADAM, x, egrad, x_new, cnt, m, lr, 0.0, 0.0, max_grad_norm, exact, exp_avg,
+                                 exp_avg_sq, beta1, beta2, eps, nc, step, ticket, st);
+    if (rc != MM_ERR_UNSUPPORTED) return rc;
+  }
   const unsigned nb = unsigned((cnt + 127) / 128);
   MMV_DISPATCH_T(dtype, MMV_DISPATCH_KIND(kind, {
     AdamArgs<T> a{T(lr), T(beta1), T(beta2), T(eps), T(max_grad_norm), nc, exact, step, ticket};

@@ -26,7 +26,7 @@ namespace mm {
 namespace {
 
 template <typename T> struct VecStep {
-  T* x; int n, m;
+  const T* x; T* xnew; int n, m;                 // (xnew == x: in place — every thread reads its whole point before it writes it)
   T* acc;                                        // gradient source: the workspace sums (cleared here); null: `grad` is final
   T* grad;
   T* slots; const T* scale_raw; T* loss_out;     // the loss record, closed by block 0 (slots null: already closed)
@@ -81,7 +81,7 @@ __global__ __launch_bounds__(128) void vec_fused_step_kernel(VecStep<T> a) {
   }
   pad_rule_point<T, KIND, MP, RULE>(xp, g, p, m, in, a.rule, beta2, alpha, o);
   if (in) {
-    store_row<T, MP>(a.x, p, m, o);
+    store_row<T, MP>(a.xnew, p, m, o);
     if (a.xpad) {
 #pragma unroll
       for (int k = 0; k < MP; ++k) a.xpad[p * MP + k] = o[k];   // (the padding of o is zero)
@@ -132,7 +132,7 @@ int vec_fused_step_t(const mm_train_step* s, int64_t rb, int64_t re, bool with_o
     if (rc != MM_OK) return rc;
   }
   const bool fuse_scale = q.x && q.optimizer == MM_OPT_RSGD && q.momentum == 0.0;
-  VecStep<T> a{static_cast<T*>(p.x), int(n), m,
+  VecStep<T> a{static_cast<const T*>(p.x), static_cast<T*>(p.x), int(n), m,
                with_objective ? ws.acc : static_cast<T*>(nullptr), static_cast<T*>(p.grad),
                with_objective ? ws.slots : static_cast<T*>(nullptr), static_cast<const T*>(q.x), static_cast<T*>(s->loss_out),
                fuse_scale ? static_cast<T*>(q.x) : static_cast<T*>(nullptr), T(q.lr), T(q.max_grad_norm),
@@ -151,6 +151,30 @@ int vec_fused_step_t(const mm_train_step* s, int64_t rb, int64_t re, bool with_o
 }
 
 }  // namespace
+
+// The per-parameter optimizer kernels (mm_vec_rsgd_step, ...) for m <= 16: the same kernel without a gradient source, a loss
+// record or a padded copy.
+int vec_rule_step(int dtype, int kind, int optimizer, const void* x, const void* grad, void* xnew, int64_t cnt, int m,
+                  double lr, double momentum, double dampening, double max_grad_norm, int exact, void* state0, void* state1,
+                  double beta1, double beta2, double eps, int nc, double* step, unsigned* ticket, hipStream_t st) {
+  static const bool off = [] { const char* e = std::getenv("MM_VEC_RULE_GENERIC"); return e && e[0] == '1'; }();
+  if (off || m > 16 || cnt >= (int64_t(1) << 31) || kind < MM_EUCLIDEAN || kind > MM_SPHERE) return MM_ERR_UNSUPPORTED;
+  const int rule = optimizer == MM_OPT_RADAM ? VRULE_ADAM : (momentum != 0.0 ? VRULE_MOMENTUM : VRULE_RSGD);
+  auto run = [&](auto tag) {
+    using T = decltype(tag);
+    VecStep<T> a{static_cast<const T*>(x), static_cast<T*>(xnew), int(cnt), m, nullptr, const_cast<T*>(static_cast<const T*>(grad)),
+                 nullptr, nullptr, nullptr, nullptr, T(0), T(0), nullptr,
+                 VecRuleArgs<T>{T(lr), T(momentum), T(dampening), T(max_grad_norm), exact, static_cast<T*>(state0),
+                                static_cast<T*>(state1),
+                                AdamArgs<T>{T(lr), T(beta1), T(beta2), T(eps), T(max_grad_norm), nc, exact, step, ticket}}};
+    if (kind == MM_EUCLIDEAN) return launch_pad<T, MM_EUCLIDEAN>(a, rule, st);
+    if (kind == MM_LORENTZ) return launch_pad<T, MM_LORENTZ>(a, rule, st);
+    return launch_pad<T, MM_SPHERE>(a, rule, st);
+  };
+  if (dtype == MM_F32) return run(float{});
+  if (dtype == MM_F64) return run(double{});
+  return MM_ERR_ARG;
+}
 
 bool vec_fused_step_supports(int dtype, int kind, int m) {
   static const bool off = [] { const char* e = std::getenv("MM_VEC_STEP_UNFUSED"); return e && e[0] == '1'; }();

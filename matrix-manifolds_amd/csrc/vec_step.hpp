@@ -22,6 +22,12 @@ bool vec_step_fusable(const mm_train_step* s);
 //   (+ the scale's, as above, from loss_out[1]).
 int vec_fused_train_step(const mm_train_step* s, int64_t rb, int64_t re, bool with_objective, hipStream_t st, bool* scale_stepped);
 
+// The per-parameter optimizer rules (mm_vec_rsgd_step / _momentum_step / mm_vec_radam_step) on a register-resident padded
+// point: m <= 16; MM_ERR_UNSUPPORTED otherwise (the caller then takes vec.hip's run-time-m kernels).
+int vec_rule_step(int dtype, int kind, int optimizer, const void* x, const void* grad, void* xnew, int64_t cnt, int m,
+                  double lr, double momentum, double dampening, double max_grad_norm, int exact, void* state0, void* state1,
+                  double beta1, double beta2, double eps, int nc, double* step, unsigned* ticket, hipStream_t st);
+
 // One launch for several vector-space parameters (points of vector factors, scales) that share an optimizer TYPE — the
 // momentum-free RSGD or Riemannian Adam — each with its own hyper-parameters and state (vec.hip, vec_*_multi_kernel).
 struct VecGroupParam {

@@ -755,7 +755,7 @@ def worker(args):
             torch.cuda.empty_cache()
         if world == 1 and n == N_NODES:
             from graphembed import manifolds as M
-            # BASELINE configs 2 and 1 (pdist fwd + bwd on vector manifolds; Gram kernels on the matrix cores for Lorentz)
+            # BASELINE configs 2 and 1 (pdist fwd + bwd on vector manifolds; Lorentz: Gram forward on the matrix cores, symmetric VALU backward)
             for name, kind, m, nn, dt in (('BASELINE config 2: facebook-class graph n=4039 -> Lorentz H^10 (11 coords) f32', 'lorentz', 11, 4039, torch.float32),
                                           ('BASELINE config 2 in f64 (the dtype run.py:32-35 sets)', 'lorentz', 11, 4039, torch.float64),
                                           ('BASELINE config 1: tree40 n=40 -> Euclidean R^10 f64 (plumbing: launch-bound)', 'euclidean', 10, 40, torch.float64)):
@@ -790,10 +790,10 @@ def worker(args):
             for name, mans, nn, dt, loss in (
                     ('BASELINE config 3 training step: SPD(3) n=5000 f32, StressLoss + RSGD (2 launches: pair kernel, fused finalize+update+tables)',
                      lambda: [M.SymmetricPositiveDefinite(3)], N_NODES, torch.float32, 'stress'),
-                    ('BASELINE config 4 training step: csphd n=1025 -> H^5 x S^5 x SPD(2) f32, StressLoss + RSGD (mixed-manifold pair kernel)',
+                    ('BASELINE config 4 training step: csphd n=1025 -> H^5 x S^5 x SPD(2) f32, StressLoss + RSGD (2 launches: mixed-manifold pair kernel, fused gradients+updates)',
                      lambda: [M.Lorentz(6), M.Sphere(6), M.SymmetricPositiveDefinite(2)], 1025, torch.float32, 'stress'),
                     ('BASELINE config 4 training step in f64', lambda: [M.Lorentz(6), M.Sphere(6), M.SymmetricPositiveDefinite(2)], 1025, torch.float64, 'stress'),
-                    ('BASELINE config 2 training step: Lorentz(11) n=4039 f32, StressLoss + RSGD', lambda: [M.Lorentz(11)], 4039, torch.float32, 'stress'),
+                    ('BASELINE config 2 training step: Lorentz(11) n=4039 f32, StressLoss + RSGD (2 launches: symmetric pair kernel, fused gradient+update)', lambda: [M.Lorentz(11)], 4039, torch.float32, 'stress'),
                     ('BASELINE config 5 training step: SPD(4) n=16384 f32, QuotientLoss + RSGD', lambda: [M.SymmetricPositiveDefinite(4)], 16384, torch.float32, 'quotient')):
                 w = TrainStepWorkload(mans(), nn, dt, dev, loss=loss)
                 el, md, ph = time_workload(w, kbase, w2, fence, use_graph, False, rank, tag=name + ': ', warm_seconds=0.05, min_timed_seconds=0.02)

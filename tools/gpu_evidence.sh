@@ -23,7 +23,7 @@ rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_BUSY_CYCL
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/bench_pmc_fetch -o p -- $P > /dev/null 2>&1
 rocprofv3 --pmc WRITE_SIZE TCC_EA0_ATOMIC_sum GRBM_GUI_ACTIVE --output-format csv -d $OUT/bench_pmc_write -o p -- $P > /dev/null 2>&1
 C="python3 /root/repo/tools/profile_case.py"
-for CASE in "pdist 3 5000 f64 0.1" "pdist 3 5000 f32 0.35" "pdist 3 5000 f64 0.35" "pdist 4 2274 f32 0.1" "pdist 4 16384 f32 0.1" "pdist 4 16384 f32 0.35" "loss 4 16384 f32" "vec 11 4039 f32 lorentz" "pdist 6 2000 f32 0.1" "pdist 9 2000 f32 0.1" "step 3 5000 f32"; do
+for CASE in "pdist 3 5000 f64 0.1" "pdist 3 5000 f32 0.35" "pdist 3 5000 f64 0.35" "pdist 4 2274 f32 0.1" "pdist 4 16384 f32 0.1" "pdist 4 16384 f32 0.35" "loss 4 16384 f32" "vec 11 4039 f32 lorentz" "pdist 6 2000 f32 0.1" "pdist 9 2000 f32 0.1" "step 3 5000 f32" "vstep 11 4039 f32 lorentz"; do
   NAME=$(echo $CASE | tr ' .' '__')
   rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/case_${NAME}_stats -o s -- $C $CASE 40 > /dev/null 2>&1
 done
@@ -33,8 +33,15 @@ for CASE in "pdist 3 5000 f32 0.35" "pdist 4 16384 f32 0.1" "loss 4 16384 f32" "
   rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/case_${NAME}_pmc_fetch -o p -- $C $CASE 3 > /dev/null 2>&1
   rocprofv3 --pmc WRITE_SIZE TCC_EA0_ATOMIC_sum --output-format csv -d $OUT/case_${NAME}_pmc_write -o p -- $C $CASE 3 > /dev/null 2>&1
 done
-# matrix-core utilisation of the Gram kernels (north_star: "MFMA utilisation against gfx950 peak")
+# matrix-core utilisation of the Gram kernels (north_star: "MFMA utilisation against gfx950 peak"): the forward is the default
+# path; the matrix-core backward is forced (the default backward up to m = 16 is the symmetric VALU kernel)
 rocprofv3 --pmc SQ_INSTS_VALU_MFMA_F32 SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_WAVE_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $OUT/case_vec_11_4039_f32_lorentz_pmc_mfma -o p -- $C vec 11 4039 f32 lorentz 3 > /dev/null 2>&1
+export MM_VEC_BWD=gram
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/case_vecgram_11_4039_f32_lorentz_stats -o s -- $C vec 11 4039 f32 lorentz 40 > /dev/null 2>&1
+rocprofv3 --pmc SQ_INSTS_VALU_MFMA_F32 SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_WAVE_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $OUT/case_vecgram_11_4039_f32_lorentz_pmc_mfma -o p -- $C vec 11 4039 f32 lorentz 3 > /dev/null 2>&1
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/case_vecgram_11_4039_f32_lorentz_pmc_fetch -o p -- $C vec 11 4039 f32 lorentz 3 > /dev/null 2>&1
+rocprofv3 --pmc WRITE_SIZE TCC_EA0_ATOMIC_sum --output-format csv -d $OUT/case_vecgram_11_4039_f32_lorentz_pmc_write -o p -- $C vec 11 4039 f32 lorentz 3 > /dev/null 2>&1
+unset MM_VEC_BWD
 # the mixed-manifold pair kernel (config 4) at csphd size and at n = 5000
 for N in 1025 5000; do
   rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/case_product_${N}_stats -o s -- $C product $N f32 40 > /dev/null 2>&1

@@ -44,7 +44,9 @@ CASES = {'bench': ('SPD(3) f32 n=5000 reference init (headline; python3 bench.py
          'case_pdist_6_2000_f32_0_1': ('SPD(6) f32 n=2000 pdist fwd + bwd (Jacobi path)', 6, 2000, 4),
          'case_pdist_9_2000_f32_0_1': ('SPD(9) f32 n=2000 pdist fwd + bwd (Jacobi path, the reference\'s largest test size)', 9, 2000, 4),
          'case_step_3_5000_f32': ('SPD(3) f32 n=5000 full training step through mm_train_step_run (pair kernel + fused finalize/update/tables)', 3, 5000, 4),
-         'case_vec_11_4039_f32_lorentz': ('Lorentz(11) f32 n=4039 (BASELINE config 2) pdist fwd + bwd', 11, 4039, 4),
+         'case_vec_11_4039_f32_lorentz': ('Lorentz(11) f32 n=4039 (BASELINE config 2) pdist fwd + bwd (default: matrix-core forward, symmetric VALU backward)', 11, 4039, 4),
+         'case_vecgram_11_4039_f32_lorentz': ('Lorentz(11) f32 n=4039 pdist fwd + bwd with MM_VEC_BWD=gram (matrix-core backward)', 11, 4039, 4),
+         'case_vstep_11_4039_f32_lorentz': ('Lorentz(11) f32 n=4039 (BASELINE config 2) full training step through mm_train_step_run (pair kernel + one per-point kernel)', 11, 4039, 4),
          'case_product_1025': ('BASELINE config 4: H^5 x S^5 x SPD(2) f32 n=1025 training step (mixed-manifold pair kernel)', 2, 1025, 4),
          'case_product_5000': ('H^5 x S^5 x SPD(2) f32 n=5000 training step (mixed-manifold pair kernel)', 2, 5000, 4)}
 for key, (title, d, n, esz) in CASES.items():
@@ -58,7 +60,7 @@ for key, (title, d, n, esz) in CASES.items():
     for name, (calls, avg, mn, mx) in sorted(st.items(), key=lambda kv: -kv[1][1]):
         line = f'  {name[:58]:58s} calls {calls:3d}  avg {avg:8.1f} us  (min {mn:.1f}, max {mx:.1f})'
         c = pm.get(name, {})
-        if 'vec_gram' in name:   # matrix-core Gram kernels: d is the vector dimension
+        if 'vec_gram' in name or 'vec_pdist_bwd_sym' in name:   # vector-manifold pair kernels: d is the vector dimension
             alg = pairs * esz + n * d * esz * 2
             line += f'  | algorithmic {alg / 1e6:.1f} MB -> {alg / avg / 1e3:.0f} GB/s = {alg / avg / 1e3 / HBM:.3f} of HBM peak'
             if 'FETCH_SIZE' in c and 'WRITE_SIZE' in c:
@@ -72,7 +74,11 @@ for key, (title, d, n, esz) in CASES.items():
                 line += (f"; MFMA: {c.get('SQ_INSTS_VALU_MFMA_F32', 0):.0f} instructions, pipe busy {util:.1%} of the kernel's cycles "
                          f"({c['SQ_VALU_MFMA_BUSY_CYCLES'] / max(c.get('SQ_INSTS_VALU_MFMA_F32', 1), 1):.0f} cycles each), "
                          f"{tf:.1f} TFLOP/s = {tf / 157.3:.1%} of the 157.3 TFLOP/s fp32 matrix peak")
-        elif 'product_pair' in name:
+            if 'sym' in name and 'SQ_INSTS_VALU' in c:
+                line += f'; VALU {c["SQ_INSTS_VALU"] / (pairs / 64):.0f} / all {c.get("SQ_ACTIVE_INST_ANY", 0) / (pairs / 64):.0f} instructions per 64 pairs'
+                if c.get('SQ_WAVE_CYCLES'):
+                    line += f'; wait {c.get("SQ_WAIT_ANY", 0) / c["SQ_WAVE_CYCLES"]:.0%} issue-wait {c.get("SQ_WAIT_INST_ANY", 0) / c["SQ_WAVE_CYCLES"]:.0%} of wave cycles'
+        elif 'product_pair_kernel' in name:
             alg = pairs * esz
             line += f'  | algorithmic {alg / 1e6:.1f} MB (4 B target per pair) -> {alg / avg / 1e3:.0f} GB/s = {alg / avg / 1e3 / HBM:.4f} of HBM peak'
             if 'FETCH_SIZE' in c and 'WRITE_SIZE' in c:

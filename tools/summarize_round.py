@@ -18,7 +18,7 @@ def stats(d):
     for f in glob.glob(os.path.join(d, '**', '*kernel_stats.csv'), recursive=True):
         for r in csv.DictReader(open(f)):
             if 'mm::' in r['Name']:
-                out[r['Name'].split('(')[0].replace('void mm::', '')] = (int(r['Calls']), float(r['AverageNs']) / 1e3,
+                out[r['Name'].replace('(anonymous namespace)::', '').split('(')[0].replace('void mm::', '')] = (int(r['Calls']), float(r['AverageNs']) / 1e3,
                                                                           float(r['MinNs']) / 1e3, float(r['MaxNs']) / 1e3)
     return out
 
@@ -29,7 +29,7 @@ def pmc(dirs):
         for f in glob.glob(os.path.join(d, '**', '*counter_collection.csv'), recursive=True):
             for r in csv.DictReader(open(f)):
                 if 'mm::' in r['Kernel_Name']:
-                    acc[r['Kernel_Name'].split('(')[0].replace('void mm::', '')][r['Counter_Name']].append(float(r['Counter_Value']))
+                    acc[r['Kernel_Name'].replace('(anonymous namespace)::', '').split('(')[0].replace('void mm::', '')][r['Counter_Name']].append(float(r['Counter_Value']))
     return {k: {c: sum(v) / len(v) for c, v in cs.items()} for k, cs in acc.items()}
 
 
@@ -66,7 +66,7 @@ for key, (title, d, n, esz) in CASES.items():
             if 'FETCH_SIZE' in c and 'WRITE_SIZE' in c:
                 tr = (2 * c['FETCH_SIZE'] + c['WRITE_SIZE']) * 1024
                 line += f'; traffic {tr / 1e6:.1f} MB (2 x FETCH {2 * c["FETCH_SIZE"] * 1024 / 1e6:.1f} + WRITE {c["WRITE_SIZE"] * 1024 / 1e6:.1f}) = {tr / alg:.2f} x algorithmic'
-            if 'SQ_VALU_MFMA_BUSY_CYCLES' in c:
+            if c.get('SQ_INSTS_VALU_MFMA_F32', 0) > 0 and 'SQ_VALU_MFMA_BUSY_CYCLES' in c:
                 # matrix-core utilisation: cycles the MFMA pipe of a SIMD is busy, summed over the 1024 SIMDs, against the
                 # kernel's duration at the warm shader clock (2.38 GHz, in-kernel stamps: profiles/r03_timeline_warm.txt)
                 util = c['SQ_VALU_MFMA_BUSY_CYCLES'] / 1024 / (avg * WARM_GHZ * 1e3)

@@ -46,12 +46,13 @@ __device__ __forceinline__ T loss_term(T m, T target, const LossArgs<T>& la, T& 
     T l = T(0);
     dldm = T(0);
     if (la.terms & 1) {
-      const T inv = T(1) / ag, q = m * inv - T(1);
+      // (Num<T>::rcp: v_rcp_f32, 1 ulp, in fp32 — an IEEE division is ten instructions per pair; 1 / x in fp64)
+      const T inv = Num<T>::rcp(ag), q = m * inv - T(1);
       l += Num<T>::abs(q);
       dldm += sign_of(q) * inv;
     }
     if (la.terms & 2) {
-      const T inv = T(1) / (m + la.eps), q = ag * inv - T(1);
+      const T inv = Num<T>::rcp(m + la.eps), q = ag * inv - T(1);
       l += Num<T>::abs(q);
       dldm -= sign_of(q) * ag * inv * inv;
     }

@@ -13,12 +13,11 @@
 // Lorentz / sphere: both sides are flushed straight into the gradient (contiguous ranges, sign pattern on the way): two
 // launches per backward — preparation and pair kernel.  Euclidean: both sides land in the structure-of-arrays accumulators
 // acc[k][node] that the ordered-pair kernel of vec.hip fills, and vec_pdist_finalize_kernel applies 2 (x sum w - .).
-// Measured (MI355X, profiles/r03_experiments.md §11): Lorentz(11) n = 4039 fp32 34.0 us against 31.3 us for the matrix-core
-// backward (vec_gram.hip) — 299 instructions per 128 pairs (183 vector, 76 scalar: the shares of a 4039-node launch are
-// ~50 rows per workgroup, so the walk's set-up is not amortised) at ~50 % of the issue rate — plus a preparation and a
-// finalize launch that the matrix-core kernel does not need: NOT the default for fp32 Lorentz / sphere.  It is the default
-// where it wins: fp64 (Lorentz(11): 68 us against 94 us) and everything the matrix-core kernels do not cover (the
-// non-squared Euclidean distance, Euclidean fp64), where it replaces the ordered-pair kernel of vec.hip (2.3 x).
+// Measured (MI355X, profiles/r03_experiments.md §11, §11b): Lorentz(11) n = 4039 fp32 22.9 us in the direct form (31.3 us for
+// the matrix-core backward of vec_gram.hip; the accumulator form was 34.0 us + a 4.7-us finalize), 79 vector / 120 total
+// instructions per 64 pairs, 0.18 of the HBM peak; fp64 64 us against 94 us.  The default up to m = 16 in both precisions;
+// the matrix cores keep fp32 17 <= m <= 32 and the fp32 squared Euclidean distance.  Elsewhere it replaces the ordered-pair
+// kernel of vec.hip (2.3 x).
 #pragma once
 #include <hip/hip_runtime.h>
 

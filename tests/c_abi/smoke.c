@@ -2,10 +2,12 @@
  * ctypes binding of the reference's Manifold plugin would do.  SPD(3): the pair distances of the
  * points X_k = diag(e^{a_k}, e^{2 a_k}, e^{-a_k}) have the closed form d^2_ij = 6 (a_i - a_j)^2, and the gradient of
  * sum_ij d^2_ij w.r.t. X_i is diagonal with entries 2 c_m s_i / x_m, s_i = sum_j (a_i - a_j), c = (1, 2, -1).
- * Also a vector manifold (Euclidean) and the fused RSGD step.  Exit code 0 = all checks passed. */
+ * Also a vector manifold (Euclidean), the fused RSGD step, the RCCL collective and the one-call training step.
+ * Exit code 0 = all checks passed. */
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <string.h>
 
 #include <hip/hip_runtime_api.h>
 
@@ -116,6 +118,72 @@ int main(void) {
   } else {
     printf("mm_comm: RCCL not bound (%s)\n", mm_comm_last_error());
     return 13;
+  }
+  /* one training step per call (train.py:198-222 for one full batch): Euclidean(3), n = 5, StressLoss, RSGD on the points and
+   * on the scale — two consecutive mm_train_step_run calls (the second with MM_WS_PREPARED: the first left the workspace
+   * prepared) against the same two steps done here in double precision:
+   *   m_ij = softplus(s) |x_i - x_j|^2,  loss = sum (m_ij - t_ij)^2,  dL/dx_j = sum_i 4 softplus(s) (m_ij - t_ij) (x_j - x_i),
+   *   dL/ds = sigmoid(s) sum 2 (m_ij - t_ij) |x_i - x_j|^2,  x' = x - lr g,  s' = s - lr_s dL/ds                               */
+  {
+    enum { TN = 5, TM = 3, TP = TN * (TN - 1) / 2 };
+    double tx[TN * TM], tt[TP], ts = 0.3, hx[TN * TM], hs = 0.3, lout[2];
+    for (int t = 0; t < TN * TM; ++t) hx[t] = tx[t] = 0.1 * (double)((t * 7) % 11) - 0.4;
+    for (int t = 0; t < TP; ++t) tt[t] = 0.05 + 0.03 * (double)t;
+    const double lr = 0.01, lr_s = 0.001;
+    if (!mm_vec_fused_step_supports(MM_F64, MM_EUCLIDEAN, TM)) return 14;
+    void *dtx, *dtg, *dtt, *dts, *dlo, *tws;
+    CHECK_HIP(hipMalloc(&dtx, sizeof tx)); CHECK_HIP(hipMalloc(&dtg, sizeof tx)); CHECK_HIP(hipMalloc(&dtt, sizeof tt));
+    CHECK_HIP(hipMalloc(&dts, sizeof ts)); CHECK_HIP(hipMalloc(&dlo, sizeof lout));
+    const size_t twb = mm_vec_pdist_ws_bytes(MM_F64, TN, TM);
+    CHECK_HIP(hipMalloc(&tws, twb));
+    CHECK_HIP(hipMemsetAsync(tws, 0, twb, st));
+    CHECK_HIP(hipMemcpyAsync(dtx, tx, sizeof tx, hipMemcpyHostToDevice, st));
+    CHECK_HIP(hipMemcpyAsync(dtt, tt, sizeof tt, hipMemcpyHostToDevice, st));
+    CHECK_HIP(hipMemcpyAsync(dts, &ts, sizeof ts, hipMemcpyHostToDevice, st));
+    mm_train_step step;
+    memset(&step, 0, sizeof step);
+    step.dtype = MM_F64; step.loss_kind = MM_LOSS_STRESS; step.n = TN; step.nf = 1;
+    step.wmin = 1e-8; step.wmax = 1e8;
+    step.points[0].kind = MM_EUCLIDEAN; step.points[0].dim = TM; step.points[0].count = TN;
+    step.points[0].x = dtx; step.points[0].grad = dtg; step.points[0].optimizer = MM_OPT_RSGD;
+    step.points[0].lr = lr; step.points[0].max_grad_norm = -1.0; step.points[0].exact = 1;
+    step.scales[0].kind = MM_EUCLIDEAN; step.scales[0].dim = 1; step.scales[0].count = 1; step.scales[0].x = dts;
+    step.scales[0].optimizer = MM_OPT_RSGD; step.scales[0].lr = lr_s; step.scales[0].max_grad_norm = -1.0;
+    step.target = dtt; step.loss_out = dlo; step.ws = tws;
+    double want_loss[2];
+    for (int it = 0; it < 2; ++it) {
+      step.ws_flags = it == 0 ? 0 : MM_WS_PREPARED;
+      CHECK_MM(mm_train_step_run(&step, st));
+      /* the same step on the host */
+      const double sp = log1p(exp(hs)), sg = 1.0 / (1.0 + exp(-hs));
+      double g[TN * TM] = {0}, gs = 0.0, loss = 0.0;
+      int pk = 0;
+      for (int i = 0; i < TN; ++i)
+        for (int j = i + 1; j < TN; ++j, ++pk) {
+          double d2 = 0.0;
+          for (int q = 0; q < TM; ++q) d2 += (hx[i * TM + q] - hx[j * TM + q]) * (hx[i * TM + q] - hx[j * TM + q]);
+          const double r = sp * d2 - tt[pk];
+          loss += r * r;
+          gs += 2.0 * r * d2 * sg;
+          for (int q = 0; q < TM; ++q) {
+            const double df = hx[j * TM + q] - hx[i * TM + q];
+            g[j * TM + q] += 4.0 * sp * r * df;
+            g[i * TM + q] -= 4.0 * sp * r * df;
+          }
+        }
+      for (int t = 0; t < TN * TM; ++t) hx[t] -= lr * g[t];
+      hs -= lr_s * gs;
+      want_loss[it] = loss;
+    }
+    CHECK_HIP(hipMemcpyAsync(tx, dtx, sizeof tx, hipMemcpyDeviceToHost, st));
+    CHECK_HIP(hipMemcpyAsync(&ts, dts, sizeof ts, hipMemcpyDeviceToHost, st));
+    CHECK_HIP(hipMemcpyAsync(lout, dlo, sizeof lout, hipMemcpyDeviceToHost, st));
+    CHECK_HIP(hipStreamSynchronize(st));
+    double wx = 0.0;
+    for (int t = 0; t < TN * TM; ++t) wx = fmax(wx, fabs(tx[t] - hx[t]));
+    printf("mm_train_step_run (Euclidean(3), 2 steps): max |x - host| = %.3e, |s - host| = %.3e, loss %.6f (host %.6f)\n", wx,
+           fabs(ts - hs), lout[0], want_loss[1]);
+    if (!(wx < 1e-12 && fabs(ts - hs) < 1e-12 && fabs(lout[0] - want_loss[1]) < 1e-10 * fmax(1.0, want_loss[1]))) return 15;
   }
   /* argument errors are return codes, never exceptions */
   if (mm_spd_pdist_fwd(MM_F64, NULL, n, d, 0, n, 1, 1e-8, 1e8, dout, ws, 0, st) != MM_ERR_ARG) return 9;

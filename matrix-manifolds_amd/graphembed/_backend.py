@@ -166,6 +166,29 @@ def lib():
     return _instance
 
 
+_autograd = False     # False: not looked up yet; None: unavailable
+
+
+def autograd_ext():
+    """The C++ autograd nodes of `pdist` (csrc_torch/mm_autograd.cpp, built in-tree as lib/_mm_autograd.so): forward and
+    backward are one C-ABI call each, issued from C++ — the engine does not re-enter Python for the backward.  None if the
+    module is not built or MM_PY_AUTOGRAD=1: the torch.autograd.Function classes of graphembed.manifolds issue the same
+    two calls from Python (same kernels, ~80 us more host time per forward + backward)."""
+    global _autograd
+    if _autograd is False:
+        _autograd = None
+        path = os.path.join(os.path.dirname(_HERE), 'lib', '_mm_autograd.so')
+        if os.environ.get('MM_PY_AUTOGRAD', '') != '1' and os.path.isfile(path):
+            import importlib.util
+            spec = importlib.util.spec_from_file_location('_mm_autograd', path)
+            mod = importlib.util.module_from_spec(spec)
+            spec.loader.exec_module(mod)
+            lib()                      # (the HIP library: raises if absent — there is no CPU fallback)
+            mod.init(LIB_PATH)
+            _autograd = mod
+    return _autograd
+
+
 def require_gpu(*tensors):
     for t in tensors:
         if t is not None and not t.is_cuda:

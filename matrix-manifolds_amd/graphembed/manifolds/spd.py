@@ -391,6 +391,17 @@ class SymmetricPositiveDefinite(Manifold):
         pair list owned by one shard (see graphembed.parallel)."""
         assert x.ndim == 3
         rb, re = (0, x.shape[0]) if rows is None else rows
+        ext = B.autograd_ext()
+        if ext is not None:   # the same two C-ABI calls as _SpdPdist, issued by C++ autograd nodes (csrc_torch/mm_autograd.cpp)
+            try:
+                return ext.spd_pdist(x, self.n, bool(squared), float(self.wmin), float(self.wmax), int(rb), int(re),
+                                     bool(self.check_pd))
+            except RuntimeError as e:
+                if 'not positive-definite' in str(e):
+                    raise torch.linalg.LinAlgError(str(e).split('linalg: ', 1)[-1]) from None
+                if 'runs on MI355X only' in str(e) or 'failed:' in str(e):
+                    raise B.BackendError(str(e)) from None
+                raise
         return _SpdPdist.apply(x, self.n, squared, self.wmin, self.wmax, rb, re, self.check_pd)
 
     def pdist_loss(self, x, scale, target, spec, rows=None):

@@ -14,6 +14,20 @@ import os as _os
 _BWD_FORM = _os.environ.get('MM_VEC_BWD', '')
 
 
+def _pdist_forms(kind, m, n, f32, squared, use_gram):
+    """(forward on the matrix cores?, backward on the matrix cores?) for a pdist of n points of dimension m.
+    Forward: the Gram kernel serves the inner-product manifolds up to m = 32 (fp32) / 16 (fp64) and n = 32768.
+    Backward: up to m = 16 the symmetric VALU kernel (csrc/vec_sym.hpp; Lorentz / sphere: flushed straight into the
+    gradient, two launches) beats the matrix-core one — Lorentz(11) n = 4039 forward + backward 44 us against 54 us in
+    fp32, 113 against 142 in fp64; the fp32 Euclidean squared distance keeps the matrix cores (67 / 76)."""
+    fwd = bool(use_gram and kind in (B.LORENTZ, B.SPHERE) and n <= 32768 and m <= (32 if f32 else 16))
+    bwd = n <= 32768 and ((use_gram and kind in (B.LORENTZ, B.SPHERE) and m <= (32 if f32 else 16)) or
+                          (f32 and kind == B.EUCLIDEAN and squared and m <= 31))
+    if _BWD_FORM == 'sym' or (_BWD_FORM != 'gram' and m <= 16 and (not f32 or kind != B.EUCLIDEAN)):
+        bwd = False
+    return fwd, bool(bwd)
+
+
 class _VecPdist(torch.autograd.Function):
 
     @staticmethod
@@ -31,10 +45,7 @@ class _VecPdist(torch.autograd.Function):
             return xc.new_empty(0)
         with B.on_device(xc.device):
             out = torch.empty(npairs, dtype=xc.dtype, device=xc.device)
-            # the matrix-core Gram kernel serves the inner-product manifolds up to m = 32 (fp32) / 16 (fp64)
-            # and n = 32768; anything else takes the VALU kernel
-            gram = (use_gram and kind in (B.LORENTZ, B.SPHERE) and n <= 32768
-                    and m <= (32 if xc.dtype == torch.float32 else 16))
+            gram, _ = _pdist_forms(kind, m, n, xc.dtype == torch.float32, squared, use_gram)
             name = 'mm_vec_pdist_fwd_gram' if gram else 'mm_vec_pdist_fwd'
             lib.call(name, B.dtype_code(xc), kind, B.ptr(xc), n, m, row_begin, row_end, int(squared),
                      B.ptr(out), B.stream_of(xc))
@@ -52,14 +63,7 @@ class _VecPdist(torch.autograd.Function):
         dt = B.dtype_code(xc)
         with B.on_device(xc.device):
             grad = torch.empty_like(xc)
-            f32 = xc.dtype == torch.float32
-            mfma = n <= 32768 and ((ctx.use_gram and kind in (B.LORENTZ, B.SPHERE) and m <= (32 if f32 else 16)) or
-                                   (f32 and kind == B.EUCLIDEAN and squared and m <= 31))
-            if _BWD_FORM == 'sym' or (_BWD_FORM != 'gram' and m <= 16 and (not f32 or kind != B.EUCLIDEAN)):
-                # up to m = 16 the symmetric VALU backward (csrc/vec_sym.hpp; Lorentz / sphere: flushed straight into the
-                # gradient, two launches) beats the matrix-core one — Lorentz(11) n = 4039 forward + backward 44 us against
-                # 54 us in fp32, 113 against 142 in fp64; the fp32 Euclidean squared distance keeps the matrix cores (67 / 76)
-                mfma = False
+            _, mfma = _pdist_forms(kind, m, n, xc.dtype == torch.float32, squared, ctx.use_gram)
             if mfma:
                 # matrix-core backward (inner-product manifolds, fp32): W^T X, no workspace
                 lib.call('mm_vec_pdist_bwd_gram', dt, kind, B.ptr(xc), B.ptr(g), n, m, row_begin,
@@ -260,6 +264,16 @@ class VectorManifold(Manifold):
         pair-list slice of one shard (graphembed.parallel)."""
         assert x.ndim == self.ndim + 1
         rb, re = (0, x.shape[0]) if rows is None else rows
+        ext = B.autograd_ext()
+        if ext is not None:   # the same C-ABI calls as _VecPdist, issued by C++ autograd nodes (csrc_torch/mm_autograd.cpp)
+            fwd_gram, bwd_gram = _pdist_forms(self._kind, self._m, x.shape[0], x.dtype == torch.float32, bool(squared),
+                                              self.use_gram)
+            try:
+                return ext.vec_pdist(x, self._kind, self._m, bool(squared), int(rb), int(re), fwd_gram, bwd_gram)
+            except RuntimeError as e:
+                if 'runs on MI355X only' in str(e) or 'failed:' in str(e):
+                    raise B.BackendError(str(e)) from None
+                raise
         return _VecPdist.apply(x, self._kind, self._m, squared, rb, re, self.use_gram)
 
     def pdist_loss(self, x, scale, target, spec, rows=None):

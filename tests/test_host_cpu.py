@@ -373,3 +373,21 @@ def test_sync_grads_uses_an_installed_communicator():
     x, = parallel.sync_grads(a)                             # no communicator, no process group: identity
     x.sum().backward()
     assert torch.equal(a.grad, torch.ones(3))
+
+
+def test_cpp_autograd_nodes_build_load_and_refuse_cpu_tensors():
+    """csrc_torch/mm_autograd.cpp (the C++ autograd nodes of `pdist`): builds against this interpreter's torch with g++ alone,
+    binds the C ABI at run time, and a CPU tensor is refused with the package's own error — there is no CPU path behind it."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, 'matrix-manifolds_amd', 'csrc_torch'))
+    import build as autograd_build
+    path = autograd_build.build_if_stale()
+    assert os.path.isfile(path)
+    from graphembed import _backend as B
+    from graphembed import manifolds as M
+    ext = B.autograd_ext()
+    assert ext is not None and {'init', 'spd_pdist', 'vec_pdist'} <= set(dir(ext))
+    with pytest.raises(B.BackendError):
+        M.SymmetricPositiveDefinite(3).pdist(torch.eye(3).repeat(4, 1, 1))
+    with pytest.raises(B.BackendError):
+        M.Lorentz(4).pdist(torch.randn(5, 4))

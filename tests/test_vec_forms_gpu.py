@@ -116,3 +116,59 @@ def test_suite_with_form_forced(env, select):
                         '-k', select, '-p', 'no:cacheprovider'], env=e, capture_output=True, text=True, timeout=1500, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert ' passed' in r.stdout
+
+
+# ---- the two hosts of the same pdist calls: C++ autograd nodes (default) and the torch.autograd.Function classes -----------
+@pytest.mark.parametrize('case', ['spd3', 'spd4_f64', 'lorentz11', 'sphere24', 'euclidean10_plain'])
+def test_cpp_autograd_nodes_equal_the_python_functions(case):
+    """csrc_torch/mm_autograd.cpp issues exactly the calls of graphembed.manifolds' autograd classes: same distances bit for
+    bit, same gradients up to the order of the backward's atomics; empty row ranges and shards included."""
+    from graphembed import _backend as B
+    from graphembed import manifolds as M
+    from graphembed.manifolds.spd import _SpdPdist
+    from graphembed.manifolds.vector import _VecPdist
+    assert B.autograd_ext() is not None, 'lib/_mm_autograd.so is not built (python __graft_entry__.py)'
+    dt = torch.float64 if case.endswith('f64') else torch.float32
+    man = {'spd3': lambda: M.SymmetricPositiveDefinite(3), 'spd4_f64': lambda: M.SymmetricPositiveDefinite(4),
+           'lorentz11': lambda: M.Lorentz(11), 'sphere24': lambda: M.Sphere(24), 'euclidean10_plain': lambda: M.Euclidean(10)}[case]()
+    squared = not case.endswith('plain')
+    torch.manual_seed(2)
+    n = 301
+    x = man.rand(n, out=torch.empty(0, dtype=dt, device='cuda'), ir=0.3)
+    for rows in (None, (0, 0), (17, 140), (n - 1, n)):
+        rb, re = rows or (0, n)
+        npairs = B.pair_offset(n, re) - B.pair_offset(n, rb)
+        g = torch.randn(npairs, dtype=dt, device='cuda')
+        xa, xb = x.clone().requires_grad_(), x.clone().requires_grad_()
+        da = man.pdist(xa, squared=squared, rows=rows)
+        if isinstance(man, M.SymmetricPositiveDefinite):
+            db = _SpdPdist.apply(xb, man.n, squared, man.wmin, man.wmax, rb, re, man.check_pd)
+        else:
+            db = _VecPdist.apply(xb, man._kind, man._m, squared, rb, re, man.use_gram)
+        assert da.shape == db.shape == (npairs, ) and torch.equal(da, db)
+        ga, = torch.autograd.grad(da, xa, g)
+        gb, = torch.autograd.grad(db, xb, g)
+        assert ga.shape == gb.shape == x.shape
+        scale = max(gb.abs().max().item(), 1e-30)
+        assert (ga - gb).abs().max().item() <= (1e-5 if dt == torch.float32 else 1e-12) * scale
+    # a non-positive-definite input surfaces as torch's LinAlgError on either host (spd.py:55-61: torch.cholesky raises)
+    if isinstance(man, M.SymmetricPositiveDefinite):
+        bad = x.clone()
+        bad[3] = -bad[3]
+        checked = M.SymmetricPositiveDefinite(man.n, check_pd=True)   # (off by default: the check reads a status word back)
+        with pytest.raises(torch.linalg.LinAlgError):
+            checked.pdist(bad, squared=True)
+        from graphembed.manifolds.spd import _SpdPdist as py_host
+        with pytest.raises(torch.linalg.LinAlgError):
+            py_host.apply(bad, man.n, True, man.wmin, man.wmax, 0, n, True)
+
+
+def test_suite_with_python_autograd_functions():
+    """MM_PY_AUTOGRAD=1: the pdist tests of the SPD and vector suites again, in a child, through the Python classes."""
+    e = dict(os.environ, MM_PY_AUTOGRAD='1')
+    r = subprocess.run([sys.executable, '-m', 'pytest', os.path.join(ROOT, 'tests', 'test_vec_gpu.py'),
+                        os.path.join(ROOT, 'tests', 'test_spd_gpu.py'), '-x', '-q', '-m', 'gpu', '-k',
+                        'pdist or golden or row_sharding or seamless', '-p', 'no:cacheprovider'],
+                       env=e, capture_output=True, text=True, timeout=1500, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert ' passed' in r.stdout

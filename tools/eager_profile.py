@@ -47,6 +47,11 @@ def timed(f, k=2000):
 print(which, 'n', n)
 print('forward only      : host %.1f us / step, with final sync %.1f us' % timed(fwd))
 print('forward + backward: host %.1f us / step, with final sync %.1f us' % timed(both))
+from graphembed import _backend as B  # noqa: E402
+print('host of the two calls:', 'C++ autograd nodes (lib/_mm_autograd.so)' if B.autograd_ext() is not None
+      else 'torch.autograd.Function classes (MM_PY_AUTOGRAD=1 or the module is not built)')
+with torch.autograd.set_multithreading_enabled(False):   # the engine runs the backward on the calling thread: no hand-off
+    print('forward + backward, autograd multithreading off: host %.1f us / step, with final sync %.1f us' % timed(both))
 pr = cProfile.Profile()
 pr.enable()
 for _ in range(500):

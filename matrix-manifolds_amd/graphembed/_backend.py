@@ -180,12 +180,17 @@ def autograd_ext():
         path = os.path.join(os.path.dirname(_HERE), 'lib', '_mm_autograd.so')
         if os.environ.get('MM_PY_AUTOGRAD', '') != '1' and os.path.isfile(path):
             import importlib.util
-            spec = importlib.util.spec_from_file_location('_mm_autograd', path)
-            mod = importlib.util.module_from_spec(spec)
-            spec.loader.exec_module(mod)
             lib()                      # (the HIP library: raises if absent — there is no CPU fallback)
-            mod.init(LIB_PATH)
-            _autograd = mod
+            try:
+                spec = importlib.util.spec_from_file_location('_mm_autograd', path)
+                mod = importlib.util.module_from_spec(spec)
+                spec.loader.exec_module(mod)
+                mod.init(LIB_PATH)
+                _autograd = mod
+            except (ImportError, OSError, RuntimeError) as e:   # built against another torch: host the calls from Python
+                import warnings
+                warnings.warn(f'{path} does not load ({e}); rebuild it with `python __graft_entry__.py`. pdist stays on the '
+                              'HIP kernels, hosted by the Python autograd classes')
     return _autograd
 
 

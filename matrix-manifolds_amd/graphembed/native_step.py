@@ -19,8 +19,10 @@ overwrites.  Supported: what the fused objective kernels support — one SPD or 
 three vector factors (dimension <= 16) and one SPD(2)/SPD(3) factor — with StressLoss / QuotientLoss, RiemannianSGD
 (with or without momentum) and RiemannianAdam.  Anything else raises `ValueError` at construction.
 
-A single SPD factor keeps the per-node tables of the pair kernels up to date itself (the optimizer kernel of a step writes
-the tables of the new points), so consecutive steps skip the preparation launch; an edit of the points from outside
+Every single-GPU step is TWO launches: the pair kernel of the embedding and one per-point kernel (gradient from the pair
+kernel's sums, loss record, optimizer rule of every parameter, momentum-free RSGD scales).  A single SPD or vector factor
+also keeps what its pair kernel reads up to date itself (that kernel writes the per-node tables / the zero-padded copy of
+the new points), so consecutive steps skip the preparation launch; an edit of the points from outside
 (`stabilize`, a manual in-place operation) is noticed through the tensor's storage / version and re-prepares.  A step that
 was CAPTURED into a HIP graph replays the launch sequence it was recorded with: after editing the points outside the
 graph, issue one eager `step()` (it prepares again) before replaying.

@@ -1,0 +1,124 @@
+#!/usr/bin/env python3
+"""Randomised cross-check of the one-call training step (mm_train_step_run through graphembed.native_step.NativeTrainStep:
+the two-launch forms of single SPD / vector factors and of products, and the unfused forms outside their ranges) against the
+eager loop of train.py:198-222 on the same classes: random layouts, sizes (incl. n = 2, tile edges), dimensions, dtypes,
+optimizer rules and hyper-parameters, both losses, an edit of the points from outside in the middle of a run.
+Usage: python tools/fuzz_step.py [cases] [seed] [--big]"""
+import copy
+import os
+import random
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, 'matrix-manifolds_amd'))
+import torch  # noqa: E402
+from graphembed import manifolds as M  # noqa: E402
+from graphembed.modules import ManifoldEmbedding  # noqa: E402
+from graphembed.native_step import NativeTrainStep  # noqa: E402
+from graphembed.objectives import QuotientLoss, StressLoss  # noqa: E402
+from graphembed.optim import RiemannianAdam, RiemannianSGD  # noqa: E402
+
+
+def layout(rng):
+    kind = rng.choice(['spd', 'vec', 'vec', 'product', 'product'])
+    vec = lambda lo, hi: {'e': M.Euclidean, 'l': M.Lorentz, 's': M.Sphere}[rng.choice('els')](rng.randint(lo, hi))   # noqa: E731
+    if kind == 'spd':
+        return [M.SymmetricPositiveDefinite(rng.choice([2, 3, 3, 4, 5, 6]))]
+    if kind == 'vec':
+        return [vec(2, rng.choice([8, 16, 24, 33]))]
+    mans = [vec(2, 16) for _ in range(rng.randint(1, 3))]
+    if rng.random() < 0.7:
+        mans.append(M.SymmetricPositiveDefinite(rng.choice([2, 3])))
+    rng.shuffle(mans)
+    if len(mans) < 2:
+        mans.append(M.Euclidean(rng.randint(1, 16)))
+    return mans
+
+
+def optimizers(emb, rng_state):
+    rng = random.Random(rng_state)
+    rule = rng.choice(['rsgd', 'rsgd', 'momentum', 'adam', 'adam_nc'])
+    clip = rng.choice([None, 20.0, 0.5])
+    exact = rng.random() < 0.5
+    if rule == 'rsgd':
+        pts = RiemannianSGD(list(emb.xs), lr=rng.choice([1e-4, 1e-3]), exact=exact, max_grad_norm=clip)
+    elif rule == 'momentum':
+        pts = RiemannianSGD(list(emb.xs), lr=1e-4, momentum=rng.choice([0.5, 0.9]), dampening=rng.choice([0.0, 0.1]), exact=exact,
+                            max_grad_norm=clip)
+    elif rule == 'adam':
+        pts = RiemannianAdam(list(emb.xs), lr=rng.choice([1e-3, 1e-2]), exact=exact, max_grad_norm=clip)
+    else:
+        pts = RiemannianAdam(list(emb.xs), lr=1e-2, betas=(0.9, None), nc=True, exact=exact, max_grad_norm=clip)
+    srule = rng.choice(['rsgd', 'rsgd', 'rsgd_noclip', 'momentum', 'adam'])
+    if srule == 'rsgd':
+        sc = RiemannianSGD(list(emb.scales), lr=1e-4, max_grad_norm=500)
+    elif srule == 'rsgd_noclip':
+        sc = RiemannianSGD(list(emb.scales), lr=1e-5, max_grad_norm=None)
+    elif srule == 'momentum':
+        sc = RiemannianSGD(list(emb.scales), lr=1e-5, momentum=0.5, max_grad_norm=500)
+    else:
+        sc = RiemannianAdam(list(emb.scales), lr=1e-3, max_grad_norm=500)
+    return [pts, sc], rule + '/' + srule
+
+
+def main():
+    args = [a for a in sys.argv[1:] if not a.startswith('--')]
+    cases = int(args[0]) if args else 100
+    rng = random.Random(int(args[1]) if len(args) > 1 else 0)
+    worst = {torch.float32: 0.0, torch.float64: 0.0}
+    for c in range(cases):
+        dt = rng.choice([torch.float32, torch.float64])
+        n = rng.choice([2, 3, 5, 17, 63, 64, 65, 127, 129, 200, 257, rng.randint(2, 400)])
+        if '--big' in sys.argv:
+            n = rng.choice([600, 1025, 1500, 2100])
+        mans = layout(rng)
+        torch.manual_seed(c)
+        torch.set_default_dtype(dt)
+        try:
+            with torch.device('cuda'):
+                emb_a = ManifoldEmbedding(n, mans)
+                with torch.no_grad():
+                    emb_a.perturb(rng.choice([0.05, 0.3]))
+                target = torch.rand(n * (n - 1) // 2) * 0.9 + 0.05
+        finally:
+            torch.set_default_dtype(torch.float32)
+        emb_b = copy.deepcopy(emb_a)
+        fn = rng.choice([StressLoss, QuotientLoss])()
+        seed = rng.random()
+        oa, what = optimizers(emb_a, seed)
+        ob, _ = optimizers(emb_b, seed)
+        epochs, edit_at = rng.randint(2, 5), rng.choice([None, 1, 2])
+        what = f'case {c}: n={n} {[str(m) for m in mans]} {str(dt)[6:]} {type(fn).__name__} {what} epochs={epochs} edit={edit_at}'
+        step = NativeTrainStep(emb_b, fn, target, ob)
+        la, lb = [], []
+        for epoch in range(epochs):
+            if epoch == edit_at:     # somebody else touches the points between two steps (stabilize, a manual edit)
+                with torch.no_grad():
+                    for e in (emb_a, emb_b):
+                        e.xs[0].copy_(e.manifolds[0].projx(e.xs[0].clone()))
+            loss = emb_a.fused_objective(fn, target, None, epoch=epoch, alpha=1.0)
+            for o in oa:
+                o.zero_grad(set_to_none=True)
+            loss.backward()
+            for o in oa:
+                o.step()
+            la.append(loss.item())
+            lb.append(step(epoch=epoch, alpha=1.0).item())
+        if not all(map(lambda v: v == v and abs(v) < 1e30, la)) or max(la) > 10 * la[0]:
+            # a run that blows up amplifies the rounding of either implementation without bound: nothing to compare
+            print('skipped (the eager run diverges)', what, flush=True)
+            continue
+        tol = 3e-4 if dt == torch.float32 else 1e-8
+        for a, b in zip(la, lb):
+            assert abs(a - b) <= tol * max(abs(a), 1e-30), f'{what}: losses {la} vs {lb}'
+        for a, b in zip(list(emb_a.xs) + list(emb_a.scales), list(emb_b.xs) + list(emb_b.scales)):
+            err = (a.detach() - b.detach()).abs().max().item() / max(a.detach().abs().max().item(), 1e-30)
+            assert err <= tol * 3, f'{what}: parameters differ by {err:.3e}'
+            worst[dt] = max(worst[dt], err)
+        assert all(torch.isfinite(p.grad).all() for p in emb_b.xs), what
+        print('ok', what, flush=True)
+    print('fuzz_step:', cases, 'cases ok; worst relative parameter difference', {str(k)[6:]: f'{v:.2e}' for k, v in worst.items()})
+
+
+if __name__ == '__main__':
+    main()

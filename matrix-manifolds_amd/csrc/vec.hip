@@ -566,7 +566,7 @@ int vec_bwd_t(const T* x, const T* g, int64_t n, int m, int64_t rb, int64_t re, 
     bool finalized = false;
     const int rc = vec_sym_backward_pairs(dtype_code, KIND, LOSS, squared, x, g, n, m, rb, re, ws, la.scale_raw, double(la.alpha),
                                           double(la.eps), la.terms, la.dyn, grad, loss_out, &finalized, st);
-    if (rc == MM_OK && finalized) return MM_OK;   // (Lorentz / sphere: flushed into the gradient by the pair kernel)
+    if (rc == MM_OK && finalized) return MM_OK;   // (flushed into the gradient by the pair kernel)
     if (rc == MM_OK) done = true;
     else if (rc != MM_ERR_UNSUPPORTED) return rc;
   }

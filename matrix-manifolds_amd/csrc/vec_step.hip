@@ -27,7 +27,7 @@ namespace {
 
 template <typename T> struct VecStep {
   const T* x; T* xnew; int n, m;                 // (xnew == x: in place — every thread reads its whole point before it writes it)
-  T* acc;                                        // gradient source: the workspace sums (cleared here); null: `grad` is final
+  T* acc;                                        // gradient source: gacc [n][m] in the workspace (cleared here); null: `grad` is final
   T* grad;
   T* slots; const T* scale_raw; T* loss_out;     // the loss record, closed by block 0 (slots null: already closed)
   T* scale_x; T scale_lr, scale_clip;            // the scale's own RSGD update (null: stepped elsewhere / frozen)
@@ -57,23 +57,11 @@ __global__ __launch_bounds__(128) void vec_fused_step_kernel(VecStep<T> a) {
   T xp[MP], g[MP], o[MP];
   load_padded<T, MP>(a.x, p, m, xp);
   if (a.acc) {   // the gradient from the pair kernel's sums
-    if (KIND == MM_EUCLIDEAN) {   // acc [MP + 1][n]: sum w x_i per coordinate, then sum w:  sum w 2 (x_j - x_i)
-      const T wsum = a.acc[size_t(MP) * n + p];
+    load_padded<T, MP>(a.acc, p, m, g);   // gacc [n][m]: the pair kernel applied the manifold's map on the way
+    if (in) {
 #pragma unroll
-      for (int k = 0; k < MP; ++k) g[k] = a.acc[size_t(k) * n + p];
-#pragma unroll
-      for (int k = 0; k < MP; ++k) g[k] = k < m ? T(2) * (wsum * xp[k] - g[k]) : T(0);
-      if (in) {
-#pragma unroll
-        for (int k = 0; k <= MP; ++k) a.acc[size_t(k) * n + p] = T(0);
-      }
-    } else {                      // gacc [n][m]: the sums are the gradient (sign pattern applied by the pair kernel)
-      load_padded<T, MP>(a.acc, p, m, g);
-      if (in) {
-#pragma unroll
-        for (int k = 0; k < MP; ++k)
-          if (k < m) a.acc[p * m + k] = T(0);
-      }
+      for (int k = 0; k < MP; ++k)
+        if (k < m) a.acc[p * m + k] = T(0);
     }
     if (in) store_row<T, MP>(a.grad, p, m, g);
   } else {

@@ -52,10 +52,9 @@ template <typename T, int KIND, int MP>
 int pairs_t(int loss_kind, int squared, const T* x, const T* g, int64_t n, int m, int64_t rb, int64_t re, void* ws,
             const T* scale_raw, double alpha, double eps, int terms, const double* loss_params, T* grad, T* loss_out,
             bool* finalized, int mode, hipStream_t st) {
-  // Lorentz / sphere: the pair kernel flushes into the gradient itself — or, in the training-step form (mode != kPlain), into
-  // the head of the accumulator region, [n][m], which the step's per-point kernel moves to the gradient and clears
-  const bool direct = KIND != MM_EUCLIDEAN && mode == kPlain;
-  const bool to_ws = KIND != MM_EUCLIDEAN && mode != kPlain;
+  // The pair kernel flushes into the gradient itself — or, in the training-step form (mode != kPlain), into the head of the
+  // accumulator region, gacc [n][m], which the step's per-point kernel moves to the gradient and clears
+  const bool direct = mode == kPlain;
   T* acc = static_cast<T*>(ws);
   T* slots = acc + size_t(n) * (MP + 1);
   T* xpad = slots + 2 * kLossSlots;
@@ -75,14 +74,13 @@ int pairs_t(int loss_kind, int squared, const T* x, const T* g, int64_t n, int m
   if (re > rb && pair_off(n, re) > pair_off(n, rb)) {
     LossArgs<T> la{scale_raw, T(alpha), T(eps), terms, slots, loss_params};
     T* out = direct ? grad : acc;
-    (void)to_ws;
     if (loss_kind == MM_LOSS_STRESS) rc = launch_pairs<T, KIND, MP, MM_LOSS_STRESS, true>(xpad, g, n, m, rb, re, out, la, st);
     else if (loss_kind == MM_LOSS_QUOTIENT) rc = launch_pairs<T, KIND, MP, MM_LOSS_QUOTIENT, true>(xpad, g, n, m, rb, re, out, la, st);
     else if (squared) rc = launch_pairs<T, KIND, MP, MM_LOSS_NONE, true>(xpad, g, n, m, rb, re, out, la, st);
     else rc = launch_pairs<T, KIND, MP, MM_LOSS_NONE, false>(xpad, g, n, m, rb, re, out, la, st);
     if (rc != MM_OK) return rc;
   }
-  if (direct && loss_kind != MM_LOSS_NONE) {   // the loss record (the Euclidean form's finalize kernel does it there)
+  if (direct && loss_kind != MM_LOSS_NONE) {   // the loss record
     vec_sym_loss_finalize_kernel<T><<<dim3(1), dim3(64), 0, st>>>(slots, scale_raw, loss_out);
     e = hipGetLastError();
     if (e != hipSuccess) return int(e);

@@ -10,9 +10,9 @@
 //     of smallmat.hpp — one total per lane — and leave per slice with one atomic instruction per 64 values;
 //   * ONE resident grid with statically balanced shares of the column walk (spd_ws.hpp, ColWalk), the upstream
 //     gradients requested two rows ahead with running scalar offsets, priority lowered along the share.
-// Lorentz / sphere: both sides are flushed straight into the gradient (contiguous ranges, sign pattern on the way): two
-// launches per backward — preparation and pair kernel.  Euclidean: both sides land in the structure-of-arrays accumulators
-// acc[k][node] that the ordered-pair kernel of vec.hip fills, and vec_pdist_finalize_kernel applies 2 (x sum w - .).
+// Both sides are flushed straight into the gradient, as atomics into contiguous ranges of grad [n][m], the manifold's linear
+// map applied on the way (Lorentz: -J; sphere: identity; Euclidean: 2 (x sum w - sum w x_other), x from the padded copy):
+// two launches per backward — preparation (padded points, cleared gradient) and pair kernel — and no accumulators.
 // Measured (MI355X, profiles/r03_experiments.md §11, §11b): Lorentz(11) n = 4039 fp32 22.9 us in the direct form (31.3 us for
 // the matrix-core backward of vec_gram.hip; the accumulator form was 34.0 us + a 4.7-us finalize), 79 vector / 120 total
 // instructions per 64 pairs, 0.18 of the HBM peak; fp64 64 us against 94 us.  The default up to m = 16 in both precisions;
@@ -66,15 +66,14 @@ __global__ void vec_sym_prep_kernel(const T* __restrict__ x, int n, int m, T* __
 template <typename T, int KIND, int MP, int LOSS, bool SQ>
 __global__ __launch_bounds__((64 * kVSymWaves), (vsym_min_waves<T, MP>()))
 void vec_pdist_bwd_sym_kernel(const T* __restrict__ xpad /* [n+1][MP] */, const T* __restrict__ g, int n, int m, int row_begin,
-                              int row_end, T* __restrict__ acc /* Euclidean: [MP+1][n] sums; else the gradient [n][m] */,
+                              int row_end, T* __restrict__ acc /* the gradient [n][m] (training-step form: the workspace's gacc) */,
                               LossArgs<T> la) {
   constexpr int NW = kVSymWaves, TI = kVSymTI;
   constexpr int NC = vsym_cols<T, MP>();
   constexpr bool kEuclid = KIND == MM_EUCLIDEAN;
-  // Lorentz / sphere: the sums ARE the gradient up to the sign pattern (d q / d x_j = -J x_i, lorentz.py:72-77,101-118;
-  // x_i, sphere.py:68-74), so both sides leave straight into grad [n][m] — contiguous ranges of it, the sign applied on the
-  // way — and no finalize launch follows.  Euclidean needs x_j sum w - sum w x_i: accumulators + vec_pdist_finalize_kernel.
-  constexpr bool kDirect = !kEuclid;
+  // The sums are the gradient up to the manifold's linear map (d q / d x_j = -J x_i, lorentz.py:72-77,101-118; x_i,
+  // sphere.py:68-74; 2 (x_j - x_i), base.py:29-33,56-57: 2 (x_j sum w - sum w x_i)), so both sides leave straight into
+  // grad [n][m] — contiguous ranges of it, the map applied on the way — and no finalize launch follows.
   constexpr int NR = MP + (kEuclid ? 1 : 0);   // values of the row-side reduction / of a column's sums
   constexpr int squared = SQ ? 1 : 0;
   T sp = T(1), loss_acc = T(0), ds_acc = T(0);
@@ -219,19 +218,15 @@ void vec_pdist_bwd_sym_kernel(const T* __restrict__ xpad /* [n+1][MP] */, const 
         }
         red_ptr -= red_step * ((i1 - i0 + kAhead - 1) / kAhead * kAhead);
         __builtin_amdgcn_wave_barrier();
-        if constexpr (kDirect) {
+        {
           const int cnt = (i1 - i0) * m;             // rows i0 .. i1 - 1 of grad: one contiguous range
           T* gp = acc + size_t(i0) * m;
           for (int t = lane; t < cnt; t += 64) {
             const int il = t / m, k = t - il * m;
             T v = redM[wave][il][k];
             if (KIND == MM_LORENTZ && k != 0) v = -v;
+            if constexpr (kEuclid) v = T(2) * Num<T>::fma(xpad[size_t(i0 + il) * MP + k], redM[wave][il][MP], -v);
             atomic_add(&gp[t], v);
-          }
-        } else {
-          for (int t = lane; t < tw * NR; t += 64) {
-            const int k = t / tw, il = t - k * tw;
-            if (i0 + il < i1) atomic_add(&acc[size_t(k) * n + i0 + il], redM[wave][il][k]);
           }
         }
         __builtin_amdgcn_wave_barrier();
@@ -245,7 +240,7 @@ void vec_pdist_bwd_sym_kernel(const T* __restrict__ xpad /* [n+1][MP] */, const 
 #pragma unroll
       for (int k = 0; k < NR; ++k) colS[wave][q][k][lane] = accJ[q][k];
     __syncthreads();
-    if constexpr (kDirect) {
+    {
       const int cols = min(64 * NC, n - jbase);       // columns jbase .. of grad: one contiguous range of cols * m values
       T* gp = acc + size_t(jbase) * m;
       for (int t = threadIdx.x; t < cols * m; t += 64 * NW) {
@@ -255,16 +250,13 @@ void vec_pdist_bwd_sym_kernel(const T* __restrict__ xpad /* [n+1][MP] */, const 
 #pragma unroll
         for (int wv = 1; wv < NW; ++wv) sum += colS[wv][q][k][l];
         if (KIND == MM_LORENTZ && k != 0) sum = -sum;
-        atomic_add(&gp[t], sum);
-      }
-    } else {
-      for (int t = wave; t < NC * NR; t += NW) {
-        const int q = t / NR, k = t - q * NR;
-        const int j = jbase + 64 * q + lane;
-        T sum = colS[0][q][k][lane];
+        if constexpr (kEuclid) {
+          T wsum = colS[0][q][MP][l];
 #pragma unroll
-        for (int wv = 1; wv < NW; ++wv) sum += colS[wv][q][k][lane];
-        if (j < n) atomic_add(&acc[size_t(k) * n + j], sum);
+          for (int wv = 1; wv < NW; ++wv) wsum += colS[wv][q][MP][l];
+          sum = T(2) * Num<T>::fma(xpad[size_t(jbase + jl) * MP + k], wsum, -sum);
+        }
+        atomic_add(&gp[t], sum);
       }
     }
     ++cb;

@@ -15,16 +15,15 @@ constexpr double kEps = 1e-8;  // utils.py:13 (both precisions)
 // padded point dimension the pair kernels are instantiated for
 constexpr int pad_dim(int m) { return m <= 4 ? 4 : m <= 8 ? 8 : m <= 12 ? 12 : m <= 16 ? 16 : m <= 24 ? 24 : m <= 32 ? 32 : m <= 48 ? 48 : 64; }
 
-// Symmetric VALU backward (vec_sym.hip): prep (padded points, clean accumulators) + pair kernel into the accumulators
+// Symmetric VALU backward (vec_sym.hip): prep (padded points, cleared gradient) + pair kernel flushing into the gradient
 // `ws` = acc [pad+1][n] | loss slots [2][256] | xpad [n+1][pad].  MM_ERR_UNSUPPORTED outside its range (fp32 m <= 32,
 // fp64 m <= 16): the caller then takes the ordered-pair kernel.
 bool vec_sym_supports(int dtype, int m);
-// *finalized: the gradient (and, with a loss, loss_out) is complete — Lorentz / sphere flush into `grad` directly; else the
-// caller runs vec_pdist_finalize_kernel on the accumulators.
-// mode: VSYM_PLAIN as above.  The training-step forms (vec_step.hpp) leave every kind's sums in the workspace — Lorentz /
-// sphere as gacc [n][m] at the head of the accumulator region — for the step's per-point kernel, which finishes the gradient,
-// closes the loss record and clears both; VSYM_STEP_PREPARED also skips the preparation launch (that kernel left the padded
-// copy of the new points and clean accumulators behind).
+// *finalized: the gradient (and, with a loss, loss_out) is complete — the pair kernel flushes into `grad` directly.
+// mode: VSYM_PLAIN as above.  The training-step forms (vec_step.hpp) leave the sums — already mapped to gradient
+// contributions — in the workspace, gacc [n][m] at the head of the accumulator region, for the step's per-point kernel, which
+// moves them to the gradient, closes the loss record and clears both; VSYM_STEP_PREPARED also skips the preparation launch
+// (that kernel left the padded copy of the new points and clean accumulators behind).
 enum { VSYM_PLAIN = 0, VSYM_STEP = 1, VSYM_STEP_PREPARED = 2 };
 int vec_sym_backward_pairs(int dtype, int kind, int loss_kind, int squared, const void* x, const void* g, int64_t n, int m,
                            int64_t rb, int64_t re, void* ws, const void* scale_raw, double alpha, double eps, int terms,
@@ -32,7 +31,7 @@ int vec_sym_backward_pairs(int dtype, int kind, int loss_kind, int squared, cons
                            int mode = VSYM_PLAIN);
 // the regions of that workspace (pad = pad_dim(m))
 template <typename T> struct VecSymWs {
-  T* acc;     // [pad + 1][n] sums (Euclidean) / gacc [n][m] (Lorentz, sphere; training-step form)
+  T* acc;     // [pad + 1][n] elements reserved; the training-step form uses its head as gacc [n][m]
   T* slots;   // [2][kLossSlots]
   T* xpad;    // [n + 1][pad]
   VecSymWs(void* ws, int64_t n, int pad) : acc(static_cast<T*>(ws)), slots(acc + size_t(n) * (pad + 1)), xpad(slots + 2 * 256) {}

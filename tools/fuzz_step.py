@@ -68,6 +68,8 @@ def main():
     worst = {torch.float32: 0.0, torch.float64: 0.0}
     for c in range(cases):
         dt = rng.choice([torch.float32, torch.float64])
+        if os.environ.get('FUZZ_FORCE_F64') == '1':    # (same case stream in double precision: tells a rounding effect from a bug)
+            dt = torch.float64
         n = rng.choice([2, 3, 5, 17, 63, 64, 65, 127, 129, 200, 257, rng.randint(2, 400)])
         if '--big' in sys.argv:
             n = rng.choice([600, 1025, 1500, 2100])
@@ -113,7 +115,11 @@ def main():
             assert abs(a - b) <= tol * max(abs(a), 1e-30), f'{what}: losses {la} vs {lb}'
         for a, b in zip(list(emb_a.xs) + list(emb_a.scales), list(emb_b.xs) + list(emb_b.scales)):
             err = (a.detach() - b.detach()).abs().max().item() / max(a.detach().abs().max().item(), 1e-30)
-            assert err <= tol * 3, f'{what}: parameters differ by {err:.3e}'
+            # (QuotientLoss has kinks: in fp32 a pair within rounding of |m / (alpha g) - 1| = 0 takes the other sign in one of
+            # the two implementations and moves its two points by lr / (alpha g) — case 271 of seed 101: 7.9e-3 in fp32, 7e-15 with
+            # FUZZ_FORCE_F64=1.  The losses above still have to agree.)
+            ptol = 3e-2 if (dt == torch.float32 and isinstance(fn, QuotientLoss)) else tol * 3
+            assert err <= ptol, f'{what}: parameters differ by {err:.3e}'
             worst[dt] = max(worst[dt], err)
         assert all(torch.isfinite(p.grad).all() for p in emb_b.xs), what
         print('ok', what, flush=True)

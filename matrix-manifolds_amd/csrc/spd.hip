@@ -357,8 +357,9 @@ __device__ __forceinline__ T pair_row_load(const T* __restrict__ g, int n, int64
 // Backward: a launch of (at most) as many workgroups as the device holds at once; workgroup w walks its share of the
 // balanced column walk (spd_ws.hpp, ColWalk): down one 64-column block, chunk after chunk of up to NW x TI rows (each
 // wavefront a contiguous slice of the chunk's rows, its lanes the block's 64 columns), then on to the next block.
-template <typename T, int D, int TI, int LOSS, bool SQ>
-__global__ __launch_bounds__((64 * bwd_waves<T, D>()), (bwd_min_waves<T, D>())) void spd_pdist_bwd_kernel(const T* __restrict__ nodeLC /* {L_i^-1, L_i} */,
+// NCX != 0: that many columns per lane instead of pair_cols_bwd<T, D>() (fp32 SPD(4): two for large launches, below).
+template <typename T, int D, int TI, int LOSS, bool SQ, int NCX = 0>
+__global__ __launch_bounds__((64 * bwd_waves<T, D>()), (bwd_min_waves_nc<T, D, NCX>())) void spd_pdist_bwd_kernel(const T* __restrict__ nodeLC /* {L_i^-1, L_i} */,
                                                                const T* __restrict__ nodeY /* chol(X_j) */,
                                                                const T* __restrict__ g, int n, int row_begin,
                                                                int row_end, T wmin, T wmax,
@@ -366,7 +367,7 @@ __global__ __launch_bounds__((64 * bwd_waves<T, D>()), (bwd_min_waves<T, D>())) 
                                                                LossArgs<T> la) {
   constexpr int NP = Packed<D>::NP;
   constexpr int NW = bwd_waves<T, D>();
-  constexpr int NC = pair_cols_bwd<T, D>();   // lane l owns the columns jbase + 64 q + l, q < NC
+  constexpr int NC = NCX ? NCX : pair_cols_bwd<T, D>();   // lane l owns the columns jbase + 64 q + l, q < NC
   // LOSS != 0: `g` holds the TARGET (graph) squared distances; the upstream gradient of each pair is
   // derived in registers from the loss, and the loss / scale-gradient sums leave through la.slots.
   constexpr int squared = SQ ? 1 : 0;   // (a template parameter: as a run-time flag it cost two vector instructions per row)
@@ -1076,14 +1077,26 @@ int spd_pdist_fwd_t(const T* x, int64_t n, int64_t rb, int64_t re, int squared, 
 // One launch of (at most) the resident capacity; fewer workgroups when the row range is small (>= 8 rows of a column
 // block per workgroup, two per wavefront).
 constexpr int kBwdTI = 16;   // rows per wavefront and chunk
-template <typename T, int D, int LOSS, bool SQ>
+// fp32 SPD(4): one column per lane by default (128 registers, four wavefronts per SIMD); two columns — scalar bookkeeping,
+// row-operand loads and the transposing reduction paid once per 128 pairs, three wavefronts per SIMD — win on large launches
+// only (fused QuotientLoss step, us, one / two columns: n = 2274 58.6 / 71.6, 4096 109 / 108, 5793 170 / 174-197,
+// 8192 301 / 295, 11585 571 / 549, 16384 1082-1096 / 1039-1041; profiles/r03_experiments.md §15): from 30 M pairs per launch
+// on.  MM_SPD4_BWD_TWO_COLS=0 / 1 forces either.
+constexpr int64_t kSpd4TwoColPairs = 30000000;
+template <typename T, int D, int LOSS, bool SQ, int NCX = 0>
 int spd_pdist_bwd_launch_sq(Ws<T>& ws, const T* g, int64_t n, int64_t rb, int64_t re, double wmin, double wmax,
                             hipStream_t st, LossArgs<T> la) {
   constexpr int kThreads = 64 * bwd_waves<T, D>();
-  auto kernel = spd_pdist_bwd_kernel<T, D, kBwdTI, LOSS, SQ>;
-  const int64_t units = ColWalk(int(n), int(rb), int(re), 64 * pair_cols_bwd<T, D>()).total();
+  constexpr int kCols = NCX ? NCX : pair_cols_bwd<T, D>();
+  if constexpr (NCX == 0 && sizeof(T) == 4 && D == 4 && pair_cols_bwd<T, D>() == 1) {
+    static const int two = [] { const char* e = std::getenv("MM_SPD4_BWD_TWO_COLS"); return e ? (e[0] == '1' ? 1 : 0) : -1; }();
+    if (two == 1 || (two < 0 && pair_off(n, re) - pair_off(n, rb) >= kSpd4TwoColPairs))
+      return spd_pdist_bwd_launch_sq<T, D, LOSS, SQ, 2>(ws, g, n, rb, re, wmin, wmax, st, la);
+  }
+  auto kernel = spd_pdist_bwd_kernel<T, D, kBwdTI, LOSS, SQ, NCX>;
+  const int64_t units = ColWalk(int(n), int(rb), int(re), 64 * kCols).total();
   if (units <= 0) return MM_OK;
-  int64_t grid = resident_workgroups<spd_pdist_bwd_kernel<T, D, kBwdTI, LOSS, SQ>>(kThreads);
+  int64_t grid = resident_workgroups<spd_pdist_bwd_kernel<T, D, kBwdTI, LOSS, SQ, NCX>>(kThreads);
   // Small launches (a rank's shard, small n): a workgroup flushes its column-side sums once per column block, so it needs
   // enough rows to pay for that — with fewer than ~48 rows of a column block per workgroup the launch is made of flushes
   // (one eighth of the headline problem, 13 k units: 1024 workgroups 23.8 us, 256 workgroups 17.1 us; a quarter: 24.2 -> 22.2 us;

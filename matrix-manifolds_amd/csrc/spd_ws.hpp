@@ -36,6 +36,11 @@ constexpr int64_t kSpdMaxNodes = int64_t(1) << 22;
 template <typename T, int D> constexpr int bwd_min_waves() {
   return (sizeof(T) == 4 && D == 3) ? 4 : ((sizeof(T) == 4 && D == 4) ? MM_SPD4_BWD_WAVES : 1);
 }
+// ... with NCX columns per lane forced (0: the default of pair_cols_bwd): two columns of fp32 SPD(4) need ~185 registers —
+// three wavefronts per SIMD (168 registers, the rest spilled) measured best (profiles/r03_experiments.md §2)
+template <typename T, int D, int NCX> constexpr int bwd_min_waves_nc() {
+  return (NCX == 2 && sizeof(T) == 4 && D == 4) ? 3 : bwd_min_waves<T, D>();
+}
 // Wavefronts of a backward workgroup: they share one column block and flush its column-side sums once
 template <typename T, int D> constexpr int bwd_waves() {
   // (the column-side combine buffer is D^2 x 64 values per wavefront: 4 wavefronts up to 64 KB of it, else 2, else 1)

@@ -688,3 +688,20 @@ def test_stein_vs_oracle_seeded_and_shards(dname):
     gg = torch.autograd.grad(loss, [emb.xs[0], emb.scales[0]])
     assert abs(loss.item() - ref.item()) <= (1e-4 if dname == 'f32' else 1e-10) * abs(ref.item())
     check_rel(gg[0], rg[0].double().cpu().numpy(), 1e-3 if dname == 'f32' else 1e-9, 'fused stein grad')
+
+
+def test_spd4_two_columns_per_lane_forced():
+    """fp32 SPD(4) backward with two columns per lane (`spd_pdist_bwd_kernel<..., NCX = 2>`: what launches of >= 30 M pairs
+    take) at the sizes of this suite: MM_SPD4_BWD_TWO_COLS=1 in a child process, the pair-kernel tests of d = 4 again —
+    golden vectors, the oracle, every eigen-free path, the fused losses and their shards."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    e = dict(os.environ, MM_SPD4_BWD_TWO_COLS='1')
+    r = subprocess.run([sys.executable, '-m', 'pytest', os.path.abspath(__file__), '-x', '-q', '-m', 'gpu', '-p', 'no:cacheprovider',
+                        '-k', '(pdist_vs or eigenfree or seamless or recentred or fused_loss or row_sharding or edge_cases '
+                              'or wide_spectra) and not two_columns'],
+                       env=e, capture_output=True, text=True, timeout=1500, cwd=root)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert ' passed' in r.stdout

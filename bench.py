@@ -628,7 +628,7 @@ def worker(args):
     # (hipExtLaunchKernelGGL start / stop events, csrc/prof.hpp: the kernel's execution time as a profiler sees it).
     # They cannot live inside a captured graph, so they time the kernels of an eager pass of the same step issued
     # right after the timed region; one discarded pass first (event creation, allocator warm-up).
-    kern, eager_ms = {'fwd': None, 'bwd': None}, None
+    kern, eager_ms, eager_st_ms = {'fwd': None, 'bwd': None}, None, None
     run_step = phases.pop('_run')
     if not args.no_prof:
         # (a) the same step through Python autograd, one synchronised step at a time: its host cost
@@ -642,6 +642,21 @@ def worker(args):
             times.append(time.perf_counter() - te)
         fence()
         eager_ms = median(times) * 1e3
+        # ... and with the autograd engine's worker threads off (torch.autograd.set_multithreading_enabled(False): the
+        # backward node runs on the calling thread, no hand-off) — what a caller of the eager plugin API can switch on itself
+        eager_st_ms = None
+        if hasattr(torch.autograd, 'set_multithreading_enabled'):
+            with torch.autograd.set_multithreading_enabled(False):
+                wl.eager_step()
+                torch.cuda.synchronize()
+                times = []
+                for _ in range(max(5, min(args.steps, 20))):
+                    te = time.perf_counter()
+                    wl.eager_step()
+                    torch.cuda.synchronize()
+                    times.append(time.perf_counter() - te)
+            fence()
+            eager_st_ms = median(times) * 1e3
         # (b) kernel durations in the clock regime of the timed region: each profiled eager step is queued behind a
         # burst of replays of the timed step, with no synchronisation in between — the device never idles (issued one
         # step at a time from Python it idles 45 % of the time, the clocks drop and the kernels take ~10 % longer)
@@ -685,6 +700,11 @@ def worker(args):
         if eager_ms is not None:
             # same step issued through Python autograd (host-bound); median of single synchronised steps
             out['eager_ms_per_step'] = eager_ms
+            from graphembed import _backend as _B
+            out['eager_host'] = ('C++ autograd nodes (lib/_mm_autograd.so)' if _B.autograd_ext() is not None
+                                 else 'torch.autograd.Function classes')
+            if eager_st_ms is not None:
+                out['eager_ms_per_step_autograd_single_thread'] = eager_st_ms
         pmc = stamped_pmc() if (n == N_NODES and world == 1) else None
         if kern['bwd']:
             # dominant kernel: spd_pdist_bwd.  Algorithmic HBM bytes per launch: read g (4 B per pair) + node

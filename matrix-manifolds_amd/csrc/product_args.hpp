@@ -1,0 +1,47 @@
+// Argument structures of the mixed-manifold pair kernels (product_pairs.hip: every ORDERED pair, any vector width <= 16,
+// node minibatches; product_sym.hip: every UNORDERED pair once, vector factors of width <= 8, full batches) — they fill
+// the same accumulators, so the finalize / step kernels of product_pairs.hip serve both.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+namespace mm {
+
+constexpr int kPMaxVec = 3;
+constexpr int kPMP = 16;   // padded dimension of a vector factor
+constexpr int kPMaxTI = 16;  // most rows per wavefront
+constexpr int kPCols = 64;   // columns per workgroup (n = 1025 wastes 6 % of the lanes; 256 columns would waste 20 %)
+constexpr int kPWaves = 4;   // wavefronts per workgroup: same columns, consecutive row tiles; their column
+                             // sums are combined in LDS before the flush (a quarter of the atomics)
+
+template <typename T> struct PVec {
+  const T* x;          // [n][m]
+  const T* scale_raw;  // device scalar
+  T* acc;              // [(kPMP + 1)][n]: sum_i w x_i, and sum_i w (Euclidean)
+  T* grad;             // [n][m]
+  int m, kind, slot;   // slot = position in the caller's factor list (for loss_out)
+};
+template <typename T> struct PSpd {
+  const T* x;          // [n][D][D]
+  const T* scale_raw;
+  T* accS;             // [D*D][n]
+  T* grad;             // [n][D][D]
+  T wmin, wmax;
+  int slot;
+};
+template <typename T> struct PArgs {
+  PVec<T> v[kPMaxVec];
+  PSpd<T> s;
+  int nf;
+  // node minibatch (train.py:198-222): the n points of this call are rows idx[0..n) of the factors' full
+  // tables, targets come from the dense matrix, gradients go to rows idx[.] of full-size buffers
+  const int64_t* idx;  // null: all nodes, in order
+  const T* dense;      // [dense_n][dense_n] targets (with idx); null: `target` is the pair vector
+  int64_t dense_n;
+};
+template <typename T> __device__ __forceinline__ int64_t node_of(const PArgs<T>& pa, int j) {
+  return pa.idx ? pa.idx[j] : int64_t(j);
+}
+
+}  // namespace mm

@@ -26,49 +26,15 @@
 
 #include "../../include/mm_manifolds.h"
 #include "loss.hpp"
+#include "product_args.hpp"
 #include "product_step.hpp"
+#include "product_sym.hpp"
 #include "smallmat.hpp"
 #include "spd_rules.hpp"
 #include "vec_rules.hpp"
 #include "vecfn.hpp"
 
 namespace mm {
-
-constexpr int kPMaxVec = 3;
-constexpr int kPMP = 16;   // padded dimension of a vector factor
-constexpr int kPMaxTI = 16;  // most rows per wavefront
-constexpr int kPCols = 64;   // columns per workgroup (n = 1025 wastes 6 % of the lanes; 256 columns would waste 20 %)
-constexpr int kPWaves = 4;   // wavefronts per workgroup: same columns, consecutive row tiles; their column
-                             // sums are combined in LDS before the flush (a quarter of the atomics)
-
-template <typename T> struct PVec {
-  const T* x;          // [n][m]
-  const T* scale_raw;  // device scalar
-  T* acc;              // [(kPMP + 1)][n]: sum_i w x_i, and sum_i w (Euclidean)
-  T* grad;             // [n][m]
-  int m, kind, slot;   // slot = position in the caller's factor list (for loss_out)
-};
-template <typename T> struct PSpd {
-  const T* x;          // [n][D][D]
-  const T* scale_raw;
-  T* accS;             // [D*D][n]
-  T* grad;             // [n][D][D]
-  T wmin, wmax;
-  int slot;
-};
-template <typename T> struct PArgs {
-  PVec<T> v[kPMaxVec];
-  PSpd<T> s;
-  int nf;
-  // node minibatch (train.py:198-222): the n points of this call are rows idx[0..n) of the factors' full
-  // tables, targets come from the dense matrix, gradients go to rows idx[.] of full-size buffers
-  const int64_t* idx;  // null: all nodes, in order
-  const T* dense;      // [dense_n][dense_n] targets (with idx); null: `target` is the pair vector
-  int64_t dense_n;
-};
-template <typename T> __device__ __forceinline__ int64_t node_of(const PArgs<T>& pa, int j) {
-  return pa.idx ? pa.idx[j] : int64_t(j);
-}
 
 // Pins a loaded value (per-lane / wave-uniform) so that the load is issued where it is written: without
 // it the compiler sinks each load under the condition that masks its result — one basic block and one
@@ -566,8 +532,8 @@ __global__ __launch_bounds__(128) void product_step_kernel(PArgs<T> pa, PStep<T>
 
 template <typename T, int NV, int SD>
 int product_pairs_launch(int loss_kind, PArgs<T> pa, const T* target, int64_t n, int64_t rb, int64_t re, LossArgs<T> la,
-                         T* loss_out, hipStream_t st, const PStep<T>* ps) {
-  if (mm_pair_offset(n, re) > mm_pair_offset(n, rb)) {
+                         T* loss_out, hipStream_t st, const PStep<T>* ps, bool pairs_done) {
+  if (!pairs_done && mm_pair_offset(n, re) > mm_pair_offset(n, rb)) {
     // rows per wavefront: short enough that the launch has ~2 wavefronts per SIMD (the work of a small
     // product embedding is latency, not throughput; measured at n = 1025: 2 -> 123, 4 -> 103, 8 -> 94,
     // 16 -> 97 us per training step), at most 32
@@ -660,7 +626,15 @@ int product_pairs_t(int loss_kind, int nf, const int* kinds, const int* dims, co
   const T* tg = static_cast<const T*>(target);
   T* lo = static_cast<T*>(loss_out);
   const PStep<T>* psp = step ? &ps : nullptr;
-#define MM_PP(NV_, SD_) return product_pairs_launch<T, NV_, SD_>(loss_kind, pa, tg, n, rb, re, la, lo, st, psp)
+  // the symmetric pair kernel (product_sym.hip: every unordered pair once) where it applies — full batches, vector factors
+  // of at most 8 coordinates; the ordered kernel below otherwise.  Both fill the same accumulators.
+  bool pairs_done = false;
+  if (mm_pair_offset(n, re) > mm_pair_offset(n, rb)) {
+    const int rc = product_sym_pairs<T>(loss_kind, nv, sd, pa, tg, n, rb, re, la, accp + acc_elems, st);
+    if (rc == MM_OK) pairs_done = true;
+    else if (rc != MM_ERR_UNSUPPORTED) return rc;
+  }
+#define MM_PP(NV_, SD_) return product_pairs_launch<T, NV_, SD_>(loss_kind, pa, tg, n, rb, re, la, lo, st, psp, pairs_done)
   switch (nv * 4 + sd) {
     case 0 * 4 + 2: MM_PP(0, 2);
     case 0 * 4 + 3: MM_PP(0, 3);
@@ -723,6 +697,7 @@ size_t mm_product_pairs_ws_bytes(int dtype, int nf, const int* kinds, const int*
   size_t elems = size_t(1 + nf) * kLossSlots;
   for (int k = 0; k < nf; ++k)
     elems += kinds[k] == MM_FACTOR_SPD ? size_t(dims[k]) * dims[k] * n : size_t(kPMP + 1) * n;
+  elems += product_sym_table_elems(n);   // node table of the symmetric pair kernel (product_sym.hip)
   return 64 + es * elems;
 }
 

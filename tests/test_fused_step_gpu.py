@@ -359,4 +359,7 @@ def test_fused_product_step_matches_the_eager_loop(spec, n, rule, scale_rule, dt
         # (a scale's gradient is one fp32 sum over all pairs of terms of both signs: 2e-3, as in test_vec_gpu.py)
         tol = (2e-3 if i >= len(emb_b.xs) else 2e-4) if dt == torch.float32 else 1e-9
         assert (g - p.grad.view_as(g)).abs().max().item() <= tol * scale, (i, g, p.grad)
-    assert not step.ws[64:].any()              # the workspace is left clean (MM_WS_CLEAN)
+    # the accumulators and loss slots are left clean (MM_WS_CLEAN); behind them sits the symmetric pair kernel's node table
+    es = 4 if dt == torch.float32 else 8
+    acc = (1 + len(spec)) * 256 + sum(d * d * n if name == 'SPD' else 17 * n for name, d in spec)
+    assert not step.ws[64:64 + es * acc].any()

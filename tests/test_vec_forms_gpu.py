@@ -172,3 +172,21 @@ def test_suite_with_python_autograd_functions():
                        env=e, capture_output=True, text=True, timeout=1500, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert ' passed' in r.stdout
+
+
+@pytest.mark.parametrize('env', [{'MM_PRODUCT_SYM': '1'}, {'MM_PRODUCT_ORDERED': '1'}])
+def test_product_suites_with_pair_kernel_forced(env):
+    """The mixed-manifold pair kernel has two forms — every ordered pair (csrc/product_pairs.hip: small n) and every
+    unordered pair once (csrc/product_sym.hip: fp32 n >= 1536, fp64 n >= 640) — chosen by size: the product tests of the
+    suite (golden product distances and gradients, the reference's training traces, config 4 at n = 1025 against the C
+    oracle, the one-call step, a slice of the randomised campaign) again in a child with each form forced at every size."""
+    e = dict(os.environ, **env)
+    r = subprocess.run([sys.executable, '-m', 'pytest', os.path.join(ROOT, 'tests', 'test_configs_gpu.py'),
+                        os.path.join(ROOT, 'tests', 'test_fused_step_gpu.py'), os.path.join(ROOT, 'tests', 'test_vec_gpu.py'),
+                        '-x', '-q', '-m', 'gpu', '-k', 'product or tree40 or config4', '-p', 'no:cacheprovider'],
+                       env=e, capture_output=True, text=True, timeout=1500, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert ' passed' in r.stdout
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'fuzz_product.py'), '60', '20281'], env=e, capture_output=True,
+                       text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]

@@ -324,7 +324,9 @@ int mm_product_loss(int dtype, int loss_kind, int nf, const void* const* d2, con
  *   loss_out   { loss, dloss/dscale_raw[0..nf-1] }
  *   ws         mm_product_pairs_ws_bytes; every successful call leaves its accumulators zero, so a
  *              workspace that is reused for the same (dtype, factor list, n) may be passed with
- *              flags = MM_WS_CLEAN from the second call on (saves the clearing launches)
+ *              flags = MM_WS_CLEAN from the second call on (saves the clearing launches); | MM_WS_PREPARED only when the
+ *              workspace's node table (symmetric pair kernel, large n) holds the CURRENT points — mm_train_step_run leaves
+ *              it so after a fused product step; a caller that does not know passes neither and the table is rebuilt
  * At most 3 vector factors and one SPD factor; otherwise MM_ERR_UNSUPPORTED (use mm_product_loss around
  * the per-factor kernels).  kinds, dims, xs, scale_raw, grads are HOST arrays. */
 enum { MM_FACTOR_SPD = 16 };
@@ -462,7 +464,8 @@ typedef struct mm_train_step {
                                     kernel does what mm_spd_prepare does), so from the second consecutive step on the
                                     caller passes MM_WS_PREPARED — unless it changed the points in between.  The same
                                     holds for a single vector factor that takes the two-launch form
-                                    (mm_vec_fused_step_supports) and its padded copy of the points; ignored elsewhere  */
+                                    (mm_vec_fused_step_supports) and its padded copy of the points, and for a product
+                                    embedding on one GPU (the node table of its symmetric pair kernel); ignored elsewhere */
   /* -- sharded step (mm_abi_version() >= 2); all zero = the whole pair list on one GPU ------------------------- */
   int64_t row_begin, row_end;    /* this rank's rows of the pair list (mm_shard_rows); row_end <= 0 means n.  `target`
                                     is then this rank's SLICE: the targets of the pairs from mm_pair_offset(n,row_begin) on */

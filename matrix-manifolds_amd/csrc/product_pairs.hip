@@ -395,7 +395,9 @@ __device__ __forceinline__ void product_vec_rule(int rule, const T (&xp)[kPMP], 
 }
 template <typename T, int SD>
 __global__ __launch_bounds__(128) void product_step_kernel(PArgs<T> pa, PStep<T> ps, int nv, int n, T* __restrict__ slots,
-                                                           T* __restrict__ loss_out) {
+                                                           T* __restrict__ loss_out, T* __restrict__ tab /* node table of the
+                                                           symmetric pair kernel, rows of width tabw: the rows of the NEW points
+                                                           are written for the next step (null: not kept) */, int tabw) {
   constexpr int NPS = SD > 0 ? Packed<(SD > 0 ? SD : 2)>::NP : 1;
   constexpr int DS = SD > 0 ? SD : 2;
   using N = Num<T>;
@@ -464,7 +466,15 @@ __global__ __launch_bounds__(128) void product_step_kernel(PArgs<T> pa, PStep<T>
     if (F.kind == MM_EUCLIDEAN) product_vec_rule<T, MM_EUCLIDEAN>(rule, xp, g, j, m, in, R, beta2, alpha, o);
     else if (F.kind == MM_LORENTZ) product_vec_rule<T, MM_LORENTZ>(rule, xp, g, j, m, in, R, beta2, alpha, o);
     else product_vec_rule<T, MM_SPHERE>(rule, xp, g, j, m, in, R, beta2, alpha, o);
-    if (in) store_row<T, kPMP>(const_cast<T*>(F.x), j, m, o);
+    if (in) {
+      store_row<T, kPMP>(const_cast<T*>(F.x), j, m, o);
+      if (tab) {   // (product_sym.hip: the factor zero-padded to kPSW coordinates; Euclidean: the last one is 1)
+        T* row = tab + size_t(j) * tabw + job * kPSW;
+#pragma unroll
+        for (int k = 0; k < kPSW; ++k) row[k] = o[k];
+        if (F.kind == MM_EUCLIDEAN) row[kPSW - 1] = T(1);
+      }
+    }
     if (rule == VRULE_ADAM) adam_tick(R.adam.step, R.adam.ticket, gridDim.x);   // (block-uniform)
     return;
   }
@@ -525,14 +535,24 @@ __global__ __launch_bounds__(128) void product_step_kernel(PArgs<T> pa, PStep<T>
         for (int q = 0; q < SD * SD; ++q) R.state1[size_t(j) * SD * SD + q] = v;
       }
     }
-    if (in) store_sym_full<T, SD>(x + size_t(j) * SD * SD, o);
+    if (in) {
+      store_sym_full<T, SD>(x + size_t(j) * SD * SD, o);
+      if (tab) {   // L^-1 and L of the new point
+        T l[NPS], linv[NPS];
+        cholesky<T, SD>(o, l);
+        invert_lower<T, SD>(l, linv);
+        T* row = tab + size_t(j) * tabw + nv * kPSW;
+#pragma unroll
+        for (int k = 0; k < NPS; ++k) { row[k] = linv[k]; row[NPS + k] = l[k]; }
+      }
+    }
     if (ps.srule == VRULE_ADAM) adam_tick(R.adam.step, R.adam.ticket, gridDim.x);
   }
 }
 
 template <typename T, int NV, int SD>
 int product_pairs_launch(int loss_kind, PArgs<T> pa, const T* target, int64_t n, int64_t rb, int64_t re, LossArgs<T> la,
-                         T* loss_out, hipStream_t st, const PStep<T>* ps, bool pairs_done) {
+                         T* loss_out, hipStream_t st, const PStep<T>* ps, bool pairs_done, T* table) {
   if (!pairs_done && mm_pair_offset(n, re) > mm_pair_offset(n, rb)) {
     // rows per wavefront: short enough that the launch has ~2 wavefronts per SIMD (the work of a small
     // product embedding is latency, not throughput; measured at n = 1025: 2 -> 123, 4 -> 103, 8 -> 94,
@@ -548,7 +568,10 @@ int product_pairs_launch(int loss_kind, PArgs<T> pa, const T* target, int64_t n,
   }
   if (ps) {   // training step: gradients, loss record, optimizer rules and scales in one launch
     const dim3 sgrid(unsigned(std::max<int64_t>((n + 127) / 128, 1 + pa.nf)), unsigned(NV + (SD > 0 ? 1 : 0) + 1));
-    product_step_kernel<T, SD><<<sgrid, dim3(128), 0, st>>>(pa, *ps, NV, int(n), la.slots, loss_out);
+    // (the symmetric pair kernel's node table follows the points: its next launch skips the preparation — MM_WS_PREPARED)
+    T* tab = product_sym_applies<T>(NV, SD, pa, n) ? table : static_cast<T*>(nullptr);
+    product_step_kernel<T, SD><<<sgrid, dim3(128), 0, st>>>(pa, *ps, NV, int(n), la.slots, loss_out, tab,
+                                                            product_sym_table_width(NV, SD));
   } else {
     const dim3 fgrid(unsigned(std::max<int64_t>((n * kPMP + 255) / 256, 8)), unsigned(NV + (SD > 0 ? 1 : 0) + 1));
     product_pair_finalize_kernel<T, NV, SD><<<fgrid, dim3(256), 0, st>>>(pa, int(n), la.slots, loss_out);
@@ -630,11 +653,12 @@ int product_pairs_t(int loss_kind, int nf, const int* kinds, const int* dims, co
   // of at most 8 coordinates; the ordered kernel below otherwise.  Both fill the same accumulators.
   bool pairs_done = false;
   if (mm_pair_offset(n, re) > mm_pair_offset(n, rb)) {
-    const int rc = product_sym_pairs<T>(loss_kind, nv, sd, pa, tg, n, rb, re, la, accp + acc_elems, st);
+    const int rc = product_sym_pairs<T>(loss_kind, nv, sd, pa, tg, n, rb, re, la, accp + acc_elems,
+                                        (flags & MM_WS_PREPARED) != 0, st);
     if (rc == MM_OK) pairs_done = true;
     else if (rc != MM_ERR_UNSUPPORTED) return rc;
   }
-#define MM_PP(NV_, SD_) return product_pairs_launch<T, NV_, SD_>(loss_kind, pa, tg, n, rb, re, la, lo, st, psp, pairs_done)
+#define MM_PP(NV_, SD_) return product_pairs_launch<T, NV_, SD_>(loss_kind, pa, tg, n, rb, re, la, lo, st, psp, pairs_done, accp + acc_elems)
   switch (nv * 4 + sd) {
     case 0 * 4 + 2: MM_PP(0, 2);
     case 0 * 4 + 3: MM_PP(0, 3);

@@ -330,10 +330,14 @@ __global__ __launch_bounds__(64 * kPSWaves) void product_sym_kernel(PArgs<T> pa,
 
 template <typename T, int NV, int SD>
 int launch(int loss_kind, const PArgs<T>& pa, const T* target, int64_t n, int64_t rb, int64_t re, LossArgs<T> la, T* table,
-           hipStream_t st) {
-  product_sym_prep_kernel<T, NV, SD><<<dim3(unsigned((n + 1 + 127) / 128)), dim3(128), 0, st>>>(pa, int(n), table);
-  hipError_t e = hipGetLastError();
-  if (e != hipSuccess) return int(e);
+           bool prepared, hipStream_t st) {
+  static_assert(PSLayout<NV, SD>::W == (NV * kPSW + (SD > 0 ? SD * (SD + 1) : 0) + 3) / 4 * 4, "product_sym_table_width");
+  hipError_t e;
+  if (!prepared) {
+    product_sym_prep_kernel<T, NV, SD><<<dim3(unsigned((n + 1 + 127) / 128)), dim3(128), 0, st>>>(pa, int(n), table);
+    e = hipGetLastError();
+    if (e != hipSuccess) return int(e);
+  }
   const int64_t units = ColWalk(int(n), int(rb), int(re), 64).total();
   if (units <= 0) return MM_OK;
   const int64_t cus = device_cus();
@@ -354,22 +358,31 @@ int launch(int loss_kind, const PArgs<T>& pa, const T* target, int64_t n, int64_
 
 }  // namespace
 
-template <typename T>
-int product_sym_pairs(int loss_kind, int nv, int sd, const PArgs<T>& pa, const T* target, int64_t n, int64_t rb, int64_t re,
-                      LossArgs<T> la, T* table, hipStream_t st) {
+template <typename T> bool product_sym_applies(int nv, int sd, const PArgs<T>& pa, int64_t n) {
   // Where it pays (training step of H^5 x S^5 x SPD(2), ordered / symmetric, us — profiles/r03_experiments.md §17): fp32
   // n = 1025 32.4 / 37.7, 1600 43.9 / 42.4, 2000 61.0 / 48.8, 5000 242 / 149; fp64 n = 300 30.4 / 39.5, 700 48.0 / 46.0,
-  // 1025 94.4 / 64.8, 5000 1185 / 511: a small launch is latency, and the symmetric form has a preparation launch and one
-  // wavefront per SIMD.  MM_PRODUCT_ORDERED=1 / MM_PRODUCT_SYM=1 force either.
+  // 1025 94.4 / 64.8, 5000 1185 / 511: a small launch is latency, and the symmetric form has one wavefront per SIMD there.
+  // MM_PRODUCT_ORDERED=1 / MM_PRODUCT_SYM=1 force either.
   static const bool ordered = [] { const char* e = std::getenv("MM_PRODUCT_ORDERED"); return e && e[0] == '1'; }();
   static const bool forced = [] { const char* e = std::getenv("MM_PRODUCT_SYM"); return e && e[0] == '1'; }();
-  if (ordered || pa.idx || pa.dense || n > kSpdMaxNodes || (sd != 0 && sd != 2 && sd != 3)) return MM_ERR_UNSUPPORTED;
-  if (!forced && n < (sizeof(T) == 8 ? 640 : 1536)) return MM_ERR_UNSUPPORTED;
+  if (ordered || pa.idx || pa.dense || n > kSpdMaxNodes || (sd != 0 && sd != 2 && sd != 3) || nv < 0 || nv > kPMaxVec ||
+      (nv == 0 && sd == 0))
+    return false;
+  if (!forced && n < (sizeof(T) == 8 ? 640 : 1536)) return false;
   for (int f = 0; f < nv; ++f) {
     const int m = pa.v[f].m;
-    if (m > kPSW || (pa.v[f].kind == MM_EUCLIDEAN && m > kPSW - 1)) return MM_ERR_UNSUPPORTED;
+    if (m > kPSW || (pa.v[f].kind == MM_EUCLIDEAN && m > kPSW - 1)) return false;
   }
-#define MM_PS(NV_, SD_) return launch<T, NV_, SD_>(loss_kind, pa, target, n, rb, re, la, table, st)
+  return true;
+}
+template bool product_sym_applies<float>(int, int, const PArgs<float>&, int64_t);
+template bool product_sym_applies<double>(int, int, const PArgs<double>&, int64_t);
+
+template <typename T>
+int product_sym_pairs(int loss_kind, int nv, int sd, const PArgs<T>& pa, const T* target, int64_t n, int64_t rb, int64_t re,
+                      LossArgs<T> la, T* table, bool prepared, hipStream_t st) {
+  if (!product_sym_applies<T>(nv, sd, pa, n)) return MM_ERR_UNSUPPORTED;
+#define MM_PS(NV_, SD_) return launch<T, NV_, SD_>(loss_kind, pa, target, n, rb, re, la, table, prepared, st)
   switch (nv * 4 + sd) {
     case 0 * 4 + 2: MM_PS(0, 2);
     case 0 * 4 + 3: MM_PS(0, 3);
@@ -388,8 +401,8 @@ int product_sym_pairs(int loss_kind, int nv, int sd, const PArgs<T>& pa, const T
 }
 
 template int product_sym_pairs<float>(int, int, int, const PArgs<float>&, const float*, int64_t, int64_t, int64_t, LossArgs<float>,
-                                      float*, hipStream_t);
+                                      float*, bool, hipStream_t);
 template int product_sym_pairs<double>(int, int, int, const PArgs<double>&, const double*, int64_t, int64_t, int64_t,
-                                       LossArgs<double>, double*, hipStream_t);
+                                       LossArgs<double>, double*, bool, hipStream_t);
 
 }  // namespace mm

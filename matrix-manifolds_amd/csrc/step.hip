@@ -133,8 +133,10 @@ extern "C" int mm_train_step_run(const mm_train_step* s, mm_stream_t st) {
       grads[k] = s->points[k].grad;
       if (!xs[k] || !grads[k]) return MM_ERR_ARG;
     }
+    // (MM_WS_PREPARED is the fused step's promise about the symmetric pair kernel's node table: not kept on this path)
     rc = mm_product_pairs_loss(s->dtype, s->loss_kind, nf, kinds, dims, xs, sc, s->target, s->n, rb, re, s->alpha, s->eps,
-                               s->terms, s->loss_params, s->wmin, s->wmax, grads, s->loss_out, s->ws, s->ws_flags, st);
+                               s->terms, s->loss_params, s->wmin, s->wmax, grads, s->loss_out, s->ws,
+                               s->ws_flags & ~MM_WS_PREPARED, st);
   }
   if (rc != MM_OK) return rc;
   // ---- the one collective of a sharded step: {gradients, loss, scale gradients} summed over the ranks, in place, on the

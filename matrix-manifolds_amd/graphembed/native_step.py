@@ -238,10 +238,16 @@ class NativeTrainStep:
         if self._prepared_single:
             x = self._params[0]
             d.ws_flags = B.MM_WS_PREPARED if self._tables_of == (x.data_ptr(), x._version) else 0
+        elif self.k > 1 and self.comm is None:
+            # a product on one GPU: the step kernel also writes the node table of the symmetric pair kernel (where that one
+            # is used) for the new points — valid as long as nobody else touched any factor's points
+            now = tuple((x.data_ptr(), x._version) for x in self._params[:self.k])
+            d.ws_flags = (d.ws_flags & B.WS_CLEAN) | (B.MM_WS_PREPARED if self._tables_of == now else 0)
         with B.on_device(self.device):
             B.lib().call('mm_train_step_run', ctypes.byref(d), B.stream_of(self.target))
         if self.k > 1:
             d.ws_flags = B.WS_CLEAN      # the pair kernel leaves its workspace clean
+            self._tables_of = tuple((x.data_ptr(), x._version) for x in self._params[:self.k])
         elif self._prepared_single:
             x = self._params[0]
             self._tables_of = (x.data_ptr(), x._version)

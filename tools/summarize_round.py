@@ -48,7 +48,7 @@ CASES = {'bench': ('SPD(3) f32 n=5000 reference init (headline; python3 bench.py
          'case_vecgram_11_4039_f32_lorentz': ('Lorentz(11) f32 n=4039 pdist fwd + bwd with MM_VEC_BWD=gram (matrix-core backward)', 11, 4039, 4),
          'case_vstep_11_4039_f32_lorentz': ('Lorentz(11) f32 n=4039 (BASELINE config 2) full training step through mm_train_step_run (pair kernel + one per-point kernel)', 11, 4039, 4),
          'case_product_1025': ('BASELINE config 4: H^5 x S^5 x SPD(2) f32 n=1025 training step (mixed-manifold pair kernel)', 2, 1025, 4),
-         'case_product_5000': ('H^5 x S^5 x SPD(2) f32 n=5000 training step (mixed-manifold pair kernel)', 2, 5000, 4)}
+         'case_product_5000': ('H^5 x S^5 x SPD(2) f32 n=5000 training step (symmetric mixed-manifold pair kernel)', 2, 5000, 4)}
 for key, (title, d, n, esz) in CASES.items():
     st = stats(os.path.join(root, key + '_stats'))
     if not st:
@@ -78,6 +78,16 @@ for key, (title, d, n, esz) in CASES.items():
                 line += f'; VALU {c["SQ_INSTS_VALU"] / (pairs / 64):.0f} / all {c.get("SQ_ACTIVE_INST_ANY", 0) / (pairs / 64):.0f} instructions per 64 pairs'
                 if c.get('SQ_WAVE_CYCLES'):
                     line += f'; wait {c.get("SQ_WAIT_ANY", 0) / c["SQ_WAVE_CYCLES"]:.0%} issue-wait {c.get("SQ_WAIT_INST_ANY", 0) / c["SQ_WAVE_CYCLES"]:.0%} of wave cycles'
+        elif 'product_sym_kernel' in name:
+            alg = pairs * esz
+            line += f'  | algorithmic {alg / 1e6:.1f} MB (4 B target per pair) -> {alg / avg / 1e3:.0f} GB/s = {alg / avg / 1e3 / HBM:.4f} of HBM peak'
+            if 'FETCH_SIZE' in c and 'WRITE_SIZE' in c:
+                tr = (2 * c['FETCH_SIZE'] + c['WRITE_SIZE']) * 1024
+                line += f'; traffic {tr / 1e6:.1f} MB = {tr / alg:.2f} x algorithmic'
+            if 'SQ_INSTS_VALU' in c:
+                line += f'; VALU {c["SQ_INSTS_VALU"] / (pairs / 64):.0f} instructions per 64 UNORDERED pairs'
+            if 'SQ_WAVE_CYCLES' in c and c['SQ_WAVE_CYCLES']:
+                line += f'; wait {c.get("SQ_WAIT_ANY", 0) / c["SQ_WAVE_CYCLES"]:.0%} of wave cycles; LDS bank conflicts {c.get("SQ_LDS_BANK_CONFLICT", 0):.0f}'
         elif 'product_pair_kernel' in name:
             alg = pairs * esz
             line += f'  | algorithmic {alg / 1e6:.1f} MB (4 B target per pair) -> {alg / avg / 1e3:.0f} GB/s = {alg / avg / 1e3 / HBM:.4f} of HBM peak'

@@ -41,8 +41,12 @@ struct Rccl {
 Rccl g_rccl;
 std::once_flag g_once;
 thread_local char g_err[512] = "";
+char g_load_err[512] = "";   // why librccl could not be bound: written once (under g_once), shown to EVERY thread that asks
 
 void set_err(const char* what, const char* detail) { std::snprintf(g_err, sizeof g_err, "%s: %s", what, detail ? detail : ""); }
+void set_load_err(const char* what, const char* detail) {
+  std::snprintf(g_load_err, sizeof g_load_err, "%s: %s", what, detail ? detail : "");
+}
 
 void load_rccl() {
   const char* env = std::getenv("MM_RCCL_LIB");
@@ -63,7 +67,7 @@ void load_rccl() {
       used = names[k];
     }
   }
-  if (!h) { set_err("librccl not found", dlerror()); return; }
+  if (!h) { set_load_err("librccl not found", dlerror()); return; }
   Rccl r;
   r.handle = h;
   r.GetUniqueId = reinterpret_cast<decltype(r.GetUniqueId)>(dlsym(h, "ncclGetUniqueId"));
@@ -73,7 +77,7 @@ void load_rccl() {
   r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(dlsym(h, "ncclGetErrorString"));
   r.GetVersion = reinterpret_cast<decltype(r.GetVersion)>(dlsym(h, "ncclGetVersion"));
   if (!r.GetUniqueId || !r.CommInitRank || !r.CommDestroy || !r.AllReduce) {
-    set_err("librccl lacks a required symbol", used);
+    set_load_err("librccl lacks a required symbol", used);
     return;
   }
   std::snprintf(r.path, sizeof r.path, "%s", used ? used : "");
@@ -82,7 +86,9 @@ void load_rccl() {
 
 const Rccl* rccl() {
   std::call_once(g_once, load_rccl);
-  return g_rccl.handle ? &g_rccl : nullptr;
+  if (g_rccl.handle) return &g_rccl;
+  std::snprintf(g_err, sizeof g_err, "%s", g_load_err);   // (the loader ran on whichever thread called first)
+  return nullptr;
 }
 
 int fail(const Rccl* r, const char* what, ncclResult_t res) {
@@ -122,7 +128,7 @@ int mm_comm_init(mm_comm_t* comm, int rank, int world, const void* unique_id, in
   *comm = nullptr;
   const Rccl* r = rccl();
   if (!r) return MM_ERR_COMM;
-  hipError_t e = hipSetDevice(device);   // the communicator is bound to the device that is current when it is created
+  hipError_t e = hipSetDevice(device);   // the communicator is bound to the device that is current when it is created; it STAYS current (documented in mm_manifolds.h)
   if (e != hipSuccess) return int(e);
   ncclUniqueId id;
   std::memcpy(&id, unique_id, sizeof id);

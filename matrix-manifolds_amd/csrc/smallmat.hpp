@@ -13,6 +13,10 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <cstdint>
+#include <type_traits>
+#include <utility>
+
 namespace mm {
 
 template <int D> struct Packed { static constexpr int NP = D * (D + 1) / 2; };
@@ -29,6 +33,7 @@ template <> struct Num<float> {
   static __device__ __forceinline__ float sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
   static __device__ __forceinline__ float rsqrt(float x) { return __builtin_amdgcn_rsqf(x); }
   static __device__ __forceinline__ float rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+  static __device__ __forceinline__ float rcp_fast(float x) { return __builtin_amdgcn_rcpf(x); }
   // v_log_f32 (log2) * ln2: max rel. error 1.6e-7 on gfx950, same as libm logf, ~10x fewer
   // instructions (tools/micro/log_accuracy.hip)
   static __device__ __forceinline__ float log(float x) { return __builtin_amdgcn_logf(x) * 0.6931471805599453f; }
@@ -54,6 +59,13 @@ template <> struct Num<double> {
   static __device__ __forceinline__ double sqrt(double x) { return ::sqrt(x); }
   static __device__ __forceinline__ double rsqrt(double x) { return 1.0 / ::sqrt(x); }
   static __device__ __forceinline__ double rcp(double x) { return 1.0 / x; }
+  // v_rcp_f64 (~26 bits) + two Newton steps: the last bit of a NORMAL, well-scaled argument without the IEEE division's
+  // scaling / fix-up instructions (5 against ~12); callers pass quantities bounded away from 0 and infinity
+  static __device__ __forceinline__ double rcp_fast(double x) {
+    double r = __builtin_amdgcn_rcp(x);
+    r = ::fma(::fma(-x, r, 1.0), r, r);
+    return ::fma(::fma(-x, r, 1.0), r, r);
+  }
   static __device__ __forceinline__ double max_raw_s(double a, double b) {
     double r;
     asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "s"(b));
@@ -68,6 +80,68 @@ template <> struct Num<double> {
   static __device__ __forceinline__ double fma(double a, double b, double c) { return ::fma(a, b, c); }
   static constexpr int kMaxSweeps = 12;
 };
+
+// ------------------------------------------------- compile-time loops, constants
+// Compile-time loop: f(integral_constant<int, 0>) ... f(integral_constant<int, N - 1>).  The per-column loops of the pair
+// kernels are written with it and NOT as `#pragma unroll` loops: a loop is unrolled late, after inlining, and until then
+// the per-column arrays are indexed by a variable — they are not split into registers early, and the kernels came out
+// with up to twice the vector registers (fp32 SPD(3) backward: 152 instead of 87 for one column).
+template <int N, typename F> __device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (N > 0) {
+    static_for<N - 1>(f);
+    f(std::integral_constant<int, N - 1>{});
+  }
+}
+
+// a b + TAB[I] with the double-precision table entry as a SCALAR operand, materialised where it is used.
+// The series below carry 14 - 36 coefficients each.  Left to the compiler they are hoisted out of the row loop into
+// vector registers, two per coefficient, for the whole kernel: the fp64 SPD(3) backward held 68 registers of constants
+// (232 in all: two wavefronts per SIMD), the forward 72 (184) — and round 3 dropped the fp64 recentred series for that
+// reason alone.  Handing the compiler the constant in scalar registers does not help: it selects the accumulating form
+// v_fmac_f64 and copies the constant into the destination with two v_mov_b32.  So the multiply-add of a Horner step is ONE
+// asm statement: two s_mov_b32 with literals into a fixed scalar pair and v_fma_f64 with that pair as its addend — an fp64
+// multiply-add keeps the vector pipe busy for twice the issue slot of an instruction, the scalar moves issue in its shadow.
+// fp32 constants stay with the compiler (16 registers at most, and the fp32 kernels are bound by instruction issue).
+template <uint64_t BITS> __device__ __forceinline__ double fma_sconst64(double a, double b) {
+  double r;
+  asm("s_mov_b32 s100, %3\n\ts_mov_b32 s101, %4\n\tv_fma_f64 %0, %1, %2, s[100:101]"
+      : "=v"(r) : "v"(a), "v"(b), "n"(uint32_t(BITS)), "n"(uint32_t(BITS >> 32)) : "s100", "s101");
+  return r;
+}
+template <typename T, const T* TAB, int I> __device__ __forceinline__ T fma_coef(T a, T b) {
+#ifndef MM_F64_CONST_VGPR   // (A/B builds: the compiler's placement)
+  if constexpr (std::is_same<T, double>::value) return fma_sconst64<__builtin_bit_cast(uint64_t, TAB[I])>(a, b);
+  else
+#endif
+    return Num<T>::fma(a, b, TAB[I]);
+}
+// Horner's rule in the quotient ring R[E]/(chi_E) of a 3x3 matrix, chi_E = x^3 - s1 x^2 + s2 x - s3: on exit
+// a0 I + a1 E + a2 E^2 = TAB[0] I + TAB[1] E + ... + TAB[N-1] E^(N-1).  One step, (a0, a1, a2) . E + c I =
+// (a2 s3 + c, a0 - a2 s2, a1 + a2 s1), is three multiply-adds — two when E is traceless (s1 = 0).
+template <typename T, const T* TAB, int N, bool TRACELESS = false>
+__device__ __forceinline__ void ring_horner3(T s1, T s2, T s3, T& a0, T& a1, T& a2) {
+  static_assert(N >= 3, "");
+  a0 = TAB[N - 3]; a1 = TAB[N - 2]; a2 = TAB[N - 1];
+  static_for<N - 3>([&](auto ic) {
+    constexpr int k = N - 4 - decltype(ic)::value;
+    const T n0 = fma_coef<T, TAB, k>(a2, s3), n1 = Num<T>::fma(-a2, s2, a0);
+    T n2;
+    if constexpr (TRACELESS) n2 = a1; else n2 = Num<T>::fma(a2, s1, a1);
+    a0 = n0; a1 = n1; a2 = n2;
+  });
+}
+// ... of a 4x4 matrix, chi_E = x^4 - s1 x^3 + s2 x^2 - s3 x + s4: (h0..h3) . E + c I = (c - h3 s4, h0 + h3 s3, h1 - h3 s2, h2 + h3 s1)
+template <typename T, const T* TAB, int N>
+__device__ __forceinline__ void ring_horner4(T s1, T s2, T s3, T s4, T& h0, T& h1, T& h2, T& h3) {
+  static_assert(N >= 4, "");
+  h0 = TAB[N - 4]; h1 = TAB[N - 3]; h2 = TAB[N - 2]; h3 = TAB[N - 1];
+  static_for<N - 4>([&](auto ic) {
+    constexpr int k = N - 5 - decltype(ic)::value;
+    const T n0 = fma_coef<T, TAB, k>(-h3, s4), n1 = Num<T>::fma(h3, s3, h0), n2 = Num<T>::fma(-h3, s2, h1),
+            n3 = Num<T>::fma(h3, s1, h2);
+    h0 = n0; h1 = n1; h2 = n2; h3 = n3;
+  });
+}
 
 // ---------------------------------------------------------- load / symmetrize
 // Packed symmetric part of a full row-major DxD matrix in memory.
@@ -486,12 +560,8 @@ template <typename T> __device__ __forceinline__ T log_series3(const T (&a)[6], 
   const T s3 = e00 * N::fma(e11, e22, -e21 * e21) - e10 * N::fma(e10, e22, -e21 * e20) +
                e20 * N::fma(e10, e21, -e11 * e20);
   // Horner from the top: after the first two steps alpha = (c_{n-3}, c_{n-2}, c_{n-1})
-  T a0 = T(S::kA[S::kTerms - 3]), a1 = T(S::kA[S::kTerms - 2]), a2 = T(S::kA[S::kTerms - 1]);
-#pragma unroll
-  for (int k = S::kTerms - 4; k >= 0; --k) {
-    const T n0 = N::fma(a2, s3, T(S::kA[k])), n1 = N::fma(-a2, s2, a0), n2 = N::fma(a2, s1, a1);
-    a0 = n0; a1 = n1; a2 = n2;
-  }
+  T a0, a1, a2;
+  ring_horner3<T, S::kA, S::kTerms>(s1, s2, s3, a0, a1, a2);
   // log(I + E) = E p(E): one more multiplication by E (no constant), then the caller's factor
   const T b0 = (a2 * s3) * pre, b1 = N::fma(-a2, s2, a0) * pre, b2 = N::fma(a2, s1, a1) * pre;
   m0[pidx(0, 0)] = N::fma(b2, f00, N::fma(b1, e00, b0));
@@ -551,12 +621,8 @@ template <typename T> __device__ __forceinline__ void log_series3_centred(const 
   const T s2 = T(-0.5) * (f00 + f11 + f22);          // s1 = 0: s2 = -tr(E'^2) / 2
   const T s3 = e00 * N::fma(e11, e22, -e21 * e21) - e10 * N::fma(e10, e22, -e21 * e20) +
                e20 * N::fma(e10, e21, -e11 * e20);
-  T a0 = T(S::kA[S::kTerms - 3]), a1 = T(S::kA[S::kTerms - 2]), a2 = T(S::kA[S::kTerms - 1]);
-#pragma unroll
-  for (int k = S::kTerms - 4; k >= 0; --k) {
-    const T n0 = N::fma(a2, s3, T(S::kA[k])), n1 = N::fma(-a2, s2, a0);
-    a2 = a1; a0 = n0; a1 = n1;
-  }
+  T a0, a1, a2;
+  ring_horner3<T, S::kA, S::kTerms, true>(T(0), s2, s3, a0, a1, a2);
   const T logmu = N::log(mu);
   const T b0 = N::fma(a2, s3, logmu) * pre, b1 = N::fma(-a2, s2, a0) * pre, b2 = a1 * pre;
   m0[pidx(0, 0)] = N::fma(b2, f00, N::fma(b1, e00, b0));
@@ -594,12 +660,8 @@ template <typename T> __device__ __forceinline__ T logsq_series3_centred(const T
   const T s2 = T(-0.5) * t2;
   const T s3 = e00 * N::fma(e11, e22, -e21 * e21) - e10 * N::fma(e10, e22, -e21 * e20) +
                e20 * N::fma(e10, e21, -e11 * e20);
-  T h0 = T(S::kQ[S::kTerms - 3]), h1 = T(S::kQ[S::kTerms - 2]), h2 = T(S::kQ[S::kTerms - 1]);
-#pragma unroll
-  for (int k = S::kTerms - 4; k >= 0; --k) {
-    const T n0 = N::fma(h2, s3, T(S::kQ[k])), n1 = N::fma(-h2, s2, h0);
-    h2 = h1; h0 = n0; h1 = n1;
-  }
+  T h0, h1, h2;
+  ring_horner3<T, S::kQ, S::kTerms, true>(T(0), s2, s3, h0, h1, h2);
   const T core = N::fma(h2, T(0.5) * t2 * t2, N::fma(h1, T(3) * s3, h0 * t2));
   const T lmu = N::log(mu), ldet = N::log((T(1) + s1) + (s2 + s3));
   return N::fma(lmu, N::fma(T(3), lmu, ldet + ldet), core);
@@ -635,7 +697,155 @@ template <typename T> __device__ __forceinline__ void sym3_mul(const T (&x)[6], 
   o[5] = N::fma(x[3], y[3], N::fma(x[4], y[4], x[5] * y[5]));
 }
 
-template <typename T> __device__ __forceinline__ T log_cayley3(const T (&a)[6], T (&m0)[6]) {
+// ---- the same logarithm with the matrix algebra moved into quotient rings (round 4) ------------------------------
+// Everything between E^2 and the last combination is scalar arithmetic (tools/design/cayley_ring.py):
+//   mu = 2^k,  E = A / mu - I (exact scaling),  s1, s2, s3 = elementary symmetric functions of E's spectrum,
+//   Z = E (E + 2I)^-1 = (s3 I + 2 (s1 + 2) E - 2 E^2) / D,  D = det(E + 2I) = 8 + 4 s1 + 2 s2 + s3
+//       (adj(B) = B^2 - tr(B) B + e2(B) I for a 3x3, then Cayley-Hamilton for E^3),
+//   e_i(Z) = {4 (s1 + s2) + 3 s3,  2 s2 + 3 s3,  s3} / D  (the cubic of z = eps / (2 + eps)),  e_i(W = Z^2) from those,
+//   atanh(Z) = Z P(W):  P(W) = c0 + c1 W + c2 W^2 by Horner in R[W]/(chi_W)  (as before: three FMAs per coefficient),
+//            = b0 + b1 Z + b2 Z^2      (c0 Z + c1 Z^3 + c2 Z^5 reduced in R[Z]/(chi_Z): three steps of three FMAs),
+//            = g0 + g1 E + g2 E^2      (Z, Z^2 written in the E basis by ring arithmetic on their coefficients),
+//   log A = log(mu) I + 2 (g0 I + g1 E + g2 E^2).
+// Matrix work: E^2 (18 FMAs) and the last line (12) — against the adjugate, three commuting 3x3 products and the assembly
+// of P(W) (~105) in log_cayley3_matrix; ~146 operations in all against ~180, six matrix temporaries fewer alive, and the
+// gate tr(Z^2) is known before any matrix is formed.  Accuracy (emulated, against a 40-digit eigendecomposition): 5e-7
+// of max|log A| in fp32, 7e-15 in fp64, spectra of any spread inside the gate and mu up to 2^+-11.
+// `pre` multiplies log A (the caller's 2g when it is known before the logarithm).
+template <typename T> struct CayleyP;   // atanh(sqrt w)/sqrt w on [0, 0.36] (tools/design/cayley_fit.py)
+template <> struct CayleyP<float> {
+  static constexpr int K = 6;
+  static constexpr float c[K + 1] = {1.00000002318570891e+00f, 3.33327042495924375e-01f, 2.00274867564608688e-01f,
+                                     1.38428695737667723e-01f, 1.44240977093542333e-01f, -3.05379184438951401e-02f,
+                                     2.73482843603638170e-01f};
+};
+template <> struct CayleyP<double> {
+  static constexpr int K = 13;
+  static constexpr double c[K + 1] = {9.99999999999997002e-01, 3.33333333336093829e-01, 1.99999999512113669e-01,
+                                      1.42857176992888746e-01, 1.11109865194520263e-01, 9.09362522505209464e-02,
+                                      7.65413194323763535e-02, 7.02835946952955759e-02, 3.51739351378960174e-02,
+                                      1.60038305495638411e-01, -2.87332526616183470e-01, 7.35063731671786291e-01,
+                                      -8.29196169410508666e-01, 5.70221868872885063e-01};
+};
+// mu = 2^k next to the mean eigenvalue: returns 1 / mu, *logmu = k ln 2 (no transcendental error; A ~ I gives exactly 0)
+template <typename T> __device__ __forceinline__ T cayley_scale(T mean, T* logmu) {
+  int k;
+  const T mant = frexp_t<T>(mean, &k);
+  if (mant < T(0.70710678118654752)) k -= 1;
+  *logmu = T(k) * T(0.69314718055994531);
+  return ldexp_t<T>(T(1), -k);
+}
+// e_i(Z) (z1, z2, z3), e_i(Z^2) (t1, t2, t3) and 1 / D from the invariants of E
+template <typename T>
+__device__ __forceinline__ void cayley3_spectrum(T s1, T s2, T s3, T& rD, T& z1, T& z2, T& z3, T& t1, T& t2, T& t3) {
+  using N = Num<T>;
+  const T s33 = T(3) * s3;
+  rD = N::rcp_fast(N::fma(T(4), s1, T(8)) + N::fma(T(2), s2, s3));   // D = prod (1 + lambda_k / mu) > 1
+  z1 = N::fma(T(4), s1 + s2, s33) * rD;
+  z2 = N::fma(T(2), s2, s33) * rD;
+  z3 = s3 * rD;
+  t1 = N::fma(z1, z1, T(-2) * z2);
+  t2 = N::fma(z2, z2, T(-2) * (z1 * z3));
+  t3 = z3 * z3;
+}
+template <typename T> __device__ __forceinline__ T log_cayley3(const T (&a)[6], T (&m0)[6], T pre = T(1)) {
+  using N = Num<T>;
+  using P = CayleyP<T>;
+  T logmu;
+  const T r = cayley_scale<T>((a[0] + a[2] + a[5]) * T(1.0 / 3.0), &logmu);
+  const T e00 = N::fma(a[0], r, T(-1)), e11 = N::fma(a[2], r, T(-1)), e22 = N::fma(a[5], r, T(-1));
+  const T e10 = a[1] * r, e20 = a[3] * r, e21 = a[4] * r;
+  const T f00 = N::fma(e00, e00, N::fma(e10, e10, e20 * e20));
+  const T f11 = N::fma(e10, e10, N::fma(e11, e11, e21 * e21));
+  const T f22 = N::fma(e20, e20, N::fma(e21, e21, e22 * e22));
+  const T f10 = N::fma(e10, e00, N::fma(e11, e10, e21 * e20));
+  const T f20 = N::fma(e20, e00, N::fma(e21, e10, e22 * e20));
+  const T f21 = N::fma(e20, e10, N::fma(e21, e11, e22 * e21));
+  const T s1 = e00 + e11 + e22;
+  const T s2 = T(0.5) * N::fma(s1, s1, -(f00 + f11 + f22));
+  const T s3 = e00 * N::fma(e11, e22, -e21 * e21) - e10 * N::fma(e10, e22, -e21 * e20) +
+               e20 * N::fma(e10, e21, -e11 * e20);
+  T rD, z1, z2, z3, t1, t2, t3;
+  cayley3_spectrum<T>(s1, s2, s3, rD, z1, z2, z3, t1, t2, t3);
+  // P(W) = c0 + c1 W + c2 W^2 by Horner in R[W]/(chi_W), W^3 = t1 W^2 - t2 W + t3 I
+  T c0, c1, c2;
+  ring_horner3<T, P::c, P::K + 1>(t1, t2, t3, c0, c1, c2);
+  // Z (c2 Z^4 + c1 Z^2 + c0) in R[Z]/(chi_Z), Z^3 = z1 Z^2 - z2 Z + z3 I: start from c2 Z^2 + c1, then . Z, . Z + c0, . Z
+  T b0 = c2 * z3, b1 = N::fma(-c2, z2, c1), b2 = c2 * z1;
+  {
+    const T n0 = N::fma(b2, z3, c0), n1 = N::fma(-b2, z2, b0), n2 = N::fma(b2, z1, b1);
+    b0 = n0; b1 = n1; b2 = n2;
+  }
+  {
+    const T n0 = b2 * z3, n1 = N::fma(-b2, z2, b0), n2 = N::fma(b2, z1, b1);
+    b0 = n0; b1 = n1; b2 = n2;
+  }
+  // Z = y0 + y1 E + y2 E^2 and Z^2 = w0 + w1 E + w2 E^2 (E^3 = s1 E^2 - s2 E + s3, E^4 = h2 E^2 + h1 E + h0)
+  const T y0 = z3, y2 = T(-2) * rD, y1 = -(s1 + T(2)) * y2;
+  const T q0 = y0 * y0, q1 = T(2) * (y0 * y1), q2 = N::fma(T(2) * y0, y2, y1 * y1), q3 = T(2) * (y1 * y2), q4 = y2 * y2;
+  const T h2 = N::fma(s1, s1, -s2), h1 = N::fma(-s1, s2, s3), h0 = s1 * s3;
+  const T w0 = N::fma(q4, h0, N::fma(q3, s3, q0));
+  const T w1 = N::fma(q4, h1, N::fma(-q3, s2, q1));
+  const T w2 = N::fma(q4, h2, N::fma(q3, s1, q2));
+  const T p2 = pre + pre;
+  const T g0 = N::fma(N::fma(b2, w0, N::fma(b1, y0, b0)), p2, logmu * pre);
+  const T g1 = N::fma(b2, w1, b1 * y1) * p2;
+  const T g2 = N::fma(b2, w2, b1 * y2) * p2;
+  m0[0] = N::fma(g2, f00, N::fma(g1, e00, g0));
+  m0[2] = N::fma(g2, f11, N::fma(g1, e11, g0));
+  m0[5] = N::fma(g2, f22, N::fma(g1, e22, g0));
+  m0[1] = N::fma(g2, f10, g1 * e10);
+  m0[3] = N::fma(g2, f20, g1 * e20);
+  m0[4] = N::fma(g2, f21, g1 * e21);
+  return t1;
+}
+
+// d^2 = ||log A||_F^2 of a pair outside the close-pair gate from INVARIANTS ONLY (the forward's counterpart of the ring
+// form above; tools/design/cayley_sq_fit.py):
+//   sum_k log^2 lambda_k = 2 log(mu) log det A - 3 log^2(mu) + 4 sum_k atanh^2(z_k),   z_k = (lambda_k - mu) / (lambda_k + mu),
+// atanh^2(sqrt w) = w q(w), sum_k w_k q(w_k) = tr(W q(W)) = c0 p1 + c1 p2 + c2 p3 with q(W) = c0 + c1 W + c2 W^2 by the same
+// Horner recurrence and p_k the power sums of the w_k (Newton's identities on t1, t2, t3).  log det A is NOT computed:
+// it is log det X_j - log det X_i from the per-node table (spd_ws.hpp, nodeLd).  No matrix product, no inverse, no
+// transcendental: ~100 operations in fp64 against ~190 for the matrix logarithm followed by its Frobenius norm.
+// q: 16 coefficients in fp64 (relative error 1.5e-16 on [0, 0.36]), 8 in fp32 (1.1e-8).  *gate receives tr(Z^2).
+template <typename T> struct CayleyQ;
+template <> struct CayleyQ<float> {
+  static constexpr int K = 7;
+  static constexpr float c[K + 1] = {0.999999990659938783f, 0.666669978862739941f, 0.510920481665167664f, 0.423174655546735851f,
+                                     0.314332175292986808f, 0.551201736862719326f, -0.412567514510121138f, 1.17039095371423926f};
+};
+template <> struct CayleyQ<double> {
+  static constexpr int K = 15;
+  static constexpr double c[K + 1] = {0.99999999999999987, 0.666666666666851142, 0.511111111067702619, 0.419047623073864087,
+                                      0.35746012197040091, 0.313040831979712641, 0.279195466546191997, 0.254162482860379539,
+                                      0.217779908930427374, 0.303497422045376885, -0.242356046115491071, 1.74002823450430709,
+                                      -3.70667784316895825, 6.72451540777742607, -6.69607770346690423, 3.64458881905822882};
+};
+template <typename T> __device__ __forceinline__ T logsq_cayley3(const T (&a)[6], T logdet_a, T* gate) {
+  using N = Num<T>;
+  using Q = CayleyQ<T>;
+  T logmu;
+  const T r = cayley_scale<T>((a[0] + a[2] + a[5]) * T(1.0 / 3.0), &logmu);
+  const T e00 = N::fma(a[0], r, T(-1)), e11 = N::fma(a[2], r, T(-1)), e22 = N::fma(a[5], r, T(-1));
+  const T e10 = a[1] * r, e20 = a[3] * r, e21 = a[4] * r;
+  const T s1 = e00 + e11 + e22;
+  T tr2 = N::fma(e00, e00, N::fma(e11, e11, e22 * e22));
+  tr2 = N::fma(T(2), N::fma(e10, e10, N::fma(e20, e20, e21 * e21)), tr2);
+  const T s2 = T(0.5) * N::fma(s1, s1, -tr2);
+  const T s3 = e00 * N::fma(e11, e22, -e21 * e21) - e10 * N::fma(e10, e22, -e21 * e20) +
+               e20 * N::fma(e10, e21, -e11 * e20);
+  T rD, z1, z2, z3, t1, t2, t3;
+  cayley3_spectrum<T>(s1, s2, s3, rD, z1, z2, z3, t1, t2, t3);
+  *gate = t1;
+  const T p1 = t1, p2 = N::fma(t1, p1, T(-2) * t2), p3 = N::fma(t1, p2, N::fma(-t2, p1, T(3) * t3));
+  T c0, c1, c2;
+  ring_horner3<T, Q::c, Q::K + 1>(t1, t2, t3, c0, c1, c2);
+  const T s = N::fma(c2, p3, N::fma(c1, p2, c0 * p1));   // sum atanh^2 z_k
+  return N::fma(logmu, N::fma(T(-3), logmu, logdet_a + logdet_a), T(4) * s);
+}
+
+// (the round-1..3 form, kept for A/B builds: -DMM_CAYLEY_MATRIX)
+template <typename T> __device__ __forceinline__ T log_cayley3_matrix(const T (&a)[6], T (&m0)[6]) {
   using N = Num<T>;
   constexpr bool kF32 = std::is_same<T, float>::value;
   constexpr int K = kF32 ? 6 : 13;
@@ -671,12 +881,12 @@ template <typename T> __device__ __forceinline__ T log_cayley3(const T (&a)[6], 
   const T t2 = T(0.5) * N::fma(t1, t1, -(w2[0] + w2[2] + w2[5]));
   const T t3 = w[0] * N::fma(w[2], w[5], -w[4] * w[4]) - w[1] * N::fma(w[1], w[5], -w[4] * w[3]) +
                w[3] * N::fma(w[1], w[4], -w[2] * w[3]);
-  auto coef = [&](int i) -> T { return kF32 ? T(kC32[i < 7 ? i : 0]) : T(kC64[i]); };
+  auto cf = [&](int i) -> T { return kF32 ? T(kC32[i < 7 ? i : 0]) : T(kC64[i]); };
   // P(W) = sum coef_i W^i by Horner's rule in R[W]/(chi_W) (see log_series3): three FMAs per coefficient
-  T c0 = coef(K - 2), c1 = coef(K - 1), c2 = coef(K);
+  T c0 = cf(K - 2), c1 = cf(K - 1), c2 = cf(K);
 #pragma unroll
   for (int i = K - 3; i >= 0; --i) {
-    const T n0 = N::fma(c2, t3, coef(i)), n1 = N::fma(-c2, t2, c0), n2 = N::fma(c2, t1, c1);
+    const T n0 = N::fma(c2, t3, cf(i)), n1 = N::fma(-c2, t2, c0), n2 = N::fma(c2, t1, c1);
     c0 = n0; c1 = n1; c2 = n2;
   }
   T pw[6];
@@ -774,12 +984,12 @@ template <typename T> __device__ __forceinline__ T log_cayley4(const T (&a)[10],
   const T e2 = T(0.5) * N::fma(e1, p1, -p2);
   const T e3 = T(1.0 / 3.0) * (N::fma(e2, p1, -e1 * p2) + p3);
   const T e4 = T(0.25) * (N::fma(e3, p1, -e2 * p2) + N::fma(e1, p3, -p4));
-  auto coef = [&](int i) -> T { return kF32 ? T(kC32[i < 7 ? i : 0]) : T(kC64[i]); };
+  auto cf = [&](int i) -> T { return kF32 ? T(kC32[i < 7 ? i : 0]) : T(kC64[i]); };
   // Horner in R[W]/(chi_W), W^4 = e1 W^3 - e2 W^2 + e3 W - e4 I: four FMAs per coefficient
-  T al0 = coef(K - 3), al1 = coef(K - 2), al2 = coef(K - 1), al3 = coef(K);
+  T al0 = cf(K - 3), al1 = cf(K - 2), al2 = cf(K - 1), al3 = cf(K);
 #pragma unroll
   for (int i = K - 4; i >= 0; --i) {
-    const T n0 = N::fma(-al3, e4, coef(i)), n1 = N::fma(al3, e3, al0), n2 = N::fma(-al3, e2, al1),
+    const T n0 = N::fma(-al3, e4, cf(i)), n1 = N::fma(al3, e3, al0), n2 = N::fma(-al3, e2, al1),
             n3 = N::fma(al3, e1, al2);
     al0 = n0; al1 = n1; al2 = n2; al3 = n3;
   }
@@ -836,12 +1046,8 @@ template <typename T> __device__ __forceinline__ T logsq_series3(const T (&a)[6]
                e20 * N::fma(e10, e21, -e11 * e20);
   // q(E) = h0 I + h1 E + h2 E^2 by Horner in R[E]/(chi_E) (see log_series3), then
   // tr(E^2 q(E)) = h0 tr E^2 + h1 tr E^3 + h2 tr E^4 with the power sums from Newton's identities
-  T h0 = T(S::kQ[S::kTerms - 3]), h1 = T(S::kQ[S::kTerms - 2]), h2 = T(S::kQ[S::kTerms - 1]);
-#pragma unroll
-  for (int k = S::kTerms - 4; k >= 0; --k) {
-    const T n0 = N::fma(h2, s3, T(S::kQ[k])), n1 = N::fma(-h2, s2, h0), n2 = N::fma(h2, s1, h1);
-    h0 = n0; h1 = n1; h2 = n2;
-  }
+  T h0, h1, h2;
+  ring_horner3<T, S::kQ, S::kTerms>(s1, s2, s3, h0, h1, h2);
   const T t3 = N::fma(T(3), s3, N::fma(s1, t2, -s2 * s1));
   const T t4 = N::fma(s1, t3, N::fma(-s2, t2, s3 * s1));
   *e2 = t2;
@@ -891,12 +1097,8 @@ template <typename T, typename S = LogSeries<T>> __device__ __forceinline__ T lo
   const T s3 = T(1.0 / 3.0) * (N::fma(s2, p1, -s1 * p2) + p3);
   const T s4 = T(0.25) * (N::fma(s3, p1, -s2 * p2) + N::fma(s1, p3, -p4));
   // p(E) by Horner in R[E]/(chi_E), then one more multiplication by E (log(I + E) = E p(E))
-  T h0 = T(S::kA[S::kTerms - 4]), h1 = T(S::kA[S::kTerms - 3]), h2 = T(S::kA[S::kTerms - 2]), h3 = T(S::kA[S::kTerms - 1]);
-#pragma unroll
-  for (int k = S::kTerms - 5; k >= 0; --k) {
-    const T n0 = N::fma(-h3, s4, T(S::kA[k])), n1 = N::fma(h3, s3, h0), n2 = N::fma(-h3, s2, h1), n3 = N::fma(h3, s1, h2);
-    h0 = n0; h1 = n1; h2 = n2; h3 = n3;
-  }
+  T h0, h1, h2, h3;
+  ring_horner4<T, S::kA, S::kTerms>(s1, s2, s3, s4, h0, h1, h2, h3);
   const T al[4] = {(-h3 * s4) * pre, N::fma(h3, s3, h0) * pre, N::fma(-h3, s2, h1) * pre, N::fma(h3, s1, h2) * pre};
 #pragma unroll
   for (int k = 0; k < 10; ++k) m0[k] = N::fma(al[3], e3[k], N::fma(al[2], e2[k], al[1] * e[k]));
@@ -945,12 +1147,8 @@ template <typename T, typename S = LogSqSeries<T>> __device__ __forceinline__ T 
   const T s4 = T(0.25) * (N::fma(s3, p1, -s2 * p2) + N::fma(s1, p3, -p4));
   const T p5 = N::fma(s1, p4, -s2 * p3) + N::fma(s3, p2, -s4 * p1);
   if (det) *det = ((T(1) + s1) + s2) + (s3 + s4);   // det(I + E) (the recentred form needs log det)
-  T h0 = T(S::kQ[S::kTerms - 4]), h1 = T(S::kQ[S::kTerms - 3]), h2 = T(S::kQ[S::kTerms - 2]), h3 = T(S::kQ[S::kTerms - 1]);
-#pragma unroll
-  for (int k = S::kTerms - 5; k >= 0; --k) {
-    const T n0 = N::fma(-h3, s4, T(S::kQ[k])), n1 = N::fma(h3, s3, h0), n2 = N::fma(-h3, s2, h1), n3 = N::fma(h3, s1, h2);
-    h0 = n0; h1 = n1; h2 = n2; h3 = n3;
-  }
+  T h0, h1, h2, h3;
+  ring_horner4<T, S::kQ, S::kTerms>(s1, s2, s3, s4, h0, h1, h2, h3);
   return N::fma(h3, p5, N::fma(h2, p4, N::fma(h1, p3, h0 * p2)));
 }
 

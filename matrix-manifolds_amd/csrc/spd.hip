@@ -169,15 +169,39 @@ template <typename T, int D> __device__ __forceinline__ void log_close(const T (
                                                                      T pre = T(1)) {
   if constexpr (D == 3) log_series3<T>(a, m0, pre); else log_series4<T>(a, m0, pre);
 }
-template <typename T, int D> __device__ __forceinline__ T log_cayley(const T (&a)[Packed<D>::NP], T (&m0)[Packed<D>::NP]) {
-  if constexpr (D == 3) return log_cayley3<T>(a, m0); else return log_cayley4<T>(a, m0);
+// `pre` multiplies log A (folded into three scalars by the 3x3 ring form; 4x4: applied to the matrix)
+template <typename T, int D> __device__ __forceinline__ T log_cayley(const T (&a)[Packed<D>::NP], T (&m0)[Packed<D>::NP], T pre = T(1)) {
+#ifdef MM_CAYLEY_MATRIX   // (A/B builds: the round-3 form with the adjugate and three matrix products)
+  constexpr bool kRing = false;
+#else
+  constexpr bool kRing = D == 3;
+#endif
+  if constexpr (kRing) {
+    return log_cayley3<T>(a, m0, pre);
+  } else {
+    T gate;
+    if constexpr (D == 3) gate = log_cayley3_matrix<T>(a, m0); else gate = log_cayley4<T>(a, m0);
+#pragma unroll
+    for (int k = 0; k < Packed<D>::NP; ++k) m0[k] *= pre;
+    return gate;
+  }
+}
+// the forward's far path takes the invariants-only form where log det A is at hand (all-pairs kernels: per-node table)
+template <typename T, int D> constexpr bool fwd_uses_logdet() {
+#ifdef MM_CAYLEY_MATRIX
+  return false;
+#else
+  return D == 3 && std::is_same<T, double>::value;
+#endif
 }
 
 // Forward-only value of one pair.  SPD(3) in fp32 takes the closed-form (trigonometric)
 // eigenvalues; a wavefront in which any pair has a wide spectrum (w_max > 32 w_min, where
 // the closed form's absolute error would show in log w_min) re-solves with Jacobi.
-template <typename T, int D, bool CHOL = false, typename TL>
-__device__ __forceinline__ T pair_value(const TL (&li)[Packed<D>::NP], const T (&xj)[Packed<D>::NP], T wmin, T wmax) {
+// HAS_LD: `logdet_a` = log det A = log det X_j - log det X_i is known (per-node table).
+template <typename T, int D, bool CHOL = false, bool HAS_LD = false, typename TL>
+__device__ __forceinline__ T pair_value(const TL (&li)[Packed<D>::NP], const T (&xj)[Packed<D>::NP], T wmin, T wmax,
+                                        T logdet_a = T(0)) {
   if constexpr (D == 3 && std::is_same<T, float>::value) {
     float a[6], w[3], v[3][3];
     pair_a<float, 3, CHOL>(li, xj, a);
@@ -214,6 +238,11 @@ __device__ __forceinline__ T pair_value(const TL (&li)[Packed<D>::NP], const T (
       T e2;
       const T sq = logsq_series3<T>(a, &e2);
       if (__builtin_expect(!__any(!(e2 <= T(kCloseGate))), 1)) return sq;
+      if constexpr (HAS_LD && fwd_uses_logdet<T, D>()) {   // eigenvalue ratios up to ~16: invariants only (smallmat.hpp, logsq_cayley3)
+        T gate;
+        const T sc = logsq_cayley3<T>(a, logdet_a, &gate);
+        if (__builtin_expect(!__any(!(gate <= T(kCayleyGate))), 1)) return sc;
+      }
     } else {
       if (__builtin_expect(!__any(!(close_gate<T, D>(a) <= T(kCloseGate))), 1)) return logsq_series4<T>(a);
 #ifndef MM_NO_CENTRED
@@ -233,17 +262,6 @@ __device__ __forceinline__ T pair_value(const TL (&li)[Packed<D>::NP], const T (
 }
 
 // ------------------------------------------------------------------ forward
-// Compile-time loop: f(integral_constant<int, 0>) ... f(integral_constant<int, N - 1>).  The per-column loops of the pair
-// kernels are written with it and NOT as `#pragma unroll` loops: a loop is unrolled late, after inlining, and until then
-// the per-column arrays are indexed by a variable — they are not split into registers early, and the kernels came out
-// with up to twice the vector registers (fp32 SPD(3) backward: 152 instead of 87 for one column).
-template <int N, typename F> __device__ __forceinline__ void static_for(F&& f) {
-  if constexpr (N > 0) {
-    static_for<N - 1>(f);
-    f(std::integral_constant<int, N - 1>{});
-  }
-}
-
 // Columns per lane of the pair kernels: two for fp32 SPD(2), SPD(3) — the second pair of a row shares the row operand's
 // scalar loads and the loop's scalar bookkeeping (every instruction of a wavefront, scalar ones included, takes an issue
 // slot of its SIMD) and, in the backward, the row-side reduction (one reduction of M_a + M_b); wider matrices and fp64
@@ -257,10 +275,12 @@ template <typename T, int D> constexpr int pair_cols_bwd() { return (sizeof(T) =
 // `global_store_dword v_off, v, s[ptr]`, lanes on consecutive j -> 256-B coalesced segments of the row-major pair vector.
 template <typename T, int D, int TI, bool SQ>
 __global__ __launch_bounds__(kBlock) void spd_pdist_fwd_kernel(const T* __restrict__ nodeL,
-                                                               const T* __restrict__ nodeY /* column operand: chol(X_j) */, int n, int row_begin,
+                                                               const T* __restrict__ nodeY /* column operand: chol(X_j) */,
+                                                               const T* __restrict__ nodeLd /* log det X */, int n, int row_begin,
                                                                int row_end, T wmin, T wmax, T* __restrict__ out) {
   constexpr int NP = Packed<D>::NP;
   constexpr int NC = pair_cols<T, D>();
+  constexpr bool kLd = fwd_uses_logdet<T, D>();   // log det A = nodeLd[j] - nodeLd[i] feeds the far path
   static_assert(TI % 2 == 0, "the row loop is unrolled twice");
   const TileId tile = fold_tile<TI, kBlock * NC>(n, row_begin, row_end);
   if (!tile.ok) return;
@@ -271,7 +291,7 @@ __global__ __launch_bounds__(kBlock) void spd_pdist_fwd_kernel(const T* __restri
   if (wave_j0 + 64 * NC - 1 <= i0) return;  // whole wavefront below the diagonal
   int jv[NC];          // column for the validity test (never above a row for lanes beyond n)
   unsigned joff[NC];   // byte offset of the column in a row of the pair vector
-  T xj[NC][NP];
+  T xj[NC][NP], ldj[NC];
   static_for<NC>([&](auto qc) {
     constexpr int q = decltype(qc)::value;
     const int j = wave_j0 + 64 * q + lane;
@@ -283,9 +303,11 @@ __global__ __launch_bounds__(kBlock) void spd_pdist_fwd_kernel(const T* __restri
     for (int k = 0; k < NP; ++k) xj[q][k] = T(0);
 #pragma unroll
     for (int k = 0; k < D; ++k) xj[q][pidx(k, k)] = T(1);
+    ldj[q] = T(0);
     if (jin) {
 #pragma unroll
       for (int k = 0; k < NP; ++k) xj[q][k] = nodeY[size_t(j) * NP + k];
+      if constexpr (kLd) ldj[q] = nodeLd[j];
     }
   });
   const int64_t base = pair_off(n, row_begin);
@@ -294,9 +316,10 @@ __global__ __launch_bounds__(kBlock) void spd_pdist_fwd_kernel(const T* __restri
   // row operand: wave-uniform -> scalar loads, issued one row ahead (the row after the tile's last is read too: inside the
   // workspace — nodeL is followed by nodeX — and never used)
   unsigned roff = unsigned(i0) * unsigned(NP * sizeof(T));
-  T lrow[2][NP];
+  T lrow[2][NP], ldrow[2] = {T(0), T(0)};
 #pragma unroll
   for (int k = 0; k < NP; ++k) lrow[0][k] = nodeL[size_t(i0) * NP + k];
+  if constexpr (kLd) ldrow[0] = nodeLd[i0];
   for (int ib = i0; ib < i1; ib += 2) {
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
@@ -307,10 +330,13 @@ __global__ __launch_bounds__(kBlock) void spd_pdist_fwd_kernel(const T* __restri
       const T* rowp = reinterpret_cast<const T*>(reinterpret_cast<const char*>(nodeL) + roff);
 #pragma unroll
       for (int k = 0; k < NP; ++k) lrow[u ^ 1][k] = rowp[k];
+      // (row irow + 1 <= n - 1 of the log-det table whenever the slot's result is used; the masked slot past the range reads
+      // at most nodeLd[n + 1], inside the table that follows it in the workspace)
+      if constexpr (kLd) ldrow[u ^ 1] = nodeLd[irow + 1];
       const T (&li)[NP] = lrow[u];
       static_for<NC>([&](auto qc) {
         constexpr int q = decltype(qc)::value;
-        T s = Num<T>::max_raw_s(pair_value<T, D, true>(li, xj[q], wmin, wmax), wmin);
+        T s = Num<T>::max_raw_s(pair_value<T, D, true, kLd>(li, xj[q], wmin, wmax, ldj[q] - ldrow[u]), wmin);
         if constexpr (!SQ) s = Num<T>::sqrt(s);
         // (re-defined in this block: a zero-extension hoisted out of the loop hides from instruction selection that the
         // lane offset is 32 bits wide, and the store gets a 64-bit vector address instead of `v_off, s[ptr]`)
@@ -593,8 +619,8 @@ __global__ __launch_bounds__((64 * bwd_waves<T, D>()), (bwd_min_waves_nc<T, D, N
               static_for<NC>([&](auto qc) {
                 constexpr int q = decltype(qc)::value;
                 T m0[NP];
-                const T gate = log_cayley<T, D>(a[q], m0);
-                if (__builtin_expect(!__any(!(gate <= T(kCayleyGate))), 1)) finish(qc, m0, false); else jacobi_path(qc);
+                const T gate = log_cayley<T, D>(a[q], m0, g_first ? gs[q] + gs[q] : T(1));
+                if (__builtin_expect(!__any(!(gate <= T(kCayleyGate))), 1)) finish(qc, m0, g_first); else jacobi_path(qc);
               });
             }
           } else {
@@ -1042,14 +1068,14 @@ int spd_pdist_prepare(const T* x, int64_t n, Ws<T>& ws, int flags, hipStream_t s
 
 constexpr int kFwdTI = 8;   // rows of a forward tile (sweep on MI355X, SPD(3) fp32, n = 5000: 8 / 16 / 32 rows -> 28.8 / 30.1 / 33.0 us)
 template <typename T, int D, int TI>
-int spd_pdist_fwd_launch(const T* nl, const T* nc, int64_t n, int64_t rb, int64_t re, int squared, double wmin, double wmax,
+int spd_pdist_fwd_launch(const T* nl, const T* nc, const T* nld, int64_t n, int64_t rb, int64_t re, int squared, double wmin, double wmax,
                          T* out, hipStream_t st) {
   const dim3 grid = fold_grid<TI, kBlock * pair_cols<T, D>()>(n, rb, re);
   if (squared)
-    launch_timed(PROF_SPD_FWD, spd_pdist_fwd_kernel<T, D, TI, true>, grid, dim3(kBlock), st, nl, nc, int(n), int(rb), int(re),
+    launch_timed(PROF_SPD_FWD, spd_pdist_fwd_kernel<T, D, TI, true>, grid, dim3(kBlock), st, nl, nc, nld, int(n), int(rb), int(re),
                  T(wmin), T(wmax), out);
   else
-    launch_timed(PROF_SPD_FWD, spd_pdist_fwd_kernel<T, D, TI, false>, grid, dim3(kBlock), st, nl, nc, int(n), int(rb), int(re),
+    launch_timed(PROF_SPD_FWD, spd_pdist_fwd_kernel<T, D, TI, false>, grid, dim3(kBlock), st, nl, nc, nld, int(n), int(rb), int(re),
                  T(wmin), T(wmax), out);
   MM_CHECK_LAUNCH();
   return MM_OK;
@@ -1069,9 +1095,9 @@ int spd_pdist_fwd_t(const T* x, int64_t n, int64_t rb, int64_t re, int squared, 
   if constexpr (D <= 4) {
     const dim3 g8 = fold_grid<kFwdTI, kBlock * pair_cols<T, D>()>(n, rb, re);
     if (int64_t(g8.x) * g8.y < 4 * int64_t(device_cus()))
-      return spd_pdist_fwd_launch<T, D, 2>(nl, nc, n, rb, re, squared, wmin, wmax, out, st);
+      return spd_pdist_fwd_launch<T, D, 2>(nl, nc, ws.nodeLd, n, rb, re, squared, wmin, wmax, out, st);
   }
-  return spd_pdist_fwd_launch<T, D, kFwdTI>(nl, nc, n, rb, re, squared, wmin, wmax, out, st);
+  return spd_pdist_fwd_launch<T, D, kFwdTI>(nl, nc, ws.nodeLd, n, rb, re, squared, wmin, wmax, out, st);
 }
 
 // One launch of (at most) the resident capacity; fewer workgroups when the row range is small (>= 8 rows of a column

@@ -33,8 +33,11 @@ constexpr int64_t kSpdMaxNodes = int64_t(1) << 22;
 #ifndef MM_SPD4_FWD_NC
 #define MM_SPD4_FWD_NC 1
 #endif
+#ifndef MM_SPD3_F64_BWD_WAVES
+#define MM_SPD3_F64_BWD_WAVES 1
+#endif
 template <typename T, int D> constexpr int bwd_min_waves() {
-  return (sizeof(T) == 4 && D == 3) ? 4 : ((sizeof(T) == 4 && D == 4) ? MM_SPD4_BWD_WAVES : 1);
+  return (sizeof(T) == 4 && D == 3) ? 4 : ((sizeof(T) == 4 && D == 4) ? MM_SPD4_BWD_WAVES : ((sizeof(T) == 8 && D == 3) ? MM_SPD3_F64_BWD_WAVES : 1));
 }
 // ... with NCX columns per lane forced (0: the default of pair_cols_bwd): two columns of fp32 SPD(4) need ~185 registers —
 // three wavefronts per SIMD (168 registers, the rest spilled) measured best (profiles/r03_experiments.md §2)

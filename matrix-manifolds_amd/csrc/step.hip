@@ -116,10 +116,16 @@ extern "C" int mm_train_step_run(const mm_train_step* s, mm_stream_t st) {
   if (nf == 1) {
     const mm_step_param& p = s->points[0];
     if (!p.x || !p.grad) return MM_ERR_ARG;
-    if (p.kind == MM_FACTOR_SPD)
+    if (p.kind == MM_FACTOR_SPD) {
+      // MM_WS_PREPARED ("the workspace holds the tables of the current points") is honoured only where this call keeps that
+      // promise for the NEXT step: the sharded fused step (its optimizer kernel rewrites the tables, below) or frozen points.
+      // On the plain unfused path the per-point optimizer kernels do not touch the tables, so a caller that derives the
+      // flag from the dimension alone would otherwise run its second step on stale Cholesky factors.
+      const bool tables_kept = spd_fused || p.optimizer == MM_OPT_NONE;
       rc = mm_spd_pdist_loss(s->dtype, s->loss_kind, p.x, s->target, s->scales[0].x, s->n, p.dim, rb, re, s->alpha, s->eps,
                              s->terms, s->loss_params, s->wmin, s->wmax, s->loss_out, p.grad, s->ws,
-                             s->ws_flags & MM_WS_PREPARED, st);
+                             tables_kept ? (s->ws_flags & MM_WS_PREPARED) : 0, st);
+    }
     else
       rc = mm_vec_pdist_loss(s->dtype, p.kind, s->loss_kind, p.x, s->target, s->scales[0].x, s->n, p.dim, rb, re, s->alpha,
                              s->eps, s->terms, s->loss_params, s->loss_out, p.grad, s->ws, st);

@@ -176,6 +176,10 @@ bool vec_step_fusable(const mm_train_step* s) {
   const mm_step_param& p = s->points[0];
   if (p.kind == MM_FACTOR_SPD || !p.x || !p.grad || p.count != s->n || s->n < 1 || s->n > kSpdMaxNodes || !s->ws) return false;
   if (!vec_fused_step_supports(s->dtype, p.kind, p.dim)) return false;
+  // (anything else takes the unfused path, where mm_vec_pdist_loss reports MM_ERR_UNSUPPORTED / MM_ERR_ARG as before: the
+  // fused pair kernel would read an unknown loss kind as "no loss" and step the points on the targets)
+  if (s->loss_kind != MM_LOSS_STRESS && s->loss_kind != MM_LOSS_QUOTIENT) return false;
+  if (s->loss_kind == MM_LOSS_QUOTIENT && !(s->terms & 3)) return false;
   if (p.optimizer == MM_OPT_RSGD) return p.momentum == 0.0 || p.state0;
   if (p.optimizer == MM_OPT_RADAM) return p.state0 && p.state1 && p.step && p.ticket;
   return false;

@@ -8,10 +8,26 @@ import sysconfig
 HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(HERE, 'mm_autograd.cpp')
 OUT = os.path.join(os.path.dirname(HERE), 'lib', '_mm_autograd.so')
+STAMP = os.path.join(os.path.dirname(HERE), 'lib', '_mm_autograd.stamp')   # torch version + source hash the binary was built from
+
+
+def _stamp_of():
+    """What the binary depends on besides its source: the torch it was compiled against (headers and libraries) — a binary
+    built for another torch loads and then calls through mismatched types."""
+    import hashlib
+    import torch
+    return f'torch {torch.__version__}\nsource {hashlib.sha256(open(SRC, "rb").read()).hexdigest()}\n'
+
+
+def is_current():
+    try:
+        return os.path.isfile(OUT) and open(STAMP).read() == _stamp_of()
+    except OSError:
+        return False
 
 
 def build_if_stale(force=False):
-    if not force and os.path.isfile(OUT) and os.path.getmtime(OUT) >= os.path.getmtime(SRC):
+    if not force and is_current():
         return OUT
     import pybind11
     import torch
@@ -26,7 +42,11 @@ def build_if_stale(force=False):
     cmd += [SRC, '-o', OUT, '-L' + tlib, '-ltorch', '-ltorch_cpu', '-ltorch_python', '-lc10', '-lc10_hip', '-ltorch_hip', '-ldl',
             '-Wl,-rpath,' + tlib]
     os.makedirs(os.path.dirname(OUT), exist_ok=True)
+    if os.path.isfile(STAMP):
+        os.remove(STAMP)
     subprocess.check_call(cmd)
+    with open(STAMP, 'w') as f:
+        f.write(_stamp_of())
     return OUT
 
 

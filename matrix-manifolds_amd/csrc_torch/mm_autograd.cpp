@@ -30,6 +30,8 @@ struct Abi {
   bool ready = false;
 } abi;
 
+constexpr int kAbiBuiltFor = 2;   // include/mm_manifolds.h, mm_abi_version()
+
 template <typename F> void bind(void* h, F& f, const char* name) {
   f = reinterpret_cast<F>(dlsym(h, name));
   if (!f) throw std::runtime_error(std::string("libmm_manifolds.so lacks ") + name);
@@ -39,6 +41,12 @@ void init(const std::string& path) {
   void* h = dlopen(path.c_str(), RTLD_NOW | RTLD_NOLOAD);
   if (!h) h = dlopen(path.c_str(), RTLD_NOW);
   if (!h) throw std::runtime_error("cannot load " + path + ": " + dlerror());
+  // the entry points below are bound by NAME: a library with an older C ABI would be called through mismatched signatures
+  int (*abi_version)() = nullptr;
+  bind(h, abi_version, "mm_abi_version");
+  if (abi_version() < kAbiBuiltFor)
+    throw std::runtime_error(path + " has C-ABI version " + std::to_string(abi_version()) + ", this module was written for " +
+                             std::to_string(kAbiBuiltFor) + ": rebuild both with `python __graft_entry__.py`");
   bind(h, abi.spd_ws_bytes, "mm_spd_pdist_ws_bytes");
   bind(h, abi.spd_fwd, "mm_spd_pdist_fwd");
   bind(h, abi.spd_bwd, "mm_spd_pdist_bwd");

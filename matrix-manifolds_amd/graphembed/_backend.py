@@ -182,6 +182,10 @@ def autograd_ext():
             import importlib.util
             lib()                      # (the HIP library: raises if absent — there is no CPU fallback)
             try:
+                stamp = os.path.join(os.path.dirname(path), '_mm_autograd.stamp')
+                built_for = open(stamp).read().splitlines()[0] if os.path.isfile(stamp) else None
+                if built_for != f'torch {torch.__version__}':   # (csrc_torch/build.py writes it; a binary for another torch loads and then misbehaves)
+                    raise ImportError(f'built for {built_for}, this interpreter has torch {torch.__version__}')
                 spec = importlib.util.spec_from_file_location('_mm_autograd', path)
                 mod = importlib.util.module_from_spec(spec)
                 spec.loader.exec_module(mod)

@@ -1,0 +1,131 @@
+"""Overlay of this package onto a maintainer's checkout of the reference (option A).
+
+This package defines the hot path only (`manifolds`, `modules`, `optim`, `objectives`, `data`, `pyx`, `metrics`,
+`utils`).  The reference's control plane — `graphembed.train`, `.train_da`, `.products`, `.monitor`, `.linalg`,
+`.inference` (run.py:15-18, 76-81; `graphembed/__init__.py:1-9`) — is NOT rebuilt here.  When another `graphembed`
+package follows this one on `sys.path` (the maintainer's checkout), `install()`
+
+  * appends its directories to `__path__` of this package and of its sub-packages, so every sub-module this package does
+    not define (`graphembed.train`, `graphembed.products.embedding`, `graphembed.manifolds.universal`, …) is imported
+    from the checkout, while the names defined here keep shadowing the reference's, and
+  * gives the modules defined here a module-level `__getattr__` (PEP 562) that resolves a name they do NOT define
+    (`graphembed.manifolds.Universal`, `graphembed.objectives.KLDiveregenceLoss`, `graphembed.utils.PLT_MUTEX`,
+    `graphembed.modules.EmbeddingBase`, …) in the checkout's counterpart.
+
+Nothing of the reference is copied or shipped: without a second `graphembed` on the path (the GPU box, the tests) this
+module does nothing.
+"""
+import importlib
+import importlib.util
+import os
+import sys
+
+_OURS = os.path.dirname(os.path.abspath(__file__))
+_ROOT = 'graphembed'
+_SUBPACKAGES = ('manifolds', 'optim', 'data', 'pyx')
+_MODULES = ('modules', 'objectives', 'utils', 'metrics')
+_loaded = {}
+
+
+def later_packages():
+    """Directories of other `graphembed` packages on sys.path, in path order (this one excluded)."""
+    out = []
+    for p in sys.path:
+        cand = os.path.join(p or os.getcwd(), _ROOT)
+        try:
+            if not os.path.isfile(os.path.join(cand, '__init__.py')) or os.path.samefile(cand, _OURS):
+                continue
+        except OSError:
+            continue
+        if cand not in out:
+            out.append(cand)
+    return out
+
+
+def _counterpart(stem):
+    """The checkout's `<stem>.py`, loaded once under a private name (its `from graphembed... import` lines see the
+    merged package)."""
+    if stem in _loaded:
+        return _loaded[stem]
+    mod = None
+    for base in later_packages():
+        path = os.path.join(base, stem + '.py')
+        if os.path.isfile(path):
+            name = f'{_ROOT}._overlaid_{stem}'
+            spec = importlib.util.spec_from_file_location(name, path)
+            mod = importlib.util.module_from_spec(spec)
+            mod.__package__ = _ROOT
+            sys.modules[name] = mod
+            try:
+                spec.loader.exec_module(mod)
+            except BaseException:
+                sys.modules.pop(name, None)
+                raise
+            break
+    _loaded[stem] = mod
+    return mod
+
+
+def _module_getattr(stem):
+    def __getattr__(name):
+        if not name.startswith('__'):
+            mod = _counterpart(stem)
+            if mod is not None and hasattr(mod, name):
+                return getattr(mod, name)
+        raise AttributeError(f"module '{_ROOT}.{stem}' has no attribute '{name}'")
+    return __getattr__
+
+
+def _package_getattr(modname, rel):
+    def __getattr__(name):
+        if name.startswith('__'):
+            raise AttributeError(name)
+        full = f'{modname}.{name}'
+        try:                                   # a sub-module / sub-package of the checkout (graphembed.linalg, data.preprocess)
+            return importlib.import_module(full)
+        except ModuleNotFoundError as e:
+            if e.name != full:
+                raise
+        ours = os.path.join(_OURS, rel)
+        for base in later_packages():          # a name one of the checkout's sub-modules defines (manifolds.Universal)
+            d = os.path.join(base, rel)
+            if not os.path.isdir(d):
+                continue
+            for fn in sorted(os.listdir(d)):
+                stem, ext = os.path.splitext(fn)
+                if ext != '.py' or stem == '__init__' or os.path.exists(os.path.join(ours, fn)):
+                    continue
+                with open(os.path.join(d, fn), encoding='utf-8', errors='replace') as f:
+                    if name not in f.read():   # (do not import every module of the checkout to find one name)
+                        continue
+                sub = importlib.import_module(f'{modname}.{stem}')
+                if hasattr(sub, name):
+                    return getattr(sub, name)
+        raise AttributeError(f"module '{modname}' has no attribute '{name}'")
+    return __getattr__
+
+
+def install():
+    """Idempotent; a no-op unless another `graphembed` package follows this one on sys.path."""
+    later = later_packages()
+    if not later:
+        return False
+    root = sys.modules[_ROOT]
+    for base in later:
+        if base not in root.__path__:
+            root.__path__.append(base)
+    root.__dict__.setdefault('__getattr__', _package_getattr(_ROOT, ''))
+    for sub in _SUBPACKAGES:
+        mod = sys.modules.get(f'{_ROOT}.{sub}')
+        if mod is None:
+            continue
+        for base in later:
+            d = os.path.join(base, sub)
+            if os.path.isdir(d) and d not in mod.__path__:
+                mod.__path__.append(d)
+        mod.__dict__.setdefault('__getattr__', _package_getattr(f'{_ROOT}.{sub}', sub))
+    for stem in _MODULES:
+        mod = sys.modules.get(f'{_ROOT}.{stem}')
+        if mod is not None:
+            mod.__dict__.setdefault('__getattr__', _module_getattr(stem))
+    return True

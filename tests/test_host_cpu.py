@@ -378,13 +378,15 @@ def test_sync_grads_uses_an_installed_communicator():
 def test_cpp_autograd_nodes_build_load_and_refuse_cpu_tensors():
     """csrc_torch/mm_autograd.cpp (the C++ autograd nodes of `pdist`): builds against this interpreter's torch with g++ alone,
     binds the C ABI at run time, and a CPU tensor is refused with the package's own error — there is no CPU path behind it."""
-    import sys
-    sys.path.insert(0, os.path.join(ROOT, 'matrix-manifolds_amd', 'csrc_torch'))
-    import build as autograd_build
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('_mm_autograd_build', os.path.join(ROOT, 'matrix-manifolds_amd', 'csrc_torch', 'build.py'))
+    autograd_build = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(autograd_build)
     path = autograd_build.build_if_stale()
-    assert os.path.isfile(path)
+    assert os.path.isfile(path) and autograd_build.is_current()   # (the stamp: torch version + source hash the binary was built from)
     from graphembed import _backend as B
     from graphembed import manifolds as M
+    B._autograd = False     # (an earlier test may have looked the module up before it was built)
     ext = B.autograd_ext()
     assert ext is not None and {'init', 'spd_pdist', 'vec_pdist'} <= set(dir(ext))
     with pytest.raises(B.BackendError):

@@ -243,6 +243,28 @@ def median(v):
     return v[len(v) // 2] if v else None
 
 
+N_SIMD = 256 * 4             # MI355X: 256 CUs x 4 SIMDs
+ISSUE_CYCLES = 2.0           # one instruction of a wavefront per ~2 cycles per SIMD, of any kind
+
+
+def shader_clock_mhz(lib, run, dev, bursts=6):
+    """Shader clock in the regime of the timed region: mm_prof_clock_probe (s_memtime cycles per 100-MHz s_memrealtime tick of
+    a one-wavefront dependent chain) enqueued right behind a burst of replays of the timed step; median over a few bursts."""
+    import torch
+    from graphembed import _backend as B
+    out = torch.zeros(2, dtype=torch.int64, device=dev)
+    vals = []
+    for _ in range(bursts):
+        for _ in range(16):
+            run()
+        lib.call('mm_prof_clock_probe', B.ptr(out), 20000, B.stream_of(out))
+        torch.cuda.synchronize()
+        c, r = (int(v) for v in out.tolist())
+        if r > 0:
+            vals.append(100.0 * c / r)
+    return median(vals)
+
+
 class PdistWorkload:
     """d2 = man.pdist(x, squared=True, rows=shard); grad = d d2 / d x . g  (+ one all-reduce for N > 1)."""
 
@@ -537,9 +559,18 @@ def time_workload(wl, steps, warmup, fence, use_graph, graph_collective=False, r
     wall_us = (time.perf_counter() - tw) / k2 * 1e6
     kern_us = median([e0.elapsed_time(e1) * 1e3 for e0, e1, _ in ev])
     coll_us = median([e1.elapsed_time(e2) * 1e3 for _, e1, e2 in ev])
+    # SURVEY.md §8d's form of the figure: the MEDIAN of single synchronised steps (each one issued into an idle device and
+    # waited for: launch latency and the synchronisation are inside it), next to the pipelined mean the headline reports
+    sync_us = []
+    for _ in range(max(20, min(steps, 50))):
+        fence()
+        ts = time.perf_counter()
+        run()
+        fence()
+        sync_us.append((time.perf_counter() - ts) * 1e6)
     phases = {'steps': steps, 'kernels_us': kern_us, 'allreduce_us': coll_us if world > 1 else 0.0,
               'host_gap_us': max(0.0, wall_us - kern_us - (coll_us if world > 1 else 0.0)),
-              'step_wall_us': wall_us}
+              'step_wall_us': wall_us, 'synchronised_step_us_median': median(sync_us), 'synchronised_steps': len(sync_us)}
     if in_graph_collective:
         phases['note'] = 'all-reduce inside the graph: kernels_us includes it'
     phases['_run'] = run          # (for the caller's kernel-timing pass; removed before the phases are reported)
@@ -671,6 +702,12 @@ def worker(args):
         fence()
         lib.call('mm_prof_enable', 0)
         kern = collect_kernel_us(lib)
+    clock_mhz = None
+    if not args.no_prof:
+        try:
+            clock_mhz = shader_clock_mhz(lib, run_step, dev)
+        except Exception as exc:  # noqa: BLE001 — a diagnostic: never fails the run
+            print(f'[bench] shader clock probe failed ({type(exc).__name__}: {exc})', file=sys.stderr)
     per_rank = gather_objects({'rank': rank, 'rows': list(wl.rows), 'pairs': wl.hi - wl.lo, **phases,
                                'fwd_kernel_us': kern['fwd'], 'bwd_kernel_us': kern['bwd']}, world)
 
@@ -696,6 +733,8 @@ def worker(args):
                        'untimed_warm_seconds': 0.05},
             'per_rank': per_rank,
             'kernel_source_hash': kernel_source_hash(),
+            # the same step measured SURVEY.md §8d's way: median of single synchronised steps (launch latency + sync inside)
+            'ms_per_step_median_synchronised': (phases.get('synchronised_step_us_median') or 0.0) / 1e3 or None,
         }
         if eager_ms is not None:
             # same step issued through Python autograd (host-bound); median of single synchronised steps
@@ -720,6 +759,18 @@ def worker(args):
                                'algorithmic_bytes': by, 'avg_launch_us': kern['bwd'],
                                'measured_in': 'eager steps queued behind replays of the timed step right after the timed region (device never idle); HIP events attached to the kernel dispatch on the launch stream (hipExtLaunchKernelGGL)',
                                'valu_insts_per_64_pairs': rk.get('valu_insts_per_64_pairs')}
+            # the honest ceiling (SURVEY.md §8d "vector-ALU"): these kernels issue one instruction of a wavefront
+            # per ~2 cycles per SIMD whatever its kind, so issue time = instructions per wavefront-row x rows / SIMDs x 2 cycles
+            # at the shader clock of THIS run; the fraction of the kernel's duration it fills is how close the kernel is to
+            # that machine limit.  Instruction count: the stamped counters of this very kernel build (null when stale).
+            insts = rk.get('insts_any_per_64_pairs')
+            if insts and clock_mhz:
+                issue_us = insts * (pairs_local / 64.0) / N_SIMD * ISSUE_CYCLES / clock_mhz
+                out['roofline'].update({'valu_issue_frac': issue_us / kern['bwd'], 'issue_time_us': issue_us,
+                                        'insts_per_64_pairs': insts, 'shader_clock_mhz': clock_mhz,
+                                        'issue_model': f'{insts:.0f} instructions per 64 pairs x {pairs_local / 64.0:.0f} wavefront-rows / {N_SIMD} SIMDs x {ISSUE_CYCLES:.0f} cycles / clock'})
+            else:
+                out['roofline'].update({'valu_issue_frac': None, 'shader_clock_mhz': clock_mhz})
             if kern['fwd']:
                 byf = pairs_local * esz + n * 12 * esz
                 tf = kern['fwd'] * 1e-6
@@ -770,6 +821,20 @@ def worker(args):
                 np_ = d * (d + 1) // 2
                 byb = (w.hi - w.lo) * w.esz + nn * 4 * np_ * w.esz
                 rec['bwd_hbm_frac'] = byb / (kk['bwd'] * 1e-6) / 1e9 / HBM_PEAK_GBS
+                tname = 'double' if dt == torch.float64 else 'float'
+                rec['roofline'] = {'bound': 'hbm', 'kernel': f'spd_pdist_bwd_kernel<{tname},{d},...>', 'achieved': byb / (kk['bwd'] * 1e-6) / 1e9,
+                                   'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': rec['bwd_hbm_frac'], 'traffic': None,
+                                   'algorithmic_bytes': byb, 'avg_launch_us': kk['bwd']}
+                if kk['fwd']:
+                    byf = (w.hi - w.lo) * w.esz + nn * 2 * np_ * w.esz
+                    rec['roofline_fwd'] = {'bound': 'hbm', 'kernel': f'spd_pdist_fwd_kernel<{tname},{d},...>', 'achieved': byf / (kk['fwd'] * 1e-6) / 1e9,
+                                           'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': byf / (kk['fwd'] * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                                           'traffic': None, 'algorithmic_bytes': byf, 'avg_launch_us': kk['fwd']}
+            if rank == 0 and out is not None and dt == torch.float64 and nn == N_NODES and 'roofline' in rec:
+                # the headline workload in the dtype run.py:32-35 sets: its own roofline blocks on the JSON line
+                key = 'roofline_f64' if ir == 0.1 else 'roofline_f64_mid_training'
+                out[key] = dict(rec['roofline'], workload=name, ms_per_step=rec['ms_per_step'],
+                                fwd=rec.get('roofline_fwd'))
             extra.append(rec)
             del w
             torch.cuda.empty_cache()

@@ -54,6 +54,11 @@ int mm_prof_enable(int on);
 /* Waits for the recorded events of kernel `id`; returns their count and summed
  * duration since the previous collect. */
 int mm_prof_collect(int id, int64_t* launches, double* total_ms);
+/* Shader clock at this moment of the stream: one wavefront runs `iters` dependent multiply-adds between two readings of
+ * s_memtime (shader cycles) and s_memrealtime (the constant 100 MHz reference); out (device, 2 x uint64) receives the two
+ * differences — clock [MHz] = 100 * out[0] / out[1].  Enqueued behind the kernels whose clock regime is to be read
+ * (bench.py: behind a burst of replays of the timed step), so that an instruction budget can be priced in time. */
+int mm_prof_clock_probe(void* out, int iters, mm_stream_t stream);
 
 /* ---- pair-list geometry (host-side helpers, no GPU work) ----------------- */
 /* number of pairs in rows < row:  row*(2n-row-1)/2 */
@@ -117,6 +122,21 @@ int mm_spd_pdist_loss(int dtype, int loss_kind, const void* x, const void* targe
                       const void* scale_raw, int64_t n, int d, int64_t row_begin, int64_t row_end,
                       double alpha, double eps, int terms, const double* loss_params, double wmin, double wmax,
                       void* loss_out, void* grad_x, void* ws, int flags, mm_stream_t stream);
+
+/* The same objective for a NODE MINIBATCH, with no gather or scatter launch around it (train.py:198-222 draws
+ * idx = randperm(n)[a:b]; ManifoldEmbedding.compute_dists(idx) gathers x[idx], modules.py:86; GraphDataset.__getitem__
+ * gathers dense[idx][:, idx], data/dataset.py:19-27; autograd's index backward scatters the gradient rows):
+ *   x        the FULL table [n_total, d, d]; the `bs` points of the step are its rows idx[0..bs) (device int64, DISTINCT)
+ *   dense    the dataset's dense n_total x n_total matrix of squared graph distances: target of pair (a, b) = dense[idx[a]][idx[b]]
+ *   grad_x   [n_total, d, d], OVERWRITTEN: rows idx[.] with the gradient, every other row with zero — the dense
+ *            gradient the reference's optimizers see
+ *   ws       mm_spd_pdist_ws_bytes(dtype, n_total, d): the per-node tables are those of the FULL embedding (flags =
+ *            MM_WS_PREPARED skips their preparation when they are current); row_begin / row_end shard the pair list of
+ *            the BATCH (0 .. bs).  Every d of mm_spd_max_dim(). */
+int mm_spd_pdist_loss_subset(int dtype, int loss_kind, const void* x, const void* dense, const void* scale_raw,
+                             int64_t n_total, int d, const int64_t* idx, int64_t bs, int64_t row_begin, int64_t row_end,
+                             double alpha, double eps, int terms, const double* loss_params, double wmin, double wmax,
+                             void* loss_out, void* grad_x, void* ws, int flags, mm_stream_t stream);
 
 /* Stein divergence S(X,Y) = log det((X+Y)/2) - (log det X + log det Y)/2 — the second SPD "distance" of the
  * reference (SymmetricPositiveDefinite(use_stein_div=True): spd.py:183-194 stein_div / stein_pdiv,
@@ -208,6 +228,13 @@ int mm_vec_pdist_loss(int dtype, int kind, int loss_kind, const void* x, const v
                       const void* scale_raw, int64_t n, int m, int64_t row_begin, int64_t row_end,
                       double alpha, double eps, int terms, const double* loss_params, void* loss_out, void* grad_x, void* ws,
                       mm_stream_t stream);
+/* ... for a NODE MINIBATCH, the counterpart of mm_spd_pdist_loss_subset (same arguments: the FULL table x [n_total, m], the dense
+ * target matrix, idx int64[bs] distinct, grad_x [n_total, m] OVERWRITTEN — zero rows outside the batch; ws as
+ * mm_vec_pdist_ws_bytes(dtype, n_total, m)); every kind, every m <= mm_vec_max_dim(). */
+int mm_vec_pdist_loss_subset(int dtype, int kind, int loss_kind, const void* x, const void* dense, const void* scale_raw,
+                             int64_t n_total, int m, const int64_t* idx, int64_t bs, int64_t row_begin, int64_t row_end,
+                             double alpha, double eps, int terms, const double* loss_params, void* loss_out, void* grad_x,
+                             void* ws, mm_stream_t stream);
 /* Element-wise dist over cnt pairs (x[k],y[k]).  out may be NULL (backward only);
  * grad_x/grad_y may both be NULL (forward only), else g [cnt] is required. */
 int mm_vec_dist(int dtype, int kind, const void* x, const void* y, const void* g, int64_t cnt, int m,
@@ -475,6 +502,14 @@ typedef struct mm_train_step {
   void* reduce_buf;              /* [reduce_count] of `dtype`: ONE allocation that contains every points[k].grad and
                                     loss_out (MM_ERR_ARG otherwise) — the message of the collective                 */
   int64_t reduce_count;
+  /* -- node minibatch (mm_abi_version() >= 3); NULL / 0 = full batch -------------------------------------------------
+     train.py:198-222 with batch_size set: the step's pair list is that of the `batch` nodes batch_idx[.] (device int64,
+     distinct); `target` is then the DENSE n x n matrix of squared graph distances (GraphDataset.pdists), row_begin /
+     row_end shard the batch's pair list, and the optimizer still steps all n points — those outside the batch with a
+     zero gradient (the reference's dense x.grad; momentum and Adam state keep moving them).  Single SPD(d) or vector
+     factor; MM_ERR_UNSUPPORTED for products (mm_product_pairs_loss_subset + the optimizer entry points serve those). */
+  const int64_t* batch_idx;
+  int64_t batch;
 } mm_train_step;
 int mm_train_step_run(const mm_train_step* step, mm_stream_t stream);
 /* Largest d for which a single SPD(d) factor takes the two-launch form above (and therefore leaves the workspace holding

@@ -1,6 +1,7 @@
 // Library info and pair-list geometry helpers (host side; no GPU work).
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
 #include <vector>
 
 #include "../../include/mm_manifolds.h"
@@ -32,31 +33,66 @@ void prof_span(int id, hipEvent_t* start, hipEvent_t* stop) {
 }
 }  // namespace mm
 
+namespace mm {
+__global__ void clock_probe_kernel(unsigned long long* out, int iters) {
+  const unsigned long long c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+  float a = float(threadIdx.x) * 1e-3f + 1.0f;
+  for (int i = 0; i < iters; ++i) a = __builtin_fmaf(a, 0.999999f, 1e-7f);   // a dependent chain: nothing to overlap, nothing to skip
+  const unsigned long long c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+  if (threadIdx.x == 0) { out[0] = c1 - c0; out[1] = r1 - r0; }
+  if (a == 12345.678f) out[1] = 0;   // (keeps the chain alive)
+}
+}  // namespace mm
+
 extern "C" {
 
-int mm_abi_version(void) { return 2; }   // 2: mm_comm_*, sharded mm_train_step (row range + communicator), MM_OPT_NONE
+int mm_prof_clock_probe(void* out, int iters, mm_stream_t stream) {
+  if (!out || iters < 1) return MM_ERR_ARG;
+  mm::clock_probe_kernel<<<dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream)>>>(static_cast<unsigned long long*>(out), iters);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? MM_OK : int(e);
+}
+
+int mm_abi_version(void) { return 3; }   // 2: mm_comm_*, sharded mm_train_step (row range + communicator), MM_OPT_NONE; 3: mm_train_step.batch_idx / batch, *_loss_subset for single factors
 
 const char* mm_target_arch(void) { return "gfx950"; }
 
 int64_t mm_pair_offset(int64_t n, int64_t row) { return row * (2 * n - row - 1) / 2; }
 
-// Shard r owns the rows whose first pair index falls in [P*r/world, P*(r+1)/world):
-// contiguous, disjoint, covering, and balanced to within one row (< n pairs).
-static int64_t first_row_at_or_after(int64_t n, int64_t target) {
-  int64_t lo = 0, hi = n;  // smallest row with pair_offset(row) >= target
+// Shard r owns a contiguous row range; the cuts balance the COST of the ranks' pair kernels, not their pair counts.
+// A pair of a LONG row costs more than a pair of a short one: every column block of a row adds its row-side sums to the
+// same NP accumulator addresses, so the float atomics of row i contend (n - i) / 64 deep — the first rank of 8 (1059
+// rows, 256 column blocks each, n = 16384) ran 11 % longer than the last (5793 short rows) under equal pair counts
+// (profiles/r03_shard_kernel_times.json: 192.7 against 173.1 us).  Model: cost of a pair in a row of L pairs
+// = 1 + L / K, K = 100 000 pairs (fitted to that measurement; n = 5000: at most 5 % — its rows are 40 blocks deep and
+// its shards showed no such slope).  Row cost L (K + L), prefix sums in closed form, exact integer arithmetic (the
+// Python restatement graphembed._backend.shard_rows computes the same cuts); MM_SHARD_K overrides K (0: pair counts).
+static __int128 shard_cost_before(int64_t n, int64_t row, int64_t K) {   // cost of rows [0, row)
+  const __int128 m1 = n - 1, m0 = n - 1 - row;                          // row lengths run from m1 down to m0 + 1
+  const __int128 sum1 = m1 * (m1 + 1) / 2 - m0 * (m0 + 1) / 2;
+  if (K <= 0) return sum1;
+  const __int128 sum2 = m1 * (m1 + 1) * (2 * m1 + 1) / 6 - m0 * (m0 + 1) * (2 * m0 + 1) / 6;
+  return sum1 * K + sum2;
+}
+static int64_t shard_K() {
+  static const int64_t k = [] { const char* e = std::getenv("MM_SHARD_K"); return e ? std::atoll(e) : int64_t(100000); }();
+  return k;
+}
+static int64_t first_row_at_or_after(int64_t n, __int128 target, int64_t K) {
+  int64_t lo = 0, hi = n;  // smallest row with cost_before(row) >= target
   while (lo < hi) {
     const int64_t mid = (lo + hi) / 2;
-    if (mm_pair_offset(n, mid) >= target) hi = mid; else lo = mid + 1;
+    if (shard_cost_before(n, mid, K) >= target) hi = mid; else lo = mid + 1;
   }
   return lo;
 }
 
 int mm_shard_rows(int64_t n, int world, int rank, int64_t* row_begin, int64_t* row_end) {
   if (n < 0 || world <= 0 || rank < 0 || rank >= world || !row_begin || !row_end) return MM_ERR_ARG;
-  const int64_t P = n * (n - 1) / 2;
-  const __int128 p = P;
-  *row_begin = rank == 0 ? 0 : first_row_at_or_after(n, (int64_t)(p * rank / world));
-  *row_end = rank == world - 1 ? n : first_row_at_or_after(n, (int64_t)(p * (rank + 1) / world));
+  const int64_t K = shard_K();
+  const __int128 total = n > 0 ? shard_cost_before(n, n, K) : 0;
+  *row_begin = rank == 0 ? 0 : first_row_at_or_after(n, total * rank / world, K);
+  *row_end = rank == world - 1 ? n : first_row_at_or_after(n, total * (rank + 1) / world, K);
   return MM_OK;
 }
 

@@ -108,20 +108,27 @@ template <uint64_t BITS> __device__ __forceinline__ double fma_sconst64(double a
       : "=v"(r) : "v"(a), "v"(b), "n"(uint32_t(BITS)), "n"(uint32_t(BITS >> 32)) : "s100", "s101");
   return r;
 }
-template <typename T, const T* TAB, int I> __device__ __forceinline__ T fma_coef(T a, T b) {
+// TAB: a coefficient table type with `static constexpr T at(int)` and kTerms.  The entry is read in a constant expression
+// (the index is a template argument): a table reached through a POINTER template argument is an odr-used device variable —
+// HIP emits it as an externally initialised __constant__, its loads are not folded, and the whole table was fetched with
+// one scalar load, spilled and reloaded in front of every use.
+template <typename T, typename TAB, int I> __device__ __forceinline__ T fma_coef(T a, T b) {
+  constexpr T c = TAB::at(I);
 #ifndef MM_F64_CONST_VGPR   // (A/B builds: the compiler's placement)
-  if constexpr (std::is_same<T, double>::value) return fma_sconst64<__builtin_bit_cast(uint64_t, TAB[I])>(a, b);
+  if constexpr (std::is_same<T, double>::value) return fma_sconst64<__builtin_bit_cast(uint64_t, c)>(a, b);
   else
 #endif
-    return Num<T>::fma(a, b, TAB[I]);
+    return Num<T>::fma(a, b, c);
 }
 // Horner's rule in the quotient ring R[E]/(chi_E) of a 3x3 matrix, chi_E = x^3 - s1 x^2 + s2 x - s3: on exit
 // a0 I + a1 E + a2 E^2 = TAB[0] I + TAB[1] E + ... + TAB[N-1] E^(N-1).  One step, (a0, a1, a2) . E + c I =
 // (a2 s3 + c, a0 - a2 s2, a1 + a2 s1), is three multiply-adds — two when E is traceless (s1 = 0).
-template <typename T, const T* TAB, int N, bool TRACELESS = false>
+template <typename T, typename TAB, bool TRACELESS = false>
 __device__ __forceinline__ void ring_horner3(T s1, T s2, T s3, T& a0, T& a1, T& a2) {
+  constexpr int N = TAB::kTerms;
   static_assert(N >= 3, "");
-  a0 = TAB[N - 3]; a1 = TAB[N - 2]; a2 = TAB[N - 1];
+  constexpr T top0 = TAB::at(N - 3), top1 = TAB::at(N - 2), top2 = TAB::at(N - 1);
+  a0 = top0; a1 = top1; a2 = top2;
   static_for<N - 3>([&](auto ic) {
     constexpr int k = N - 4 - decltype(ic)::value;
     const T n0 = fma_coef<T, TAB, k>(a2, s3), n1 = Num<T>::fma(-a2, s2, a0);
@@ -131,10 +138,12 @@ __device__ __forceinline__ void ring_horner3(T s1, T s2, T s3, T& a0, T& a1, T& 
   });
 }
 // ... of a 4x4 matrix, chi_E = x^4 - s1 x^3 + s2 x^2 - s3 x + s4: (h0..h3) . E + c I = (c - h3 s4, h0 + h3 s3, h1 - h3 s2, h2 + h3 s1)
-template <typename T, const T* TAB, int N>
+template <typename T, typename TAB>
 __device__ __forceinline__ void ring_horner4(T s1, T s2, T s3, T s4, T& h0, T& h1, T& h2, T& h3) {
+  constexpr int N = TAB::kTerms;
   static_assert(N >= 4, "");
-  h0 = TAB[N - 4]; h1 = TAB[N - 3]; h2 = TAB[N - 2]; h3 = TAB[N - 1];
+  constexpr T top0 = TAB::at(N - 4), top1 = TAB::at(N - 3), top2 = TAB::at(N - 2), top3 = TAB::at(N - 1);
+  h0 = top0; h1 = top1; h2 = top2; h3 = top3;
   static_for<N - 4>([&](auto ic) {
     constexpr int k = N - 5 - decltype(ic)::value;
     const T n0 = fma_coef<T, TAB, k>(-h3, s4), n1 = Num<T>::fma(h3, s3, h0), n2 = Num<T>::fma(-h3, s2, h1),
@@ -531,6 +540,7 @@ template <> struct LogSeries<float> {
   static constexpr int kTerms = 8;
   static constexpr float kA[kTerms] = {9.999999337e-01f, -4.999999402e-01f, 3.333568549e-01f, -2.500212282e-01f,
                                        1.987095623e-01f, -1.655023071e-01f, 1.650813480e-01f, -1.450413880e-01f};
+  static constexpr float at(int i) { return kA[i]; }
 };
 template <> struct LogSeries<double> {
   static constexpr int kTerms = 20;
@@ -540,6 +550,7 @@ template <> struct LogSeries<double> {
     1.11111071374215928e-01, -9.99999703591583217e-02, 9.09107326619259803e-02, -8.33346464041358065e-02,
     7.68821017515587124e-02, -7.13938378893102243e-02, 6.72936081364212679e-02, -6.30553787420979894e-02,
     5.31216751520414421e-02, -5.03380364382464973e-02, 8.02156472153527783e-02, -7.58480457039158590e-02};
+  static constexpr double at(int i) { return kA[i]; }
 };
 
 template <typename T> __device__ __forceinline__ T log_series3(const T (&a)[6], T (&m0)[6], T pre = T(1)) {
@@ -561,7 +572,7 @@ template <typename T> __device__ __forceinline__ T log_series3(const T (&a)[6], 
                e20 * N::fma(e10, e21, -e11 * e20);
   // Horner from the top: after the first two steps alpha = (c_{n-3}, c_{n-2}, c_{n-1})
   T a0, a1, a2;
-  ring_horner3<T, S::kA, S::kTerms>(s1, s2, s3, a0, a1, a2);
+  ring_horner3<T, S>(s1, s2, s3, a0, a1, a2);
   // log(I + E) = E p(E): one more multiplication by E (no constant), then the caller's factor
   const T b0 = (a2 * s3) * pre, b1 = N::fma(-a2, s2, a0) * pre, b2 = N::fma(a2, s1, a1) * pre;
   m0[pidx(0, 0)] = N::fma(b2, f00, N::fma(b1, e00, b0));
@@ -593,6 +604,7 @@ template <> struct LogSeriesWide<float> {
                                        1.997873233e-01f, -1.664636323e-01f, 1.466440033e-01f, -1.286147090e-01f,
                                        7.866430935e-02f, -6.903477397e-02f, 2.371349367e-01f, -2.228347962e-01f,
                                        -2.667691364e-01f, 2.562672116e-01f, 4.274908187e-01f, -4.061057313e-01f};
+  static constexpr float at(int i) { return kA[i]; }
 };
 // true if the pair is OUTSIDE the recentred series' range (NaN counts as outside): ||A - mu I||_F^2 > kCentredGate3 mu^2.
 // Evaluated from A alone, in the branch that needs it (rows that failed the close-pair gate): the close-pair path keeps
@@ -622,7 +634,7 @@ template <typename T> __device__ __forceinline__ void log_series3_centred(const 
   const T s3 = e00 * N::fma(e11, e22, -e21 * e21) - e10 * N::fma(e10, e22, -e21 * e20) +
                e20 * N::fma(e10, e21, -e11 * e20);
   T a0, a1, a2;
-  ring_horner3<T, S::kA, S::kTerms, true>(T(0), s2, s3, a0, a1, a2);
+  ring_horner3<T, S, true>(T(0), s2, s3, a0, a1, a2);
   const T logmu = N::log(mu);
   const T b0 = N::fma(a2, s3, logmu) * pre, b1 = N::fma(-a2, s2, a0) * pre, b2 = a1 * pre;
   m0[pidx(0, 0)] = N::fma(b2, f00, N::fma(b1, e00, b0));
@@ -646,6 +658,7 @@ template <> struct LogSqSeriesWide<float> {
                                        7.596244972e-01f, -6.985597554e-01f, 6.746606801e-01f, -6.295878238e-01f,
                                        3.395295792e-01f, -3.133767555e-01f, 1.520582314e+00f, -1.462563750e+00f,
                                        -1.927056128e+00f, 1.871837175e+00f, 2.893810986e+00f, -2.795949233e+00f};
+  static constexpr float at(int i) { return kQ[i]; }
 };
 template <typename T> __device__ __forceinline__ T logsq_series3_centred(const T (&a)[6]) {
   using N = Num<T>;
@@ -661,7 +674,7 @@ template <typename T> __device__ __forceinline__ T logsq_series3_centred(const T
   const T s3 = e00 * N::fma(e11, e22, -e21 * e21) - e10 * N::fma(e10, e22, -e21 * e20) +
                e20 * N::fma(e10, e21, -e11 * e20);
   T h0, h1, h2;
-  ring_horner3<T, S::kQ, S::kTerms, true>(T(0), s2, s3, h0, h1, h2);
+  ring_horner3<T, S, true>(T(0), s2, s3, h0, h1, h2);
   const T core = N::fma(h2, T(0.5) * t2 * t2, N::fma(h1, T(3) * s3, h0 * t2));
   const T lmu = N::log(mu), ldet = N::log((T(1) + s1) + (s2 + s3));
   return N::fma(lmu, N::fma(T(3), lmu, ldet + ldet), core);
@@ -718,6 +731,8 @@ template <> struct CayleyP<float> {
   static constexpr float c[K + 1] = {1.00000002318570891e+00f, 3.33327042495924375e-01f, 2.00274867564608688e-01f,
                                      1.38428695737667723e-01f, 1.44240977093542333e-01f, -3.05379184438951401e-02f,
                                      2.73482843603638170e-01f};
+  static constexpr int kTerms = K + 1;
+  static constexpr float at(int i) { return c[i]; }
 };
 template <> struct CayleyP<double> {
   static constexpr int K = 13;
@@ -726,6 +741,8 @@ template <> struct CayleyP<double> {
                                       7.65413194323763535e-02, 7.02835946952955759e-02, 3.51739351378960174e-02,
                                       1.60038305495638411e-01, -2.87332526616183470e-01, 7.35063731671786291e-01,
                                       -8.29196169410508666e-01, 5.70221868872885063e-01};
+  static constexpr int kTerms = K + 1;
+  static constexpr double at(int i) { return c[i]; }
 };
 // mu = 2^k next to the mean eigenvalue: returns 1 / mu, *logmu = k ln 2 (no transcendental error; A ~ I gives exactly 0)
 template <typename T> __device__ __forceinline__ T cayley_scale(T mean, T* logmu) {
@@ -769,7 +786,7 @@ template <typename T> __device__ __forceinline__ T log_cayley3(const T (&a)[6], 
   cayley3_spectrum<T>(s1, s2, s3, rD, z1, z2, z3, t1, t2, t3);
   // P(W) = c0 + c1 W + c2 W^2 by Horner in R[W]/(chi_W), W^3 = t1 W^2 - t2 W + t3 I
   T c0, c1, c2;
-  ring_horner3<T, P::c, P::K + 1>(t1, t2, t3, c0, c1, c2);
+  ring_horner3<T, P>(t1, t2, t3, c0, c1, c2);
   // Z (c2 Z^4 + c1 Z^2 + c0) in R[Z]/(chi_Z), Z^3 = z1 Z^2 - z2 Z + z3 I: start from c2 Z^2 + c1, then . Z, . Z + c0, . Z
   T b0 = c2 * z3, b1 = N::fma(-c2, z2, c1), b2 = c2 * z1;
   {
@@ -813,6 +830,8 @@ template <> struct CayleyQ<float> {
   static constexpr int K = 7;
   static constexpr float c[K + 1] = {0.999999990659938783f, 0.666669978862739941f, 0.510920481665167664f, 0.423174655546735851f,
                                      0.314332175292986808f, 0.551201736862719326f, -0.412567514510121138f, 1.17039095371423926f};
+  static constexpr int kTerms = K + 1;
+  static constexpr float at(int i) { return c[i]; }
 };
 template <> struct CayleyQ<double> {
   static constexpr int K = 15;
@@ -820,6 +839,8 @@ template <> struct CayleyQ<double> {
                                       0.35746012197040091, 0.313040831979712641, 0.279195466546191997, 0.254162482860379539,
                                       0.217779908930427374, 0.303497422045376885, -0.242356046115491071, 1.74002823450430709,
                                       -3.70667784316895825, 6.72451540777742607, -6.69607770346690423, 3.64458881905822882};
+  static constexpr int kTerms = K + 1;
+  static constexpr double at(int i) { return c[i]; }
 };
 template <typename T> __device__ __forceinline__ T logsq_cayley3(const T (&a)[6], T logdet_a, T* gate) {
   using N = Num<T>;
@@ -839,7 +860,7 @@ template <typename T> __device__ __forceinline__ T logsq_cayley3(const T (&a)[6]
   *gate = t1;
   const T p1 = t1, p2 = N::fma(t1, p1, T(-2) * t2), p3 = N::fma(t1, p2, N::fma(-t2, p1, T(3) * t3));
   T c0, c1, c2;
-  ring_horner3<T, Q::c, Q::K + 1>(t1, t2, t3, c0, c1, c2);
+  ring_horner3<T, Q>(t1, t2, t3, c0, c1, c2);
   const T s = N::fma(c2, p3, N::fma(c1, p2, c0 * p1));   // sum atanh^2 z_k
   return N::fma(logmu, N::fma(T(-3), logmu, logdet_a + logdet_a), T(4) * s);
 }
@@ -1015,6 +1036,7 @@ template <> struct LogSqSeries<float> {   // log^2(1+x) = x^2 q(x), q of degree 
   static constexpr float kQ[kTerms] = {9.999999990e-01f, -9.999985182e-01f, 9.166654125e-01f, -8.335515341e-01f,
                                        7.613116690e-01f, -6.914147801e-01f, 6.401787542e-01f, -7.263483416e-01f,
                                        6.811261199e-01f};
+  static constexpr float at(int i) { return kQ[i]; }
 };
 template <> struct LogSqSeries<double> {  // degree 19: max error 4.7e-17 x^2 (tools/design/series_fit64.py)
   static constexpr int kTerms = 20;
@@ -1024,6 +1046,7 @@ template <> struct LogSqSeries<double> {  // degree 19: max error 4.7e-17 x^2 (t
     5.65793368886221559e-01, -5.32539418364275541e-01, 5.03324479906769540e-01, -4.77427984436160913e-01,
     4.54016324988081366e-01, -4.33266732950779887e-01, 4.19186214916998590e-01, -4.01958766939621959e-01,
     3.42135448468324777e-01, -3.29342696720597350e-01, 5.48091271953506265e-01, -5.29456865029041324e-01};
+  static constexpr double at(int i) { return kQ[i]; }
 };
 // ||A - I||_F^2 with the arithmetic of logsq_series3 (the forward's close-pair gate: shared with the series)
 template <typename T> __device__ __forceinline__ T close_dev3(const T (&a)[6]) {
@@ -1047,7 +1070,7 @@ template <typename T> __device__ __forceinline__ T logsq_series3(const T (&a)[6]
   // q(E) = h0 I + h1 E + h2 E^2 by Horner in R[E]/(chi_E) (see log_series3), then
   // tr(E^2 q(E)) = h0 tr E^2 + h1 tr E^3 + h2 tr E^4 with the power sums from Newton's identities
   T h0, h1, h2;
-  ring_horner3<T, S::kQ, S::kTerms>(s1, s2, s3, h0, h1, h2);
+  ring_horner3<T, S>(s1, s2, s3, h0, h1, h2);
   const T t3 = N::fma(T(3), s3, N::fma(s1, t2, -s2 * s1));
   const T t4 = N::fma(s1, t3, N::fma(-s2, t2, s3 * s1));
   *e2 = t2;
@@ -1098,7 +1121,7 @@ template <typename T, typename S = LogSeries<T>> __device__ __forceinline__ T lo
   const T s4 = T(0.25) * (N::fma(s3, p1, -s2 * p2) + N::fma(s1, p3, -p4));
   // p(E) by Horner in R[E]/(chi_E), then one more multiplication by E (log(I + E) = E p(E))
   T h0, h1, h2, h3;
-  ring_horner4<T, S::kA, S::kTerms>(s1, s2, s3, s4, h0, h1, h2, h3);
+  ring_horner4<T, S>(s1, s2, s3, s4, h0, h1, h2, h3);
   const T al[4] = {(-h3 * s4) * pre, N::fma(h3, s3, h0) * pre, N::fma(-h3, s2, h1) * pre, N::fma(h3, s1, h2) * pre};
 #pragma unroll
   for (int k = 0; k < 10; ++k) m0[k] = N::fma(al[3], e3[k], N::fma(al[2], e2[k], al[1] * e[k]));
@@ -1148,7 +1171,7 @@ template <typename T, typename S = LogSqSeries<T>> __device__ __forceinline__ T 
   const T p5 = N::fma(s1, p4, -s2 * p3) + N::fma(s3, p2, -s4 * p1);
   if (det) *det = ((T(1) + s1) + s2) + (s3 + s4);   // det(I + E) (the recentred form needs log det)
   T h0, h1, h2, h3;
-  ring_horner4<T, S::kQ, S::kTerms>(s1, s2, s3, s4, h0, h1, h2, h3);
+  ring_horner4<T, S>(s1, s2, s3, s4, h0, h1, h2, h3);
   return N::fma(h3, p5, N::fma(h2, p4, N::fma(h1, p3, h0 * p2)));
 }
 

@@ -15,5 +15,7 @@ bool spd_step_fusable(const mm_train_step* s);
 // !with_objective: the gradient in points[0].grad is final (sharded step, after the all-reduce): optimizer rule + tables.
 // Either way the workspace holds the tables of the NEW points afterwards: the next call may pass MM_WS_PREPARED.
 int spd_fused_train_step(const mm_train_step* s, int64_t rb, int64_t re, bool with_objective, hipStream_t st, bool* scale_stepped);
+// The same with the objective over a node minibatch (s->batch_idx, s->batch; rows [rb, re) of the BATCH's pair list): spd_subset.hip
+int spd_fused_train_step_subset(const mm_train_step* s, int64_t rb, int64_t re, hipStream_t st, bool* scale_stepped);
 
 }  // namespace mm

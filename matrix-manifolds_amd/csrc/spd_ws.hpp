@@ -33,8 +33,12 @@ constexpr int64_t kSpdMaxNodes = int64_t(1) << 22;
 #ifndef MM_SPD4_FWD_NC
 #define MM_SPD4_FWD_NC 1
 #endif
+// fp64 SPD(3) backward: three wavefronts per SIMD (168 registers) since its series constants are scalar operands
+// (smallmat.hpp, fma_sconst64) and the Cayley logarithm is the ring form — 187 registers left alone; the values spilled
+// for the cap land in the Jacobi fallback.  Same box, n = 5000: reference init 96.4 -> 91.9 us, mid-training spread
+// 127.8 -> 122.4, spectra beyond the Cayley gate (||log X|| = 0.6) 339 -> 353 (profiles/r04_experiments.md).
 #ifndef MM_SPD3_F64_BWD_WAVES
-#define MM_SPD3_F64_BWD_WAVES 1
+#define MM_SPD3_F64_BWD_WAVES 3
 #endif
 template <typename T, int D> constexpr int bwd_min_waves() {
   return (sizeof(T) == 4 && D == 3) ? 4 : ((sizeof(T) == 4 && D == 4) ? MM_SPD4_BWD_WAVES : ((sizeof(T) == 8 && D == 3) ? MM_SPD3_F64_BWD_WAVES : 1));

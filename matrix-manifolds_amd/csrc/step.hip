@@ -72,10 +72,15 @@ extern "C" int mm_train_step_run(const mm_train_step* s, mm_stream_t st) {
   if (!s || s->nf < 1 || s->nf > 4 || !s->loss_out || s->n < 0) return MM_ERR_ARG;
   if (s->dtype != MM_F32 && s->dtype != MM_F64) return MM_ERR_ARG;
   const int nf = s->nf;
+  // a node minibatch (train.py:198-222 with batch_size set): the pair list is that of the batch's nodes
+  const bool batched = s->batch_idx != nullptr;
+  if (batched && (s->batch < 0 || s->batch > s->n)) return MM_ERR_ARG;
+  if (batched && nf != 1) return MM_ERR_UNSUPPORTED;   // (products: mm_product_pairs_loss_subset + the optimizer entry points)
+  const int64_t np = batched ? s->batch : s->n;        // points of the pair list
   // this rank's rows of the pair list (all of them on one GPU)
-  const int64_t rb = s->row_begin, re = s->row_end <= 0 ? s->n : s->row_end;
-  if (rb < 0 || re > s->n || rb > re) return MM_ERR_ARG;
-  if (!s->target && mm_pair_offset(s->n, re) > mm_pair_offset(s->n, rb)) return MM_ERR_ARG;
+  const int64_t rb = s->row_begin, re = s->row_end <= 0 ? np : s->row_end;
+  if (rb < 0 || re > np || rb > re) return MM_ERR_ARG;
+  if (!s->target && mm_pair_offset(np, re) > mm_pair_offset(np, rb)) return MM_ERR_ARG;
   if (s->comm) {
     // the message of the collective is ONE buffer holding every gradient and the loss record
     if (!s->reduce_buf || s->reduce_count <= 0) return MM_ERR_ARG;
@@ -92,13 +97,14 @@ extern "C" int mm_train_step_run(const mm_train_step* s, mm_stream_t st) {
   // the new points (sharded: pair kernel -> finalize -> all-reduce -> optimizer rule + tables)
   const bool spd_fused = nf == 1 && mm::spd_step_fusable(s);
   // ---- ... and so does a single vector factor where the symmetric VALU pair kernel is the objective (vec_step.hpp)
-  const bool vec_fused = nf == 1 && !spd_fused && mm::vec_step_fusable(s);
+  const bool vec_fused = nf == 1 && !spd_fused && !batched && mm::vec_step_fusable(s);
   // ---- ... and a product embedding on one GPU: the mixed-manifold pair kernel + ONE kernel for everything else
   const bool product_fused = nf > 1 && !s->comm && mm::product_step_fusable(s);
   bool points_done = false;
   bool scale_done[4] = {false, false, false, false};
   if (spd_fused && !s->comm) {
-    rc = mm::spd_fused_train_step(s, rb, re, true, static_cast<hipStream_t>(st), &scale_done[0]);
+    rc = batched ? mm::spd_fused_train_step_subset(s, rb, re, static_cast<hipStream_t>(st), &scale_done[0])
+                 : mm::spd_fused_train_step(s, rb, re, true, static_cast<hipStream_t>(st), &scale_done[0]);
     if (rc != MM_OK) return rc;
     points_done = true;
   } else if (vec_fused && !s->comm) {
@@ -122,11 +128,18 @@ extern "C" int mm_train_step_run(const mm_train_step* s, mm_stream_t st) {
       // On the plain unfused path the per-point optimizer kernels do not touch the tables, so a caller that derives the
       // flag from the dimension alone would otherwise run its second step on stale Cholesky factors.
       const bool tables_kept = spd_fused || p.optimizer == MM_OPT_NONE;
-      rc = mm_spd_pdist_loss(s->dtype, s->loss_kind, p.x, s->target, s->scales[0].x, s->n, p.dim, rb, re, s->alpha, s->eps,
-                             s->terms, s->loss_params, s->wmin, s->wmax, s->loss_out, p.grad, s->ws,
-                             tables_kept ? (s->ws_flags & MM_WS_PREPARED) : 0, st);
-    }
-    else
+      const int flags = tables_kept ? (s->ws_flags & MM_WS_PREPARED) : 0;
+      if (batched)
+        rc = mm_spd_pdist_loss_subset(s->dtype, s->loss_kind, p.x, s->target, s->scales[0].x, s->n, p.dim, s->batch_idx, s->batch,
+                                      rb, re, s->alpha, s->eps, s->terms, s->loss_params, s->wmin, s->wmax, s->loss_out, p.grad,
+                                      s->ws, flags, st);
+      else
+        rc = mm_spd_pdist_loss(s->dtype, s->loss_kind, p.x, s->target, s->scales[0].x, s->n, p.dim, rb, re, s->alpha, s->eps,
+                               s->terms, s->loss_params, s->wmin, s->wmax, s->loss_out, p.grad, s->ws, flags, st);
+    } else if (batched) {
+      rc = mm_vec_pdist_loss_subset(s->dtype, p.kind, s->loss_kind, p.x, s->target, s->scales[0].x, s->n, p.dim, s->batch_idx,
+                                    s->batch, rb, re, s->alpha, s->eps, s->terms, s->loss_params, s->loss_out, p.grad, s->ws, st);
+    } else
       rc = mm_vec_pdist_loss(s->dtype, p.kind, s->loss_kind, p.x, s->target, s->scales[0].x, s->n, p.dim, rb, re, s->alpha,
                              s->eps, s->terms, s->loss_params, s->loss_out, p.grad, s->ws, st);
   } else {

@@ -86,16 +86,24 @@ __global__ __launch_bounds__(kVBlock) void vec_pdist_fwd_kernel(const T* __restr
 // LOSS != 0 (mm_vec_pdist_loss): `g` holds the TARGET squared distances; the upstream gradient of a
 // pair is derived in registers from the loss (loss.hpp) and the loss / scale-gradient sums (counted
 // once per unordered pair, in its i < j visit) leave through la.slots.
-template <typename T, int KIND, int MP, int TI, int LOSS>
+// SUB: a NODE MINIBATCH (train.py:198-222; modules.py:86 gathers x[idx] first): the n points of the launch are the nodes
+// idx[0..n) of an embedding of n_total points — points are read from rows idx[.] of the full table, the target of pair
+// (a, b) is dense[idx[a]][idx[b]] (`g` = the dense n_total x n_total matrix, data/dataset.py:19-27) and the sums go to the
+// accumulator slots of the NODES ([MP+1][n_total]), from which the finalize kernel over the full embedding writes the
+// dense gradient (zero rows outside the batch): no gather and no scatter-add around the kernel, any m the library has.
+template <typename T, int KIND, int MP, int TI, int LOSS, bool SUB = false>
 __global__ __launch_bounds__(kVBlock) void vec_pdist_bwd_kernel(const T* __restrict__ x, const T* __restrict__ g, int n,
                                                                 int m, int row_begin, int row_end, int squared,
-                                                                T* __restrict__ acc /* [MP+1][n] */, LossArgs<T> la) {
+                                                                T* __restrict__ acc /* [MP+1][n] */, LossArgs<T> la,
+                                                                const int64_t* __restrict__ idx = nullptr, int n_total = 0) {
   const int j = blockIdx.x * kVBlock + threadIdx.x;
   const int i0 = blockIdx.y * TI, i1 = min(i0 + TI, n);
   const bool jin = j < n;
   const bool jown = jin && j >= row_begin && j < row_end;  // pairs (j, i>j) belong to this shard
+  const int ns = SUB ? n_total : n;                        // stride of the per-node accumulators
+  const int jn = SUB ? int(idx[jin ? j : 0]) : (jin ? j : 0);   // the column's node
   T xj[MP], a[MP];
-  load_point<T, MP>(x, jin ? j : 0, m, xj);
+  load_point<T, MP>(x, jn, m, xj);
 #pragma unroll
   for (int k = 0; k < MP; ++k) a[k] = T(0);
   T wsum = T(0), sp = T(1), loss_acc = T(0), ds_acc = T(0);
@@ -115,13 +123,14 @@ __global__ __launch_bounds__(kVBlock) void vec_pdist_bwd_kernel(const T* __restr
       const bool valid = jin && i < i1 && (up ? (i >= row_begin && i < row_end) : (jown && i > j));
       const int lo = up ? i : j, hi = up ? j : i;
       ok[u] = valid;
-      wv[u] = valid ? g[vpair_off(n, lo) - base + (hi - lo - 1)] : T(0);
+      if constexpr (SUB) wv[u] = valid ? g[size_t(idx[lo]) * size_t(n_total) + size_t(idx[hi])] : T(0);
+      else wv[u] = valid ? g[vpair_off(n, lo) - base + (hi - lo - 1)] : T(0);
     }
 #pragma unroll
     for (int u = 0; u < UNR; ++u) {
       const int i = min(ib + u, i1 - 1);  // (rows past the tile carry wv = 0)
       T xi[MP];
-      load_point<T, MP>(x, i, m, xi);
+      load_point<T, MP>(x, SUB ? int(idx[i]) : i, m, xi);
       const T q = pair_q<T, KIND, MP>(xi, xj);
       T w;
       if constexpr (LOSS == MM_LOSS_NONE) {
@@ -143,8 +152,8 @@ __global__ __launch_bounds__(kVBlock) void vec_pdist_bwd_kernel(const T* __restr
   if (jin) {
 #pragma unroll
     for (int k = 0; k < MP; ++k)
-      if (k < m) atomic_add(&acc[size_t(k) * n + j], a[k]);
-    if (KIND == MM_EUCLIDEAN) atomic_add(&acc[size_t(MP) * n + j], wsum);
+      if (k < m) atomic_add(&acc[size_t(k) * ns + jn], a[k]);
+    if (KIND == MM_EUCLIDEAN) atomic_add(&acc[size_t(MP) * ns + jn], wsum);
   }
   if constexpr (LOSS != MM_LOSS_NONE) {
     __shared__ T lossW[kVBlock / 64][2];
@@ -597,6 +606,33 @@ int vec_loss_t(int loss_kind, const T* x, const T* target, const T* scale_raw, i
   return vec_bwd_t<T, KIND, MP, MM_LOSS_QUOTIENT>(x, target, n, m, rb, re, 1, grad, ws, st, la, loss_out);
 }
 
+// node minibatch: clear the accumulators of ALL nodes, ordered-pair kernel over the batch (SUB), finalize over ALL nodes
+template <typename T, int KIND, int MP>
+int vec_loss_subset_t(int loss_kind, const T* x, const T* dense, const T* scale_raw, int64_t n_total, int m, const int64_t* idx,
+                      int64_t bs, int64_t rb, int64_t re, double alpha, double eps, int terms, const double* loss_params, T* loss_out,
+                      T* grad, void* ws, hipStream_t st) {
+  constexpr int TI = 64;
+  T* acc = static_cast<T*>(ws);
+  T* slots = acc + size_t(n_total) * (MP + 1);
+  LossArgs<T> la{scale_raw, T(alpha), T(eps), terms, slots, loss_params};
+  hipError_t e = hipMemsetAsync(acc, 0, sizeof(T) * (size_t(n_total) * (MP + 1) + 2 * kLossSlots), st);
+  if (e != hipSuccess) return int(e);
+  if (re > rb && bs > 1) {
+    const dim3 grid(int((bs + kVBlock - 1) / kVBlock), int((bs + TI - 1) / TI));
+    if (loss_kind == MM_LOSS_STRESS)
+      vec_pdist_bwd_kernel<T, KIND, MP, TI, MM_LOSS_STRESS, true><<<grid, dim3(kVBlock), 0, st>>>(
+          x, dense, int(bs), m, int(rb), int(re), 1, acc, la, idx, int(n_total));
+    else
+      vec_pdist_bwd_kernel<T, KIND, MP, TI, MM_LOSS_QUOTIENT, true><<<grid, dim3(kVBlock), 0, st>>>(
+          x, dense, int(bs), m, int(rb), int(re), 1, acc, la, idx, int(n_total));
+    MMV_CHECK();
+  }
+  vec_pdist_finalize_kernel<T, KIND, MP><<<dim3(int((n_total + 127) / 128)), dim3(128), 0, st>>>(
+      x, acc, int(n_total), m, grad, slots, scale_raw, loss_out);
+  MMV_CHECK();
+  return MM_OK;
+}
+
 #define MMV_DISPATCH_MP(m, ...)                             \
   switch (pad_dim(m)) {                                     \
     case 4: { constexpr int MP = 4; return __VA_ARGS__; }   \
@@ -726,6 +762,23 @@ int mm_vec_pdist_loss(int dtype, int kind, int loss_kind, const void* x, const v
                          loss_out, grad_x, ws, st);
   MMV_DISPATCH_T(dtype, MMV_DISPATCH_KIND(kind, MMV_DISPATCH_MP(m, (vec_loss_t<T, KIND, MP>(
       loss_kind, static_cast<const T*>(x), static_cast<const T*>(target), static_cast<const T*>(scale_raw), n, m,
+      row_begin, row_end, alpha, eps, terms, loss_params, static_cast<T*>(loss_out), static_cast<T*>(grad_x), ws, st)))))
+}
+
+int mm_vec_pdist_loss_subset(int dtype, int kind, int loss_kind, const void* x, const void* dense, const void* scale_raw,
+                             int64_t n_total, int m, const int64_t* idx, int64_t bs, int64_t row_begin, int64_t row_end, double alpha,
+                             double eps, int terms, const double* loss_params, void* loss_out, void* grad_x, void* ws,
+                             mm_stream_t stream) {
+  if (!x || !grad_x || !ws || !loss_out || n_total < 1 || n_total > (1 << 30) || m < 1 || bs < 0 || bs > n_total || row_begin < 0 ||
+      row_end > bs || row_begin > row_end)
+    return MM_ERR_ARG;
+  if (m > kVecMaxDim) return MM_ERR_UNSUPPORTED;
+  if (loss_kind != MM_LOSS_STRESS && loss_kind != MM_LOSS_QUOTIENT) return MM_ERR_UNSUPPORTED;
+  if (loss_kind == MM_LOSS_QUOTIENT && !(terms & 3)) return MM_ERR_ARG;
+  if ((!dense || !idx) && mm_pair_offset(bs, row_end) > mm_pair_offset(bs, row_begin)) return MM_ERR_ARG;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  MMV_DISPATCH_T(dtype, MMV_DISPATCH_KIND(kind, MMV_DISPATCH_MP(m, (vec_loss_subset_t<T, KIND, MP>(
+      loss_kind, static_cast<const T*>(x), static_cast<const T*>(dense), static_cast<const T*>(scale_raw), n_total, m, idx, bs,
       row_begin, row_end, alpha, eps, terms, loss_params, static_cast<T*>(loss_out), static_cast<T*>(grad_x), ws, st)))))
 }
 

@@ -30,6 +30,7 @@ SIGNATURES = {
     'mm_target_arch': (_c.c_char_p, []),
     'mm_prof_enable': (_i, [_i]),
     'mm_prof_collect': (_i, [_i, _c.POINTER(_i64), _c.POINTER(_dbl)]),
+    'mm_prof_clock_probe': (_i, [_vp, _i, _vp]),
     'mm_pair_offset': (_i64, [_i64, _i64]),
     'mm_shard_rows': (_i, [_i64, _i, _i, _c.POINTER(_i64), _c.POINTER(_i64)]),
     'mm_graph_layer_f1': (_i, [_vp, _vp, _i64, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
@@ -79,6 +80,10 @@ SIGNATURES = {
     'mm_spd_pdist_bwd': (_i, [_i, _vp, _vp, _i64, _i, _i64, _i64, _i, _dbl, _dbl, _vp, _vp, _i, _vp]),
     'mm_spd_pdist_loss': (_i, [_i, _i, _vp, _vp, _vp, _i64, _i, _i64, _i64, _dbl, _dbl, _i, _vp, _dbl, _dbl, _vp, _vp,
                                 _vp, _i, _vp]),
+    'mm_spd_pdist_loss_subset': (_i, [_i, _i, _vp, _vp, _vp, _i64, _i, _vp, _i64, _i64, _i64, _dbl, _dbl, _i, _vp, _dbl, _dbl,
+                                       _vp, _vp, _vp, _i, _vp]),
+    'mm_vec_pdist_loss_subset': (_i, [_i, _i, _i, _vp, _vp, _vp, _i64, _i, _vp, _i64, _i64, _i64, _dbl, _dbl, _i, _vp, _vp, _vp,
+                                       _vp, _vp]),
     'mm_spd_stein_pdiv_fwd': (_i, [_i, _vp, _i64, _i, _i64, _i64, _i, _dbl, _vp, _vp, _i, _vp]),
     'mm_spd_stein_pdiv_bwd': (_i, [_i, _vp, _vp, _i64, _i, _i64, _i64, _i, _dbl, _vp, _vp, _i, _vp]),
     'mm_spd_stein_div': (_i, [_i, _vp, _vp, _vp, _i64, _i, _i, _dbl, _vp, _vp, _vp, _vp]),
@@ -259,24 +264,33 @@ def pair_offset(n, row):
 
 
 def shard_rows(n, world, rank):
-    """Row range of shard ``rank``: contiguous, balanced by pair count.
+    """Row range of shard ``rank``: contiguous, balanced by the COST of the pair kernel — a pair of a row of L pairs counts
+    1 + L / K (K = 100 000: the row-side atomics of long rows contend; csrc/common.hip has the measurement).
 
-    Same rule as ``mm_shard_rows`` (csrc/common.hip), restated in Python so that
-    host logic can be tested without the library."""
-    P = n * (n - 1) // 2
+    Same rule as ``mm_shard_rows`` (csrc/common.hip), restated in Python (exact integers) so that host logic can be
+    tested without the library.  MM_SHARD_K overrides K in both (0: balance pair counts)."""
+    K = int(os.environ.get('MM_SHARD_K', 100000))
+
+    def cost_before(row):
+        m1, m0 = n - 1, n - 1 - row
+        sum1 = m1 * (m1 + 1) // 2 - m0 * (m0 + 1) // 2
+        if K <= 0:
+            return sum1
+        return sum1 * K + m1 * (m1 + 1) * (2 * m1 + 1) // 6 - m0 * (m0 + 1) * (2 * m0 + 1) // 6
 
     def first_row_at_or_after(target):
         lo, hi = 0, n
         while lo < hi:
             mid = (lo + hi) // 2
-            if pair_offset(n, mid) >= target:
+            if cost_before(mid) >= target:
                 hi = mid
             else:
                 lo = mid + 1
         return lo
 
-    rb = 0 if rank == 0 else first_row_at_or_after(P * rank // world)
-    re = n if rank == world - 1 else first_row_at_or_after(P * (rank + 1) // world)
+    total = cost_before(n) if n > 0 else 0
+    rb = 0 if rank == 0 else first_row_at_or_after(total * rank // world)
+    re = n if rank == world - 1 else first_row_at_or_after(total * (rank + 1) // world)
     return rb, re
 
 

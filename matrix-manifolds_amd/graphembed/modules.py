@@ -202,6 +202,74 @@ class _ProductPairsLoss(torch.autograd.Function):
         return (None, None, None, None, None, None, None) + tuple(B.take_grads(ctx, up, 'grads'))
 
 
+def _single_subset_factor(man):
+    """(kind, dim) of a single factor whose node minibatches run inside ITS OWN pair kernel (mm_spd_pdist_loss_subset: every
+    SPD(d) the library is built for; mm_vec_pdist_loss_subset: every vector manifold up to mm_vec_max_dim), else None."""
+    from graphembed import _backend as B
+    from graphembed.manifolds.vector import VectorManifold
+    kind = getattr(man, '_kind', None)
+    if isinstance(man, VectorManifold) and kind in (B.EUCLIDEAN, B.LORENTZ, B.SPHERE):
+        m = getattr(man, '_m', None)
+        return (kind, m) if m is not None and m <= B.lib().raw('mm_vec_max_dim')() else None
+    if hasattr(man, 'wmin') and hasattr(man, 'n') and not getattr(man, 'use_stein_div', False):
+        return (B.FACTOR_SPD, man.n) if 2 <= man.n <= B.lib().raw('mm_spd_max_dim')() else None
+    return None
+
+
+class _SingleSubsetLoss(torch.autograd.Function):
+    """Objective and gradients of a node minibatch of ONE factor, evaluated inside that factor's own pair kernel
+    (mm_spd_pdist_loss_subset / mm_vec_pdist_loss_subset): the index vector addresses the rows of the full table, the
+    targets dense[idx[a]][idx[b]] and the gradient rows — what train.py:206-217 does with x[idx] (modules.py:86),
+    dataset[idx] (data/dataset.py:19-27) and autograd's index backward, without a gather, a scatter-add or a zero fill
+    (the per-node kernel writes the whole dense gradient).  SPD(4...9) and vectors wider than 16 — the sizes the
+    mixed-manifold pair kernel does not take."""
+
+    @staticmethod
+    def forward(ctx, spec, rows, man, factor, cache, idx, dense, x, scale):
+        from graphembed import _backend as B
+        B.require_gpu(x, dense)
+        lib = B.lib()
+        lkind, alpha, eps, terms = spec[:4]
+        dyn = spec[4] if len(spec) > 4 else None
+        dtype, dev = x.dtype, x.device
+        n_total, bs = x.shape[0], idx.numel()
+        rb, re = (0, bs) if rows is None else rows
+        dt = B.dtype_code(x)
+        kind, dim = factor
+        if dense.dtype != dtype or not dense.is_contiguous() or dense.shape != (n_total, n_total):
+            raise ValueError('dense targets must be a contiguous [n, n] matrix of the embedding\'s dtype')
+        loss_code = B.LOSS_STRESS if lkind == 'stress' else B.LOSS_QUOTIENT
+        with B.on_device(dev):
+            xc = x.detach().contiguous()
+            sc = scale.detach().to(dtype).reshape(1).contiguous()
+            ic = idx.to(device=dev, dtype=torch.int64).contiguous()
+            out = torch.empty(2, dtype=dtype, device=dev)
+            grad = torch.empty_like(xc)
+            key = ('single', dtype, dev, n_total, kind, dim)
+            ws = cache.get(key) if cache is not None else None
+            if ws is None:     # kept for the embedding's lifetime: a captured graph of the step refers to it
+                nbytes = (lib.raw('mm_spd_pdist_ws_bytes')(dt, n_total, dim) if kind == B.FACTOR_SPD
+                          else lib.raw('mm_vec_pdist_ws_bytes')(dt, n_total, dim))
+                ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+                if cache is not None:
+                    cache[key] = ws
+            if kind == B.FACTOR_SPD:
+                lib.call('mm_spd_pdist_loss_subset', dt, loss_code, B.ptr(xc), B.ptr(dense), B.ptr(sc), n_total, dim, B.ptr(ic), bs,
+                         rb, re, alpha, eps, terms, B.dyn_ptr(dyn, x), man.wmin, man.wmax, B.ptr(out), B.ptr(grad), B.ptr(ws), 0,
+                         B.stream_of(x))
+            else:
+                lib.call('mm_vec_pdist_loss_subset', dt, kind, loss_code, B.ptr(xc), B.ptr(dense), B.ptr(sc), n_total, dim,
+                         B.ptr(ic), bs, rb, re, alpha, eps, terms, B.dyn_ptr(dyn, x), B.ptr(out), B.ptr(grad), B.ptr(ws),
+                         B.stream_of(x))
+        ctx.grads = [grad.reshape(x.shape), out[1].reshape(scale.shape).to(scale.dtype)]
+        return out[0]
+
+    @staticmethod
+    def backward(ctx, up):
+        from graphembed import _backend as B
+        return (None, None, None, None, None, None, None) + tuple(B.take_grads(ctx, up, 'grads'))
+
+
 class ManifoldParameter(torch.nn.Parameter):
     """A Parameter that knows the manifold it lives on (modules.py:9-23)."""
 
@@ -302,14 +370,20 @@ class ManifoldEmbedding(torch.nn.Module):
         pts, scales = (list(self.xs), list(self.scales)) if params is None else params
         spec = objective_fn.fused_spec(**kwargs)
         in_kernel_batch = (i is not None and dense is not None and dense.is_cuda and self.pair_kernel
-                           and dense.dtype == pts[0].dtype and i.numel() <= _SUBSET_MAX_NODES)
+                           and dense.dtype == pts[0].dtype)
         if in_kernel_batch:
             # node minibatch entirely inside the pair kernel: no row gathers, no target gather, no scatter-adds
             # (single factors too: at minibatch sizes a step is launches, not arithmetic)
-            factors = _pair_kernel_factors(self.manifolds)
+            factors = _pair_kernel_factors(self.manifolds) if i.numel() <= _SUBSET_MAX_NODES else None
             if factors is not None:
                 return _ProductPairsLoss.apply(None, spec, rows, tuple(self.manifolds), tuple(factors),
                                                self._pair_ws, (i, dense), *pts, *scales)
+            if self.n_components == 1:
+                # a single factor the mixed-manifold kernel does not take (SPD(4...9), vectors wider than 16): the index
+                # vector goes into the factor's own pair kernel
+                factor = _single_subset_factor(self.manifolds[0])
+                if factor is not None:
+                    return _SingleSubsetLoss.apply(spec, rows, self.manifolds[0], factor, self._pair_ws, i, dense, pts[0], scales[0])
         if self.n_components == 1 and getattr(self.manifolds[0], 'pdist_loss', None) is not None:
             if gdists is None:
                 return None

@@ -55,7 +55,7 @@ class _TrainStep(_c.Structure):
                 ('n', _c.c_int64), ('nf', _c.c_int), ('points', _StepParam * 4), ('scales', _StepParam * 4),
                 ('target', _c.c_void_p), ('loss_out', _c.c_void_p), ('ws', _c.c_void_p), ('ws_flags', _c.c_int),
                 ('row_begin', _c.c_int64), ('row_end', _c.c_int64), ('comm', _c.c_void_p), ('reduce_buf', _c.c_void_p),
-                ('reduce_count', _c.c_int64)]
+                ('reduce_count', _c.c_int64), ('batch_idx', _c.c_void_p), ('batch', _c.c_int64)]
 
 
 OPT_NONE, OPT_RSGD, OPT_RADAM = -1, 0, 1
@@ -73,7 +73,11 @@ def _factor_of(man):
 
 class NativeTrainStep:
 
-    def __init__(self, embedding, objective_fn, targets, optimizers, shard=None, comm=None):
+    def __init__(self, embedding, objective_fn, targets, optimizers, shard=None, comm=None, dense=None):
+        """`dense`: the dataset's dense [n, n] matrix of squared graph distances (GraphDataset.pdists) — enables node
+        minibatches of a single factor, `step(indices=idx, ...)` (train.py:198-222 with batch_size set): the index vector goes
+        into the pair kernel, the optimizer kernel still steps all n points (zero gradient outside the batch, as the
+        reference's dense x.grad has it).  `targets` may then be None (minibatch steps only)."""
         from graphembed.modules import _pair_kernel_factors
         from graphembed.optim import RiemannianAdam, RiemannianSGD
         if not hasattr(objective_fn, 'fused_spec'):
@@ -97,6 +101,17 @@ class NativeTrainStep:
                 raise ValueError(f'dimension {dim} exceeds the kernels\' range ({cap})')
         n = xs[0].shape[0]
         npairs = n * (n - 1) // 2
+        if dense is not None:
+            if k != 1:
+                raise ValueError('node minibatches inside the one-call step exist for a single factor')
+            if not dense.is_cuda or dense.dtype != dtype or tuple(dense.shape) != (n, n) or not dense.is_contiguous():
+                raise ValueError('dense must be a contiguous [n, n] GPU matrix of the embedding\'s dtype')
+        self.dense, self._idx = dense, None
+        if targets is None:
+            if dense is None:
+                raise ValueError('targets (pair vector) or dense (n x n matrix) is needed')
+            targets = torch.empty(0, dtype=dtype, device=dev)
+            npairs = 0
         if shard is not None:
             if shard.n != n:
                 raise ValueError(f'the shard is cut for {shard.n} points, the embedding has {n}')
@@ -214,9 +229,20 @@ class NativeTrainStep:
                 q.state0 = None
         return True
 
-    def __call__(self, **objective_kwargs):
+    def __call__(self, indices=None, **objective_kwargs):
         spec = self.objective_fn.fused_spec(**objective_kwargs)
         d = self._desc
+        if indices is not None:
+            if self.dense is None:
+                raise ValueError('a minibatch step needs the dense target matrix: NativeTrainStep(..., dense=dataset.pdists)')
+            if self.shard is not None:
+                raise ValueError('minibatch steps of NativeTrainStep run on one GPU')
+            self._idx = indices.to(device=self.device, dtype=torch.int64).contiguous()   # (kept: the enqueued kernels read it)
+            d.batch_idx, d.batch, d.target = self._idx.data_ptr(), self._idx.numel(), self.dense.data_ptr()
+        else:
+            if self.target.numel() == 0 and self.n > 1:
+                raise ValueError('this stepper was built without a target pair vector: pass indices')
+            d.batch_idx, d.batch, d.target = None, 0, self.target.data_ptr()
         d.loss_kind = B.LOSS_STRESS if spec[0] == 'stress' else B.LOSS_QUOTIENT
         d.alpha, d.eps, d.terms = float(spec[1]), float(spec[2]), int(spec[3])
         dyn = spec[4] if len(spec) > 4 else None
@@ -234,7 +260,7 @@ class NativeTrainStep:
                 q.optimizer = OPT_NONE
         if need_first:
             self._tables_of = None
-            return self._first_step_unfused(**objective_kwargs)
+            return self._first_step_unfused(indices, **objective_kwargs)
         if self._prepared_single:
             x = self._params[0]
             d.ws_flags = B.MM_WS_PREPARED if self._tables_of == (x.data_ptr(), x._version) else 0
@@ -260,9 +286,11 @@ class NativeTrainStep:
         graph replay of somebody else's step)."""
         self._tables_of = None
 
-    def _first_step_unfused(self, **objective_kwargs):
+    def _first_step_unfused(self, indices=None, **objective_kwargs):
         """First step of a heavy-ball RSGD: the momentum buffers do not exist yet — run it through the optimizers."""
-        if self.shard is not None:
+        if indices is not None:
+            loss = self.embedding.fused_objective(self.objective_fn, None, self._idx, dense=self.dense, **objective_kwargs)
+        elif self.shard is not None:
             from graphembed import parallel
             loss = parallel.sharded_fused_objective(self.embedding, self.objective_fn, self.target, self.shard,
                                                     comm=self.comm, **objective_kwargs)

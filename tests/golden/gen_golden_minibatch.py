@@ -27,12 +27,22 @@ CASES = {
     'spd3': lambda: [RM.SymmetricPositiveDefinite(3)],
     'lorentz11': lambda: [RM.Lorentz(11)],
 }
+# round 4 (`--wide`, output minibatch_wide.npz): the single factors whose minibatches run inside their OWN pair kernels
+# (mm_spd_pdist_loss_subset / mm_vec_pdist_loss_subset) — BASELINE config 5's SPD(4), a Jacobi-path SPD(6), vectors wider than 16
+WIDE = {
+    'spd4': lambda: [RM.SymmetricPositiveDefinite(4)],
+    'spd6': lambda: [RM.SymmetricPositiveDefinite(6)],
+    'lorentz24': lambda: [RM.Lorentz(24)],
+    'sphere20': lambda: [RM.Sphere(20)],
+    'euclidean40': lambda: [RM.Euclidean(40)],
+}
 
 
 def main():
     out = {}
     n, bs = 61, 23
-    for name, mans in CASES.items():
+    wide = '--wide' in sys.argv
+    for name, mans in (WIDE if wide else CASES).items():
         for dname in DT:
             torch.set_default_dtype(DT[dname])
             torch.manual_seed(zlib.crc32(repr((name, dname, 'minibatch')).encode()) % (2**31))
@@ -59,7 +69,7 @@ def main():
                 for k in range(len(emb.xs)):
                     out[f'{base}/{lname}/grad_x_{k}'] = np_(grads[k])
                     out[f'{base}/{lname}/grad_s_{k}'] = np_(grads[len(emb.xs) + k])
-    np.savez_compressed(os.path.join(HERE, 'minibatch.npz'), **out)
+    np.savez_compressed(os.path.join(HERE, 'minibatch_wide.npz' if wide else 'minibatch.npz'), **out)
     print(len(out), 'arrays')
     torch.set_default_dtype(torch.float32)
 

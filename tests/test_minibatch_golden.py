@@ -15,10 +15,22 @@ for p in (ROOT, os.path.join(ROOT, 'matrix-manifolds_amd')):
     if p not in sys.path:
         sys.path.insert(0, p)
 
-GOLD = np.load(os.path.join(ROOT, 'tests', 'golden', 'minibatch.npz'))
+GOLD = dict(np.load(os.path.join(ROOT, 'tests', 'golden', 'minibatch.npz')))
+# round 4: single factors whose minibatches run inside their own pair kernels (gen_golden_minibatch.py --wide)
+GOLD.update(np.load(os.path.join(ROOT, 'tests', 'golden', 'minibatch_wide.npz')))
 DT = {'f32': torch.float32, 'f64': torch.float64}
-CASES = ['product', 'spd3', 'lorentz11']
+WIDE = ['spd4', 'spd6', 'lorentz24', 'sphere20', 'euclidean40']
+CASES = ['product', 'spd3', 'lorentz11'] + WIDE
 LOSSES = {'stress': {}, 'quotient': dict(epoch=2, alpha=1.3)}
+
+
+def manifolds_of(case, M, spd):
+    return {'product': lambda: [M.Lorentz(6), M.Sphere(6), spd(2)], 'spd3': lambda: [spd(3)], 'lorentz11': lambda: [M.Lorentz(11)],
+            'spd4': lambda: [spd(4)], 'spd6': lambda: [spd(6)], 'lorentz24': lambda: [M.Lorentz(24)],
+            'sphere20': lambda: [M.Sphere(20)], 'euclidean40': lambda: [M.Euclidean(40)]}[case]()
+
+
+SPD_FACTOR = {'product': 2, 'spd3': 0, 'spd4': 0, 'spd6': 0}
 
 
 def sym_if_spd(a, is_spd):
@@ -41,7 +53,7 @@ def check(loss, grads, base, lname, nfac, spd_factor, tol):
 @pytest.mark.parametrize('dname', list(DT))
 def test_oracle_port_minibatch_objective(case, dname):
     from oracle import ref_port as rp
-    mans = {'product': [rp.Lorentz(6), rp.Sphere(6), rp.SPD(2)], 'spd3': [rp.SPD(3)], 'lorentz11': [rp.Lorentz(11)]}[case]
+    mans = manifolds_of(case, rp, rp.SPD)
     base = f'{case}/{dname}'
     dt = DT[dname]
     idx = torch.from_numpy(GOLD[f'{base}/idx'])
@@ -61,7 +73,7 @@ def test_oracle_port_minibatch_objective(case, dname):
         md = rp.compute_dists(mans, xs, sc, idx)
         loss = rp.stress_loss(gd, md) if lname == 'stress' else rp.quotient_loss(gd, md, **kw)
         grads = [g.double().numpy() for g in torch.autograd.grad(loss, xs + sc)]
-        spd_factor = {'product': 2, 'spd3': 0, 'lorentz11': -1}[case]
+        spd_factor = SPD_FACTOR.get(case, -1)
         check(loss.item(), grads, base, lname, len(mans), spd_factor, 2e-4 if dname == 'f32' else 1e-9)
 
 
@@ -77,9 +89,8 @@ def test_minibatch_objective_gpu(case, dname, path):
     from graphembed.objectives import QuotientLoss, StressLoss
     dt = DT[dname]
     base = f'{case}/{dname}'
-    mans = {'product': lambda: [M.Lorentz(6), M.Sphere(6), M.SymmetricPositiveDefinite(2)],
-            'spd3': lambda: [M.SymmetricPositiveDefinite(3)], 'lorentz11': lambda: [M.Lorentz(11)]}[case]()
-    spd_factor = {'product': 2, 'spd3': 0, 'lorentz11': -1}[case]
+    mans = manifolds_of(case, M, M.SymmetricPositiveDefinite)
+    spd_factor = SPD_FACTOR.get(case, -1)
     torch.set_default_dtype(dt)
     try:
         with torch.device('cuda'):
@@ -102,7 +113,10 @@ def test_minibatch_objective_gpu(case, dname, path):
                     loss = BatchedObjective(fn, ds, emb)(idx, **kw)
                 finally:
                     del lib.call
-                assert 'mm_product_pairs_loss_subset' in calls, calls    # the index vector goes into the kernel
+                # the index vector goes into the kernel: the mixed-manifold one, or the factor's own (SPD(4...9), m > 16)
+                want = {'spd4': 'mm_spd_pdist_loss_subset', 'spd6': 'mm_spd_pdist_loss_subset'}.get(
+                    case, 'mm_vec_pdist_loss_subset' if case in WIDE else 'mm_product_pairs_loss_subset')
+                assert want in calls and not any('gather' in c for c in calls), calls
             else:
                 loss = fn(ds[idx], emb.compute_dists(idx), **kw)
             grads = [g.double().cpu().numpy() for g in torch.autograd.grad(loss, params)]
@@ -113,5 +127,62 @@ def test_minibatch_objective_gpu(case, dname, path):
             rest[GOLD[f'{base}/idx']] = False
             for k in range(len(mans)):
                 assert not grads[k][rest].any()          # rows outside the batch: exactly zero, as autograd gives them
+    finally:
+        torch.set_default_dtype(torch.float32)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('case', ['spd3', 'spd4', 'spd6', 'lorentz24', 'euclidean40'])
+@pytest.mark.parametrize('dname', list(DT))
+def test_native_minibatch_step_matches_the_eager_loop(case, dname):
+    """mm_train_step with batch_idx (the one-call step over a node minibatch) against the eager loop on the same batches:
+    BatchedObjective(idx) -> backward -> optimizer.step(), three consecutive batches, RSGD and Adam; every point is stepped
+    (zero gradient outside the batch), as the reference's dense x.grad has it (train.py:206-222)."""
+    from graphembed import manifolds as M
+    from graphembed.data import GraphDataset
+    from graphembed.modules import BatchedObjective, ManifoldEmbedding
+    from graphembed.native_step import NativeTrainStep
+    from graphembed.objectives import QuotientLoss, StressLoss
+    from graphembed.optim import RiemannianAdam, RiemannianSGD
+    dt = DT[dname]
+    base = f'{case}/{dname}'
+    torch.set_default_dtype(dt)
+    try:
+        for opt_name, fn, kw in (('rsgd', StressLoss(), {}), ('adam', QuotientLoss(), dict(epoch=2, alpha=1.3))):
+            runs = []
+            for native in (False, True):
+                with torch.device('cuda'):
+                    emb = ManifoldEmbedding(61, manifolds_of(case, M, M.SymmetricPositiveDefinite))
+                    ds = GraphDataset(torch.from_numpy(GOLD[f'{base}/graph_d']).to(dt).cuda())
+                with torch.no_grad():
+                    emb.xs[0].copy_(torch.from_numpy(GOLD[f'{base}/x_0']).cuda())
+                    emb.scales[0].fill_(float(GOLD[f'{base}/scales'][0]))
+                if opt_name == 'rsgd':
+                    opts = [RiemannianSGD(list(emb.xs), lr=0.05, exact=True, max_grad_norm=20), RiemannianSGD(list(emb.scales), lr=1e-3, max_grad_norm=500)]
+                else:
+                    opts = [RiemannianAdam(list(emb.xs), lr=0.01, exact=True, max_grad_norm=20), RiemannianAdam(list(emb.scales), lr=1e-3)]
+                gen = torch.Generator().manual_seed(5)
+                batches = [torch.randperm(61, generator=gen)[:23].cuda() for _ in range(3)]
+                losses = []
+                if native:
+                    step = NativeTrainStep(emb, fn, None, opts, dense=ds.pdists)
+                    for idx in batches:
+                        losses.append(float(step(indices=idx, **kw)))
+                else:
+                    obj = BatchedObjective(fn, ds, emb)
+                    for idx in batches:
+                        loss = obj(idx, **kw)
+                        for o in opts:
+                            o.zero_grad(set_to_none=True)
+                        loss.backward()
+                        for o in opts:
+                            o.step()
+                        losses.append(float(loss))
+                runs.append((losses, emb.xs[0].detach().double().cpu().numpy(), float(emb.scales[0])))
+            (l0, x0, s0), (l1, x1, s1) = runs
+            tol = 2e-4 if dname == 'f32' else 1e-9
+            assert np.allclose(l0, l1, rtol=tol), (opt_name, l0, l1)
+            assert np.abs(x0 - x1).max() <= tol * max(np.abs(x0).max(), 1.0), (opt_name, np.abs(x0 - x1).max())
+            assert abs(s0 - s1) <= tol * max(abs(s0), 1.0)
     finally:
         torch.set_default_dtype(torch.float32)

@@ -153,6 +153,14 @@ CASES = {
     'c3_spd3_minibatch512_step_f32_radam_graph': lambda: minibatch_case([M.SymmetricPositiveDefinite(3)], 5000, 512, torch.float32, graph=True, adam=True),
     'c4_csphd_minibatch512_step_f32': lambda: minibatch_case([M.Lorentz(6), M.Sphere(6), M.SymmetricPositiveDefinite(2)], 1025, 512, torch.float32),
     'c2_lorentz11_minibatch512_step_f32': lambda: minibatch_case([M.Lorentz(11)], 4039, 512, torch.float32),
+    # round 4: node minibatches inside the single factors' own pair kernels (SPD(4...9), vectors wider than 16)
+    'c5_spd4_minibatch512_step_n16384_f32_graph': lambda: minibatch_case([M.SymmetricPositiveDefinite(4)], 16384, 512, torch.float32, graph=True),
+    'c5_spd4_minibatch512_step_n16384_f32_native_graph': lambda: native_minibatch_case([M.SymmetricPositiveDefinite(4)], 16384, 512, torch.float32),
+    'c5_spd4_minibatch512_step_n2274_f32_native_graph': lambda: native_minibatch_case([M.SymmetricPositiveDefinite(4)], 2274, 512, torch.float32),
+    'c5_spd4_minibatch512_step_n2274_f32_radam_native_graph': lambda: native_minibatch_case([M.SymmetricPositiveDefinite(4)], 2274, 512, torch.float32, adam=True),
+    'c3_spd3_minibatch512_step_f32_native_graph': lambda: native_minibatch_case([M.SymmetricPositiveDefinite(3)], 5000, 512, torch.float32),
+    'spd6_minibatch512_step_n2274_f32_native_graph': lambda: native_minibatch_case([M.SymmetricPositiveDefinite(6)], 2274, 512, torch.float32),
+    'lorentz24_minibatch512_step_n4039_f32_native_graph': lambda: native_minibatch_case([M.Lorentz(24)], 4039, 512, torch.float32),
     'sphere6_n5000_f32': lambda: pdist_case(M.Sphere(6), 5000, torch.float32),
     'euclidean10_n5000_f32': lambda: pdist_case(M.Euclidean(10), 5000, torch.float32),
     'grassmann52_n2000_f32': lambda: pdist_case(M.Grassmann(5, 2), 2000, torch.float32),
@@ -222,6 +230,49 @@ def minibatch_case(mans, n, bs, dtype, graph=False, adam=False):
             state['i'] = (i + bs) % (n - bs)
             gstep()
     t = timeit(step, iters=50)
+    P = bs * (bs - 1) // 2
+    return {'n': n, 'pairs': P, 'dtype': str(dtype).split('.')[-1], 'step_us': t, 'pairs_per_s': P / (t * 1e-6)}
+
+
+def native_minibatch_case(mans, n, bs, dtype, adam=False):
+    """node-minibatch training step through ONE C-ABI call (mm_train_step_run with batch_idx), replayed as a hipGraph with the
+    index vector refreshed in place: for a single SPD(d <= 5) factor two launches per step — the pair kernel over the batch (index
+    vector inside) and the per-point finalize / optimizer / tables kernel over all n points (the launch count is read off the rocprofv3 kernel trace of this case: tools/gpu_r04_b.sh)."""
+    from graphembed.data import GraphDataset
+    from graphembed.native_step import NativeTrainStep
+    torch.manual_seed(0)
+    torch.set_default_dtype(dtype)
+    try:
+        with torch.device('cuda'):
+            emb = ManifoldEmbedding(n, mans)
+            ds = GraphDataset(torch.rand(n * (n - 1) // 2) * 0.99 + 0.01)
+    finally:
+        torch.set_default_dtype(torch.float32)
+    if adam:
+        opts = [RiemannianAdam(list(emb.xs), lr=1e-3, exact=True, max_grad_norm=20), RiemannianAdam(list(emb.scales), lr=1e-4, max_grad_norm=500)]
+    else:
+        opts = [RiemannianSGD(list(emb.xs), lr=1e-3, exact=True, max_grad_norm=20), RiemannianSGD(list(emb.scales), lr=1e-4, max_grad_norm=500)]
+    step = NativeTrainStep(emb, StressLoss(), None, opts, dense=ds.pdists)
+    perm = torch.randperm(n, device='cuda')
+    idx_static = perm[:bs].clone()
+    for _ in range(3):
+        step(indices=idx_static)            # (the second step on: the tables of the new points are the step kernel's own)
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(side):
+        with torch.cuda.graph(g, stream=side):
+            step(indices=idx_static)
+    torch.cuda.current_stream().wait_stream(side)
+    state = {'i': 0}
+
+    def run():
+        i = state['i']
+        idx_static.copy_(perm[i:i + bs])
+        state['i'] = (i + bs) % (n - bs)
+        g.replay()
+    t = timeit(run, iters=50)
     P = bs * (bs - 1) // 2
     return {'n': n, 'pairs': P, 'dtype': str(dtype).split('.')[-1], 'step_us': t, 'pairs_per_s': P / (t * 1e-6)}
 

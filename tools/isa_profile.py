@@ -51,7 +51,7 @@ def main():
             elif op.startswith('s_'):
                 c['salu'] += 1
             if op.startswith(('global_', 'buffer_', 'flat_', 'scratch_')):
-                c['vmem'] += 1
+                c["vmem"] += 1
             if op.startswith('ds_'):
                 c['lds'] += 1
             if re.match(r'v_(fma|mul|add|fmac)_f64', op):

@@ -60,13 +60,16 @@ const char* mm_target_arch(void) { return "gfx950"; }
 int64_t mm_pair_offset(int64_t n, int64_t row) { return row * (2 * n - row - 1) / 2; }
 
 // Shard r owns a contiguous row range; the cuts balance the COST of the ranks' pair kernels, not their pair counts.
-// A pair of a LONG row costs more than a pair of a short one: every column block of a row adds its row-side sums to the
-// same NP accumulator addresses, so the float atomics of row i contend (n - i) / 64 deep — the first rank of 8 (1059
-// rows, 256 column blocks each, n = 16384) ran 11 % longer than the last (5793 short rows) under equal pair counts
-// (profiles/r03_shard_kernel_times.json: 192.7 against 173.1 us).  Model: cost of a pair in a row of L pairs
-// = 1 + L / K, K = 100 000 pairs (fitted to that measurement; n = 5000: at most 5 % — its rows are 40 blocks deep and
-// its shards showed no such slope).  Row cost L (K + L), prefix sums in closed form, exact integer arithmetic (the
-// Python restatement graphembed._backend.shard_rows computes the same cuts); MM_SHARD_K overrides K (0: pair counts).
+// A pair of a LONG row costs slightly more than a pair of a short one (every column block of a row adds its row-side sums to
+// the same NP accumulator addresses: the float atomics of row i contend (n - i) / 64 deep).  Measured on the N = 8 shards of
+// BASELINE config 5 (SPD(4), n = 16384; three rounds per rank, profiles/r04_shard_balance.txt): with equal pair counts the
+// first rank (1059 rows of 256 column blocks) takes 178.6 us at best against 169.7 - 175.3 for the others — 3 % — while a
+// model that charges 11 % (round 3's single measurement, 192.7 against 173.1) over-corrects: the last rank then takes 180.7
+// against 172.  Model: cost of a pair in a row of L pairs = 1 + L / K with K = 400 000 (first / last rank of 8 at n = 16384:
+// 3 % fewer pairs; n = 5000: 1 %; N = 4, where the times followed the pair counts to 1 %: 2 %).  The run-to-run spread of
+// one rank's kernel on these boxes is bimodal, 172 or 195 us, whatever the cut: the effect modelled here is smaller than that.
+// Row cost L (K + L), prefix sums in closed form, exact integer arithmetic (the Python restatement
+// graphembed._backend.shard_rows computes the same cuts); MM_SHARD_K overrides K (0: pair counts).
 static __int128 shard_cost_before(int64_t n, int64_t row, int64_t K) {   // cost of rows [0, row)
   const __int128 m1 = n - 1, m0 = n - 1 - row;                          // row lengths run from m1 down to m0 + 1
   const __int128 sum1 = m1 * (m1 + 1) / 2 - m0 * (m0 + 1) / 2;
@@ -75,7 +78,7 @@ static __int128 shard_cost_before(int64_t n, int64_t row, int64_t K) {   // cost
   return sum1 * K + sum2;
 }
 static int64_t shard_K() {
-  static const int64_t k = [] { const char* e = std::getenv("MM_SHARD_K"); return e ? std::atoll(e) : int64_t(100000); }();
+  static const int64_t k = [] { const char* e = std::getenv("MM_SHARD_K"); return e ? std::atoll(e) : int64_t(400000); }();
   return k;
 }
 static int64_t first_row_at_or_after(int64_t n, __int128 target, int64_t K) {

@@ -22,6 +22,8 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <climits>
+#include <cstdint>
 #include <cstdlib>
 
 #include "../../include/mm_manifolds.h"
@@ -31,6 +33,7 @@
 #include "product_sym.hpp"
 #include "smallmat.hpp"
 #include "spd_rules.hpp"
+#include "stamp.hpp"
 #include "vec_rules.hpp"
 #include "vecfn.hpp"
 
@@ -42,15 +45,15 @@ namespace mm {
 __device__ __forceinline__ void pin_v(float& v) { asm volatile("" : "+v"(v)); }
 __device__ __forceinline__ void pin_v(double& v) { asm volatile("" : "+v"(v)); }
 
-template <typename T> __device__ __forceinline__ T vec_q_rt(int kind, const T (&xi)[kPMP], const T (&xj)[kPMP]) {
+template <typename T, int PW> __device__ __forceinline__ T vec_q_rt(int kind, const T (&xi)[PW], const T (&xj)[PW]) {
   using N = Num<T>;
   T q = T(0);
   if (kind == MM_EUCLIDEAN) {
 #pragma unroll
-    for (int k = 0; k < kPMP; ++k) { const T df = xj[k] - xi[k]; q = N::fma(df, df, q); }
+    for (int k = 0; k < PW; ++k) { const T df = xj[k] - xi[k]; q = N::fma(df, df, q); }
   } else {
 #pragma unroll
-    for (int k = 1; k < kPMP; ++k) q = N::fma(xi[k], xj[k], q);
+    for (int k = 1; k < PW; ++k) q = N::fma(xi[k], xj[k], q);
     q = kind == MM_LORENTZ ? N::fma(xi[0], xj[0], -q) : N::fma(xi[0], xj[0], q);
   }
   return q;
@@ -64,11 +67,14 @@ template <typename T> __device__ __forceinline__ T vec_dq_rt(int kind, T q) {
                               : (kind == MM_LORENTZ ? PairFn<T, MM_LORENTZ>::dq(q, 1) : PairFn<T, MM_SPHERE>::dq(q, 1));
 }
 
-template <typename T, int NV, int SD, int LOSS>
+// PW: padded width of a vector factor inside the kernel — 8 when every vector factor has at most 8 coordinates (csphd:
+// 6 + 6), else kPMP = 16: the row point's LDS reads, the inner product and the column accumulation are PW wide.
+template <typename T, int NV, int SD, int LOSS, int PW>
 __global__ __launch_bounds__(kPCols * kPWaves) void product_pair_kernel(PArgs<T> pa, const T* __restrict__ target, int n,
                                                                int row_begin, int row_end, int ti, LossArgs<T> la) {
   constexpr int NPS = SD > 0 ? Packed<(SD > 0 ? SD : 2)>::NP : 1;
   constexpr int DS = SD > 0 ? SD : 2;
+  MM_PSTAMP_BEGIN();
   loss_resolve<T, LOSS>(la);
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int j = blockIdx.x * kPCols + lane;
@@ -77,15 +83,15 @@ __global__ __launch_bounds__(kPCols * kPWaves) void product_pair_kernel(PArgs<T>
   const bool jown = jin && j >= row_begin && j < row_end;
   const int64_t jnode = node_of(pa, jin ? j : n - 1);  // lanes past n: clamped, masked later
   // per-lane column data
-  T xj[NV > 0 ? NV : 1][kPMP], accv[NV > 0 ? NV : 1][kPMP], wsum[NV > 0 ? NV : 1], spv[NV > 0 ? NV : 1],
+  T xj[NV > 0 ? NV : 1][PW], accv[NV > 0 ? NV : 1][PW], wsum[NV > 0 ? NV : 1], spv[NV > 0 ? NV : 1],
       dsv[NV > 0 ? NV : 1];
 #pragma unroll
   for (int f = 0; f < NV; ++f) {
     const PVec<T>& F = pa.v[f];
 #pragma unroll
-    for (int k = 0; k < kPMP; ++k) xj[f][k] = F.x[size_t(jnode) * F.m + min(k, F.m - 1)];  // clamped, masked below
+    for (int k = 0; k < PW; ++k) xj[f][k] = F.x[size_t(jnode) * F.m + min(k, F.m - 1)];  // clamped, masked below
 #pragma unroll
-    for (int k = 0; k < kPMP; ++k) accv[f][k] = T(0);
+    for (int k = 0; k < PW; ++k) accv[f][k] = T(0);
     wsum[f] = T(0);
     dsv[f] = T(0);
     spv[f] = *F.scale_raw;
@@ -93,14 +99,13 @@ __global__ __launch_bounds__(kPCols * kPWaves) void product_pair_kernel(PArgs<T>
   T sps = T(1), dss = T(0);
   if constexpr (SD > 0) sps = *pa.s.scale_raw;
 
-  T yj[NPS], accS[DS][DS];
+  // SPD factor: the column point AND this lane's row point (lanes < ti hold one row of the tile each) are requested here,
+  // with every other load of the prologue; their Cholesky factors are formed once all requests are out (round 4: the row
+  // points were requested behind the column point's factorisation — a second memory round trip in every workgroup's life)
+  T yj[NPS], accS[DS][DS], xs_col[NPS], xs_row[NPS];
   if constexpr (SD > 0) {
-    {  // Cholesky factor of the column point, in registers (no per-node tables, no preparation launch:
-       // the factorisation is ~1 % of a row's arithmetic)
-      T xs[NPS];
-      load_sym_packed<T, SD>(pa.s.x + size_t(jnode) * SD * SD, xs);
-      cholesky<T, SD>(xs, yj);
-    }
+    load_sym_packed<T, SD>(pa.s.x + size_t(jnode) * SD * SD, xs_col);
+    load_sym_packed<T, SD>(pa.s.x + size_t(node_of(pa, min(i0 + min(lane, ti - 1), n - 1))) * SD * SD, xs_row);
 #pragma unroll
     for (int r = 0; r < SD; ++r)
 #pragma unroll
@@ -118,31 +123,33 @@ __global__ __launch_bounds__(kPCols * kPWaves) void product_pair_kernel(PArgs<T>
   T tnext = target_at(min(i0, n - 1));
   // the row points of the tile, zero-padded to kPMP, staged once (coalesced); a load under `k < m` in the
   // row loop would sit in its own basic block and serialise 16 memory round trips per factor and row
-  __shared__ T rowpt[NV > 0 ? NV : 1][kPWaves][kPMaxTI][kPMP];
-  __shared__ int rownode[kPWaves][kPMaxTI];
-  if (lane < ti) rownode[wave][lane] = int(node_of(pa, min(i0 + lane, n - 1)));
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  __shared__ T rowpt[NV > 0 ? NV : 1][kPWaves][kPMaxTI][PW];
+  // (round 4: the rows' node ids are taken per lane, node_of(i0 + r), not through an LDS table filled first — that put the
+  // row points' loads one LDS round trip and, for a node minibatch, one memory round trip BEHIND the column data's; the
+  // workgroup timeline showed 4.7 k + 3.8 k cycles of prologue, two serial latencies: tools/product_timeline.py)
   // (requested unconditionally from clamped addresses for ALL factors first, masked when they are written to LDS further
   // down: as `valid ? F.x[..] : 0` inside the loop, every factor's rows cost one serial memory round trip)
-  constexpr int kStageIts = kPMaxTI * kPMP / 64;
+  constexpr int kStageIts = kPMaxTI * PW / 64;
   T staged[NV > 0 ? NV : 1][kStageIts];
 #pragma unroll
   for (int f = 0; f < NV; ++f) {
     const PVec<T>& F = pa.v[f];
 #pragma unroll
     for (int it = 0; it < kStageIts; ++it) {
-      const int e = lane + 64 * it, r = min(e / kPMP, ti - 1), k = e % kPMP;
-      staged[f][it] = F.x[size_t(rownode[wave][r]) * F.m + min(k, F.m - 1)];
+      const int e = lane + 64 * it, r = min(e / PW, ti - 1), k = e % PW;
+      staged[f][it] = F.x[size_t(node_of(pa, min(i0 + r, n - 1))) * F.m + min(k, F.m - 1)];
     }
   }
+  MM_PSTAMP(1);
   __shared__ T rowL[kPWaves][kPMaxTI][2 * NPS];  // L_i^-1 and L_i of the tile's rows
   if constexpr (SD > 0) {
+#pragma unroll
+    for (int k = 0; k < NPS; ++k) { pin_v(xs_col[k]); pin_v(xs_row[k]); }
+    // (no per-node tables, no preparation launch: the factorisations are ~1 % of a row's arithmetic)
+    cholesky<T, SD>(xs_col, yj);
     if (lane < ti) {
-      T xs[NPS], l[NPS], li_[NPS];
-      load_sym_packed<T, SD>(pa.s.x + size_t(rownode[wave][lane]) * SD * SD, xs);
-      cholesky<T, SD>(xs, l);
+      T l[NPS], li_[NPS];
+      cholesky<T, SD>(xs_row, l);
       invert_lower<T, SD>(l, li_);
 #pragma unroll
       for (int k = 0; k < NPS; ++k) { rowL[wave][lane][k] = li_[k]; rowL[wave][lane][NPS + k] = l[k]; }
@@ -154,25 +161,26 @@ __global__ __launch_bounds__(kPCols * kPWaves) void product_pair_kernel(PArgs<T>
 #pragma unroll
     for (int it = 0; it < kStageIts; ++it) {
       pin_v(staged[f][it]);
-      const int e = lane + 64 * it, r = e / kPMP, k = e % kPMP;
-      if (e < ti * kPMP) rowpt[f][wave][r][k] = (k < pa.v[f].m && i0 + r < n) ? staged[f][it] : T(0);
+      const int e = lane + 64 * it, r = e / PW, k = e % PW;
+      if (e < ti * PW) rowpt[f][wave][r][k] = (k < pa.v[f].m && i0 + r < n) ? staged[f][it] : T(0);
     }
   }
 #pragma unroll
   for (int f = 0; f < NV; ++f) {
     pin_v(spv[f]);
 #pragma unroll
-    for (int k = 0; k < kPMP; ++k) pin_v(xj[f][k]);
+    for (int k = 0; k < PW; ++k) pin_v(xj[f][k]);
   }
   pin_v(tnext);
 #pragma unroll
   for (int f = 0; f < NV; ++f) {
 #pragma unroll
-    for (int k = 0; k < kPMP; ++k) xj[f][k] = (jin && k < pa.v[f].m) ? xj[f][k] : T(0);
+    for (int k = 0; k < PW; ++k) xj[f][k] = (jin && k < pa.v[f].m) ? xj[f][k] : T(0);
     spv[f] = softplus_of(&spv[f]);
   }
   if constexpr (SD > 0) sps = softplus_of(&sps);
   __syncthreads();
+  MM_PSTAMP(2);
   T loss_acc = T(0);
   for (int i = i0; i < i1; ++i) {  // wave-uniform row
     const bool up = i < j;
@@ -180,28 +188,32 @@ __global__ __launch_bounds__(kPCols * kPWaves) void product_pair_kernel(PArgs<T>
     const T tgt = tnext;
     tnext = target_at(min(i + 1, i1 - 1));
     // ---- phase 1: every factor's squared distance, the weighted sum
-    T m = T(0), qv[NV > 0 ? NV : 1], d2v[NV > 0 ? NV : 1], xi[NV > 0 ? NV : 1][kPMP];
+    T m = T(0), qv[NV > 0 ? NV : 1], d2v[NV > 0 ? NV : 1], xi[NV > 0 ? NV : 1][PW];
 #pragma unroll
     for (int f = 0; f < NV; ++f) {
       const PVec<T>& F = pa.v[f];
 #pragma unroll
-      for (int k = 0; k < kPMP; ++k) xi[f][k] = rowpt[f][wave][i - i0][k];  // same address in every lane: LDS broadcast
-      qv[f] = vec_q_rt<T>(F.kind, xi[f], xj[f]);
+      for (int k = 0; k < PW; ++k) xi[f][k] = rowpt[f][wave][i - i0][k];  // same address in every lane: LDS broadcast
+      qv[f] = vec_q_rt<T, PW>(F.kind, xi[f], xj[f]);
       d2v[f] = vec_value_rt<T>(F.kind, qv[f]);
       m = Num<T>::fma(spv[f], d2v[f], m);
     }
-    T li[NPS], lc[NPS], lw[DS], vv[DS][DS], d2s = T(0);
+    T li[NPS], lc[NPS], lw[DS], vv[DS][DS], mlog[NPS], d2s = T(0);
     if constexpr (SD > 0) {
 #pragma unroll
       for (int k = 0; k < NPS; ++k) { li[k] = rowL[wave][i - i0][k]; lc[k] = rowL[wave][i - i0][NPS + k]; }
       T a[NPS];
       congr_chol<T, SD>(li, yj, a);
-      jacobi_eig<T, SD, true, true>(a, vv, T(64) * Num<T>::eps() * Num<T>::eps());
       T s = T(0);
+      if constexpr (SD == 2) {
+        s = log_spd2<T>(a, pa.s.wmin, pa.s.wmax, mlog);
+      } else {
+        jacobi_eig<T, SD, true, true>(a, vv, T(64) * Num<T>::eps() * Num<T>::eps());
 #pragma unroll
-      for (int k = 0; k < SD; ++k) {  // eigenvalue clamp as _norm_log, spd.py:163-169
-        lw[k] = Num<T>::log(Num<T>::min(Num<T>::max(a[pidx(k, k)], pa.s.wmin), pa.s.wmax));
-        s = Num<T>::fma(lw[k], lw[k], s);
+        for (int k = 0; k < SD; ++k) {  // eigenvalue clamp as _norm_log, spd.py:163-169
+          lw[k] = Num<T>::log(Num<T>::min(Num<T>::max(a[pidx(k, k)], pa.s.wmin), pa.s.wmax));
+          s = Num<T>::fma(lw[k], lw[k], s);
+        }
       }
       d2s = Num<T>::max(s, pa.s.wmin);  // value clamp (gradient-transparent), spd.py:163-169
       m = Num<T>::fma(sps, d2s, m);
@@ -218,15 +230,20 @@ __global__ __launch_bounds__(kPCols * kPWaves) void product_pair_kernel(PArgs<T>
       const T w = coef * spv[f] * vec_dq_rt<T>(pa.v[f].kind, qv[f]);
       wsum[f] += w;
 #pragma unroll
-      for (int k = 0; k < kPMP; ++k) accv[f][k] = Num<T>::fma(w, xi[f][k], accv[f][k]);
+      for (int k = 0; k < PW; ++k) accv[f][k] = Num<T>::fma(w, xi[f][k], accv[f][k]);
     }
     if constexpr (SD > 0) {
       dss += once ? dldm * d2s : T(0);
       const T gs = coef * sps;
       T cm[DS], mm_[NPS], cj[DS][DS];
+      if constexpr (SD == 2) {
 #pragma unroll
-      for (int k = 0; k < SD; ++k) cm[k] = (gs + gs) * lw[k];
-      vdvt<T, SD>(vv, cm, mm_);
+        for (int k = 0; k < NPS; ++k) mm_[k] = (gs + gs) * mlog[k];
+      } else {
+#pragma unroll
+        for (int k = 0; k < SD; ++k) cm[k] = (gs + gs) * lw[k];
+        vdvt<T, SD>(vv, cm, mm_);
+      }
       lt_m_lt<T, SD>(li, lc, mm_, cj);
 #pragma unroll
       for (int r = 0; r < SD; ++r)
@@ -234,9 +251,11 @@ __global__ __launch_bounds__(kPCols * kPWaves) void product_pair_kernel(PArgs<T>
         for (int c = 0; c < SD; ++c) accS[r][c] += cj[r][c];
     }
   }
+  MM_PSTAMP(3);
   // ---- flush: the workgroup's wavefronts hold partial sums of the same columns; combine them in LDS, then
   // one coalesced atomic per accumulator row (float atomics cost ~60 ns of CU time per wave instruction)
-  __shared__ T red[kPWaves][kPMP + 1][64];
+  constexpr int kRedRows = (PW + 1 > DS * DS) ? PW + 1 : DS * DS;
+  __shared__ T red[kPWaves][kRedRows][64];
   auto combine_and_add = [&](int rows, auto&& dst_of) {  // red[w][k][lane], k < rows -> atomics on dst_of(k)
     __syncthreads();
     for (int k = wave; k < rows; k += kPWaves) {  // wave-uniform k
@@ -253,10 +272,10 @@ __global__ __launch_bounds__(kPCols * kPWaves) void product_pair_kernel(PArgs<T>
   for (int f = 0; f < NV; ++f) {
     const PVec<T>& F = pa.v[f];
 #pragma unroll
-    for (int k = 0; k < kPMP; ++k) red[wave][k][lane] = accv[f][k];
-    red[wave][kPMP][lane] = wsum[f];
-    combine_and_add(kPMP + 1, [&](int k) -> T* {
-      return (k < F.m || (k == kPMP && F.kind == MM_EUCLIDEAN)) ? F.acc + size_t(k) * n : nullptr;
+    for (int k = 0; k < PW; ++k) red[wave][k][lane] = accv[f][k];
+    red[wave][PW][lane] = wsum[f];
+    combine_and_add(PW + 1, [&](int k) -> T* {   // (the sum of the weights lives in accumulator row kPMP whatever PW is)
+      return k < F.m ? F.acc + size_t(k) * n : ((k == PW && F.kind == MM_EUCLIDEAN) ? F.acc + size_t(kPMP) * n : nullptr);
     });
   }
   if constexpr (SD > 0) {
@@ -266,21 +285,30 @@ __global__ __launch_bounds__(kPCols * kPWaves) void product_pair_kernel(PArgs<T>
       for (int c = 0; c < SD; ++c) red[wave][r * SD + c][lane] = accS[r][c];
     combine_and_add(SD * SD, [&](int k) -> T* { return pa.s.accS + size_t(k) * n; });
   }
-  // loss and scale-gradient partials: slots [1 + nf][kLossSlots]
+  MM_PSTAMP(4);
+  // loss and scale-gradient partials: slots [1 + nf][kLossSlots].  ONE transposing reduction for all of them (round 4: four
+  // butterfly sums through ds_bpermute, one after the other, were 2.5 k cycles of every workgroup's 29 k)
   const int slot = (blockIdx.x + (blockIdx.y * kPWaves + wave) * gridDim.x) & (kLossSlots - 1);
   {
-    const T v = wave_sum(loss_acc);
-    if (lane == 0) atomic_add(&la.slots[slot], v);
-  }
+    constexpr int NS = 1 + NV + (SD > 0 ? 1 : 0);
+    T sums[NS];
+    sums[0] = loss_acc;
 #pragma unroll
-  for (int f = 0; f < NV; ++f) {
-    const T v = wave_sum(dsv[f]);
-    if (lane == 0) atomic_add(&la.slots[size_t(1 + pa.v[f].slot) * kLossSlots + slot], v);
+    for (int f = 0; f < NV; ++f) sums[1 + f] = dsv[f];
+    if constexpr (SD > 0) sums[1 + NV] = dss;
+    bool writer;
+    const int which = reduce_slot<NS>(lane, writer);
+    const T total = wave_reduce_transposed<NS, T>(sums, lane);
+    if (writer) {
+      int dst = 0;   // the caller's slot of sum `which`: 0 = loss, 1 + k = d loss / d scale of factor k
+#pragma unroll
+      for (int f = 0; f < NV; ++f)
+        if (which == 1 + f) dst = 1 + pa.v[f].slot;
+      if (SD > 0 && which == 1 + NV) dst = 1 + pa.s.slot;
+      atomic_add(&la.slots[size_t(dst) * kLossSlots + slot], total);
+    }
   }
-  if constexpr (SD > 0) {
-    const T v = wave_sum(dss);
-    if (lane == 0) atomic_add(&la.slots[size_t(1 + pa.s.slot) * kLossSlots + slot], v);
-  }
+  MM_PSTAMP(5);
 }
 
 // Accumulators -> gradients (the manifold-specific map of each factor) and the loss sums.
@@ -550,6 +578,15 @@ __global__ __launch_bounds__(128) void product_step_kernel(PArgs<T> pa, PStep<T>
   }
 }
 
+inline int64_t device_cus_product() {
+  static const int64_t cus = [] {
+    int dev = 0, c = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || c < 1) c = 256;
+    return int64_t(c);
+  }();
+  return cus;
+}
+
 template <typename T, int NV, int SD>
 int product_pairs_launch(int loss_kind, PArgs<T> pa, const T* target, int64_t n, int64_t rb, int64_t re, LossArgs<T> la,
                          T* loss_out, hipStream_t st, const PStep<T>* ps, bool pairs_done, T* table) {
@@ -559,12 +596,37 @@ int product_pairs_launch(int loss_kind, PArgs<T> pa, const T* target, int64_t n,
     // 16 -> 97 us per training step), at most 32
     const int64_t cols = (n + kPCols - 1) / kPCols;
     static const int ti_env = [] { const char* e = std::getenv("MM_PRODUCT_TI"); return e ? std::atoi(e) : 0; }();
-    const int ti = (ti_env > 0 && ti_env <= kPMaxTI) ? ti_env : int(std::min<int64_t>(kPMaxTI, std::max<int64_t>(4, cols * n / 2048)));
+    // Round 4: the launch is as long as its FULLEST compute unit — ceil(workgroups / CUs) workgroups of 4 wavefronts x ti rows —
+    // so ti minimises that product, the smaller ti (more wavefronts to hide latency behind) on ties.  n = 1025, 256 CUs:
+    // ti = 6 (731 workgroups, 3 x 6 = 18 rows on the fullest CU) 16.6 us, ti = 9 (493, 2 x 9) 17.5, ti = 8 (561, 3 x 8 = 24:
+    // the round-3 choice) 18.5, ti = 12 (374, 2 x 12) 20.1 (profiles/r04_experiments.md).  Large n: the old rule's cap.
+    int ti = int(std::min<int64_t>(kPMaxTI, std::max<int64_t>(4, cols * n / 2048)));
+    if (ti <= 12) {   // (the sizes the rule was measured at: csphd; larger launches are throughput, and have the symmetric form)
+      const int64_t cus = device_cus_product();
+      int64_t best = INT64_MAX;
+      for (int t = 4; t <= kPMaxTI; ++t) {
+        const int64_t wgs = cols * ((n + kPWaves * t - 1) / (kPWaves * t));
+        const int64_t cost = ((wgs + cus - 1) / cus) * t;
+        if (wgs >= cus && cost < best) { best = cost; ti = t; }
+      }
+    }
+    if (ti_env > 0 && ti_env <= kPMaxTI) ti = ti_env;
     const dim3 grid(unsigned(cols), unsigned((n + kPWaves * ti - 1) / (kPWaves * ti)));
-    if (loss_kind == MM_LOSS_STRESS)
-      product_pair_kernel<T, NV, SD, MM_LOSS_STRESS><<<grid, dim3(kPCols * kPWaves), 0, st>>>(pa, target, int(n), int(rb), int(re), ti, la);
-    else
-      product_pair_kernel<T, NV, SD, MM_LOSS_QUOTIENT><<<grid, dim3(kPCols * kPWaves), 0, st>>>(pa, target, int(n), int(rb), int(re), ti, la);
+    int widest = 0;
+    for (int f = 0; f < NV; ++f) widest = std::max(widest, pa.v[f].m);
+    static const bool wide_env = [] { const char* e = std::getenv("MM_PRODUCT_PW16"); return e && e[0] == '1'; }();   // (A/B: always 16 wide)
+    const dim3 block(kPCols * kPWaves);
+    if (widest <= 8 && !wide_env) {
+      if (loss_kind == MM_LOSS_STRESS)
+        product_pair_kernel<T, NV, SD, MM_LOSS_STRESS, 8><<<grid, block, 0, st>>>(pa, target, int(n), int(rb), int(re), ti, la);
+      else
+        product_pair_kernel<T, NV, SD, MM_LOSS_QUOTIENT, 8><<<grid, block, 0, st>>>(pa, target, int(n), int(rb), int(re), ti, la);
+    } else {
+      if (loss_kind == MM_LOSS_STRESS)
+        product_pair_kernel<T, NV, SD, MM_LOSS_STRESS, kPMP><<<grid, block, 0, st>>>(pa, target, int(n), int(rb), int(re), ti, la);
+      else
+        product_pair_kernel<T, NV, SD, MM_LOSS_QUOTIENT, kPMP><<<grid, block, 0, st>>>(pa, target, int(n), int(rb), int(re), ti, la);
+    }
   }
   if (ps) {   // training step: gradients, loss record, optimizer rules and scales in one launch
     const dim3 sgrid(unsigned(std::max<int64_t>((n + 127) / 128, 1 + pa.nf)), unsigned(NV + (SD > 0 ? 1 : 0) + 1));
@@ -676,6 +738,11 @@ int product_pairs_t(int loss_kind, int nf, const int* kinds, const int* dims, co
 #undef MM_PP
 }
 
+#ifdef MM_PRODUCT_STAMP
+extern "C" int mm_dbg_read_product_stamps(void* host, size_t bytes) {   // (diagnostic builds: tools/product_timeline.py)
+  return int(hipMemcpyFromSymbol(host, HIP_SYMBOL(g_product_stamps), bytes));
+}
+#endif
 // ---- fused training step (product_step.hpp) --------------------------------------------------------------------
 bool product_step_fusable(const mm_train_step* s) {
   static const bool off = [] { const char* e = std::getenv("MM_PRODUCT_STEP_UNFUSED"); return e && e[0] == '1'; }();

@@ -192,18 +192,22 @@ __global__ __launch_bounds__(64 * kPSWaves) void product_sym_kernel(PArgs<T> pa,
               d2v[f] = value_rt<T>(pa.v[f].kind, qv[f]);
               m = Num<T>::fma(spv[f], d2v[f], m);
             }
-            T li[NPS], lc[NPS], lw[DS], vv[DS][DS], d2s = T(0);
+            T li[NPS], lc[NPS], lw[DS], vv[DS][DS], mlog[NPS], d2s = T(0);
             if constexpr (SD > 0) {
 #pragma unroll
               for (int k = 0; k < NPS; ++k) { li[k] = ri[VEC + k]; lc[k] = ri[VEC + NPS + k]; }
               T a[NPS];
               congr_chol<T, SD>(li, yj, a);
-              jacobi_eig<T, SD, true, true>(a, vv, T(64) * Num<T>::eps() * Num<T>::eps());
               T s = T(0);
+              if constexpr (SD == 2) {   // closed form (smallmat.hpp): no eigensolve for the 2x2 factor
+                s = log_spd2<T>(a, pa.s.wmin, pa.s.wmax, mlog);
+              } else {
+                jacobi_eig<T, SD, true, true>(a, vv, T(64) * Num<T>::eps() * Num<T>::eps());
 #pragma unroll
-              for (int k = 0; k < SD; ++k) {  // eigenvalue clamp as _norm_log, spd.py:163-169
-                lw[k] = Num<T>::log(Num<T>::min(Num<T>::max(a[pidx(k, k)], pa.s.wmin), pa.s.wmax));
-                s = Num<T>::fma(lw[k], lw[k], s);
+                for (int k = 0; k < SD; ++k) {  // eigenvalue clamp as _norm_log, spd.py:163-169
+                  lw[k] = Num<T>::log(Num<T>::min(Num<T>::max(a[pidx(k, k)], pa.s.wmin), pa.s.wmax));
+                  s = Num<T>::fma(lw[k], lw[k], s);
+                }
               }
               d2s = Num<T>::max(s, pa.s.wmin);  // value clamp (gradient-transparent), spd.py:163-169
               m = Num<T>::fma(sps, d2s, m);
@@ -228,9 +232,14 @@ __global__ __launch_bounds__(64 * kPSWaves) void product_sym_kernel(PArgs<T> pa,
               dss += coef * d2s;
               const T gs = coef * sps;
               T cm[DS], mm_[NPS], cj[DS][DS];
+              if constexpr (SD == 2) {
 #pragma unroll
-              for (int k = 0; k < SD; ++k) cm[k] = (gs + gs) * lw[k];
-              vdvt<T, SD>(vv, cm, mm_);
+                for (int k = 0; k < NPS; ++k) mm_[k] = (gs + gs) * mlog[k];
+              } else {
+#pragma unroll
+                for (int k = 0; k < SD; ++k) cm[k] = (gs + gs) * lw[k];
+                vdvt<T, SD>(vv, cm, mm_);
+              }
               lt_m_lt<T, SD>(li, lc, mm_, cj);
 #pragma unroll
               for (int a2 = 0; a2 < SD; ++a2)

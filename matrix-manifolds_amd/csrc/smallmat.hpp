@@ -1220,6 +1220,23 @@ template <typename T> __device__ __forceinline__ T logsq_series4_centred(const T
   return N::fma(lmu, N::fma(T(4), lmu, ldet + ldet), core);   // sum (L + l_k)^2 = 4 L^2 + 2 L log det A' + sum l_k^2
 }
 
+// log of a 2x2 SPD matrix in closed form (round 4; the mixed-manifold pair kernels ran a Jacobi eigensolve with eigenvectors — a
+// wave-uniform sweep loop of ~150 instructions — for the SPD(2) factor of BASELINE config 4):
+//   lambda+- = mid +- r,  mid = tr A / 2,  r = sqrt(((a00 - a11)/2)^2 + a10^2),  A - mid I = r V diag(1, -1) V^T, hence
+//   V diag(l+, l-) V^T = (l+ + l-)/2 I + (l+ - l-)/(2 r) (A - mid I),   l+- = log clamp(lambda+-)  (spd.py:163-169).
+// Returns l+^2 + l-^2; mlog = the matrix above (packed 00, 10, 11).  r = 0 gives (l+ - l-) = 0 exactly: no 0/0.
+template <typename T> __device__ __forceinline__ T log_spd2(const T (&a)[3], T wmin, T wmax, T (&mlog)[3]) {
+  using N = Num<T>;
+  const T mid = T(0.5) * (a[0] + a[2]), dh = T(0.5) * (a[0] - a[2]);
+  const T r = N::sqrt(N::fma(dh, dh, a[1] * a[1]));
+  const T lp = N::log(N::min(N::max(mid + r, wmin), wmax)), lm = N::log(N::min(N::max(mid - r, wmin), wmax));
+  const T beta = T(0.5) * (lp - lm) * N::rcp(N::max(r, N::tiny())), alpha = T(0.5) * (lp + lm);
+  mlog[0] = N::fma(beta, dh, alpha);
+  mlog[1] = beta * a[1];
+  mlog[2] = N::fma(-beta, dh, alpha);
+  return N::fma(lp, lp, lm * lm);
+}
+
 // out (packed) = V diag(f) V^T
 template <typename T, int D>
 __device__ __forceinline__ void vdvt(const T (&v)[D][D], const T (&f)[D], T (&out)[Packed<D>::NP]) {

@@ -1129,6 +1129,7 @@ constexpr int kBwdTI = 16;   // rows per wavefront and chunk
 // 8192 301 / 295, 11585 571 / 549, 16384 1082-1096 / 1039-1041; profiles/r03_experiments.md §15): from 30 M pairs per launch
 // on.  MM_SPD4_BWD_TWO_COLS=0 / 1 forces either.
 constexpr int64_t kSpd4TwoColPairs = 30000000;
+constexpr int64_t kSpd4TwoColBandPairs = 12000000;
 // SUB (node minibatch): `ws` is the workspace of the FULL embedding (n_total points), n the batch size, g the dense target matrix.
 template <typename T, int D, int LOSS, bool SQ, int NCX = 0, bool SUB = false>
 int spd_pdist_bwd_launch_sq(Ws<T>& ws, const T* g, int64_t n, int64_t rb, int64_t re, double wmin, double wmax,
@@ -1137,7 +1138,11 @@ int spd_pdist_bwd_launch_sq(Ws<T>& ws, const T* g, int64_t n, int64_t rb, int64_
   constexpr int kCols = NCX ? NCX : pair_cols_bwd<T, D>();
   if constexpr (!SUB && NCX == 0 && sizeof(T) == 4 && D == 4 && pair_cols_bwd<T, D>() == 1) {
     static const int two = [] { const char* e = std::getenv("MM_SPD4_BWD_TWO_COLS"); return e ? (e[0] == '1' ? 1 : 0) : -1; }();
-    if (two == 1 || (two < 0 && pair_off(n, re) - pair_off(n, rb) >= kSpd4TwoColPairs))
+    // (a rank's BAND of rows of a larger problem — every column block as tall as the band — takes two columns from 12 M
+    // pairs on: the N = 8 shards of n = 16384, 16.8 M pairs each, 182 - 199 -> 173 - 179 us; the last rank's TRIANGLE is like
+    // a full problem of its size and keeps one: 198 / 200 us; profiles/r04_experiments.md)
+    const int64_t pairs = pair_off(n, re) - pair_off(n, rb);
+    if (two == 1 || (two < 0 && (pairs >= kSpd4TwoColPairs || (pairs >= kSpd4TwoColBandPairs && re + 2048 <= n))))
       return spd_pdist_bwd_launch_sq<T, D, LOSS, SQ, 2>(ws, g, n, rb, re, wmin, wmax, st, la);
   }
   auto kernel = spd_pdist_bwd_kernel<T, D, kBwdTI, LOSS, SQ, NCX, SUB>;

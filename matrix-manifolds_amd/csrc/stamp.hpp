@@ -31,6 +31,30 @@ __device__ unsigned long long g_bwd_stamps[4 * 16384];
 #define MM_SPD_STAMP_END() do {} while (0)
 #endif
 
+#ifdef MM_PRODUCT_STAMP
+// ordered mixed-manifold pair kernel (product_pairs.hip): 8 slots per workgroup, written by lane 0 of wavefront 0
+//   0 start (s_memtime)  1 column data + row staging requested  2 staged rows in LDS, barrier passed  3 row loop done
+//   4 flushes done  5 end (s_memtime)  6 start (s_memrealtime, 100 MHz)  7 HW_ID << 32 | XCC_ID
+__device__ unsigned long long g_product_stamps[8 * 4096];
+#define MM_PSTAMP(k)                                                                                          \
+  do {                                                                                                        \
+    const unsigned wg_ = blockIdx.y * gridDim.x + blockIdx.x;                                                 \
+    if (threadIdx.x == 0 && wg_ < 4096) g_product_stamps[wg_ * 8 + (k)] = __builtin_amdgcn_s_memtime();       \
+  } while (0)
+#define MM_PSTAMP_BEGIN()                                                                                     \
+  do {                                                                                                        \
+    const unsigned wg_ = blockIdx.y * gridDim.x + blockIdx.x;                                                 \
+    if (threadIdx.x == 0 && wg_ < 4096) {                                                                     \
+      g_product_stamps[wg_ * 8 + 0] = __builtin_amdgcn_s_memtime();                                           \
+      g_product_stamps[wg_ * 8 + 6] = __builtin_amdgcn_s_memrealtime();                                       \
+      g_product_stamps[wg_ * 8 + 7] = stamp_hw_id();                                                          \
+    }                                                                                                         \
+  } while (0)
+#else
+#define MM_PSTAMP(k) do {} while (0)
+#define MM_PSTAMP_BEGIN() do {} while (0)
+#endif
+
 #ifdef MM_GRAM_STAMP
 __device__ unsigned long long g_gram_stamps[1024 * 4 * 26];    // symmetric backward: 26 slots per wavefront
 __device__ unsigned long long g_gramf_stamps[2048 * 4 * 16];   // forward: 16 slots per wavefront

@@ -95,9 +95,11 @@ template <typename T, int KIND, int MP, int TI, int LOSS, bool SUB = false>
 __global__ __launch_bounds__(kVBlock) void vec_pdist_bwd_kernel(const T* __restrict__ x, const T* __restrict__ g, int n,
                                                                 int m, int row_begin, int row_end, int squared,
                                                                 T* __restrict__ acc /* [MP+1][n] */, LossArgs<T> la,
-                                                                const int64_t* __restrict__ idx = nullptr, int n_total = 0) {
+                                                                const int64_t* __restrict__ idx = nullptr, int n_total = 0,
+                                                                int rows_per_block = TI /* SUB: chosen per launch */) {
   const int j = blockIdx.x * kVBlock + threadIdx.x;
-  const int i0 = blockIdx.y * TI, i1 = min(i0 + TI, n);
+  const int rpb = SUB ? rows_per_block : TI;
+  const int i0 = blockIdx.y * rpb, i1 = min(i0 + rpb, n);
   const bool jin = j < n;
   const bool jown = jin && j >= row_begin && j < row_end;  // pairs (j, i>j) belong to this shard
   const int ns = SUB ? n_total : n;                        // stride of the per-node accumulators
@@ -123,8 +125,12 @@ __global__ __launch_bounds__(kVBlock) void vec_pdist_bwd_kernel(const T* __restr
       const bool valid = jin && i < i1 && (up ? (i >= row_begin && i < row_end) : (jown && i > j));
       const int lo = up ? i : j, hi = up ? j : i;
       ok[u] = valid;
-      if constexpr (SUB) wv[u] = valid ? g[size_t(idx[lo]) * size_t(n_total) + size_t(idx[hi])] : T(0);
-      else wv[u] = valid ? g[vpair_off(n, lo) - base + (hi - lo - 1)] : T(0);
+      if constexpr (SUB) {   // dense[node(lo)][node(hi)]: the row's node is wave-uniform (a scalar load), the column's is in a register
+        const size_t in_ = size_t(idx[min(i, n - 1)]);
+        wv[u] = valid ? (up ? g[in_ * size_t(n_total) + size_t(jn)] : g[size_t(jn) * size_t(n_total) + in_]) : T(0);
+      } else {
+        wv[u] = valid ? g[vpair_off(n, lo) - base + (hi - lo - 1)] : T(0);
+      }
     }
 #pragma unroll
     for (int u = 0; u < UNR; ++u) {
@@ -611,20 +617,25 @@ template <typename T, int KIND, int MP>
 int vec_loss_subset_t(int loss_kind, const T* x, const T* dense, const T* scale_raw, int64_t n_total, int m, const int64_t* idx,
                       int64_t bs, int64_t rb, int64_t re, double alpha, double eps, int terms, const double* loss_params, T* loss_out,
                       T* grad, void* ws, hipStream_t st) {
-  constexpr int TI = 64;
+  // Rows per workgroup: a minibatch of 512 nodes is 2 column blocks — with the 64-row tiles of the full-size launches it
+  // would be 16 workgroups on 256 CUs (103 us for the 130 816 pairs of Lorentz(24)); fewer rows mean more workgroups but
+  // also more column flushes onto the same accumulator addresses.  MM_VEC_SUBSET_ROWS overrides (multiples of 8).
+  constexpr int TI = 8;
+  static const int rows_env = [] { const char* e = std::getenv("MM_VEC_SUBSET_ROWS"); return e ? std::atoi(e) : 0; }();
+  const int rows = rows_env > 0 ? (rows_env + 7) / 8 * 8 : 16;
   T* acc = static_cast<T*>(ws);
   T* slots = acc + size_t(n_total) * (MP + 1);
   LossArgs<T> la{scale_raw, T(alpha), T(eps), terms, slots, loss_params};
   hipError_t e = hipMemsetAsync(acc, 0, sizeof(T) * (size_t(n_total) * (MP + 1) + 2 * kLossSlots), st);
   if (e != hipSuccess) return int(e);
   if (re > rb && bs > 1) {
-    const dim3 grid(int((bs + kVBlock - 1) / kVBlock), int((bs + TI - 1) / TI));
+    const dim3 grid(int((bs + kVBlock - 1) / kVBlock), int((bs + rows - 1) / rows));
     if (loss_kind == MM_LOSS_STRESS)
       vec_pdist_bwd_kernel<T, KIND, MP, TI, MM_LOSS_STRESS, true><<<grid, dim3(kVBlock), 0, st>>>(
-          x, dense, int(bs), m, int(rb), int(re), 1, acc, la, idx, int(n_total));
+          x, dense, int(bs), m, int(rb), int(re), 1, acc, la, idx, int(n_total), rows);
     else
       vec_pdist_bwd_kernel<T, KIND, MP, TI, MM_LOSS_QUOTIENT, true><<<grid, dim3(kVBlock), 0, st>>>(
-          x, dense, int(bs), m, int(rb), int(re), 1, acc, la, idx, int(n_total));
+          x, dense, int(bs), m, int(rb), int(re), 1, acc, la, idx, int(n_total), rows);
     MMV_CHECK();
   }
   vec_pdist_finalize_kernel<T, KIND, MP><<<dim3(int((n_total + 127) / 128)), dim3(128), 0, st>>>(

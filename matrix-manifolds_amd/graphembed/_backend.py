@@ -265,11 +265,11 @@ def pair_offset(n, row):
 
 def shard_rows(n, world, rank):
     """Row range of shard ``rank``: contiguous, balanced by the COST of the pair kernel — a pair of a row of L pairs counts
-    1 + L / K (K = 100 000: the row-side atomics of long rows contend; csrc/common.hip has the measurement).
+    1 + L / K (K = 400 000: the row-side atomics of long rows contend; csrc/common.hip has the measurement).
 
     Same rule as ``mm_shard_rows`` (csrc/common.hip), restated in Python (exact integers) so that host logic can be
     tested without the library.  MM_SHARD_K overrides K in both (0: balance pair counts)."""
-    K = int(os.environ.get('MM_SHARD_K', 100000))
+    K = int(os.environ.get('MM_SHARD_K', 400000))
 
     def cost_before(row):
         m1, m0 = n - 1, n - 1 - row

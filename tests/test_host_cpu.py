@@ -66,8 +66,8 @@ def test_shard_rows_cover_and_balance(n, world):
         sizes.append(hi - lo)
     assert prev_end == n and sum(sizes) == P
     if n >= 64 * world:
-        # balanced by COST (a pair of a row of L pairs counts 1 + L / 100000: csrc/common.hip) to within a row or two ...
-        K = 100000
+        # balanced by COST (a pair of a row of L pairs counts 1 + L / 400000: csrc/common.hip) to within a row or two ...
+        K = 400000
         rows = [B.shard_rows(n, world, r) for r in range(world)]
         cost = [sum((n - 1 - i) * (K + n - 1 - i) for i in range(a, b)) for a, b in rows]
         assert max(cost) - min(cost) <= 2 * (n - 1) * (K + n - 1)

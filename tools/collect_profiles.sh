@@ -1,10 +1,10 @@
 #!/bin/bash
 # Copy the judged summaries of an evidence run (tools/gpu_evidence.sh TAG, merged back under gpurun_out/TAG) into profiles/:
-#   tools/collect_profiles.sh TAG [ROUND]      # ROUND = prefix of the committed files, default r03
+#   tools/collect_profiles.sh TAG [ROUND]      # ROUND = prefix of the committed files, default r04
 # profiles/pmc_head.json is the stamp written on the GPU box (same kernel-source hash as the tree that ran); the counter
 # summary it cites is regenerated here from the same CSVs.
 set -e
-TAG=$1; R=${2:-r03}
+TAG=$1; R=${2:-r04}
 cd "$(dirname "$0")/.."
 G=gpurun_out/$TAG
 cp $G/summary.txt profiles/${R}_summary.txt
@@ -12,7 +12,7 @@ cp $G/bench.json profiles/${R}_bench.json
 cp $G/configs.json profiles/${R}_configs.json
 cp $G/shard_kernel_times.json profiles/${R}_shard_kernel_times.json
 cp $G/bench_gloo2_dryrun.json profiles/${R}_bench_gloo2_dryrun.json 2>/dev/null || true
-for f in eager_euclid eager_spd timeline_cold timeline_warm; do [ -s $G/$f.txt ] && cp $G/$f.txt profiles/${R}_$f.txt; done
+for f in eager_euclid eager_spd timeline_cold timeline_warm product_timeline; do [ -s $G/$f.txt ] && cp $G/$f.txt profiles/${R}_$f.txt; done
 for d in $G/*_stats; do
   n=$(basename $d _stats)
   f=$(find $d -name "*kernel_stats.csv" | head -1)

@@ -8,7 +8,7 @@
 #      SPD(6) / SPD(9), Lorentz(11) with the MFMA counters, the mixed-manifold pair kernel at n = 1025 and n = 5000
 #   4. the warm-regime shader clock from in-kernel stamps (lib/variants/libmm_stamp.so, if built)
 #   5. a default `python3 bench.py` run, tools/bench_configs.py, tools/shard_kernel_times.py, the eager-path host profile
-TAG=${1:-r03}
+TAG=${1:-r04}
 OUT=$GRAFT_REPO_ROOT/gpurun_out/$TAG
 mkdir -p $OUT
 cd $GRAFT_REPO_ROOT
@@ -27,7 +27,7 @@ for CASE in "pdist 3 5000 f64 0.1" "pdist 3 5000 f32 0.35" "pdist 3 5000 f64 0.3
   NAME=$(echo $CASE | tr ' .' '__')
   rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/case_${NAME}_stats -o s -- $C $CASE 40 > /dev/null 2>&1
 done
-for CASE in "pdist 3 5000 f32 0.35" "pdist 4 16384 f32 0.1" "loss 4 16384 f32" "vec 11 4039 f32 lorentz"; do
+for CASE in "pdist 3 5000 f32 0.35" "pdist 3 5000 f64 0.1" "pdist 3 5000 f64 0.35" "pdist 4 16384 f32 0.1" "loss 4 16384 f32" "vec 11 4039 f32 lorentz"; do
   NAME=$(echo $CASE | tr ' .' '__')
   rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE --output-format csv -d $OUT/case_${NAME}_pmc_sq -o p -- $C $CASE 3 > /dev/null 2>&1
   rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/case_${NAME}_pmc_fetch -o p -- $C $CASE 3 > /dev/null 2>&1
@@ -61,7 +61,16 @@ if [ -f matrix-manifolds_amd/lib/variants/libmm_stamp.so ]; then
 fi
 timeout 600 python3 bench.py > $OUT/bench.json 2> $OUT/bench.err
 tail -c 400 $OUT/bench.json
-timeout 900 python3 tools/bench_configs.py > $OUT/configs.json 2> $OUT/configs.err; echo "configs rc=$?"
+timeout 1200 python3 tools/bench_configs.py > $OUT/configs.json 2> $OUT/configs.err; echo "configs rc=$?"
+# node minibatches through the one-call step: the launches of a step (kernel trace of two of the cases)
+cd /tmp
+for C5 in c5_spd4_minibatch512_step_n16384_f32_native_graph lorentz24_minibatch512_step_n4039_f32_native_graph; do
+  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/case_${C5}_stats -o s -- python3 /root/repo/tools/bench_configs.py --only $C5 > /dev/null 2>&1
+done
+cd $GRAFT_REPO_ROOT
+if [ -f matrix-manifolds_amd/lib/variants/libmm_pstamp.so ]; then
+  MM_MANIFOLDS_LIB=/root/repo/matrix-manifolds_amd/lib/variants/libmm_pstamp.so python3 tools/product_timeline.py 1025 > $OUT/product_timeline.txt 2>&1
+fi
 python3 tools/shard_kernel_times.py > $OUT/shard_kernel_times.json 2> $OUT/shard.err
 python3 tools/eager_profile.py euclid > $OUT/eager_euclid.txt 2>&1
 python3 tools/eager_profile.py spd > $OUT/eager_spd.txt 2>&1

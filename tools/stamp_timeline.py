@@ -2,7 +2,7 @@
 """Diagnostic: timeline of the SPD backward kernel's workgroups from in-kernel clock stamps (build
 `tools/snap_make.sh stamp -DMM_BWD_STAMP`, run with MM_MANIFOLDS_LIB=.../libmm_stamp.so).
 Prints residency over time, workgroup durations, the per-CU load and the SHADER CLOCK (s_memtime cycles per microsecond
-of s_memrealtime).   python tools/stamp_timeline.py [n] [--warm]
+of s_memrealtime).   python tools/stamp_timeline.py [n] [--warm] [--d=D] [--shard=R/N]
 --warm: the stamped launch is the last of >= 60 ms of back-to-back graph replays — the clock regime of bench.py's timed
 region (Clocks); without it: the 7th launch after seconds of host-side input generation (cold clocks)."""
 import ctypes
@@ -22,8 +22,12 @@ from graphembed import _backend as B  # noqa: E402
 def main():
     args = [a for a in sys.argv[1:] if not a.startswith('--')]
     n = int(args[0]) if args else 5000
+    opt = dict(a[2:].split('=') for a in sys.argv[1:] if a.startswith('--') and '=' in a)
+    d = int(opt.get('d', 3))
+    rank, world = (int(v) for v in opt.get('shard', '0/1').split('/'))
     dev = torch.device('cuda', 0)
-    wl = bench.PdistWorkload(3, n, torch.float32, 0.1, 1, 0, dev)
+    wl = bench.PdistWorkload(d, n, torch.float32, 0.1, world, rank, dev)
+    print(f'SPD({d}) n = {n}, rank {rank} of {world}: rows {wl.rows}, {wl.hi - wl.lo} pairs')
     if '--warm' in sys.argv:
         import time
         graph, _ = bench.graph_of(wl.kernels, bench.Fence(1))

@@ -47,6 +47,8 @@ CASES = {'bench': ('SPD(3) f32 n=5000 reference init (headline; python3 bench.py
          'case_vec_11_4039_f32_lorentz': ('Lorentz(11) f32 n=4039 (BASELINE config 2) pdist fwd + bwd (default: matrix-core forward, symmetric VALU backward)', 11, 4039, 4),
          'case_vecgram_11_4039_f32_lorentz': ('Lorentz(11) f32 n=4039 pdist fwd + bwd with MM_VEC_BWD=gram (matrix-core backward)', 11, 4039, 4),
          'case_vstep_11_4039_f32_lorentz': ('Lorentz(11) f32 n=4039 (BASELINE config 2) full training step through mm_train_step_run (pair kernel + one per-point kernel)', 11, 4039, 4),
+         'case_c5_spd4_minibatch512_step_n16384_f32_native_graph': ('SPD(4) f32 n=16384, node minibatches of 512 through mm_train_step_run (batch_idx): launches of a step', 4, 512, 4),
+         'case_lorentz24_minibatch512_step_n4039_f32_native_graph': ('Lorentz(24) f32 n=4039, node minibatches of 512 through mm_train_step_run', 24, 512, 4),
          'case_product_1025': ('BASELINE config 4: H^5 x S^5 x SPD(2) f32 n=1025 training step (mixed-manifold pair kernel)', 2, 1025, 4),
          'case_product_5000': ('H^5 x S^5 x SPD(2) f32 n=5000 training step (symmetric mixed-manifold pair kernel)', 2, 5000, 4)}
 for key, (title, d, n, esz) in CASES.items():

@@ -181,6 +181,23 @@ int mm_spd_map(int dtype, int op, const void* x, const void* u, int64_t m, int d
 /* SymmetricPositiveDefinite.symeig — spd.py:35-41, 63-64 (linalg/fast.py:53-91 for n = 2, 3; LAPACK on the CPU
  * otherwise): eigenvalues of sym(x[k]), ascending.   x [m,d,d] -> w [m,d] */
 int mm_spd_eigvalsh(int dtype, const void* x, int64_t m, int d, void* w, mm_stream_t stream);
+/* graphembed/linalg/fast.py:25-159 by name — the closed forms for stacks of 2x2 / 3x3 matrices (spd.py:35-46 and
+ * grassmann.py:29 pick them; monitor.py:39-45, tests/test_linalg.py:47-141 and tests/test_perf.py:14-81 call them directly),
+ * with the derivative torch's autograd gives the reference's arithmetic (upper-triangle gradients, fast.py:5-10; the
+ * `.data.clamp_` guards clamp the value and pass the derivative).  x [n,2,2] or [n,3,3]:
+ *   op                      out              out2 (optional)     reference
+ *   MM_FAST_SYMEIG2         w [n,2] asc.                         fast.py:53-70
+ *   MM_FAST_SYMEIG3         w [n,3] asc.                         fast.py:75-91
+ *   MM_FAST_CHOLESKY2       L [n,2,2]                            fast.py:94-107
+ *   MM_FAST_INVCHOLESKY2    L^-1 [n,2,2]     L [n,2,2] or NULL   fast.py:110-135
+ *   MM_FAST_SINGULAR2       s [n,2] desc.                        fast.py:138-159
+ *   MM_FAST_DET2 / DET3 / SYMDET3   det [n]                      fast.py:25-50
+ * mm_fast_bwd: grad_x [n,k,k] from the cotangents of out (and of out2, or NULL).  `eps` is the functions' `eps` argument. */
+enum { MM_FAST_SYMEIG2 = 0, MM_FAST_SYMEIG3 = 1, MM_FAST_CHOLESKY2 = 2, MM_FAST_INVCHOLESKY2 = 3, MM_FAST_SINGULAR2 = 4,
+       MM_FAST_DET2 = 5, MM_FAST_DET3 = 6, MM_FAST_SYMDET3 = 7 };
+int mm_fast_fwd(int op, int dtype, const void* x, int64_t n, double eps, void* out, void* out2, mm_stream_t stream);
+int mm_fast_bwd(int op, int dtype, const void* x, const void* grad_out, const void* grad_out2, int64_t n, double eps,
+                void* grad_x, mm_stream_t stream);
 /* SymmetricPositiveDefinite.norm — spd.py:113-117: ||L^-1 U L^-T||_F  -> out [m] */
 int mm_spd_norm(int dtype, const void* x, const void* u, int64_t m, int d, int squared, void* out,
                 mm_stream_t stream);

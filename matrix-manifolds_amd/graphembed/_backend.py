@@ -20,6 +20,8 @@ EUCLIDEAN, LORENTZ, SPHERE = 0, 1, 2
 FACTOR_SPD = 16  # MM_FACTOR_SPD: factor kind of mm_product_pairs_loss
 WS_CLEAN = 2     # MM_WS_CLEAN
 SPD_EGRAD2RGRAD, SPD_EXP, SPD_RETR, SPD_LOG, SPD_PROJX, SPD_PROJU = range(6)
+(FAST_SYMEIG2, FAST_SYMEIG3, FAST_CHOLESKY2, FAST_INVCHOLESKY2, FAST_SINGULAR2, FAST_DET2, FAST_DET3,
+ FAST_SYMDET3) = range(8)  # MM_FAST_*
 
 _c = ctypes
 _vp, _i, _i64, _dbl, _sz = _c.c_void_p, _c.c_int, _c.c_int64, _c.c_double, _c.c_size_t
@@ -92,6 +94,8 @@ SIGNATURES = {
     'mm_spd_dist_bwd': (_i, [_i, _vp, _vp, _vp, _i64, _i, _i, _dbl, _dbl, _vp, _vp, _vp]),
     'mm_spd_map': (_i, [_i, _i, _vp, _vp, _i64, _i, _dbl, _dbl, _vp, _vp]),
     'mm_spd_eigvalsh': (_i, [_i, _vp, _i64, _i, _vp, _vp]),
+    'mm_fast_fwd': (_i, [_i, _i, _vp, _i64, _dbl, _vp, _vp, _vp]),
+    'mm_fast_bwd': (_i, [_i, _i, _vp, _vp, _vp, _i64, _dbl, _vp, _vp]),
     'mm_spd_norm': (_i, [_i, _vp, _vp, _i64, _i, _i, _vp, _vp]),
     'mm_spd_rsgd_step': (_i, [_i, _vp, _vp, _i64, _i, _dbl, _dbl, _i, _vp, _vp]),
     'mm_vec_max_dim': (_i, []),

@@ -65,14 +65,27 @@ def _eigh_upper(x):
 # --------------------------------------------------------------------------
 # closed forms of linalg/fast.py
 # --------------------------------------------------------------------------
-def symeig2x2(X):
+def symeig2x2(X, eps=EPS):
     """fast.py:53-70 — reads X00, X11 and the *upper* off-diagonal only."""
     a, b, c = X[..., 0, 0], X[..., 1, 1], X[..., 0, 1]
     det = a * b - c**2
     ht = 0.5 * (a + b)
-    delta = vclamp(ht**2 - det, EPS)
+    delta = vclamp(ht**2 - det, eps)
     r = delta.sqrt()
     return torch.stack([ht - r, ht + r], dim=-1)
+
+
+def det2x2(X):
+    """fast.py:25-28 — the full matrix."""
+    return X[..., 0, 0] * X[..., 1, 1] - X[..., 0, 1] * X[..., 1, 0]
+
+
+def det3x3(X):
+    """fast.py:31-37 — cofactor expansion along the first row, the full matrix."""
+    m1 = X[..., 1, 1] * X[..., 2, 2] - X[..., 1, 2] * X[..., 2, 1]
+    m2 = X[..., 1, 0] * X[..., 2, 2] - X[..., 1, 2] * X[..., 2, 0]
+    m3 = X[..., 1, 0] * X[..., 2, 1] - X[..., 1, 1] * X[..., 2, 0]
+    return X[..., 0, 0] * m1 - X[..., 0, 1] * m2 + X[..., 0, 2] * m3
 
 
 def _symdet3x3(Y):
@@ -83,15 +96,18 @@ def _symdet3x3(Y):
             y00 * y12**2 - y22 * y01**2)
 
 
-def symeig3x3(X):
+symdet3x3 = _symdet3x3
+
+
+def symeig3x3(X, eps=EPS):
     """fast.py:75-91 — trigonometric closed form with the +eps fudge terms."""
     batch = X.shape[:-2]
     q = (X.diagonal(dim1=-2, dim2=-1).sum(-1) / 3).reshape(*batch, 1, 1)
     Y = X - q * torch.eye(3, dtype=X.dtype, device=X.device)
     p = torch.sqrt(Y.pow(2).sum((-2, -1), keepdim=True) / 6)
-    p = vclamp(p, EPS)
-    r = _symdet3x3(Y).reshape(*batch, 1, 1) / (2 * p.pow(3) + EPS)
-    r = vclamp(r, -1 + EPS, 1 - EPS)
+    p.data.clamp_(min=eps)  # (in place, as fast.py:81: sqrt's backward then divides by the CLAMPED root)
+    r = _symdet3x3(Y).reshape(*batch, 1, 1) / (2 * p.pow(3) + eps)
+    r = vclamp(r, -1 + eps, 1 - eps)
     phi = torch.acos(r) / 3
     e1 = q + 2 * p * torch.cos(phi)
     e2 = q + 2 * p * torch.cos(phi + 2 * math.pi / 3)
@@ -99,27 +115,27 @@ def symeig3x3(X):
     return torch.stack([e2, e3, e1], dim=-1).reshape(*batch, 3)
 
 
-def _chol2x2_parts(X):
+def _chol2x2_parts(X, eps=EPS):
     """fast.py:94-107 / 110-123: a, b, c of the eps-fudged 2x2 Cholesky."""
     shape = X.shape[:-2] + (1, 1)
-    x00 = vclamp(X[..., 0, 0].reshape(shape), EPS)
+    x00 = vclamp(X[..., 0, 0].reshape(shape), eps)
     x11 = X[..., 1, 1].reshape(shape)
     x01 = X[..., 0, 1].reshape(shape)
     a = x00.sqrt()
     b = x01 / a
-    c = (x11 - b**2 + EPS).sqrt()
+    c = (x11 - b**2 + eps).sqrt()
     return a, b, c
 
 
-def cholesky2x2(X):
-    a, b, c = _chol2x2_parts(X)
+def cholesky2x2(X, eps=EPS):
+    a, b, c = _chol2x2_parts(X, eps)
     z = torch.zeros_like(a)
     return torch.cat([torch.cat([a, z], -1), torch.cat([b, c], -1)], -2)
 
 
-def invcholesky2x2(X, ret_chol=False):
-    a, b, c = _chol2x2_parts(X)
-    det = vclamp(a * c, EPS)
+def invcholesky2x2(X, ret_chol=False, eps=EPS):
+    a, b, c = _chol2x2_parts(X, eps)
+    det = vclamp(a * c, eps)
     z = torch.zeros_like(a)
     l_inv = torch.cat([torch.cat([c, z], -1), torch.cat([-b, a], -1)], -2) / det
     if not ret_chol:
@@ -127,14 +143,14 @@ def invcholesky2x2(X, ret_chol=False):
     return l_inv, torch.cat([torch.cat([a, z], -1), torch.cat([b, c], -1)], -2)
 
 
-def singular_values_2x2(x):
+def singular_values_2x2(x, eps=EPS):
     """fast.py:138-159."""
     a, b, c, d = x[..., 0, 0], x[..., 0, 1], x[..., 1, 0], x[..., 1, 1]
     S1 = a**2 + b**2 + c**2 + d**2
     S2 = (a**2 + b**2 - c**2 - d**2)**2 + 4 * (a * c + b * d)**2
-    S2 = torch.sqrt(vclamp(S2, EPS))
-    s1 = vclamp(0.5 * (S1 + S2), EPS)
-    s2 = vclamp(0.5 * (S1 - S2), EPS)
+    S2 = torch.sqrt(vclamp(S2, eps))
+    s1 = vclamp(0.5 * (S1 + S2), eps)
+    s2 = vclamp(0.5 * (S1 - S2), eps)
     return torch.stack([torch.sqrt(s1), torch.sqrt(s2)], dim=-1)
 
 

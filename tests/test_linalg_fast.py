@@ -1,0 +1,180 @@
+"""`graphembed.linalg.fast` (reference: graphembed/graphembed/linalg/fast.py:25-159).
+
+CPU: the oracle port against vectors recorded from the real reference (tests/golden/gen_golden_fast.py): outputs AND the
+gradients its autograd returns — which half of a symmetric matrix carries the gradient is part of the contract.
+GPU: the kernels of csrc/fast.hip (one `mm_fast_fwd` / `mm_fast_bwd` launch per call) against the same vectors, against
+the oracle on seeded inputs, and the reference's own tests/test_linalg.py:47-141 re-expressed (`torch.symeig` is
+`torch.linalg.eigvalsh` today)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, 'matrix-manifolds_amd')):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+GOLD = np.load(os.path.join(ROOT, 'tests', 'golden', 'fast.npz'))
+DT = {'f32': torch.float32, 'f64': torch.float64}
+CASES = sorted({k.rsplit('/', 1)[0] for k in GOLD.files})   # 'fn/dtype/case/epsE'
+
+
+def _call(mod, fn, x, eps):
+    if fn == 'invcholesky2x2':
+        return (mod.invcholesky2x2(x, ret_chol=False, eps=eps)[0], )
+    if fn == 'invcholesky2x2_chol':
+        return tuple(mod.invcholesky2x2(x, ret_chol=True, eps=eps))
+    if fn in ('det2x2', 'det3x3', 'symdet3x3'):
+        return (getattr(mod, fn)(x), )
+    return (getattr(mod, fn)(x, eps=eps), )
+
+
+def _check(mod, key, device):
+    fn, dname, case, eps = key.split('/')
+    eps = float(eps[3:])
+    x = torch.from_numpy(GOLD[key + '/x']).to(device).requires_grad_()
+    ys = _call(mod, fn, x, eps)
+    loss = 0
+    # tolerances: fp32 1e-5 of the output's scale on values (the trigonometric 3x3 roots cancel: 3e-5), gradients 2e-4 of
+    # theirs (quotients by sqrt(delta), sin(3 phi)); fp64 1e-11 / 1e-8
+    vt, gt = (3e-5, 5e-4) if dname == 'f32' else (1e-11, 1e-8)
+    for k, y in enumerate(ys):
+        want = GOLD[key + f'/out{k}'].astype(np.float64)
+        assert tuple(y.shape) == want.shape, (y.shape, want.shape)
+        assert y.dtype == DT[dname]
+        got = y.detach().double().cpu().numpy()
+        assert np.abs(got - want).max() <= vt * max(np.abs(want).max(), 1.0), (key, k, np.abs(got - want).max())
+        loss = loss + (y * torch.from_numpy(GOLD[key + f'/cot{k}']).to(device)).sum()
+    loss.backward()
+    want = GOLD[key + '/grad'].astype(np.float64)
+    got = x.grad.double().cpu().numpy()
+    rows = np.isfinite(want).reshape(want.shape[0], -1).all(1)   # (fp32 symeig3x3 at |r| clamped to 1: the reference returns inf)
+    assert rows.sum() >= 0.8 * rows.size
+    # entries the reference's arithmetic never reads carry an exact zero
+    assert ((want[rows] == 0) <= (got[rows] == 0)).all(), key
+    scale = np.abs(want[rows]).reshape(rows.sum(), -1).max(1).reshape(-1, *([1] * (want.ndim - 1)))
+    err = np.abs(got[rows] - want[rows]) / np.maximum(scale, 1.0)
+    assert err.max() <= gt, (key, err.max())
+
+
+@pytest.mark.parametrize('key', CASES)
+def test_oracle_port_matches_the_reference(key):
+    from oracle import ref_port as rp
+    _check(rp, key, 'cpu')
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('key', CASES)
+def test_kernels_match_the_reference(key):
+    from graphembed.linalg import fast
+    _check(fast, key, 'cuda')
+
+
+def _rand_sym(n, d, dt):  # tests/conftest.py:27-33 of the reference
+    x = torch.rand(n, d, d, dtype=dt, device='cuda')
+    return 0.5 * (x + x.transpose(1, 2))
+
+
+def _rand_spd(n, d, dt):  # tests/conftest.py:36-43
+    x = torch.rand(n, d, d, dtype=dt, device='cuda')
+    return x @ x.transpose(1, 2) + torch.eye(d, dtype=dt, device='cuda')
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('dname', list(DT))
+def test_reference_test_linalg_re_expressed(dname):
+    """tests/test_linalg.py:47-141: eye, symeig vs LAPACK, eigenvalue gradients vs eigh's, Cholesky and its inverse and
+    their gradients vs torch's, singular values vs svd — at the reference's atol 1e-4."""
+    from graphembed.linalg import fast
+    dt = DT[dname]
+    sym = lambda t: 0.5 * (t + t.transpose(-1, -2))
+    for d, eig in ((2, fast.symeig2x2), (3, fast.symeig3x3)):
+        eyes = torch.eye(d, dtype=dt, device='cuda').expand(10, -1, -1)
+        assert (eig(eyes) - 1).abs().max().item() <= 1e-4 + 1e-7
+        for seed in range(5):
+            torch.manual_seed(seed)
+            for n in range(10, 20):
+                x = _rand_sym(n, d, dt)
+                assert (eig(x) - torch.linalg.eigvalsh(x)).abs().max().item() <= 1e-4
+            x1 = _rand_sym(100, d, dt).requires_grad_()
+            eig(x1).pow(2).sum().backward()
+            x2 = x1.detach().clone().requires_grad_()
+            torch.linalg.eigh(x2, UPLO='U')[0].pow(2).sum().backward()
+            assert (sym(x1.grad) - sym(x2.grad)).abs().max().item() <= 1e-4
+    for seed in range(5):
+        torch.manual_seed(seed)
+        for n in range(10, 20):
+            x = _rand_spd(n, 2, dt)
+            assert (torch.linalg.cholesky(x) - fast.cholesky2x2(x)).abs().max().item() <= 1e-4
+            assert (torch.linalg.inv(torch.linalg.cholesky(x)) - fast.invcholesky2x2(x)[0]).abs().max().item() <= 1e-4
+            li, l = fast.invcholesky2x2(x, ret_chol=True)
+            assert (l - torch.linalg.cholesky(x)).abs().max().item() <= 1e-4 and (li @ l - torch.eye(2, dtype=dt, device='cuda')).abs().max().item() <= 1e-4
+            x1 = x.clone().requires_grad_()
+            fast.cholesky2x2(x1).pow(2).sum().backward()
+            x2 = x.clone().requires_grad_()
+            torch.linalg.cholesky(x2).pow(2).sum().backward()
+            assert (sym(x1.grad) - sym(x2.grad)).abs().max().item() <= 1e-4
+            x1 = x.clone().requires_grad_()
+            fast.invcholesky2x2(x1)[0].pow(2).sum().backward()
+            x2 = x.clone().requires_grad_()
+            torch.linalg.inv(torch.linalg.cholesky(x2)).pow(2).sum().backward()
+            assert (sym(x1.grad) - sym(x2.grad)).abs().max().item() <= 1e-4
+        x = torch.rand(500, 2, 2, dtype=torch.float64, device='cuda').to(dt)
+        assert (fast.singular_values_2x2(x) - torch.linalg.svdvals(x)).abs().max().item() <= 1e-4
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('dname', list(DT))
+@pytest.mark.parametrize('n', [0, 1, 255, 256, 257, 100003])
+def test_kernels_match_the_oracle_on_seeded_inputs(dname, n):
+    """Tile edges of the 256-matrix workgroups (n = 255 / 256 / 257), an empty batch, a large one; batch shapes kept."""
+    from graphembed.linalg import fast
+    from oracle import ref_port as rp
+    dt = DT[dname]
+    g = torch.Generator().manual_seed(1234 + n)
+    vt, gt = (3e-5, 5e-4) if dname == 'f32' else (1e-11, 1e-8)
+    for fn, d, make in [('symeig2x2', 2, 'sym'), ('symeig3x3', 3, 'spd'), ('cholesky2x2', 2, 'spd'),
+                        ('invcholesky2x2_chol', 2, 'spd'), ('singular_values_2x2', 2, 'any'), ('det2x2', 2, 'any'),
+                        ('det3x3', 3, 'any'), ('symdet3x3', 3, 'any')]:
+        a = torch.rand(n, d, d, generator=g, dtype=torch.float64)
+        x = (a @ a.transpose(1, 2) + torch.eye(d, dtype=torch.float64) if make == 'spd' else
+             (0.5 * (a + a.transpose(1, 2)) if make == 'sym' else a - 0.3)).to(dt)
+        xg, xc = x.cuda().requires_grad_(), x.clone().requires_grad_()
+        yg, yc = _call(fast, fn, xg, 1e-8), _call(rp, fn, xc, 1e-8)
+        lg = lc = 0
+        for a_, b_ in zip(yg, yc):
+            if n == 1 and fn == 'symeig3x3':
+                b_ = b_.squeeze()
+            assert a_.shape == b_.shape, (fn, a_.shape, b_.shape)
+            if n:
+                assert (a_.detach().cpu() - b_.detach()).abs().max().item() <= vt * max(b_.detach().abs().max().item(), 1.0), fn
+            cot = torch.rand(b_.shape, generator=g, dtype=torch.float64).to(dt)
+            lg, lc = lg + (a_ * cot.cuda()).sum(), lc + (b_ * cot).sum()
+        lg.backward()
+        lc.backward()
+        if n:
+            sc = max(xc.grad.abs().max().item(), 1.0)
+            assert (xg.grad.cpu() - xc.grad).abs().max().item() <= gt * sc, fn
+        else:
+            assert xg.grad.shape == x.shape
+    # leading batch dimensions are kept (the reference's symeig2x2 / cholesky2x2 / singular_values_2x2 index with `...`)
+    x = torch.rand(3, 5, 2, 2, dtype=dt, device='cuda') + torch.eye(2, dtype=dt, device='cuda')
+    assert fast.symeig2x2(x).shape == (3, 5, 2) and fast.cholesky2x2(x).shape == (3, 5, 2, 2)
+    assert fast.singular_values_2x2(x).shape == (3, 5, 2) and fast.det2x2(x).shape == (3, 5)
+    assert fast.det2x2(x.reshape(15, 2, 2), keepdim=True).shape == (15, 1, 1)
+    with pytest.raises(Exception):
+        fast.symeig2x2(x.cpu())
+
+
+def test_module_surface_without_a_gpu():
+    """The module imports anywhere and exposes the reference's names; CPU tensors are refused loudly (no fallback)."""
+    from graphembed.linalg import fast
+    from graphembed import _backend as B
+    for name in ('det2x2', 'det3x3', 'symdet3x3', 'symeig2x2', 'symeig3x3', 'cholesky2x2', 'invcholesky2x2',
+                 'singular_values_2x2'):
+        assert callable(getattr(fast, name))
+    with pytest.raises(B.BackendError):
+        fast.symeig2x2(torch.eye(2).expand(3, -1, -1))

@@ -69,7 +69,22 @@ template <typename T> __device__ __forceinline__ T vec_dq_rt(int kind, T q) {
 
 // PW: padded width of a vector factor inside the kernel — 8 when every vector factor has at most 8 coordinates (csphd:
 // 6 + 6), else kPMP = 16: the row point's LDS reads, the inner product and the column accumulation are PW wide.
-template <typename T, int NV, int SD, int LOSS, int PW>
+// KC: the vector factors' kinds, two bits each (factor f: (KC >> 2 f) & 3), or -1 = read pa.v[f].kind in the row loop.
+// With kinds known at run time only, every row pays ~20 scalar branches around the three places the kinds differ (inner
+// product, distance function, its derivative): the csphd pair kernel 15.3 -> 13.2 us with them as constants (round 4,
+// profiles/r04_experiments.md).  Instantiated for products of one or two narrow vector factors (3 + 9 combinations; three
+// factors would be 27: they keep the run-time form).
+template <int KC, typename T> __device__ __forceinline__ int pkind_of(const PArgs<T>& pa, int f) {
+  if constexpr (KC >= 0) return (KC >> (2 * f)) & 3; else return pa.v[f].kind;
+}
+#define MM_PKIND(f) (pkind_of<KC>(pa, (f)))
+// IDX: a node minibatch — columns and rows address the factors' points, the dense targets and the accumulators through
+// pa.idx.  A template argument, not `pa.idx ? pa.idx[j] : j` in front of every dependent load: that form put a conditional
+// index load and an UNconditional s_waitcnt vmcnt(0) in front of each of the six groups of prologue loads — with or without
+// an index vector, every workgroup started with six serial memory round trips (9 k of its 27 k cycles; round 4).  Now the
+// node ids (this lane's column, and the tile's rows — lane r holds row i0 + r) are one request, everything else follows
+// in one batch, and the rows' ids reach the lanes that stage them through ds_bpermute / v_readlane.
+template <typename T, int NV, int SD, int LOSS, int PW, bool IDX, int KC = -1>
 __global__ __launch_bounds__(kPCols * kPWaves) void product_pair_kernel(PArgs<T> pa, const T* __restrict__ target, int n,
                                                                int row_begin, int row_end, int ti, LossArgs<T> la) {
   constexpr int NPS = SD > 0 ? Packed<(SD > 0 ? SD : 2)>::NP : 1;
@@ -81,7 +96,18 @@ __global__ __launch_bounds__(kPCols * kPWaves) void product_pair_kernel(PArgs<T>
   const int i0 = min((blockIdx.y * kPWaves + wave) * ti, n), i1 = min(i0 + ti, n);
   const bool jin = j < n;
   const bool jown = jin && j >= row_begin && j < row_end;
-  const int64_t jnode = node_of(pa, jin ? j : n - 1);  // lanes past n: clamped, masked later
+  int64_t jnode = jin ? j : n - 1;  // lanes past n: clamped, masked later
+  int rnode = min(i0 + min(lane, ti - 1), n - 1);      // lane r < ti: the node of row i0 + r
+  if constexpr (IDX) {
+    jnode = pa.idx[jnode];
+    rnode = int(pa.idx[rnode]);
+  }
+  auto node_of_row = [&](int r) -> int {       // r per lane
+    if constexpr (IDX) return __shfl(rnode, r); else return min(i0 + r, n - 1);
+  };
+  auto node_of_row_uniform = [&](int r) -> int {   // r wave-uniform
+    if constexpr (IDX) return __builtin_amdgcn_readlane(rnode, r); else return min(i0 + r, n - 1);
+  };
   // per-lane column data
   T xj[NV > 0 ? NV : 1][PW], accv[NV > 0 ? NV : 1][PW], wsum[NV > 0 ? NV : 1], spv[NV > 0 ? NV : 1],
       dsv[NV > 0 ? NV : 1];
@@ -105,7 +131,7 @@ __global__ __launch_bounds__(kPCols * kPWaves) void product_pair_kernel(PArgs<T>
   T yj[NPS], accS[DS][DS], xs_col[NPS], xs_row[NPS];
   if constexpr (SD > 0) {
     load_sym_packed<T, SD>(pa.s.x + size_t(jnode) * SD * SD, xs_col);
-    load_sym_packed<T, SD>(pa.s.x + size_t(node_of(pa, min(i0 + min(lane, ti - 1), n - 1))) * SD * SD, xs_row);
+    load_sym_packed<T, SD>(pa.s.x + size_t(rnode) * SD * SD, xs_row);
 #pragma unroll
     for (int r = 0; r < SD; ++r)
 #pragma unroll
@@ -116,7 +142,7 @@ __global__ __launch_bounds__(kPCols * kPWaves) void product_pair_kernel(PArgs<T>
     return jin && i != j && (i < j ? (i >= row_begin && i < row_end) : jown);
   };
   auto target_at = [&](int i) -> T {  // unconditional load from a clamped address, one row ahead of its use
-    if (pa.dense) return pa.dense[node_of(pa, min(i, n - 1)) * pa.dense_n + jnode];
+    if (pa.dense) return pa.dense[int64_t(node_of_row_uniform(min(i, n - 1) - min(i0, n - 1))) * pa.dense_n + jnode];
     const int lo = i < j ? i : j, hi = i < j ? j : i;
     return target[pair_ok(i) ? int64_t(lo) * (2 * int64_t(n) - lo - 1) / 2 - base + (hi - lo - 1) : int64_t(0)];
   };
@@ -137,7 +163,7 @@ __global__ __launch_bounds__(kPCols * kPWaves) void product_pair_kernel(PArgs<T>
 #pragma unroll
     for (int it = 0; it < kStageIts; ++it) {
       const int e = lane + 64 * it, r = min(e / PW, ti - 1), k = e % PW;
-      staged[f][it] = F.x[size_t(node_of(pa, min(i0 + r, n - 1))) * F.m + min(k, F.m - 1)];
+      staged[f][it] = F.x[size_t(node_of_row(r)) * F.m + min(k, F.m - 1)];
     }
   }
   MM_PSTAMP(1);
@@ -194,8 +220,8 @@ __global__ __launch_bounds__(kPCols * kPWaves) void product_pair_kernel(PArgs<T>
       const PVec<T>& F = pa.v[f];
 #pragma unroll
       for (int k = 0; k < PW; ++k) xi[f][k] = rowpt[f][wave][i - i0][k];  // same address in every lane: LDS broadcast
-      qv[f] = vec_q_rt<T, PW>(F.kind, xi[f], xj[f]);
-      d2v[f] = vec_value_rt<T>(F.kind, qv[f]);
+      qv[f] = vec_q_rt<T, PW>(MM_PKIND(f), xi[f], xj[f]);
+      d2v[f] = vec_value_rt<T>(MM_PKIND(f), qv[f]);
       m = Num<T>::fma(spv[f], d2v[f], m);
     }
     T li[NPS], lc[NPS], lw[DS], vv[DS][DS], mlog[NPS], d2s = T(0);
@@ -227,7 +253,7 @@ __global__ __launch_bounds__(kPCols * kPWaves) void product_pair_kernel(PArgs<T>
 #pragma unroll
     for (int f = 0; f < NV; ++f) {
       dsv[f] += once ? dldm * d2v[f] : T(0);
-      const T w = coef * spv[f] * vec_dq_rt<T>(pa.v[f].kind, qv[f]);
+      const T w = coef * spv[f] * vec_dq_rt<T>(MM_PKIND(f), qv[f]);
       wsum[f] += w;
 #pragma unroll
       for (int k = 0; k < PW; ++k) accv[f][k] = Num<T>::fma(w, xi[f][k], accv[f][k]);
@@ -578,6 +604,19 @@ __global__ __launch_bounds__(128) void product_step_kernel(PArgs<T> pa, PStep<T>
   }
 }
 
+// f(integral_constant<int, C>) for the compile-time C that equals `code` (two bits per factor, every digit a valid kind)
+template <int NV, int C = 0, typename F> bool for_kind_code(int code, F&& f) {
+  if constexpr (C >= (1 << (2 * NV))) {
+    return false;
+  } else {
+    constexpr bool valid = (C & 3) <= MM_SPHERE && ((C >> 2) & 3) <= MM_SPHERE;
+    if constexpr (valid) {
+      if (code == C) { f(std::integral_constant<int, C>{}); return true; }
+    }
+    return for_kind_code<NV, C + 1>(code, f);
+  }
+}
+
 inline int64_t device_cus_product() {
   static const int64_t cus = [] {
     int dev = 0, c = 0;
@@ -616,17 +655,28 @@ int product_pairs_launch(int loss_kind, PArgs<T> pa, const T* target, int64_t n,
     for (int f = 0; f < NV; ++f) widest = std::max(widest, pa.v[f].m);
     static const bool wide_env = [] { const char* e = std::getenv("MM_PRODUCT_PW16"); return e && e[0] == '1'; }();   // (A/B: always 16 wide)
     const dim3 block(kPCols * kPWaves);
-    if (widest <= 8 && !wide_env) {
-      if (loss_kind == MM_LOSS_STRESS)
-        product_pair_kernel<T, NV, SD, MM_LOSS_STRESS, 8><<<grid, block, 0, st>>>(pa, target, int(n), int(rb), int(re), ti, la);
-      else
-        product_pair_kernel<T, NV, SD, MM_LOSS_QUOTIENT, 8><<<grid, block, 0, st>>>(pa, target, int(n), int(rb), int(re), ti, la);
-    } else {
-      if (loss_kind == MM_LOSS_STRESS)
-        product_pair_kernel<T, NV, SD, MM_LOSS_STRESS, kPMP><<<grid, block, 0, st>>>(pa, target, int(n), int(rb), int(re), ti, la);
-      else
-        product_pair_kernel<T, NV, SD, MM_LOSS_QUOTIENT, kPMP><<<grid, block, 0, st>>>(pa, target, int(n), int(rb), int(re), ti, la);
-    }
+    auto launch = [&](auto kernel) { kernel<<<grid, block, 0, st>>>(pa, target, int(n), int(rb), int(re), ti, la); };
+    int kinds_code = 0;
+    for (int f = 0; f < NV; ++f) kinds_code |= (pa.v[f].kind & 3) << (2 * f);
+    static const bool rt_kinds = [] { const char* e = std::getenv("MM_PRODUCT_RT_KINDS"); return e && e[0] == '1'; }();   // (A/B)
+    auto by_loss = [&](auto pw, auto idx) {
+      constexpr int W = decltype(pw)::value;
+      constexpr bool I = decltype(idx)::value;
+      auto with_kinds = [&](auto kc) {
+        constexpr int K = decltype(kc)::value;
+        if (loss_kind == MM_LOSS_STRESS) launch(product_pair_kernel<T, NV, SD, MM_LOSS_STRESS, W, I, K>);
+        else launch(product_pair_kernel<T, NV, SD, MM_LOSS_QUOTIENT, W, I, K>);
+      };
+      if constexpr (W == 8 && (NV == 1 || NV == 2)) {
+        if (!rt_kinds && for_kind_code<NV>(kinds_code, with_kinds)) return;
+      }
+      with_kinds(std::integral_constant<int, -1>{});
+    };
+    auto by_idx = [&](auto pw) {
+      if (pa.idx) by_loss(pw, std::true_type{}); else by_loss(pw, std::false_type{});
+    };
+    if (widest <= 8 && !wide_env) by_idx(std::integral_constant<int, 8>{});
+    else by_idx(std::integral_constant<int, kPMP>{});
   }
   if (ps) {   // training step: gradients, loss record, optimizer rules and scales in one launch
     const dim3 sgrid(unsigned(std::max<int64_t>((n + 127) / 128, 1 + pa.nf)), unsigned(NV + (SD > 0 ? 1 : 0) + 1));

@@ -405,7 +405,11 @@ __device__ __forceinline__ void jacobi_eig(T (&a)[Packed<D>::NP], T (&v)[D][D], 
   // (D >= 6: the sweeps stay a loop — unrolled, a 9x9 solve with eigenvectors is ~30 000 instructions per call site —
   // and get a few more of them: the quadratic convergence of cyclic Jacobi starts later for larger matrices)
   constexpr int kSweeps = D <= 5 ? N::kMaxSweeps : N::kMaxSweeps + 4;
+#ifdef MM_JACOBI_ROLL_F64   // (A/B builds: the fp64 sweeps as a loop — the unrolled fp64 backward is 73 KB of code)
+  constexpr int kUnrollSweeps = (D <= 5 && !std::is_same<T, double>::value) ? N::kMaxSweeps : 1;
+#else
   constexpr int kUnrollSweeps = D <= 5 ? N::kMaxSweeps : 1;
+#endif
 #pragma unroll kUnrollSweeps
   for (int sweep = 0; sweep < kSweeps; ++sweep) {
     bool active = sweep < kMinSweeps;
@@ -744,6 +748,25 @@ template <> struct CayleyP<double> {
   static constexpr int kTerms = K + 1;
   static constexpr double at(int i) { return c[i]; }
 };
+// fp64 only — the narrow tier: the same two functions on [0, 0.16] (tools/design/cayley_sq_fit.py, relative error 2.4e-15 /
+// 3.9e-16), four and five coefficients fewer.  tr(Z^2) is known before the polynomial starts, so a wavefront whose pairs
+// all have tr(Z^2) <= 0.16 takes the short tables: every pair of the mid-training spread does (max 0.136 at
+// ||log X|| = 0.35; mu = 2^k alone contributes up to 0.087), 12 / 15 multiply-adds and twice as many scalar moves fewer.
+constexpr double kCayleyNarrow = 0.16;
+struct CayleyPn64 {
+  static constexpr double c[10] = {0.999999999999997828, 0.333333333336045998, 0.199999999442592788, 0.142857187137109386,
+                                   0.111109332105236778, 0.0909499162581166662, 0.0763574513803657068, 0.0714494792571264998,
+                                   0.0350458696353453726, 0.113663386241058913};
+  static constexpr int kTerms = 10;
+  static constexpr double at(int i) { return c[i]; }
+};
+struct CayleyQn64 {
+  static constexpr double c[11] = {1.00000000000000037, 0.666666666666100058, 0.511111111252317187, 0.419047605361109196,
+                                   0.357460995535957299, 0.313015598858362064, 0.279652848994267891, 0.248774877825649445,
+                                   0.25954346018603201, 0.0906375847139156082, 0.475855998018695552};
+  static constexpr int kTerms = 11;
+  static constexpr double at(int i) { return c[i]; }
+};
 // mu = 2^k next to the mean eigenvalue: returns 1 / mu, *logmu = k ln 2 (no transcendental error; A ~ I gives exactly 0)
 template <typename T> __device__ __forceinline__ T cayley_scale(T mean, T* logmu) {
   int k;
@@ -786,7 +809,13 @@ template <typename T> __device__ __forceinline__ T log_cayley3(const T (&a)[6], 
   cayley3_spectrum<T>(s1, s2, s3, rD, z1, z2, z3, t1, t2, t3);
   // P(W) = c0 + c1 W + c2 W^2 by Horner in R[W]/(chi_W), W^3 = t1 W^2 - t2 W + t3 I
   T c0, c1, c2;
-  ring_horner3<T, P>(t1, t2, t3, c0, c1, c2);
+#ifndef MM_CAYLEY_ONE_TIER   // (A/B builds)
+  if constexpr (std::is_same<T, double>::value) {
+    if (!__any(!(t1 <= T(kCayleyNarrow)))) ring_horner3<T, CayleyPn64>(t1, t2, t3, c0, c1, c2);
+    else ring_horner3<T, P>(t1, t2, t3, c0, c1, c2);
+  } else
+#endif
+    ring_horner3<T, P>(t1, t2, t3, c0, c1, c2);
   // Z (c2 Z^4 + c1 Z^2 + c0) in R[Z]/(chi_Z), Z^3 = z1 Z^2 - z2 Z + z3 I: start from c2 Z^2 + c1, then . Z, . Z + c0, . Z
   T b0 = c2 * z3, b1 = N::fma(-c2, z2, c1), b2 = c2 * z1;
   {
@@ -860,7 +889,13 @@ template <typename T> __device__ __forceinline__ T logsq_cayley3(const T (&a)[6]
   *gate = t1;
   const T p1 = t1, p2 = N::fma(t1, p1, T(-2) * t2), p3 = N::fma(t1, p2, N::fma(-t2, p1, T(3) * t3));
   T c0, c1, c2;
-  ring_horner3<T, Q>(t1, t2, t3, c0, c1, c2);
+#ifndef MM_CAYLEY_ONE_TIER
+  if constexpr (std::is_same<T, double>::value) {
+    if (!__any(!(t1 <= T(kCayleyNarrow)))) ring_horner3<T, CayleyQn64>(t1, t2, t3, c0, c1, c2);
+    else ring_horner3<T, Q>(t1, t2, t3, c0, c1, c2);
+  } else
+#endif
+    ring_horner3<T, Q>(t1, t2, t3, c0, c1, c2);
   const T s = N::fma(c2, p3, N::fma(c1, p2, c0 * p1));   // sum atanh^2 z_k
   return N::fma(logmu, N::fma(T(-3), logmu, logdet_a + logdet_a), T(4) * s);
 }

@@ -70,11 +70,16 @@ def test_run_py_import_block_resolves_across_both_packages():
                           ('ManifoldEmbedding', modules.ManifoldEmbedding), ('BatchedObjective', modules.BatchedObjective)]:
             assert origin(obj) == 'ours', (name, origin(obj))
         for name, obj in [('ProductManifoldEmbedding', ProductManifoldEmbedding), ('TrainingEngine', TrainingEngine),
-                          ('products.TrainingEngine', PE), ('train_da.TrainingEngine', DA), ('linalg', linalg),
+                          ('products.TrainingEngine', PE), ('train_da.TrainingEngine', DA),
                           ('monitor', graphembed.monitor), ('inference', graphembed.inference),
                           ('Universal', manifolds.Universal), ('OrthogonalGroup', manifolds.OrthogonalGroup),
                           ('EmbeddingBase', modules.EmbeddingBase)]:
             assert origin(obj) == 'reference', (name, origin(obj))
+        # graphembed.linalg has no __init__.py on either side: a namespace package over both directories — `fast` (the closed
+        # forms on the path, csrc/fast.hip) from this package, `torch_batch` (CPU-offloaded LAPACK wrappers) from the checkout
+        from graphembed.linalg import fast, torch_batch as tb
+        assert origin(fast) == 'ours' and origin(tb) == 'reference', (origin(fast), origin(tb))
+        assert [os.path.realpath(p).startswith(OURS) for p in linalg.__path__] == [True, False], list(linalg.__path__)
         from graphembed.utils import PLT_MUTEX, latest_path_by_basename_numeric_order     # train.py:15-16 (names only the checkout has)
         assert origin(graphembed._overlay._counterpart('utils')) == 'reference'
         # the engine's own base class check: the checkout's TrainingEngine drives THIS package's BatchedObjective

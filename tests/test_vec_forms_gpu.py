@@ -174,9 +174,12 @@ def test_suite_with_python_autograd_functions():
     assert ' passed' in r.stdout
 
 
-@pytest.mark.parametrize('env', [{'MM_PRODUCT_SYM': '1'}, {'MM_PRODUCT_ORDERED': '1'}])
+@pytest.mark.parametrize('env', [{'MM_PRODUCT_SYM': '1'}, {'MM_PRODUCT_ORDERED': '1'},
+                                 {'MM_PRODUCT_ORDERED': '1', 'MM_PRODUCT_RT_KINDS': '1'}])
 def test_product_suites_with_pair_kernel_forced(env):
-    """The mixed-manifold pair kernel has two forms — every ordered pair (csrc/product_pairs.hip: small n) and every
+    """(Third environment: the ordered kernel with the factor kinds read at run time instead of the instantiations that
+    have them as constants — products of one or two narrow vector factors take those by default.)
+    The mixed-manifold pair kernel has two forms — every ordered pair (csrc/product_pairs.hip: small n) and every
     unordered pair once (csrc/product_sym.hip: fp32 n >= 1536, fp64 n >= 640) — chosen by size: the product tests of the
     suite (golden product distances and gradients, the reference's training traces, config 4 at n = 1025 against the C
     oracle, the one-call step, a slice of the randomised campaign) again in a child with each form forced at every size."""

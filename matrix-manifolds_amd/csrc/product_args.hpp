@@ -2,6 +2,7 @@
 // node minibatches; product_sym.hip: every UNORDERED pair once, vector factors of width <= 8, full batches) — they fill
 // the same accumulators, so the finalize / step kernels of product_pairs.hip serve both.
 #pragma once
+#include <type_traits>
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
@@ -42,6 +43,29 @@ template <typename T> struct PArgs {
 };
 template <typename T> __device__ __forceinline__ int64_t node_of(const PArgs<T>& pa, int j) {
   return pa.idx ? pa.idx[j] : int64_t(j);
+}
+
+// KC: the vector factors' kinds, two bits each (factor f: (KC >> 2 f) & 3), or -1 = read pa.v[f].kind in the row loop.
+// With kinds known at run time only, every row pays ~20 scalar branches around the three places the kinds differ (inner
+// product, distance function, its derivative): the csphd pair kernel 15.3 -> 13.2 us with them as constants (round 4,
+// profiles/r04_experiments.md).  Instantiated for products of one or two narrow vector factors (3 + 9 combinations; three
+// factors would be 27: they keep the run-time form).
+template <int KC, typename T> __device__ __forceinline__ int pkind_of(const PArgs<T>& pa, int f) {
+  if constexpr (KC >= 0) return (KC >> (2 * f)) & 3; else return pa.v[f].kind;
+}
+#define MM_PKIND(f) (pkind_of<KC>(pa, (f)))
+
+// f(integral_constant<int, C>) for the compile-time C that equals `code` (two bits per factor, every digit a valid kind)
+template <int NV, int C = 0, typename F> bool for_kind_code(int code, F&& f) {
+  if constexpr (C >= (1 << (2 * NV))) {
+    return false;
+  } else {
+    constexpr bool valid = (C & 3) <= MM_SPHERE && ((C >> 2) & 3) <= MM_SPHERE;
+    if constexpr (valid) {
+      if (code == C) { f(std::integral_constant<int, C>{}); return true; }
+    }
+    return for_kind_code<NV, C + 1>(code, f);
+  }
 }
 
 }  // namespace mm

@@ -69,15 +69,6 @@ template <typename T> __device__ __forceinline__ T vec_dq_rt(int kind, T q) {
 
 // PW: padded width of a vector factor inside the kernel — 8 when every vector factor has at most 8 coordinates (csphd:
 // 6 + 6), else kPMP = 16: the row point's LDS reads, the inner product and the column accumulation are PW wide.
-// KC: the vector factors' kinds, two bits each (factor f: (KC >> 2 f) & 3), or -1 = read pa.v[f].kind in the row loop.
-// With kinds known at run time only, every row pays ~20 scalar branches around the three places the kinds differ (inner
-// product, distance function, its derivative): the csphd pair kernel 15.3 -> 13.2 us with them as constants (round 4,
-// profiles/r04_experiments.md).  Instantiated for products of one or two narrow vector factors (3 + 9 combinations; three
-// factors would be 27: they keep the run-time form).
-template <int KC, typename T> __device__ __forceinline__ int pkind_of(const PArgs<T>& pa, int f) {
-  if constexpr (KC >= 0) return (KC >> (2 * f)) & 3; else return pa.v[f].kind;
-}
-#define MM_PKIND(f) (pkind_of<KC>(pa, (f)))
 // IDX: a node minibatch — columns and rows address the factors' points, the dense targets and the accumulators through
 // pa.idx.  A template argument, not `pa.idx ? pa.idx[j] : j` in front of every dependent load: that form put a conditional
 // index load and an UNconditional s_waitcnt vmcnt(0) in front of each of the six groups of prologue loads — with or without
@@ -142,7 +133,8 @@ __global__ __launch_bounds__(kPCols * kPWaves) void product_pair_kernel(PArgs<T>
     return jin && i != j && (i < j ? (i >= row_begin && i < row_end) : jown);
   };
   auto target_at = [&](int i) -> T {  // unconditional load from a clamped address, one row ahead of its use
-    if (pa.dense) return pa.dense[int64_t(node_of_row_uniform(min(i, n - 1) - min(i0, n - 1))) * pa.dense_n + jnode];
+    // (a node minibatch reads dense[idx[i]][idx[j]]; the two come together: mm_product_pairs_loss_subset requires both)
+    if constexpr (IDX) return pa.dense[int64_t(node_of_row_uniform(min(i, n - 1) - min(i0, n - 1))) * pa.dense_n + jnode];
     const int lo = i < j ? i : j, hi = i < j ? j : i;
     return target[pair_ok(i) ? int64_t(lo) * (2 * int64_t(n) - lo - 1) / 2 - base + (hi - lo - 1) : int64_t(0)];
   };
@@ -604,19 +596,6 @@ __global__ __launch_bounds__(128) void product_step_kernel(PArgs<T> pa, PStep<T>
   }
 }
 
-// f(integral_constant<int, C>) for the compile-time C that equals `code` (two bits per factor, every digit a valid kind)
-template <int NV, int C = 0, typename F> bool for_kind_code(int code, F&& f) {
-  if constexpr (C >= (1 << (2 * NV))) {
-    return false;
-  } else {
-    constexpr bool valid = (C & 3) <= MM_SPHERE && ((C >> 2) & 3) <= MM_SPHERE;
-    if constexpr (valid) {
-      if (code == C) { f(std::integral_constant<int, C>{}); return true; }
-    }
-    return for_kind_code<NV, C + 1>(code, f);
-  }
-}
-
 inline int64_t device_cus_product() {
   static const int64_t cus = [] {
     int dev = 0, c = 0;
@@ -710,6 +689,7 @@ int product_pairs_t(int loss_kind, int nf, const int* kinds, const int* dims, co
   pa.idx = idx;
   pa.dense = static_cast<const T*>(dense);
   pa.dense_n = dense_n;
+  if ((idx == nullptr) != (dense == nullptr)) return MM_ERR_ARG;   // (a node minibatch is an index vector AND the dense targets)
   int nv = 0, sd = 0;
   // workspace: [64 bytes reserved] [slots (1+nf) x 256] [accumulators]
   char* wsb = static_cast<char*>(wsp);

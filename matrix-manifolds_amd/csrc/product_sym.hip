@@ -89,7 +89,8 @@ template <typename T> __device__ __forceinline__ T dq_rt(int kind, T q) {
                               : (kind == MM_LORENTZ ? PairFn<T, MM_LORENTZ>::dq(q, 1) : PairFn<T, MM_SPHERE>::dq(q, 1));
 }
 
-template <typename T, int NV, int SD, int LOSS>
+// KC: the vector factors' kinds as constants (product_args.hpp), -1 = read in the row loop
+template <typename T, int NV, int SD, int LOSS, int KC = -1>
 __global__ __launch_bounds__(64 * kPSWaves) void product_sym_kernel(PArgs<T> pa, const T* __restrict__ tab, const T* __restrict__ target,
                                                                     int n, int row_begin, int row_end, LossArgs<T> la) {
   using L = PSLayout<NV, SD>;
@@ -188,8 +189,8 @@ __global__ __launch_bounds__(64 * kPSWaves) void product_sym_kernel(PArgs<T> pa,
             for (int f = 0; f < NV; ++f) {
 #pragma unroll
               for (int k = 0; k < kPSW; ++k) xi[f][k] = ri[f * kPSW + k];
-              qv[f] = q8<T>(pa.v[f].kind, xi[f], xj[f]);
-              d2v[f] = value_rt<T>(pa.v[f].kind, qv[f]);
+              qv[f] = q8<T>(MM_PKIND(f), xi[f], xj[f]);
+              d2v[f] = value_rt<T>(MM_PKIND(f), qv[f]);
               m = Num<T>::fma(spv[f], d2v[f], m);
             }
             T li[NPS], lc[NPS], lw[DS], vv[DS][DS], mlog[NPS], d2s = T(0);
@@ -221,7 +222,7 @@ __global__ __launch_bounds__(64 * kPSWaves) void product_sym_kernel(PArgs<T> pa,
 #pragma unroll
             for (int f = 0; f < NV; ++f) {
               dsv[f] += coef * d2v[f];
-              const T w = coef * spv[f] * dq_rt<T>(pa.v[f].kind, qv[f]);
+              const T w = coef * spv[f] * dq_rt<T>(MM_PKIND(f), qv[f]);
 #pragma unroll
               for (int k = 0; k < kPSW; ++k) {
                 accv[f][k] = Num<T>::fma(w, xi[f][k], accv[f][k]);
@@ -357,10 +358,19 @@ int launch(int loss_kind, const PArgs<T>& pa, const T* target, int64_t n, int64_
   if (env_grid > 0) grid = env_grid;
   grid = std::max<int64_t>(1, std::min<int64_t>(grid, (units + 3) / 4));
   const dim3 g3{unsigned(grid), 1, 1}, b3{unsigned(64 * kPSWaves), 1, 1};
-  if (loss_kind == MM_LOSS_STRESS)
-    product_sym_kernel<T, NV, SD, MM_LOSS_STRESS><<<g3, b3, 0, st>>>(pa, table, target, int(n), int(rb), int(re), la);
-  else
-    product_sym_kernel<T, NV, SD, MM_LOSS_QUOTIENT><<<g3, b3, 0, st>>>(pa, table, target, int(n), int(rb), int(re), la);
+  int kinds_code = 0;
+  for (int f = 0; f < NV; ++f) kinds_code |= (pa.v[f].kind & 3) << (2 * f);
+  static const bool rt_kinds = [] { const char* e = std::getenv("MM_PRODUCT_RT_KINDS"); return e && e[0] == '1'; }();   // (A/B)
+  auto with_kinds = [&](auto kc) {
+    constexpr int K = decltype(kc)::value;
+    if (loss_kind == MM_LOSS_STRESS)
+      product_sym_kernel<T, NV, SD, MM_LOSS_STRESS, K><<<g3, b3, 0, st>>>(pa, table, target, int(n), int(rb), int(re), la);
+    else
+      product_sym_kernel<T, NV, SD, MM_LOSS_QUOTIENT, K><<<g3, b3, 0, st>>>(pa, table, target, int(n), int(rb), int(re), la);
+  };
+  bool launched = false;
+  if constexpr (NV == 1 || NV == 2) launched = !rt_kinds && for_kind_code<NV>(kinds_code, with_kinds);
+  if (!launched) with_kinds(std::integral_constant<int, -1>{});
   e = hipGetLastError();
   return e == hipSuccess ? MM_OK : int(e);
 }

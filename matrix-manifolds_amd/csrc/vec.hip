@@ -31,6 +31,7 @@ namespace mm {
 
 constexpr int kVBlock = 256;
 constexpr int kVecMaxDim = 64;
+constexpr int kVecSubMaxRows = 64;   // most rows per workgroup of the node-minibatch launch (their points sit in LDS)
 __host__ __device__ inline int64_t vpair_off(int64_t n, int64_t row) { return row * (2 * n - row - 1) / 2; }
 
 // q for one pair from register/scalar operands
@@ -112,6 +113,21 @@ __global__ __launch_bounds__(kVBlock) void vec_pdist_bwd_kernel(const T* __restr
   loss_resolve<T, LOSS>(la);
   if constexpr (LOSS != MM_LOSS_NONE) sp = softplus_of(la.scale_raw);
   const int64_t base = vpair_off(n, row_begin);
+  // SUB: the tile's rows are staged in LDS — their node ids with one request, all their points with one more.  (Read in
+  // the loop below, `x[idx[i] * m + k]` is two DEPENDENT scalar round trips per row: 47 us for the 130 816 pairs of a
+  // 512-node Lorentz(24) batch; round 4.)
+  constexpr int kSubRows = SUB ? kVecSubMaxRows : 1;
+  __shared__ T rowx[kSubRows][SUB ? MP : 1];
+  __shared__ int rown[kSubRows];
+  if constexpr (SUB) {
+    if (int(threadIdx.x) < rpb) rown[threadIdx.x] = int(idx[min(i0 + int(threadIdx.x), n - 1)]);
+    __syncthreads();
+    for (int e = threadIdx.x; e < rpb * MP; e += kVBlock) {
+      const int r = e / MP, k = e % MP;
+      rowx[r][k] = k < m ? x[size_t(rown[r]) * m + k] : T(0);
+    }
+    __syncthreads();
+  }
   // The per-pair arithmetic (~45 VALU ops) is far too short to hide the latency of the load
   // of g it depends on, so the upstream gradients of UNR rows are fetched as one batch first.
   constexpr int UNR = 8;
@@ -126,7 +142,7 @@ __global__ __launch_bounds__(kVBlock) void vec_pdist_bwd_kernel(const T* __restr
       const int lo = up ? i : j, hi = up ? j : i;
       ok[u] = valid;
       if constexpr (SUB) {   // dense[node(lo)][node(hi)]: the row's node is wave-uniform (a scalar load), the column's is in a register
-        const size_t in_ = size_t(idx[min(i, n - 1)]);
+        const size_t in_ = size_t(rown[min(i, i1 - 1) - i0]);
         wv[u] = valid ? (up ? g[in_ * size_t(n_total) + size_t(jn)] : g[size_t(jn) * size_t(n_total) + in_]) : T(0);
       } else {
         wv[u] = valid ? g[vpair_off(n, lo) - base + (hi - lo - 1)] : T(0);
@@ -136,7 +152,12 @@ __global__ __launch_bounds__(kVBlock) void vec_pdist_bwd_kernel(const T* __restr
     for (int u = 0; u < UNR; ++u) {
       const int i = min(ib + u, i1 - 1);  // (rows past the tile carry wv = 0)
       T xi[MP];
-      load_point<T, MP>(x, SUB ? int(idx[i]) : i, m, xi);
+      if constexpr (SUB) {
+#pragma unroll
+        for (int k = 0; k < MP; ++k) xi[k] = rowx[i - i0][k];   // (same address in every lane: LDS broadcast)
+      } else {
+        load_point<T, MP>(x, i, m, xi);
+      }
       const T q = pair_q<T, KIND, MP>(xi, xj);
       T w;
       if constexpr (LOSS == MM_LOSS_NONE) {
@@ -622,7 +643,7 @@ int vec_loss_subset_t(int loss_kind, const T* x, const T* dense, const T* scale_
   // also more column flushes onto the same accumulator addresses.  MM_VEC_SUBSET_ROWS overrides (multiples of 8).
   constexpr int TI = 8;
   static const int rows_env = [] { const char* e = std::getenv("MM_VEC_SUBSET_ROWS"); return e ? std::atoi(e) : 0; }();
-  const int rows = rows_env > 0 ? (rows_env + 7) / 8 * 8 : 16;
+  const int rows = std::min(kVecSubMaxRows, rows_env > 0 ? (rows_env + 7) / 8 * 8 : 16);
   T* acc = static_cast<T*>(ws);
   T* slots = acc + size_t(n_total) * (MP + 1);
   LossArgs<T> la{scale_raw, T(alpha), T(eps), terms, slots, loss_params};

@@ -1,8 +1,10 @@
 """Overlay of this package onto a maintainer's checkout of the reference (option A).
 
 This package defines the hot path only (`manifolds`, `modules`, `optim`, `objectives`, `data`, `pyx`, `metrics`,
-`utils`).  The reference's control plane — `graphembed.train`, `.train_da`, `.products`, `.monitor`, `.linalg`,
-`.inference` (run.py:15-18, 76-81; `graphembed/__init__.py:1-9`) — is NOT rebuilt here.  When another `graphembed`
+`utils`, `linalg.fast`).  The reference's control plane — `graphembed.train`, `.train_da`, `.products`, `.monitor`,
+`.linalg.torch_batch`, `.inference` (run.py:15-18, 76-81; `graphembed/__init__.py:1-9`) — is NOT rebuilt here.
+(`graphembed.linalg` has no `__init__.py` on either side: once the checkout's directory is on `__path__` it is a namespace
+package over both — `fast` from here, `torch_batch` from the checkout.)  When another `graphembed`
 package follows this one on `sys.path` (the maintainer's checkout), `install()`
 
   * appends its directories to `__path__` of this package and of its sub-packages, so every sub-module this package does
@@ -81,7 +83,7 @@ def _package_getattr(modname, rel):
         if name.startswith('__'):
             raise AttributeError(name)
         full = f'{modname}.{name}'
-        try:                                   # a sub-module / sub-package of the checkout (graphembed.linalg, data.preprocess)
+        try:                                   # a sub-module / sub-package of the checkout (graphembed.inference, data.preprocess)
             return importlib.import_module(full)
         except ModuleNotFoundError as e:
             if e.name != full:

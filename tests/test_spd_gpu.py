@@ -346,7 +346,10 @@ def test_close_pair_gate_is_seamless(d):
     assert err <= 5e-5, err
 
 
-@pytest.mark.parametrize('d,dname', [(3, 'f32'), (4, 'f32'), (3, 'f64')])   # (fp64 has no recentred path: Cayley / Jacobi there)
+# (fp64 has no recentred series: far rows take the Cayley-transform logarithm — SPD(3): the ring form with two tiers of tables
+# and, in the forward, the invariants-only squared distance; SPD(4): the matrix form — spreads 0.25 / 0.35 stay inside the narrow
+# tier, 0.42 / 0.5 reach the wide one)
+@pytest.mark.parametrize('d,dname', [(3, 'f32'), (4, 'f32'), (3, 'f64'), (4, 'f64')])
 @pytest.mark.parametrize('spread', [0.25, 0.35, 0.42, 0.5])
 def test_recentred_series_regime(spread, d, dname):
     """SPD(3) / SPD(4) fp32 and SPD(3) fp64 forward and backward at MODERATE pair distances (||log X|| ~ 0.35: training after the first epochs): the matrix
@@ -373,7 +376,7 @@ def test_recentred_series_regime(spread, d, dname):
     x = x32.cuda().requires_grad_()
     # forward: d^2 from the invariants of A / mu - I (logsq_series3_centred / logsq_series4_centred) on the rows that pass its gate
     d2 = man.pdist(x, squared=True).detach().double().cpu().numpy()
-    bad = np.abs(d2 - ref_d2) - ((1e-6 + 2e-5 * np.abs(ref_d2)) if f32 else (1e-13 + 1e-11 * np.abs(ref_d2)))
+    bad = np.abs(d2 - ref_d2) - ((1e-6 + 2e-5 * np.abs(ref_d2)) if f32 else (1e-13 + (1e-11 if d == 3 else 1e-10) * np.abs(ref_d2)))
     assert bad.max() <= 0, (spread, f'd2 worst excess {bad.max():.3e}')
     for squared in (True, False):
         ref_g = exact.spd_pdist_grad(xin, g32.double().numpy(), squared=squared)

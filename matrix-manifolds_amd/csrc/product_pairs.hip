@@ -83,8 +83,20 @@ __global__ __launch_bounds__(kPCols * kPWaves) void product_pair_kernel(PArgs<T>
   MM_PSTAMP_BEGIN();
   loss_resolve<T, LOSS>(la);
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int j = blockIdx.x * kPCols + lane;
-  const int i0 = min((blockIdx.y * kPWaves + wave) * ti, n), i1 = min(i0 + ti, n);
+  // XCD-aware tile order: the eight XCDs have private L2s and workgroups are dealt to them round-robin, so the workgroups
+  // that share an XCD (orig % 8: a group label, not the XCD's id) take a CONTIGUOUS run of tiles in row-major order — a band
+  // of row tiles — and the band's targets (its rows of the pair vector, and its columns of the rows above) are fetched into
+  // one L2 instead of all eight (bijective for any grid size).  -DMM_PRODUCT_NO_XCD: the plain order (A/B builds).
+#ifdef MM_PRODUCT_NO_XCD
+  const unsigned bx = blockIdx.x, by = blockIdx.y;
+#else
+  const unsigned nwg = gridDim.x * gridDim.y, orig = blockIdx.y * gridDim.x + blockIdx.x;
+  const unsigned xq = nwg / 8, xr = nwg % 8, xcd = orig % 8;
+  const unsigned tile = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + orig / 8;
+  const unsigned bx = tile % gridDim.x, by = tile / gridDim.x;
+#endif
+  const int j = bx * kPCols + lane;
+  const int i0 = min(int((by * kPWaves + wave) * ti), n), i1 = min(i0 + ti, n);
   const bool jin = j < n;
   const bool jown = jin && j >= row_begin && j < row_end;
   int64_t jnode = jin ? j : n - 1;  // lanes past n: clamped, masked later
@@ -306,7 +318,7 @@ __global__ __launch_bounds__(kPCols * kPWaves) void product_pair_kernel(PArgs<T>
   MM_PSTAMP(4);
   // loss and scale-gradient partials: slots [1 + nf][kLossSlots].  ONE transposing reduction for all of them (round 4: four
   // butterfly sums through ds_bpermute, one after the other, were 2.5 k cycles of every workgroup's 29 k)
-  const int slot = (blockIdx.x + (blockIdx.y * kPWaves + wave) * gridDim.x) & (kLossSlots - 1);
+  const int slot = (bx + (by * kPWaves + wave) * gridDim.x) & (kLossSlots - 1);
   {
     constexpr int NS = 1 + NV + (SD > 0 ? 1 : 0);
     T sums[NS];

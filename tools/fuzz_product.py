@@ -12,7 +12,7 @@ sys.path.insert(0, os.path.join(ROOT, 'matrix-manifolds_amd'))
 import torch  # noqa: E402
 from graphembed import _backend as B  # noqa: E402
 from graphembed import manifolds as M  # noqa: E402
-from graphembed.modules import ManifoldEmbedding, _pair_kernel_factors  # noqa: E402
+from graphembed.modules import ManifoldEmbedding, _pair_kernel_factors, _single_subset_factor  # noqa: E402
 from graphembed.objectives import QuotientLoss, StressLoss  # noqa: E402
 
 
@@ -39,9 +39,9 @@ def main():
         if single:   # one factor: the specialised fused kernels (mm_spd_pdist_loss, mm_vec_pdist_loss / Gram loss)
             fam = rng.choice(['spd', 'e', 'l', 's'])
             if fam == 'spd':
-                mans = [M.SymmetricPositiveDefinite(rng.choice([2, 3, 3, 4, 5]))]
+                mans = [M.SymmetricPositiveDefinite(rng.choice([2, 3, 3, 4, 4, 5, 6]))]   # (6: rolled Jacobi sweeps)
             else:
-                man = {'e': M.Euclidean, 'l': M.Lorentz, 's': M.Sphere}[fam](rng.randint(2, 32))
+                man = {'e': M.Euclidean, 'l': M.Lorentz, 's': M.Sphere}[fam](rng.choice([rng.randint(2, 32), rng.randint(17, 64)]))
                 man.use_gram = fam != 'e' and rng.random() < 0.5
                 mans = [man]
             nv = -1
@@ -72,7 +72,10 @@ def main():
         P = md.numel()
         target = md * (0.4 + 1.2 * torch.rand(P, dtype=dt, device='cuda')) + 0.05
         fn, kw = (StressLoss(), {}) if rng.random() < 0.5 else (QuotientLoss(), dict(epoch=rng.randint(0, 5), alpha=rng.uniform(0.7, 1.4)))
-        subset = n >= 4 and rng.random() < 0.5 and _pair_kernel_factors(mans) is not None
+        # node minibatch: through the mixed-manifold pair kernel, or — a single factor it does not take (SPD(4...), vectors wider
+        # than 16) — through the factor's own pair kernel in its SUB form (mm_spd_pdist_loss_subset / mm_vec_pdist_loss_subset)
+        subset = n >= 4 and rng.random() < 0.5 and (_pair_kernel_factors(mans) is not None or
+                                                     (single and _single_subset_factor(mans[0]) is not None))
         if subset:
             bs = rng.randint(2, min(n, 2048))   # (larger batches are not handled inside the kernel: fused_objective -> None)
             idx = torch.randperm(n, device='cuda')[:bs]

@@ -598,7 +598,7 @@ int vec_bwd_t(const T* x, const T* g, int64_t n, int m, int64_t rb, int64_t re, 
   static const bool ordered_env = [] { const char* e = std::getenv("MM_VEC_BWD_ORDERED"); return e && e[0] == '1'; }();
   constexpr int dtype_code = std::is_same<T, float>::value ? MM_F32 : MM_F64;
   bool done = false;
-  if (!ordered_env && vec_sym_supports(dtype_code, m)) {
+  if (!ordered_env && vec_sym_supports(dtype_code, KIND, m)) {
     bool finalized = false;
     const int rc = vec_sym_backward_pairs(dtype_code, KIND, LOSS, squared, x, g, n, m, rb, re, ws, la.scale_raw, double(la.alpha),
                                           double(la.eps), la.terms, la.dyn, grad, loss_out, &finalized, st);

@@ -97,7 +97,7 @@ int launch_pad(const VecStep<T>& a, int rule, hipStream_t st) {
     case 16: return launch_rule<T, KIND, 16>(a, rule, st);
     default: break;
   }
-  if constexpr (KIND == MM_EUCLIDEAN && sizeof(T) == 4) {   // (the symmetric pair kernel's fp32 range; Lorentz / sphere stop at 16)
+  if constexpr (KIND == MM_EUCLIDEAN) {   // (the symmetric pair kernel's range for this kind; Lorentz / sphere stop at 16)
     if (pad_dim(a.m) == 24) return launch_rule<T, KIND, 24>(a, rule, st);
     if (pad_dim(a.m) == 32) return launch_rule<T, KIND, 32>(a, rule, st);
   }
@@ -167,7 +167,7 @@ int vec_rule_step(int dtype, int kind, int optimizer, const void* x, const void*
 bool vec_fused_step_supports(int dtype, int kind, int m) {
   static const bool off = [] { const char* e = std::getenv("MM_VEC_STEP_UNFUSED"); return e && e[0] == '1'; }();
   static const bool gram = [] { const char* e = std::getenv("MM_VEC_LOSS_GRAM"); return e && e[0] == '1'; }();
-  if (off || gram || !vec_sym_supports(dtype, m)) return false;
+  if (off || gram || !vec_sym_supports(dtype, kind, m)) return false;
   if (kind == MM_EUCLIDEAN) return true;
   return (kind == MM_LORENTZ || kind == MM_SPHERE) && m <= 16;   // (fp32 17 <= m <= 32: the matrix-core objective)
 }

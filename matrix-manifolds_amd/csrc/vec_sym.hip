@@ -11,8 +11,10 @@
 
 namespace mm {
 
-bool vec_sym_supports(int dtype, int m) {
-  return (dtype == MM_F32 && m >= 1 && m <= 32) || (dtype == MM_F64 && m >= 1 && m <= 16);
+bool vec_sym_supports(int dtype, int kind, int m) {
+  // (fp64, 17 <= m <= 32: 2 x 32 doubles of column point and sums per lane — built for the Euclidean factor only, whose
+  // training step it completes: round 4)
+  return (dtype == MM_F32 && m >= 1 && m <= 32) || (dtype == MM_F64 && m >= 1 && m <= (kind == MM_EUCLIDEAN ? 32 : 16));
 }
 
 namespace {
@@ -100,7 +102,7 @@ int pairs_mp(int loss_kind, int squared, const T* x, const T* g, int64_t n, int 
     MM_VSYM_CASE(16);
     default: break;
   }
-  if constexpr (sizeof(T) == 4) {
+  if constexpr (sizeof(T) == 4 || KIND == MM_EUCLIDEAN) {
     switch (pad_dim(m)) {
       MM_VSYM_CASE(24);
       MM_VSYM_CASE(32);
@@ -129,7 +131,7 @@ int vec_sym_backward_pairs(int dtype, int kind, int loss_kind, int squared, cons
                            int64_t rb, int64_t re, void* ws, const void* scale_raw, double alpha, double eps, int terms,
                            const double* loss_params, void* grad, void* loss_out, bool* finalized, hipStream_t st, int mode) {
   *finalized = false;
-  if (!vec_sym_supports(dtype, m) || n > kSpdMaxNodes) return MM_ERR_UNSUPPORTED;
+  if (!vec_sym_supports(dtype, kind, m) || n > kSpdMaxNodes) return MM_ERR_UNSUPPORTED;
   if (dtype == MM_F32)
     return pairs_kind<float>(kind, loss_kind, squared, static_cast<const float*>(x), static_cast<const float*>(g), n, m, rb, re, ws,
                              static_cast<const float*>(scale_raw), alpha, eps, terms, loss_params, static_cast<float*>(grad),

@@ -17,8 +17,8 @@ constexpr int pad_dim(int m) { return m <= 4 ? 4 : m <= 8 ? 8 : m <= 12 ? 12 : m
 
 // Symmetric VALU backward (vec_sym.hip): prep (padded points, cleared gradient) + pair kernel flushing into the gradient
 // `ws` = acc [pad+1][n] | loss slots [2][256] | xpad [n+1][pad].  MM_ERR_UNSUPPORTED outside its range (fp32 m <= 32,
-// fp64 m <= 16): the caller then takes the ordered-pair kernel.
-bool vec_sym_supports(int dtype, int m);
+// fp64 m <= 16 — Euclidean: m <= 32 in fp64 too): the caller then takes the ordered-pair kernel.
+bool vec_sym_supports(int dtype, int kind, int m);
 // *finalized: the gradient (and, with a loss, loss_out) is complete — the pair kernel flushes into `grad` directly.
 // mode: VSYM_PLAIN as above.  The training-step forms (vec_step.hpp) leave the sums — already mapped to gradient
 // contributions — in the workspace, gacc [n][m] at the head of the accumulator region, for the step's per-point kernel, which

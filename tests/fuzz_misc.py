@@ -76,6 +76,16 @@ def main():
             print(f'FAIL case {c}: {what} n={n} {dt} squared={squared} world={world} d err {de:.2e} grad err {ge:.2e} '
                   f'max|grad| {float(grads.abs().max()):.3e} max|ref grad| {float(gref.abs().max()):.3e} '
                   f'min d {float(dref.detach().min()):.3e} bad entries {int((grads.abs() > 1e6).sum())}')
+            if fam == 'grassmann' and P:   # which pair: cosines of the principal angles of the worst node's pairs (fp64)
+                err = (grads.double().cpu() - gref).abs().reshape(n, -1).max(1).values
+                i = int(err.argmax())
+                sv = torch.linalg.svdvals(x64[i].transpose(-1, -2).unsqueeze(0) @ x64)   # [n, p]
+                sv[i] = 0.5
+                print(f'  worst node {i}: gradient error {float(err[i]):.3e}; over its pairs: largest cosine {float(sv.max()):.9f}, '
+                      f'smallest {float(sv.min()):.3e}, closest two cosines of one pair {float((sv[:, :-1] - sv[:, 1:]).abs().min()):.3e}')
+                derr = (got - dref.detach()).abs()
+                k = int(derr.argmax())
+                print(f'  worst distance entry {k}: got {float(got[k]):.7f} ref {float(dref[k]):.7f}')
             sys.exit(1)
     print(f'{cases} cases ok; worst rel err: ' + ', '.join(f'{k[0]}/{k[1]} {v:.1e}' for k, v in sorted(worst.items())))
 

@@ -219,8 +219,6 @@ def test_fused_vector_step_matches_the_eager_loop(man_name, m, rule, scale_rule,
     from graphembed import _backend as B
     from graphembed.native_step import NativeTrainStep
     from graphembed.objectives import QuotientLoss, StressLoss
-    if dt == torch.float64 and m > 16:
-        pytest.skip('the symmetric pair kernel is built up to m = 16 in fp64')
     assert B.lib().raw('mm_vec_fused_step_supports')(B.MM_F32 if dt == torch.float32 else B.MM_F64,
                                                      {'Euclidean': B.EUCLIDEAN, 'Lorentz': B.LORENTZ, 'Sphere': B.SPHERE}[man_name], m)
     n, epochs = 197, 6

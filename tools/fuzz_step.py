@@ -2,7 +2,8 @@
 """Randomised cross-check of the one-call training step (mm_train_step_run through graphembed.native_step.NativeTrainStep:
 the two-launch forms of single SPD / vector factors and of products, and the unfused forms outside their ranges) against the
 eager loop of train.py:198-222 on the same classes: random layouts, sizes (incl. n = 2, tile edges), dimensions, dtypes,
-optimizer rules and hyper-parameters, both losses, an edit of the points from outside in the middle of a run.
+optimizer rules and hyper-parameters, both losses, an edit of the points from outside in the middle of a run, node
+minibatches of single factors (mm_train_step.batch_idx) mixed with full batches.
 Usage: python tools/fuzz_step.py [cases] [seed] [--big]"""
 import copy
 import os
@@ -17,6 +18,13 @@ from graphembed.modules import ManifoldEmbedding  # noqa: E402
 from graphembed.native_step import NativeTrainStep  # noqa: E402
 from graphembed.objectives import QuotientLoss, StressLoss  # noqa: E402
 from graphembed.optim import RiemannianAdam, RiemannianSGD  # noqa: E402
+
+
+def squareform(v, n):
+    d = torch.zeros(n, n, dtype=v.dtype, device=v.device)
+    iu = torch.triu_indices(n, n, 1, device=v.device)
+    d[iu[0], iu[1]] = v
+    return (d + d.t()).contiguous()
 
 
 def layout(rng):
@@ -85,27 +93,43 @@ def main():
         finally:
             torch.set_default_dtype(torch.float32)
         emb_b = copy.deepcopy(emb_a)
+        # node minibatches (train.py:198-222 with batch_size set; single factors: mm_train_step.batch_idx — the index vector inside
+        # the factor's own pair kernel, every point stepped): a fresh slice of a randperm every epoch, full batches in between
+        minibatch = len(mans) == 1 and n >= 4 and rng.random() < 0.4
+        dense = squareform(target, n) if minibatch else None
         fn = rng.choice([StressLoss, QuotientLoss])()
         seed = rng.random()
         oa, what = optimizers(emb_a, seed)
         ob, _ = optimizers(emb_b, seed)
         epochs, edit_at = rng.randint(2, 5), rng.choice([None, 1, 2])
-        what = f'case {c}: n={n} {[str(m) for m in mans]} {str(dt)[6:]} {type(fn).__name__} {what} epochs={epochs} edit={edit_at}'
-        step = NativeTrainStep(emb_b, fn, target, ob)
+        what = (f'case {c}: n={n} {[str(m) for m in mans]} {str(dt)[6:]} {type(fn).__name__} {what} epochs={epochs} edit={edit_at}'
+                + (' minibatch' if minibatch else ''))
+        step = NativeTrainStep(emb_b, fn, target, ob, dense=dense)
+        batch_rng = random.Random(seed + 1.0)
         la, lb = [], []
         for epoch in range(epochs):
             if epoch == edit_at:     # somebody else touches the points between two steps (stabilize, a manual edit)
                 with torch.no_grad():
                     for e in (emb_a, emb_b):
                         e.xs[0].copy_(e.manifolds[0].projx(e.xs[0].clone()))
-            loss = emb_a.fused_objective(fn, target, None, epoch=epoch, alpha=1.0)
+            idx = None
+            if minibatch and batch_rng.random() < 0.75:
+                bs = batch_rng.randint(2, n)
+                idx = torch.randperm(n, generator=torch.Generator().manual_seed(batch_rng.randint(0, 2**31)))[:bs].cuda()
+            if idx is None:
+                loss = emb_a.fused_objective(fn, target, None, epoch=epoch, alpha=1.0)
+            else:
+                loss = emb_a.fused_objective(fn, None, idx, dense=dense, epoch=epoch, alpha=1.0)
+                if loss is None:    # (no in-kernel route for this factor / batch size: the gather -> compute_dists -> objective path)
+                    iu = torch.triu_indices(idx.numel(), idx.numel(), 1, device='cuda')
+                    loss = fn(dense[idx][:, idx][iu[0], iu[1]], emb_a.compute_dists(idx), epoch=epoch, alpha=1.0)
             for o in oa:
                 o.zero_grad(set_to_none=True)
             loss.backward()
             for o in oa:
                 o.step()
             la.append(loss.item())
-            lb.append(step(epoch=epoch, alpha=1.0).item())
+            lb.append((step(epoch=epoch, alpha=1.0) if idx is None else step(indices=idx, epoch=epoch, alpha=1.0)).item())
         if not all(map(lambda v: v == v and abs(v) < 1e30, la)) or max(la) > 10 * la[0]:
             # a run that blows up amplifies the rounding of either implementation without bound: nothing to compare
             print('skipped (the eager run diverges)', what, flush=True)

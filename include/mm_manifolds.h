@@ -509,7 +509,9 @@ typedef struct mm_train_step {
                                     caller passes MM_WS_PREPARED — unless it changed the points in between.  The same
                                     holds for a single vector factor that takes the two-launch form
                                     (mm_vec_fused_step_supports) and its padded copy of the points, and for a product
-                                    embedding on one GPU (the node table of its symmetric pair kernel); ignored elsewhere */
+                                    embedding on one GPU (the node table of its symmetric pair kernel); ignored elsewhere.
+                                    A node-minibatch step (batch_idx) of a VECTOR factor does not rewrite the padded copy:
+                                    the next full-batch step must not pass MM_WS_PREPARED (an SPD factor's does rewrite its tables) */
   /* -- sharded step (mm_abi_version() >= 2); all zero = the whole pair list on one GPU ------------------------- */
   int64_t row_begin, row_end;    /* this rank's rows of the pair list (mm_shard_rows); row_end <= 0 means n.  `target`
                                     is then this rank's SLICE: the targets of the pairs from mm_pair_offset(n,row_begin) on */

@@ -190,7 +190,8 @@ class NativeTrainStep:
         # a single SPD factor: the optimizer kernel of a step also writes the per-node tables of the NEW points, so the next
         # step skips the preparation launch (MM_WS_PREPARED) — as long as nobody else touched the points in between
         # (and so does the per-point kernel of a single vector factor: the zero-padded copy of the new points)
-        if k == 1 and factors[0][0] == B.FACTOR_SPD:
+        self._single_spd = k == 1 and factors[0][0] == B.FACTOR_SPD
+        if self._single_spd:
             self._prepared_single = factors[0][1] <= lib.raw('mm_spd_fused_step_max_dim')()
         else:
             self._prepared_single = k == 1 and bool(lib.raw('mm_vec_fused_step_supports')(dt, factors[0][0], factors[0][1]))
@@ -276,7 +277,11 @@ class NativeTrainStep:
             self._tables_of = tuple((x.data_ptr(), x._version) for x in self._params[:self.k])
         elif self._prepared_single:
             x = self._params[0]
-            self._tables_of = (x.data_ptr(), x._version)
+            # (a MINIBATCH step of a vector factor takes the unfused kernels: the zero-padded copy of the points in the workspace
+            # is not rewritten, so the next full-batch step must prepare it again — tools/fuzz_step.py, round 4: a full batch
+            # behind a minibatch read the stale copy.  The SPD step kernel writes the tables of all points in either form.)
+            stale = indices is not None and not self._single_spd
+            self._tables_of = None if stale else (x.data_ptr(), x._version)
         return self.loss_out[0]
 
     def invalidate_tables(self):

@@ -186,3 +186,55 @@ def test_native_minibatch_step_matches_the_eager_loop(case, dname):
             assert abs(s0 - s1) <= tol * max(abs(s0), 1.0)
     finally:
         torch.set_default_dtype(torch.float32)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('man_name,m', [('Euclidean', 5), ('Sphere', 3), ('Lorentz', 11), ('SPD', 3)])
+def test_full_batch_step_behind_a_minibatch_step(man_name, m):
+    """One NativeTrainStep alternating node minibatches and full batches (found by tools/fuzz_step.py, round 4): a vector
+    factor's minibatch step takes the unfused kernels and does not rewrite the zero-padded copy of the points the fused
+    full-batch step reads, so the stepper must prepare it again — it passed MM_WS_PREPARED and the full batch behind a
+    minibatch ran on stale points (loss 641.2 against 630.7).  Against the eager loop, fp64."""
+    import copy
+    from graphembed import manifolds as M
+    from graphembed.modules import ManifoldEmbedding
+    from graphembed.native_step import NativeTrainStep
+    from graphembed.objectives import StressLoss
+    from graphembed.optim import RiemannianSGD
+    n = 64
+    torch.set_default_dtype(torch.float64)
+    try:
+        torch.manual_seed(3)
+        man = M.SymmetricPositiveDefinite(m) if man_name == 'SPD' else getattr(M, man_name)(m)
+        with torch.device('cuda'):
+            emb_a = ManifoldEmbedding(n, [man])
+            with torch.no_grad():
+                emb_a.perturb(0.3)
+            target = torch.rand(n * (n - 1) // 2) * 0.9 + 0.05
+        dense = torch.zeros(n, n, device='cuda')
+        iu = torch.triu_indices(n, n, 1, device='cuda')
+        dense[iu[0], iu[1]] = target
+        dense = (dense + dense.t()).contiguous()
+        emb_b = copy.deepcopy(emb_a)
+        fn = StressLoss()
+        opts = lambda e: [RiemannianSGD(list(e.xs), lr=1e-3, exact=True, max_grad_norm=20),  # noqa: E731
+                          RiemannianSGD(list(e.scales), lr=1e-4, max_grad_norm=500)]
+        oa, ob = opts(emb_a), opts(emb_b)
+        step = NativeTrainStep(emb_b, fn, target, ob, dense=dense)
+        gen = torch.Generator().manual_seed(11)
+        plan = [None, torch.randperm(n, generator=gen)[:23].cuda(), None, torch.randperm(n, generator=gen)[:40].cuda(), None, None]
+        for idx in plan:
+            if idx is None:
+                loss = emb_a.fused_objective(fn, target, None)
+            else:
+                loss = emb_a.fused_objective(fn, None, idx, dense=dense)
+            for o in oa:
+                o.zero_grad(set_to_none=True)
+            loss.backward()
+            for o in oa:
+                o.step()
+            got = step() if idx is None else step(indices=idx)
+            assert abs(got.item() - loss.item()) <= 1e-9 * abs(loss.item()), (idx is None, got.item(), loss.item())
+        assert (emb_a.xs[0] - emb_b.xs[0]).abs().max().item() <= 1e-10
+    finally:
+        torch.set_default_dtype(torch.float32)

@@ -106,7 +106,7 @@ def main():
                 + (' minibatch' if minibatch else ''))
         step = NativeTrainStep(emb_b, fn, target, ob, dense=dense)
         batch_rng = random.Random(seed + 1.0)
-        la, lb = [], []
+        la, lb, per_pair = [], [], []
         for epoch in range(epochs):
             if epoch == edit_at:     # somebody else touches the points between two steps (stabilize, a manual edit)
                 with torch.no_grad():
@@ -129,8 +129,9 @@ def main():
             for o in oa:
                 o.step()
             la.append(loss.item())
+            per_pair.append(loss.item() / max(1, (n if idx is None else idx.numel()) * ((n if idx is None else idx.numel()) - 1) // 2))
             lb.append((step(epoch=epoch, alpha=1.0) if idx is None else step(indices=idx, epoch=epoch, alpha=1.0)).item())
-        if not all(map(lambda v: v == v and abs(v) < 1e30, la)) or max(la) > 10 * la[0]:
+        if not all(map(lambda v: v == v and abs(v) < 1e30, la)) or max(per_pair) > 10 * per_pair[0]:   # (per pair: batches differ in size)
             # a run that blows up amplifies the rounding of either implementation without bound: nothing to compare
             print('skipped (the eager run diverges)', what, flush=True)
             continue

@@ -28,7 +28,10 @@ def main():
         n = rng.choice([9, 40, 65, 130, rng.randint(5, 200)])
         pool = [lambda: M.Euclidean(rng.randint(1, 12)), lambda: M.Lorentz(rng.randint(2, 12)),
                 lambda: M.Sphere(rng.randint(2, 12)), lambda: M.SymmetricPositiveDefinite(rng.choice([2, 3])),
-                lambda: M.SymmetricPositiveDefinite(4), lambda: M.Grassmann(4, 2)]
+                lambda: M.SymmetricPositiveDefinite(4), lambda: M.Grassmann(4, 2),
+                # (round 4: single factors whose minibatches run inside their OWN pair kernels — wide vectors, SPD(5), SPD(6))
+                lambda: M.Lorentz(rng.randint(17, 40)), lambda: M.Euclidean(rng.randint(17, 64)),
+                lambda: M.SymmetricPositiveDefinite(rng.choice([5, 6]))]
         k = rng.choice([1, 1, 2, 3])
         mk = [rng.choice(pool) for _ in range(k)]
         seeds = rng.randint(0, 10**6)

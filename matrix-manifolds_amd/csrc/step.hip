@@ -75,6 +75,7 @@ extern "C" int mm_train_step_run(const mm_train_step* s, mm_stream_t st) {
   // a node minibatch (train.py:198-222 with batch_size set): the pair list is that of the batch's nodes
   const bool batched = s->batch_idx != nullptr;
   if (batched && (s->batch < 0 || s->batch > s->n)) return MM_ERR_ARG;
+  if (!batched && s->batch != 0) return MM_ERR_ARG;   // (a batch size without an index vector: not silently a full batch)
   if (batched && nf != 1) return MM_ERR_UNSUPPORTED;   // (products: mm_product_pairs_loss_subset + the optimizer entry points)
   const int64_t np = batched ? s->batch : s->n;        // points of the pair list
   // this rank's rows of the pair list (all of them on one GPU)

@@ -371,6 +371,13 @@ class ManifoldEmbedding(torch.nn.Module):
         spec = objective_fn.fused_spec(**kwargs)
         in_kernel_batch = (i is not None and dense is not None and dense.is_cuda and self.pair_kernel
                            and dense.dtype == pts[0].dtype)
+        if in_kernel_batch and i.numel() == 0:
+            # an empty batch has no pairs: a zero loss whose backward gives every parameter its (dense) zero gradient, as the
+            # reference's sum over an empty pair list does
+            zero = pts[0].sum() * 0
+            for t in list(pts[1:]) + list(scales):
+                zero = zero + t.sum() * 0
+            return zero
         if in_kernel_batch:
             # node minibatch entirely inside the pair kernel: no row gathers, no target gather, no scatter-adds
             # (single factors too: at minibatch sizes a step is launches, not arithmetic)

@@ -239,7 +239,13 @@ class NativeTrainStep:
             if self.shard is not None:
                 raise ValueError('minibatch steps of NativeTrainStep run on one GPU')
             self._idx = indices.to(device=self.device, dtype=torch.int64).contiguous()   # (kept: the enqueued kernels read it)
-            d.batch_idx, d.batch, d.target = self._idx.data_ptr(), self._idx.numel(), self.dense.data_ptr()
+            batch = self._idx.numel()
+            if batch == 0:
+                # an EMPTY batch is still a minibatch step (no pairs: zero loss, zero gradients, the optimizers step on them —
+                # what the reference's loop does with an empty index tensor); an empty tensor has no storage, and a null
+                # batch_idx means "full batch" to the C side — which would read the dense matrix as a pair vector
+                self._idx = torch.zeros(1, dtype=torch.int64, device=self.device)
+            d.batch_idx, d.batch, d.target = self._idx.data_ptr(), batch, self.dense.data_ptr()
         else:
             if self.target.numel() == 0 and self.n > 1:
                 raise ValueError('this stepper was built without a target pair vector: pass indices')

@@ -238,3 +238,57 @@ def test_full_batch_step_behind_a_minibatch_step(man_name, m):
         assert (emb_a.xs[0] - emb_b.xs[0]).abs().max().item() <= 1e-10
     finally:
         torch.set_default_dtype(torch.float32)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('layout', ['spd4', 'spd3', 'lorentz24', 'euclidean5', 'product'])
+@pytest.mark.parametrize('loss_name', ['stress', 'quotient'])
+def test_degenerate_batches(layout, loss_name):
+    """Batches of 0, 1 and 2 nodes through every in-kernel minibatch route (the mixed-manifold pair kernel, the single factors'
+    own pair kernels) and through the one-call step: no pairs -> a zero loss with (dense) zero gradients, as the reference's sum
+    over an empty pair list; two nodes -> the one pair's loss.  Round 4: an EMPTY index tensor has no storage, and the one-call
+    step took its null pointer for "full batch" — it read the dense matrix as a pair vector and stepped the points on it."""
+    from graphembed import manifolds as M
+    from graphembed.modules import ManifoldEmbedding
+    from graphembed.native_step import NativeTrainStep
+    from graphembed.objectives import QuotientLoss, StressLoss
+    from graphembed.optim import RiemannianSGD
+    mans = {'spd4': lambda: [M.SymmetricPositiveDefinite(4)], 'spd3': lambda: [M.SymmetricPositiveDefinite(3)],
+            'lorentz24': lambda: [M.Lorentz(24)], 'euclidean5': lambda: [M.Euclidean(5)],
+            'product': lambda: [M.Lorentz(6), M.Sphere(6), M.SymmetricPositiveDefinite(2)]}[layout]()
+    fn = StressLoss() if loss_name == 'stress' else QuotientLoss()
+    kw = dict(epoch=1, alpha=1.0)
+    n = 37
+    torch.manual_seed(5)
+    with torch.device('cuda'):
+        emb = ManifoldEmbedding(n, mans)
+    dense = torch.rand(n, n, device='cuda')
+    dense = (dense + dense.t()).contiguous()
+    dense.fill_diagonal_(0)
+    params = list(emb.xs) + list(emb.scales)
+    for bs in (0, 1, 2):
+        idx = torch.randperm(n, device='cuda')[:bs]
+        loss = emb.fused_objective(fn, None, idx, dense=dense, **kw)
+        assert loss is not None
+        gs = torch.autograd.grad(loss, params)
+        assert all(g.shape == p.shape and bool(torch.isfinite(g).all()) for g, p in zip(gs, params))
+        if bs < 2:
+            assert loss.item() == 0.0 and all(not g.any() for g in gs)
+        else:
+            iu = torch.triu_indices(bs, bs, 1, device='cuda')
+            ref = fn(dense[idx][:, idx][iu[0], iu[1]], emb.compute_dists(idx), **kw)
+            assert abs(loss.item() - ref.item()) <= 2e-5 * abs(ref.item())
+    if len(mans) == 1:
+        opts = [RiemannianSGD(list(emb.xs), lr=1e-3), RiemannianSGD(list(emb.scales), lr=1e-4)]
+        step = NativeTrainStep(emb, fn, None, opts, dense=dense)
+        before = emb.xs[0].detach().clone()
+        for bs in (0, 1):
+            got = step(indices=torch.randperm(n, device='cuda')[:bs], **kw)
+            assert got.item() == 0.0
+            assert torch.equal(emb.xs[0].detach(), before) or (emb.xs[0].detach() - before).abs().max().item() <= 1e-6   # (RSGD on zero gradients: exp(x, 0))
+        got = step(indices=torch.randperm(n, device='cuda')[:2], **kw)
+        assert got.item() > 0 and bool(torch.isfinite(emb.xs[0]).all())
+        from graphembed import _backend as B
+        with pytest.raises(B.BackendError):      # a batch size without an index vector is refused, not run as a full batch
+            step._desc.batch_idx, step._desc.batch = None, 5
+            B.lib().call('mm_train_step_run', __import__('ctypes').byref(step._desc), B.stream_of(dense))

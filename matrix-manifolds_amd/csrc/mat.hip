@@ -76,60 +76,6 @@ template <typename T, int P> __device__ __forceinline__ void symeig(const T (&s)
   for (int k = 0; k < P; ++k) w[k] = a[pidx(k, k)];
 }
 
-// One-sided Jacobi (Hestenes) on a p x p matrix: on exit b = g V has mutually orthogonal columns, i.e. g = U diag(sigma) V^T
-// with sigma_k = ||b_k|| and u_k = b_k / sigma_k.  The rotations are those of the two-sided method on g^T g (same formulas
-// as jacobi_eig, smallmat.hpp) but applied to g itself, so the small singular values keep their accuracy: through the
-// eigenvalues of g^T g a cosine below sqrt(eps) (3e-4 in fp32) is rounding noise, and a principal angle next to pi/2 came
-// out 3e-4 off, its gradient direction arbitrary (found by tests/fuzz_misc.py, round 4: gr(9,4), one pair in 8256).
-// Wave-uniform sweep loop: runs while any lane has a pair of columns with |<b_p, b_q>| > eps ||b_p|| ||b_q||.
-template <typename T, int P> __device__ __forceinline__ void svd_onesided(const T (&g)[P][P], T (&b)[P][P], T (&v)[P][P]) {
-  using N = Num<T>;
-#pragma unroll
-  for (int r = 0; r < P; ++r)
-#pragma unroll
-    for (int c = 0; c < P; ++c) { b[r][c] = g[r][c]; v[r][c] = (r == c) ? T(1) : T(0); }
-  if constexpr (P == 1) return;
-  // (4 eps: with eps itself the test sits at the rounding of the inner product and some matrices never pass it; emulated in
-  // fp32 / fp64 on 400 matrices with cosines from 1 - 1e-8 to 1e-9: at most 6 sweeps, singular values to 4e-7 / 1e-15 absolute)
-  const T tol2 = T(16) * N::eps() * N::eps();
-  for (int sweep = 0; sweep < N::kMaxSweeps + 4; ++sweep) {
-    bool active = false;
-#pragma unroll
-    for (int p = 0; p < P - 1; ++p) {
-#pragma unroll
-      for (int q = p + 1; q < P; ++q) {
-        T app = T(0), aqq = T(0), apq = T(0);
-#pragma unroll
-        for (int r = 0; r < P; ++r) {
-          app = N::fma(b[r][p], b[r][p], app);
-          aqq = N::fma(b[r][q], b[r][q], aqq);
-          apq = N::fma(b[r][p], b[r][q], apq);
-        }
-        active = active || (apq * apq > tol2 * (app * aqq));
-        const T h = aqq - app;
-        const T ah = N::abs(h) + T(1e-15);
-        const T sa_ = (h < T(0)) ? -apq : apq;
-        const T sa2 = sa_ + sa_;
-        const T rr = N::rsqrt(N::fma(ah, ah, sa2 * sa2));
-        const T x = N::fma(ah * rr, T(0.5), T(0.5));     // cos^2 t
-        const T ci = N::rsqrt(x);
-        const T c = x * ci;
-        const T sn = (sa_ * rr) * ci;
-#pragma unroll
-        for (int r = 0; r < P; ++r) {
-          const T bp = b[r][p], bq = b[r][q];
-          b[r][p] = N::fma(c, bp, -sn * bq);
-          b[r][q] = N::fma(sn, bp, c * bq);
-          const T vp = v[r][p], vq = v[r][q];
-          v[r][p] = N::fma(c, vp, -sn * vq);
-          v[r][q] = N::fma(sn, vp, c * vq);
-        }
-      }
-    }
-    if (!__any(active)) break;
-  }
-}
-
 // M = V diag(f) V^T
 template <typename T, int P> __device__ __forceinline__ void vfvt(const T (&v)[P][P], const T (&f)[P], T (&m)[P][P]) {
 #pragma unroll
@@ -296,7 +242,9 @@ __device__ __forceinline__ T grass_pair(const T (&g)[P][P], T (&dg)[P][P]) {
   } else {
     // singular values from a one-sided Jacobi on G itself (not from the eigenvalues of G^T G: see svd_onesided)
     T b[P][P], v[P][P], nn[P];
-    svd_onesided<T, P>(g, b, v);
+    // (4 eps: with eps itself the test sits at the rounding of the inner product and some matrices never pass it; emulated
+    // in fp32 / fp64 on 400 matrices with cosines from 1 - 1e-8 to 1e-9: at most 6 sweeps, singular values to 4e-7 / 1e-15)
+    svd_onesided<T, P, true>(g, b, v, T(16) * N::eps() * N::eps());
     // sigma_k^2: the column norm ||b_k||^2 for the small ones (what the one-sided method is for); for cosines next to 1
     // (small angles: the reference's own initialisation) the Rayleigh quotient v_k^T (G^T G) v_k / v_k^T v_k — the rotations
     // leave ~6 eps of norm drift in b and v, which the quotient cancels and which acos would amplify ~100 x at sigma ~ 1 - 1e-4

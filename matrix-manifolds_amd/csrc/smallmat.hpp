@@ -476,6 +476,66 @@ __device__ __forceinline__ void jacobi_eig(T (&a)[Packed<D>::NP], T (&v)[D][D]) 
   jacobi_eig<T, D, WITH_V>(a, v, Num<T>::eps() * Num<T>::eps());
 }
 
+// One-sided Jacobi (Hestenes) on a D x D matrix g: on exit b = g V has mutually orthogonal columns, i.e. g = U diag(sigma) V^T
+// with sigma_k = ||b_k|| and u_k = b_k / sigma_k.  The rotations are those of the two-sided method on g^T g (the formulas of
+// jacobi_eig above) but applied to g itself, so the SMALL singular values keep their relative accuracy: through the
+// eigenvalues of g^T g anything below sqrt(eps) sigma_max is rounding noise.  Two users (round 4):
+//   * Grassmann principal angles (mat.hip): g = x^T y — a cosine next to 0 came out 3e-4 off in fp32;
+//   * the SPD pair matrix A = B B^T, B = L_i^-1 L_j (pair_core, spd_pair.hpp): g = B^T, so V = the eigenvectors of A and
+//     sigma_k^2 its eigenvalues — in fp32, forming A first costs eps cond(A) of relative accuracy in its small eigenvalues
+//     (1.3e-2 of d^2 at cond(X) = 1e4, garbage at 1e6), the rotations on B keep 3e-7 / 3e-6 (emulated with LAPACK's SVD).
+// Wave-uniform sweep loop: runs while any lane has a pair of columns with <b_p, b_q>^2 > tol2 ||b_p||^2 ||b_q||^2.
+template <typename T, int D, bool WITH_V>
+__device__ __forceinline__ void svd_onesided(const T (&g)[D][D], T (&b)[D][D], T (&v)[D][D], T tol2) {
+  using N = Num<T>;
+#pragma unroll
+  for (int r = 0; r < D; ++r)
+#pragma unroll
+    for (int c = 0; c < D; ++c) {
+      b[r][c] = g[r][c];
+      if (WITH_V) v[r][c] = (r == c) ? T(1) : T(0);
+    }
+  if constexpr (D == 1) return;
+  for (int sweep = 0; sweep < N::kMaxSweeps + 4; ++sweep) {
+    bool active = false;
+#pragma unroll
+    for (int p = 0; p < D - 1; ++p) {
+#pragma unroll
+      for (int q = p + 1; q < D; ++q) {
+        T app = T(0), aqq = T(0), apq = T(0);
+#pragma unroll
+        for (int r = 0; r < D; ++r) {
+          app = N::fma(b[r][p], b[r][p], app);
+          aqq = N::fma(b[r][q], b[r][q], aqq);
+          apq = N::fma(b[r][p], b[r][q], apq);
+        }
+        active = active || (apq * apq > tol2 * (app * aqq));
+        const T h = aqq - app;
+        const T ah = N::abs(h) + T(1e-15);
+        const T sa_ = (h < T(0)) ? -apq : apq;
+        const T sa2 = sa_ + sa_;
+        const T rr = N::rsqrt(N::fma(ah, ah, sa2 * sa2));
+        const T x = N::fma(ah * rr, T(0.5), T(0.5));     // cos^2 t
+        const T ci = N::rsqrt(x);
+        const T c = x * ci;
+        const T sn = (sa_ * rr) * ci;
+#pragma unroll
+        for (int r = 0; r < D; ++r) {
+          const T bp = b[r][p], bq = b[r][q];
+          b[r][p] = N::fma(c, bp, -sn * bq);
+          b[r][q] = N::fma(sn, bp, c * bq);
+          if (WITH_V) {
+            const T vp = v[r][p], vq = v[r][q];
+            v[r][p] = N::fma(c, vp, -sn * vq);
+            v[r][q] = N::fma(sn, vp, c * vq);
+          }
+        }
+      }
+    }
+    if (!__any(active)) break;
+  }
+}
+
 // ------------------------------------------ closed-form eigenvalues, 3x3 (fp32)
 // Trigonometric solution of the characteristic cubic (the method of the reference's
 // fast.symeig3x3, linalg/fast.py:75-91, without its eps fudge terms): q = tr/3,

@@ -84,16 +84,56 @@ __device__ __forceinline__ void pair_a(const TL (&li)[Packed<D>::NP], const T (&
 template <typename T, int D, bool WITH_V, bool CHOL = false, typename TL>
 __device__ __forceinline__ T pair_core(const TL (&li)[Packed<D>::NP], const T (&xj)[Packed<D>::NP], T wmin, T wmax,
                                        T (&w)[D], T (&lw)[D], T (&v)[D][D]) {
-  T a[Packed<D>::NP];
-  pair_a<T, D, CHOL>(li, xj, a);
   // eigenvalues only: sum log^2 w is second-order in the residual coupling -> tol2 = eps;
   // with eigenvectors: residual coupling <= 8 eps relative (gradient error ~1e-6, a quarter of
   // the wavefronts at the reference init would otherwise run a 4th sweep for the last bit)
-  jacobi_eig<T, D, WITH_V, true>(a, v, WITH_V ? T(64) * Num<T>::eps() * Num<T>::eps() : Num<T>::eps());
+  const T tol2 = WITH_V ? T(64) * Num<T>::eps() * Num<T>::eps() : Num<T>::eps();
+  T ev[D];
+  {
+    T a[Packed<D>::NP];
+    pair_a<T, D, CHOL>(li, xj, a);
+    jacobi_eig<T, D, WITH_V, true>(a, v, tol2);
+#pragma unroll
+    for (int k = 0; k < D; ++k) ev[k] = a[pidx(k, k)];
+  }
+#ifndef MM_SPD_JACOBI_TWO_SIDED   // (A/B builds: the round-1..3 route only)
+  if constexpr (CHOL && D <= 4 && std::is_same<T, float>::value) {
+    // fp32, ill-conditioned pairs: forming A = B B^T (B = L_i^-1 L_j) costs eps cond(A) of relative accuracy in A's small
+    // eigenvalues whatever solves it afterwards — 1.2 (!) of d^2 at cond(X) = 1e4, where fp64 is fine.  A wavefront that
+    // holds a pair with lambda_max > 256 lambda_min (or a non-positive / NaN spectrum) solves again, by a one-sided Jacobi on
+    // B^T: V = eigenvectors of A, squared column norms = its eigenvalues, with the relative accuracy of B's entries
+    // (smallmat.hpp, svd_onesided).  Measured (tools/illcond_probe.py, max relative error of d^2 against fp64 on the same
+    // inputs): SPD(3) cond(X) = 1e4 1.2 -> 1.3e-4, 1e6 1.2 -> 6e-3; SPD(4) 7.6e-2 -> 8.9e-5, 0.94 -> 4.4e-3.  Always taking this
+    // route would cost the whole Jacobi regime 30 - 75 % (profiles/r04_experiments.md): it is a second solve for rows that need it.
+    T mn = ev[0], mx = ev[0];
+#pragma unroll
+    for (int k = 1; k < D; ++k) { mn = Num<T>::min(mn, ev[k]); mx = Num<T>::max(mx, ev[k]); }
+    if (__any(!(mx <= T(256) * mn))) {
+      T g[D][D], b[D][D];
+#pragma unroll
+      for (int r = 0; r < D; ++r)
+#pragma unroll
+        for (int c = 0; c < D; ++c) {
+          if (c > r) { g[c][r] = T(0); continue; }        // g = B^T: g[c][r] = B[r][c]
+          T acc = li[pidx(r, c)] * xj[pidx(c, c)];
+#pragma unroll
+          for (int k = c + 1; k <= r; ++k) acc = Num<T>::fma(li[pidx(r, k)], xj[pidx(k, c)], acc);
+          g[c][r] = acc;
+        }
+      svd_onesided<T, D, WITH_V>(g, b, v, tol2);
+#pragma unroll
+      for (int k = 0; k < D; ++k) {
+        ev[k] = T(0);
+#pragma unroll
+        for (int r = 0; r < D; ++r) ev[k] = Num<T>::fma(b[r][k], b[r][k], ev[k]);
+      }
+    }
+  }
+#endif
   T s = T(0);
 #pragma unroll
   for (int k = 0; k < D; ++k) {
-    w[k] = Num<T>::min(Num<T>::max(a[pidx(k, k)], wmin), wmax);
+    w[k] = Num<T>::min(Num<T>::max(ev[k], wmin), wmax);
     lw[k] = Num<T>::log(w[k]);
     s = Num<T>::fma(lw[k], lw[k], s);
   }
@@ -189,8 +229,13 @@ __device__ __forceinline__ T pair_value(const TL (&li)[Packed<D>::NP], const T (
     eig3_trig(a, w);
     const bool wide = !(w[0] * 32.f > w[2]);  // true for NaN / non-positive spectra too
     if (__any(wide)) {
-      jacobi_eig<float, 3, false, true>(a, v, Num<float>::eps());
-      w[0] = a[pidx(0, 0)]; w[1] = a[pidx(1, 1)]; w[2] = a[pidx(2, 2)];
+      if constexpr (CHOL) {   // (wide spectra = ill-conditioned pairs: the eigenvalues from B = L_i^-1 L_j itself, pair_core)
+        float lw[3];
+        return pair_core<float, 3, false, true>(li, xj, wmin, wmax, w, lw, v);
+      } else {
+        jacobi_eig<float, 3, false, true>(a, v, Num<float>::eps());
+        w[0] = a[pidx(0, 0)]; w[1] = a[pidx(1, 1)]; w[2] = a[pidx(2, 2)];
+      }
     }
     float s = 0.f;
 #pragma unroll

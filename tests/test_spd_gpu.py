@@ -271,11 +271,42 @@ def test_wide_spectra_take_the_jacobi_path(dname):
     ref = torch.linalg.eigvalsh(a).log().pow(2).sum(-1)
     d2 = SPD(3).pdist(x64.to(DT[dname]).cuda(), squared=True)
     got = d2.double().cpu()
-    # fp32: forming A = L^-1 X L^-T costs ~eps*cond(A) relative accuracy in the small eigenvalues
-    # whatever the eigensolver (cond up to ~1e4 here), hence the looser relative term
+    # fp32: the reference value here comes from the UNROUNDED points, and rounding X to fp32 moves d^2 by ~eps cond(X)
+    # (cond up to ~1e4 here), hence the looser relative term; the solver's own accuracy on ill-conditioned pairs is held
+    # against the rounded inputs in test_ill_conditioned_points_fp32
     tol = (1e-6, 2e-4) if dname == 'f32' else (1e-12, 1e-10)
     bad = (got - ref).abs() - (tol[0] + tol[1] * ref.abs())
     assert bad.max() <= 0, f'worst excess {bad.max():.3e} at d2={ref[bad.argmax()]:.3f}'
+
+
+@pytest.mark.parametrize('d,cond,vtol,gtol', [(2, 1e2, 1e-3, 1e-4), (2, 1e4, 5e-3, 3e-3), (3, 1e2, 2e-5, 3e-5), (3, 1e4, 1e-3, 2e-3),
+                                              (4, 1e2, 2e-5, 3e-5), (4, 1e4, 1e-3, 2e-3)])
+def test_ill_conditioned_points_fp32(d, cond, vtol, gtol):
+    """fp32 on ill-conditioned SPD points (cond(X) = 1e2, 1e4 — pair matrices with spectra over four to eight decades), against the
+    fp64 checker on the SAME (rounded) inputs.  Forming A = B B^T, B = L_i^-1 L_j, costs eps cond(A) of relative accuracy in A's
+    small eigenvalues whatever solves it: the rounds 1-3 route was 1.2 (!) of d^2 off at cond(X) = 1e4 for SPD(3) (7.6e-2 for
+    SPD(4), 1.5 for SPD(2)).  A wavefront that holds such a pair now solves again by a one-sided Jacobi on B itself
+    (spd_pair.hpp pair_core, smallmat.hpp svd_onesided): measured 1.3e-4 / 8.9e-5 / 4.9e-4 (tools/illcond_probe.py)."""
+    from graphembed.manifolds import SymmetricPositiveDefinite as SPD
+    from oracle import exact
+    gen = torch.Generator().manual_seed(int(d * 10 + np.log10(cond)))
+    n = 160
+    q = torch.linalg.qr(torch.randn(n, d, d, dtype=torch.float64, generator=gen))[0]
+    lam = torch.exp((torch.rand(n, d, dtype=torch.float64, generator=gen) - 0.5) * np.log(cond))
+    lam[:, 0], lam[:, -1] = cond ** -0.5, cond ** 0.5
+    x32 = ((q * lam.unsqueeze(1)) @ q.transpose(1, 2)).float()
+    x32 = 0.5 * (x32 + x32.transpose(1, 2))
+    xin = x32.double().numpy()
+    ref = exact.spd_pdist(xin)
+    g = torch.randn(n * (n - 1) // 2, dtype=torch.float64, generator=gen)
+    ref_g = exact.spd_pdist_grad(xin, g.numpy())
+    x = x32.cuda().requires_grad_()
+    d2 = SPD(d).pdist(x, squared=True)
+    gr, = torch.autograd.grad(d2, x, g.float().cuda())
+    err = np.abs(d2.detach().double().cpu().numpy() - ref) / np.abs(ref)
+    assert err.max() <= vtol, (err.max(), np.median(err))
+    gerr = np.abs(gr.double().cpu().numpy() - ref_g).max() / np.abs(ref_g).max()
+    assert gerr <= gtol, gerr
 
 
 @pytest.mark.parametrize('d', [3, 4])

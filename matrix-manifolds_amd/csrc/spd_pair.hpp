@@ -81,7 +81,9 @@ __device__ __forceinline__ void pair_a(const TL (&li)[Packed<D>::NP], const T (&
   if constexpr (CHOL) congr_chol<T, D>(li, yj, a); else congr_lower<T, D>(li, yj, a);
 }
 
-template <typename T, int D, bool WITH_V, bool CHOL = false, typename TL>
+// SECOND: allow the second (one-sided) solve for ill-conditioned fp32 pairs — off in the two-column SPD(4) backward, whose 168
+// registers have no room for it (with it the hot path spilled: fused QuotientLoss kernel at n = 16 384 1044 -> 2619 us)
+template <typename T, int D, bool WITH_V, bool CHOL = false, bool SECOND = true, typename TL>
 __device__ __forceinline__ T pair_core(const TL (&li)[Packed<D>::NP], const T (&xj)[Packed<D>::NP], T wmin, T wmax,
                                        T (&w)[D], T (&lw)[D], T (&v)[D][D]) {
   // eigenvalues only: sum log^2 w is second-order in the residual coupling -> tol2 = eps;
@@ -97,7 +99,7 @@ __device__ __forceinline__ T pair_core(const TL (&li)[Packed<D>::NP], const T (&
     for (int k = 0; k < D; ++k) ev[k] = a[pidx(k, k)];
   }
 #ifndef MM_SPD_JACOBI_TWO_SIDED   // (A/B builds: the round-1..3 route only)
-  if constexpr (CHOL && D <= 4 && std::is_same<T, float>::value) {
+  if constexpr (SECOND && CHOL && D <= 4 && std::is_same<T, float>::value) {
     // fp32, ill-conditioned pairs: forming A = B B^T (B = L_i^-1 L_j) costs eps cond(A) of relative accuracy in A's small
     // eigenvalues whatever solves it afterwards — 1.2 (!) of d^2 at cond(X) = 1e4, where fp64 is fine.  A wavefront that
     // holds a pair with lambda_max > 256 lambda_min (or a non-positive / NaN spectrum) solves again, by a one-sided Jacobi on
@@ -603,7 +605,7 @@ __global__ __launch_bounds__((64 * bwd_waves<T, D>()), (bwd_min_waves_nc<T, D, N
           auto jacobi_path = [&](auto qc) __attribute__((always_inline)) {
             constexpr int q = decltype(qc)::value;
             T w[D], lw[D], v[D][D];
-            const T s = pair_core<T, D, true, true>(li, xj[q], wmin, wmax, w, lw, v);
+            const T s = pair_core<T, D, true, true, !(D == 4 && NC == 2)>(li, xj[q], wmin, wmax, w, lw, v);
             gs[q] = upstream_of<T, LOSS>(gs[q], s, valid[q], squared, wmin, sp, la, loss_acc, ds_acc);
             T cm[D];
 #pragma unroll

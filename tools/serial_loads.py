@@ -47,7 +47,7 @@ def main():
     import subprocess
     for prologue, groups, n, nm in sorted(out, reverse=True):
         try:
-            nm = subprocess.run(['/opt/rocm/lib/llvm/bin/llvm-cxxfilt', nm], capture_output=True, text=True).stdout.strip() or nm
+            nm = subprocess.run(['c++filt', nm], capture_output=True, text=True).stdout.strip() or nm
         except OSError:
             pass
         print(f'{prologue:3d} drained load groups before the first loop ({groups:3d} in all, {n:6d} instructions)  {nm[:150]}')

@@ -110,7 +110,7 @@ __device__ __forceinline__ T pair_core(const TL (&li)[Packed<D>::NP], const T (&
     T mn = ev[0], mx = ev[0];
 #pragma unroll
     for (int k = 1; k < D; ++k) { mn = Num<T>::min(mn, ev[k]); mx = Num<T>::max(mx, ev[k]); }
-    if (__any(!(mx <= T(256) * mn))) {
+    if (__builtin_expect(__any(!(mx <= T(256) * mn)), 0)) {   // (cold: laid out behind the loop)
       T g[D][D], b[D][D];
 #pragma unroll
       for (int r = 0; r < D; ++r)

@@ -100,7 +100,9 @@ def main():
         tol = 3e-4 if dt == torch.float32 else 1e-9
         # the quotient loss has kinks: a pair that sits within rounding of one flips a +-1 — compare with slack
         kink = isinstance(fn, QuotientLoss)
-        le = abs(tot - ref.item()) / max(abs(ref.item()), 1e-30)
+        # (a loss that nearly vanishes — case 793 of seed 57007: ONE pair whose distance matches its target to 2e-3 — is a
+        # difference of nearly equal numbers: measured against the size of its terms)
+        le = abs(tot - ref.item()) / max(abs(ref.item()), 1e-2 * float((target.double() ** 2).sum()) if not subset else 0.0, 1e-30)
         # (a gradient that cancels to ~0 — a scale's — is measured against the largest gradient of the step)
         gmax = max(float(b.abs().max()) for b in rg)
         ge = max(float((a - b).abs().max()) / max(float(b.abs().max()), 1e-3 * gmax, 1e-30) for a, b in zip(gs, rg))

@@ -490,6 +490,13 @@ typedef struct mm_step_param {
   unsigned* ticket;      /* Adam: device counter, zero between calls                                               */
 } mm_step_param;
 typedef struct mm_train_step {
+  size_t struct_size;            /* sizeof(mm_train_step) of the CALLER's header (mm_abi_version() >= 4): the library reads
+                                    exactly that many bytes and takes every later field as zero, so a caller compiled against an
+                                    older header of this layout keeps working when fields are appended; a value that is not a
+                                    plausible size of this struct (below the ABI-4 base, or a caller of ABI <= 3 whose first
+                                    member was `dtype`) is MM_ERR_ARG, and a LONGER struct whose extra tail is not all zero —
+                                    a feature this library does not have — MM_ERR_UNSUPPORTED.  `mm_train_step s = {0};
+                                    s.struct_size = sizeof s;` */
   int dtype, loss_kind, terms;
   double alpha, eps;             /* quotient loss: target scale and 1 / (epoch + 1)                                */
   const double* loss_params;     /* optional device {alpha, eps} overriding the two values above                   */

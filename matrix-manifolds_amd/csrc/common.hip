@@ -53,7 +53,7 @@ int mm_prof_clock_probe(void* out, int iters, mm_stream_t stream) {
   return e == hipSuccess ? MM_OK : int(e);
 }
 
-int mm_abi_version(void) { return 3; }   // 2: mm_comm_*, sharded mm_train_step (row range + communicator), MM_OPT_NONE; 3: mm_train_step.batch_idx / batch, *_loss_subset for single factors
+int mm_abi_version(void) { return 4; }   // 2: mm_comm_*, sharded mm_train_step (row range + communicator), MM_OPT_NONE; 3: mm_train_step.batch_idx / batch, *_loss_subset for single factors; 4: mm_train_step.struct_size (first member: the struct is versioned by its size from here on)
 
 const char* mm_target_arch(void) { return "gfx950"; }
 

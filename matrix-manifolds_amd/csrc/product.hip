@@ -113,7 +113,8 @@ __global__ __launch_bounds__(256) void pair_gather_kernel(const T* __restrict__ 
   const int a = blockIdx.y;
   const int b = a + 1 + blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= bs) return;
-  const int64_t ia = idx[a], ibb = idx[b];
+  // (clamped into the matrix: the indices are caller data; the host layer raises IndexError for host-side tensors)
+  const int64_t ia = int64_t(min(uint64_t(idx[a]), uint64_t(n - 1))), ibb = int64_t(min(uint64_t(idx[b]), uint64_t(n - 1)));
   out[int64_t(a) * (2 * int64_t(bs) - a - 1) / 2 + (b - a - 1)] = dense[ia * n + ibb];
 }
 

@@ -42,7 +42,9 @@ template <typename T> struct PArgs {
   int64_t dense_n;
 };
 template <typename T> __device__ __forceinline__ int64_t node_of(const PArgs<T>& pa, int j) {
-  return pa.idx ? pa.idx[j] : int64_t(j);
+  // (a minibatch comes with its dense target matrix, dense_n = the tables' row count: ids are clamped into them — the index
+  // vector is caller data no kernel validates; a bad index yields wrong numbers, not an access outside the buffers)
+  return pa.idx ? int64_t(min(uint64_t(pa.idx[j]), uint64_t(pa.dense_n - 1))) : int64_t(j);
 }
 
 // KC: the vector factors' kinds, two bits each (factor f: (KC >> 2 f) & 3), or -1 = read pa.v[f].kind in the row loop.

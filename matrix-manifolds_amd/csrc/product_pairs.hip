@@ -102,8 +102,9 @@ __global__ __launch_bounds__(kPCols * kPWaves) void product_pair_kernel(PArgs<T>
   int64_t jnode = jin ? j : n - 1;  // lanes past n: clamped, masked later
   int rnode = min(i0 + min(lane, ti - 1), n - 1);      // lane r < ti: the node of row i0 + r
   if constexpr (IDX) {
-    jnode = pa.idx[jnode];
-    rnode = int(pa.idx[rnode]);
+    // (clamped into the tables: the index vector is unvalidated caller data — spd_pair.hpp, batch_node)
+    jnode = int64_t(min(uint64_t(pa.idx[jnode]), uint64_t(pa.dense_n - 1)));
+    rnode = int(min(uint64_t(pa.idx[rnode]), uint64_t(pa.dense_n - 1)));
   }
   auto node_of_row = [&](int r) -> int {       // r per lane
     if constexpr (IDX) return __shfl(rnode, r); else return min(i0 + r, n - 1);

@@ -391,6 +391,14 @@ __device__ __forceinline__ T upstream_of(T loaded, T dsq, bool valid, int square
 }
 
 // ------------------------------------------------------------------ backward
+// Node of batch position k of a node minibatch: the low word of the 64-bit index (node ids are < 2^22), CLAMPED into the
+// per-node tables — the index vector is caller data the kernels cannot validate (host-side tensors are checked by the
+// Python layer, graphembed.modules.distinct_in_range; device-side ones by nobody): a negative or too large index then
+// yields wrong numbers for that batch, not a read or an atomic outside the workspace.  One s_min_u32 / v_min_u32 per load.
+__device__ __forceinline__ int batch_node(const int* __restrict__ idx32, size_t k, int n_total) {
+  return int(min(unsigned(idx32[2 * k]), unsigned(n_total - 1)));
+}
+
 // One row of the pair vector for this lane: element (row, j) lives at pair_off(n, row) - base + (j - row - 1).
 // The row's base is wave-uniform (scalar registers), the lane part is a 32-bit byte offset, so the load is
 // `global_load_dword v, v_off, s[base]` with ONE vector instruction of address arithmetic (a clamp).  Lanes at or
@@ -484,7 +492,7 @@ __global__ __launch_bounds__((64 * bwd_waves<T, D>()), (bwd_min_waves_nc<T, D, N
       joff[q] = unsigned(min(j, n - 1)) * unsigned(sizeof(T));
       int jn = j;                       // the column's node
       if constexpr (SUB) {
-        jn = idx32[2 * size_t(min(j, n - 1))];
+        jn = batch_node(idx32, size_t(min(j, n - 1)), n_total);
         joff[q] = unsigned(jn) * unsigned(sizeof(T));   // its offset in a row of the dense target matrix
       }
 #pragma unroll
@@ -522,8 +530,8 @@ __global__ __launch_bounds__((64 * bwd_waves<T, D>()), (bwd_min_waves_nc<T, D, N
         constexpr int kAhead = 2;
         // SUB: the node of a row comes from the index vector — scalar loads issued one row ahead of their use (the operand
         // table) resp. right behind the previous request (the target row)
-        const int first_node = SUB ? __builtin_amdgcn_readfirstlane(idx32[2 * size_t(i0)]) : i0;
-        int next_node = SUB ? __builtin_amdgcn_readfirstlane(idx32[2 * size_t(min(i0 + 1, n - 1))]) : 0;   // node of row i0 + 1
+        const int first_node = SUB ? __builtin_amdgcn_readfirstlane(batch_node(idx32, size_t(i0), n_total)) : i0;
+        int next_node = SUB ? __builtin_amdgcn_readfirstlane(batch_node(idx32, size_t(min(i0 + 1, n - 1)), n_total)) : 0;   // node of row i0 + 1
         unsigned roff = unsigned(first_node) * unsigned(2 * NP * sizeof(T));   // byte offset of the row's operands (the table is < 4 GB)
         T lrow[2][2 * NP];
 #pragma unroll
@@ -549,7 +557,7 @@ __global__ __launch_bounds__((64 * bwd_waves<T, D>()), (bwd_min_waves_nc<T, D, N
               dst[q] = *reinterpret_cast<const T*>(grow + joff[q]);
             });
             req_row = min(req_row + 1, glast);   // (requests past the slice read its last row again; never used)
-            req_node = __builtin_amdgcn_readfirstlane(idx32[2 * size_t(req_row)]);
+            req_node = __builtin_amdgcn_readfirstlane(batch_node(idx32, size_t(req_row), n_total));
           } else {
             static_for<NC>([&](auto qc) {
               constexpr int q = decltype(qc)::value;
@@ -575,7 +583,7 @@ __global__ __launch_bounds__((64 * bwd_waves<T, D>()), (bwd_min_waves_nc<T, D, N
           // runs on a pointer one iteration ahead and every scalar load pays a 64-bit add for its negative offset
           if constexpr (SUB) {
             roff = unsigned(next_node) * unsigned(2 * NP * sizeof(T));
-            next_node = __builtin_amdgcn_readfirstlane(idx32[2 * size_t(min(irow + 2, n - 1))]);
+            next_node = __builtin_amdgcn_readfirstlane(batch_node(idx32, size_t(min(irow + 2, n - 1)), n_total));
           } else {
             roff += unsigned(2 * NP * sizeof(T));
           }
@@ -719,7 +727,7 @@ __global__ __launch_bounds__((64 * bwd_waves<T, D>()), (bwd_min_waves_nc<T, D, N
         for (int t = lane; t < tw * NP; t += 64) {
           const int k = t / tw, il = t - k * tw;
           if (i0 + il < i1) {
-            const int node = SUB ? idx32[2 * size_t(i0 + il)] : i0 + il;
+            const int node = SUB ? batch_node(idx32, size_t(i0 + il), n_total) : i0 + il;
             atomic_add(&accM[size_t(k) * ns + node], redM[wave][il][k]);
           }
         }
@@ -744,7 +752,7 @@ __global__ __launch_bounds__((64 * bwd_waves<T, D>()), (bwd_min_waves_nc<T, D, N
 #pragma unroll
       for (int wv = 1; wv < NW; ++wv) sum += colS[wv][q][k][lane];
       if (j < n) {
-        const int node = SUB ? idx32[2 * size_t(j)] : j;
+        const int node = SUB ? batch_node(idx32, size_t(j), n_total) : j;
         atomic_add(&accS[size_t(k) * ns + node], sum);
       }
     }

@@ -4,6 +4,8 @@
 // (graphembed/graphed.py) this package replays it as one launch, and for callers that cannot capture — the
 // reference's own eager loop — this entry point removes the ~15 foreign-function calls, tensor wrappers and
 // autograd nodes a step otherwise costs on the host (130-400 us of Python for 100 us of kernels).
+#include <cstddef>
+#include <cstring>
 #include <hip/hip_runtime.h>
 
 #include "../../include/mm_manifolds.h"
@@ -68,7 +70,31 @@ bool inside(const void* p, size_t bytes, const void* base, size_t size) {
 
 }  // namespace
 
-extern "C" int mm_train_step_run(const mm_train_step* s, mm_stream_t st) {
+static int train_step_run(const mm_train_step* s, mm_stream_t st);
+
+// The struct is versioned by its size (struct_size, first member, ABI 4): the caller's bytes are copied into a zeroed struct
+// of THIS library's layout — fields the caller's header did not have yet read as zero (= feature off), and a longer struct of a
+// newer header is accepted as long as the tail this library does not know is all zero.
+extern "C" int mm_train_step_run(const mm_train_step* step, mm_stream_t st) {
+  if (!step) return MM_ERR_ARG;
+  constexpr size_t kBase = offsetof(mm_train_step, batch) + sizeof(step->batch);   // the layout ABI 4 started with
+  static_assert(kBase <= sizeof(mm_train_step), "fields are appended behind `batch`");
+  const size_t have = step->struct_size;
+  // (an ABI <= 3 caller has `dtype` and `loss_kind` where struct_size is: 0 ... 2^33, never a size in this window)
+  if (have < kBase || have > 16 * sizeof(mm_train_step)) return MM_ERR_ARG;
+  mm_train_step local;
+  std::memset(&local, 0, sizeof local);
+  std::memcpy(&local, step, have < sizeof local ? have : sizeof local);
+  if (have > sizeof local) {
+    const unsigned char* tail = reinterpret_cast<const unsigned char*>(step) + sizeof local;
+    for (size_t k = 0; k < have - sizeof local; ++k)
+      if (tail[k]) return MM_ERR_UNSUPPORTED;
+  }
+  local.struct_size = sizeof local;
+  return train_step_run(&local, st);
+}
+
+static int train_step_run(const mm_train_step* s, mm_stream_t st) {
   if (!s || s->nf < 1 || s->nf > 4 || !s->loss_out || s->n < 0) return MM_ERR_ARG;
   if (s->dtype != MM_F32 && s->dtype != MM_F64) return MM_ERR_ARG;
   const int nf = s->nf;

@@ -104,7 +104,8 @@ __global__ __launch_bounds__(kVBlock) void vec_pdist_bwd_kernel(const T* __restr
   const bool jin = j < n;
   const bool jown = jin && j >= row_begin && j < row_end;  // pairs (j, i>j) belong to this shard
   const int ns = SUB ? n_total : n;                        // stride of the per-node accumulators
-  const int jn = SUB ? int(idx[jin ? j : 0]) : (jin ? j : 0);   // the column's node
+  // (node ids of a minibatch are clamped into the table: unvalidated caller data, see spd_pair.hpp batch_node)
+  const int jn = SUB ? int(min(uint64_t(idx[jin ? j : 0]), uint64_t(n_total - 1))) : (jin ? j : 0);   // the column's node
   T xj[MP], a[MP];
   load_point<T, MP>(x, jn, m, xj);
 #pragma unroll
@@ -120,7 +121,7 @@ __global__ __launch_bounds__(kVBlock) void vec_pdist_bwd_kernel(const T* __restr
   __shared__ T rowx[kSubRows][SUB ? MP : 1];
   __shared__ int rown[kSubRows];
   if constexpr (SUB) {
-    if (int(threadIdx.x) < rpb) rown[threadIdx.x] = int(idx[min(i0 + int(threadIdx.x), n - 1)]);
+    if (int(threadIdx.x) < rpb) rown[threadIdx.x] = int(min(uint64_t(idx[min(i0 + int(threadIdx.x), n - 1)]), uint64_t(n_total - 1)));
     __syncthreads();
     for (int e = threadIdx.x; e < rpb * MP; e += kVBlock) {
       const int r = e / MP, k = e % MP;

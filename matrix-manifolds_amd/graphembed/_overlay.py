@@ -20,6 +20,7 @@ module does nothing.
 import importlib
 import importlib.util
 import os
+import re
 import sys
 
 _OURS = os.path.dirname(os.path.abspath(__file__))
@@ -29,8 +30,21 @@ _MODULES = ('modules', 'objectives', 'utils', 'metrics')
 _loaded = {}
 
 
+_later_cache = {}
+
+
 def later_packages():
-    """Directories of other `graphembed` packages on sys.path, in path order (this one excluded)."""
+    """Directories of other `graphembed` packages on sys.path, in path order (this one excluded).  Cached per state of
+    sys.path: an attribute miss on an overlaid module must not rescan the path every time."""
+    key = tuple(sys.path)
+    hit = _later_cache.get(key)
+    if hit is None:
+        _later_cache.clear()
+        hit = _later_cache[key] = tuple(_scan_later_packages())
+    return list(hit)
+
+
+def _scan_later_packages():
     out = []
     for p in sys.path:
         cand = os.path.join(p or os.getcwd(), _ROOT)
@@ -71,11 +85,37 @@ def _counterpart(stem):
 def _module_getattr(stem):
     def __getattr__(name):
         if not name.startswith('__'):
-            mod = _counterpart(stem)
+            try:
+                mod = _counterpart(stem)
+            except Exception as e:  # noqa: BLE001 — the checkout's counterpart does not import here: a miss, with the cause
+                raise AttributeError(f"module '{_ROOT}.{stem}' has no attribute '{name}' (the checkout's {stem}.py does not "
+                                     f"import: {type(e).__name__}: {e})") from e
             if mod is not None and hasattr(mod, name):
                 return getattr(mod, name)
         raise AttributeError(f"module '{_ROOT}.{stem}' has no attribute '{name}'")
     return __getattr__
+
+
+def _defines(path, name):
+    """True when the source file binds `name` at its top level (def / class / assignment / import ... as): a textual test
+    that keeps an attribute miss (`hasattr(graphembed, 'torch')`, pytest / inspect / pickle probes) from importing every
+    module of the checkout that merely MENTIONS the name."""
+    pat = re.compile(r'^(?:(?:async\s+)?def\s+{0}\b|class\s+{0}\b|{0}\s*(?::[^=\n]+)?=[^=]|'
+                     r'(?:from\s+\S+\s+)?import\s+.*\b{0}\b\s*(?:,|$|#)|.*\bas\s+{0}\b)'.format(re.escape(name)), re.M)
+    try:
+        with open(path, encoding='utf-8', errors='replace') as f:
+            return pat.search(f.read()) is not None
+    except OSError:
+        return False
+
+
+def _is_submodule(modname, name):
+    """Is `modname.name` a module file or package directory on the merged __path__?  (Nothing is imported to find out.)"""
+    mod = sys.modules.get(modname)
+    for d in list(getattr(mod, '__path__', ())):
+        if os.path.isfile(os.path.join(d, name + '.py')) or os.path.isdir(os.path.join(d, name)):
+            return True
+    return False
 
 
 def _package_getattr(modname, rel):
@@ -83,11 +123,15 @@ def _package_getattr(modname, rel):
         if name.startswith('__'):
             raise AttributeError(name)
         full = f'{modname}.{name}'
-        try:                                   # a sub-module / sub-package of the checkout (graphembed.inference, data.preprocess)
-            return importlib.import_module(full)
-        except ModuleNotFoundError as e:
-            if e.name != full:
-                raise
+        if _is_submodule(modname, name):       # a sub-module / sub-package of the checkout (graphembed.inference, data.preprocess)
+            try:
+                return importlib.import_module(full)
+            except ModuleNotFoundError as e:
+                if e.name != full:
+                    # the checkout's module exists but one of ITS imports is missing here (train.py: tensorboard): that is the
+                    # caller's error when the module was asked for by name — and stays an AttributeError for getattr-with-default
+                    # probes, with the cause attached
+                    raise AttributeError(f"module '{modname}' has no usable attribute '{name}': {e}") from e
         ours = os.path.join(_OURS, rel)
         for base in later_packages():          # a name one of the checkout's sub-modules defines (manifolds.Universal)
             d = os.path.join(base, rel)
@@ -97,10 +141,13 @@ def _package_getattr(modname, rel):
                 stem, ext = os.path.splitext(fn)
                 if ext != '.py' or stem == '__init__' or os.path.exists(os.path.join(ours, fn)):
                     continue
-                with open(os.path.join(d, fn), encoding='utf-8', errors='replace') as f:
-                    if name not in f.read():   # (do not import every module of the checkout to find one name)
-                        continue
-                sub = importlib.import_module(f'{modname}.{stem}')
+                if not _defines(os.path.join(d, fn), name):   # (only a module that BINDS the name is imported)
+                    continue
+                try:
+                    sub = importlib.import_module(f'{modname}.{stem}')
+                except Exception as e:  # noqa: BLE001 — a speculative import must not turn an attribute miss into its error
+                    raise AttributeError(f"module '{modname}' has no attribute '{name}' "
+                                         f"({modname}.{stem} defines it but does not import: {type(e).__name__}: {e})") from e
                 if hasattr(sub, name):
                     return getattr(sub, name)
         raise AttributeError(f"module '{modname}' has no attribute '{name}'")

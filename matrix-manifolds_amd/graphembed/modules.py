@@ -29,6 +29,7 @@ class _TakeRows(torch.autograd.Function):
 def take_rows(x, i):
     if i is None:
         return x
+    i = normalise_indices(i, x.shape[0])   # host-side: IndexError out of range, python-style negatives wrapped (x[idx] semantics)
     if i.dtype != torch.int64 or i.device != x.device:
         i = i.to(device=x.device, dtype=torch.int64)
     return _TakeRows.apply(x, i)
@@ -216,6 +217,38 @@ def _single_subset_factor(man):
     return None
 
 
+def distinct_in_range(indices, n):
+    """Gate of every in-kernel node-minibatch route (mm_product_pairs_loss_subset, mm_{spd,vec}_pdist_loss_subset,
+    mm_train_step.batch_idx): the kernels address table rows, rows of the dense target matrix and accumulator slots
+    through the index vector — they read the low 32-bit word of each index and do no range check of their own — so
+    the indices must be in [0, n) (the reference's `x[i]` raises IndexError otherwise, modules.py:86) and distinct
+    (its indexing backward accumulates repeated rows; the per-node kernels write each gradient row once).  Slices of
+    a `randperm` (train.py:206-209) always are.  HOST-side index tensors are checked here: out of range raises
+    IndexError, in-range negatives (python-style) and repeats return False = "take the gather / scatter route".
+    DEVICE-side index tensors cannot be checked without a synchronisation and are taken as documented (the kernels
+    clamp node ids into the tables, so a bad device-side index gives wrong numbers, not a stray write)."""
+    if indices.is_cuda or indices.numel() == 0:
+        return True
+    lo, hi = int(indices.min()), int(indices.max())
+    if lo < -n or hi >= n:
+        raise IndexError(f'index out of range for an embedding of {n} points: [{lo}, {hi}]')
+    if lo < 0:
+        return False
+    return bool(torch.unique(indices).numel() == indices.numel())
+
+
+def normalise_indices(indices, n):
+    """Host-side node indices as the reference's `x[idx]` reads them: out of range raises IndexError, python-style
+    negatives are wrapped (index_select and the gather kernels take non-negative indices only).  Device-side
+    tensors are returned as they are (no synchronisation on the training path)."""
+    if indices is None or indices.is_cuda or indices.numel() == 0:
+        return indices
+    lo, hi = int(indices.min()), int(indices.max())
+    if lo < -n or hi >= n:
+        raise IndexError(f'index out of range for an embedding of {n} points: [{lo}, {hi}]')
+    return indices if lo >= 0 else torch.where(indices < 0, indices + n, indices)
+
+
 class _SingleSubsetLoss(torch.autograd.Function):
     """Objective and gradients of a node minibatch of ONE factor, evaluated inside that factor's own pair kernel
     (mm_spd_pdist_loss_subset / mm_vec_pdist_loss_subset): the index vector addresses the rows of the full table, the
@@ -371,6 +404,11 @@ class ManifoldEmbedding(torch.nn.Module):
         spec = objective_fn.fused_spec(**kwargs)
         in_kernel_batch = (i is not None and dense is not None and dense.is_cuda and self.pair_kernel
                            and dense.dtype == pts[0].dtype)
+        if in_kernel_batch and not distinct_in_range(i, self.n):
+            # (host-side indices with repeats or python-style negatives: the kernels address tables, targets and gradient
+            # rows through the index vector unchecked — such a batch goes the gather / scatter way, like the reference's)
+            in_kernel_batch = False
+            i = normalise_indices(i, self.n)
         if in_kernel_batch and i.numel() == 0:
             # an empty batch has no pairs: a zero loss whose backward gives every parameter its (dense) zero gradient, as the
             # reference's sum over an empty pair list does
@@ -424,24 +462,13 @@ class BatchedObjective(torch.nn.Module):
     check_indices = True   # validate CPU index tensors before the in-kernel minibatch path (~20 us per step)
 
     def _distinct_in_range(self, indices, n):
-        """The in-kernel node-minibatch path (mm_product_pairs_loss_subset) addresses table rows, targets and
-        gradient rows through the index vector: the indices must be in range (the reference's `x[i]` raises
-        IndexError otherwise) and distinct (its indexing backward accumulates repeated rows; the kernel's
-        finalize writes each row once).  Slices of a `randperm` (train.py:206-209) always are; anything else
-        is checked here when the indices are host-side, and device-side index tensors — nothing to check
-        without a synchronisation — take the path as documented.  Returns False to fall back to the
-        gather / scatter path (repeats), raises IndexError when out of range."""
-        if not self.check_indices or indices.is_cuda or indices.numel() == 0:
-            return True
-        lo, hi = int(indices.min()), int(indices.max())
-        if lo < -n or hi >= n:
-            raise IndexError(f'index out of range for an embedding of {n} points: [{lo}, {hi}]')
-        if lo < 0:
-            return False
-        return bool(torch.unique(indices).numel() == indices.numel())
+        """`distinct_in_range` (module level) under this objective's `check_indices` switch."""
+        return not self.check_indices or distinct_in_range(indices, n)
 
     def forward(self, indices, *args, **kwargs):
         emb = self.embedding
+        if self.check_indices and indices is not None:
+            indices = normalise_indices(indices, len(emb))   # IndexError like the reference's x[idx]; negatives wrapped
         if self.fused and not args and indices is not None and emb.xs[0].is_cuda \
                 and hasattr(self.objective_fn, 'fused_spec') and hasattr(self.dataset, 'pdists'):
             dense = self.dataset.pdists   # the pair kernel gathers rows and targets itself

@@ -50,12 +50,16 @@ class _StepParam(_c.Structure):
 
 
 class _TrainStep(_c.Structure):
-    _fields_ = [('dtype', _c.c_int), ('loss_kind', _c.c_int), ('terms', _c.c_int), ('alpha', _c.c_double),
+    _fields_ = [('struct_size', _c.c_size_t), ('dtype', _c.c_int), ('loss_kind', _c.c_int), ('terms', _c.c_int), ('alpha', _c.c_double),
                 ('eps', _c.c_double), ('loss_params', _c.c_void_p), ('wmin', _c.c_double), ('wmax', _c.c_double),
                 ('n', _c.c_int64), ('nf', _c.c_int), ('points', _StepParam * 4), ('scales', _StepParam * 4),
                 ('target', _c.c_void_p), ('loss_out', _c.c_void_p), ('ws', _c.c_void_p), ('ws_flags', _c.c_int),
                 ('row_begin', _c.c_int64), ('row_end', _c.c_int64), ('comm', _c.c_void_p), ('reduce_buf', _c.c_void_p),
                 ('reduce_count', _c.c_int64), ('batch_idx', _c.c_void_p), ('batch', _c.c_int64)]
+
+    def __init__(self, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        self.struct_size = _c.sizeof(type(self))   # the struct is versioned by its size (mm_abi_version() >= 4)
 
 
 OPT_NONE, OPT_RSGD, OPT_RADAM = -1, 0, 1
@@ -72,6 +76,8 @@ def _factor_of(man):
 
 
 class NativeTrainStep:
+
+    check_indices = True   # distinctness of HOST-side minibatch indices (a torch.unique per step); the range check always runs
 
     def __init__(self, embedding, objective_fn, targets, optimizers, shard=None, comm=None, dense=None):
         """`dense`: the dataset's dense [n, n] matrix of squared graph distances (GraphDataset.pdists) — enables node
@@ -238,6 +244,13 @@ class NativeTrainStep:
                 raise ValueError('a minibatch step needs the dense target matrix: NativeTrainStep(..., dense=dataset.pdists)')
             if self.shard is not None:
                 raise ValueError('minibatch steps of NativeTrainStep run on one GPU')
+            # the kernels behind mm_train_step.batch_idx address table rows, dense-target rows and accumulator slots through
+            # the index vector unchecked: host-side indices are validated here as BatchedObjective does (IndexError out of range
+            # like the reference's x[idx], python-style negatives wrapped); device-side ones cannot be without a synchronisation
+            from graphembed.modules import distinct_in_range, normalise_indices
+            indices = normalise_indices(indices, self.n)
+            if self.check_indices and not distinct_in_range(indices, self.n):
+                raise ValueError('the node indices of a minibatch step must be distinct (slices of a randperm are: train.py:206-209)')
             self._idx = indices.to(device=self.device, dtype=torch.int64).contiguous()   # (kept: the enqueued kernels read it)
             batch = self._idx.numel()
             if batch == 0:

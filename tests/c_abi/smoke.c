@@ -142,6 +142,9 @@ int main(void) {
     CHECK_HIP(hipMemcpyAsync(dts, &ts, sizeof ts, hipMemcpyHostToDevice, st));
     mm_train_step step;
     memset(&step, 0, sizeof step);
+    /* an unversioned struct (struct_size 0, or an ABI <= 3 caller whose first member was dtype) is refused, not misread */
+    if (mm_train_step_run(&step, st) != MM_ERR_ARG) return 16;
+    step.struct_size = sizeof step;
     step.dtype = MM_F64; step.loss_kind = MM_LOSS_STRESS; step.n = TN; step.nf = 1;
     step.wmin = 1e-8; step.wmax = 1e8;
     step.points[0].kind = MM_EUCLIDEAN; step.points[0].dim = TM; step.points[0].count = TN;

@@ -353,6 +353,34 @@ def test_train_step_struct_layout_matches_the_header(tmp_path):
         assert getattr(cls, name).offset == int(off), (which, name)
 
 
+def test_train_step_struct_is_versioned_by_its_size():
+    """mm_train_step.struct_size (ABI 4; advisor, round 4: the struct grew at its tail without a version field, so a caller
+    built against the shorter header was read past its end).  The size checks return before anything touches a GPU."""
+    from graphembed import _backend as B
+    from graphembed.native_step import _TrainStep
+    lib = B.lib()
+    assert lib.raw('mm_abi_version')() >= 4
+    run = lib.raw('mm_train_step_run')
+    d = _TrainStep()
+    assert d.struct_size == ctypes.sizeof(_TrainStep) and _TrainStep.struct_size.offset == 0
+    d.dtype, d.n, d.nf = B.dtype_code(torch.zeros(1)), 4, 9          # nf = 9: MM_ERR_ARG from the body, i.e. the size was accepted
+    assert run(ctypes.byref(d), None) == -1
+    # an unversioned struct, and what an ABI <= 3 caller has in these bytes ({dtype, loss_kind} = small integers)
+    for bad in (0, 1, (2 << 32) | 1, ctypes.sizeof(_TrainStep) - 8, 64 * ctypes.sizeof(_TrainStep)):
+        d.struct_size = bad
+        assert run(ctypes.byref(d), None) == -1, bad
+
+    # a caller built against a LONGER (future) header: accepted while the tail the library does not know is zero
+    class Longer(ctypes.Structure):
+        _fields_ = [('base', _TrainStep), ('future_field', ctypes.c_int64), ('future_ptr', ctypes.c_void_p)]
+    e = Longer()
+    e.base.struct_size = ctypes.sizeof(Longer)
+    e.base.dtype, e.base.n, e.base.nf = d.dtype, 4, 9
+    assert run(ctypes.byref(e), None) == -1                            # (again the body's nf check)
+    e.future_field = 3
+    assert run(ctypes.byref(e), None) == -2                            # MM_ERR_UNSUPPORTED: a feature this library lacks
+
+
 def test_sync_grads_uses_an_installed_communicator():
     """graphembed.parallel routes the step's collective through the installed communicator object (the RCCL one on a
     GPU box) and falls back to torch.distributed without one."""

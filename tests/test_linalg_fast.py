@@ -219,3 +219,23 @@ def test_module_surface_without_a_gpu():
         assert callable(getattr(fast, name))
     with pytest.raises(B.BackendError):
         fast.symeig2x2(torch.eye(2).expand(3, -1, -1))
+
+
+@pytest.mark.gpu
+def test_double_backward_raises_instead_of_dropping_the_graph():
+    """The backward is a kernel launch: under create_graph=True it must refuse (once_differentiable), not return a gradient
+    that silently has no graph (advisor, round 4; the reference's pure-torch fast.py is twice differentiable)."""
+    from graphembed.linalg import fast
+    x = _rand_spd(5, 2, torch.float64).requires_grad_()
+    l = fast.cholesky2x2(x)
+    g, = torch.autograd.grad(l.sum(), x, create_graph=True)
+    with pytest.raises(RuntimeError, match='once_differentiable|differentiated twice'):
+        g.sum().backward()
+
+
+def test_cpu_tensors_raise_without_a_checkout():
+    from graphembed.linalg import fast
+    if fast._reference_fast() is not None:
+        pytest.skip('a reference checkout follows the package on sys.path: CPU tensors are its business')
+    with pytest.raises(Exception):
+        fast.symeig2x2(torch.eye(2).expand(3, 2, 2))

@@ -292,3 +292,66 @@ def test_degenerate_batches(layout, loss_name):
         with pytest.raises(B.BackendError):      # a batch size without an index vector is refused, not run as a full batch
             step._desc.batch_idx, step._desc.batch = None, 5
             B.lib().call('mm_train_step_run', __import__('ctypes').byref(step._desc), B.stream_of(dense))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('case', ['spd4', 'lorentz24', 'spd3'])
+def test_bad_minibatch_indices_are_caught_on_every_route(case):
+    """The in-kernel minibatch routes address tables, dense targets and accumulators through the index vector (advisor, round 4:
+    NativeTrainStep and the single-factor subset loss bypassed BatchedObjective's check).  HOST-side indices: out of range
+    raises IndexError like the reference's x[idx] (modules.py:86) on every route; python-style negatives are wrapped; repeats go
+    the gather / scatter way (BatchedObjective, fused_objective) or raise (NativeTrainStep has no such route).  DEVICE-side
+    indices cannot be checked without a synchronisation: the kernels clamp node ids into the tables, so a bad index yields
+    finite wrong numbers and no stray access."""
+    from graphembed import manifolds as M
+    from graphembed.data import GraphDataset
+    from graphembed.modules import BatchedObjective, ManifoldEmbedding
+    from graphembed.native_step import NativeTrainStep
+    from graphembed.objectives import StressLoss
+    from graphembed.optim import RiemannianSGD
+    n = 61
+    base = f'{case}/f32'
+    with torch.device('cuda'):
+        emb = ManifoldEmbedding(n, manifolds_of(case, M, M.SymmetricPositiveDefinite))
+        ds = GraphDataset(torch.from_numpy(GOLD[f'{base}/graph_d']).float().cuda())
+    with torch.no_grad():
+        emb.xs[0].copy_(torch.from_numpy(GOLD[f'{base}/x_0']).cuda())
+    fn = StressLoss()
+    obj = BatchedObjective(fn, ds, emb)
+    opts = [RiemannianSGD(list(emb.xs), lr=0.01, exact=True, max_grad_norm=20), RiemannianSGD(list(emb.scales), lr=1e-3)]
+    step = NativeTrainStep(emb, fn, None, opts, dense=ds.pdists)
+    good = torch.tensor([3, 17, 40, 8, 59])
+    for bad in (torch.tensor([3, 17, n, 8]), torch.tensor([3, -n - 1, 5])):
+        with pytest.raises(IndexError):
+            obj(bad)
+        with pytest.raises(IndexError):
+            emb.fused_objective(fn, None, bad, dense=ds.pdists)
+        with pytest.raises(IndexError):
+            step(indices=bad)
+    # python-style negatives: the same batch as their wrapped form, on every route
+    neg = torch.tensor([3, 17 - n, 40, 8 - n, -2])
+    ref = float(obj(good))
+    assert abs(float(obj(neg)) - ref) <= 1e-5 * abs(ref)
+    assert abs(float(emb.fused_objective(fn, ds[good], neg)) - ref) <= 1e-5 * abs(ref)     # (gather route: targets given)
+    # repeats: the reference accumulates the repeated row's gradient; the gather route does, the native step refuses
+    rep = torch.tensor([3, 17, 3, 8])
+    assert emb.fused_objective(fn, None, rep, dense=ds.pdists) is None           # no in-kernel route, no targets: caller gathers
+    loss = obj(rep)
+    x = emb.xs[0]
+    g, = torch.autograd.grad(loss, x)
+    assert bool(torch.isfinite(g).all()) and float(g[3].abs().sum()) > 0
+    with pytest.raises(ValueError):
+        step(indices=rep)
+    # the steps above that raised must not have moved anything; a good batch still steps
+    before = emb.xs[0].detach().clone()
+    l1 = float(step(indices=good))
+    assert abs(l1 - ref) <= 1e-5 * abs(ref) and not torch.equal(before, emb.xs[0].detach())
+    # device-side garbage is clamped inside the kernels: finite numbers, nothing written outside the workspace
+    junk = torch.tensor([3, 17, 2 ** 31 + 5, -7, 10 ** 9], device='cuda')
+    lj = step(indices=junk)
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(lj)) and bool(torch.isfinite(emb.xs[0]).all())
+    lo = emb.fused_objective(fn, None, junk, dense=ds.pdists)
+    gj, = torch.autograd.grad(lo, emb.xs[0])
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(lo)) and bool(torch.isfinite(gj).all())

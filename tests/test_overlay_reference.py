@@ -93,6 +93,63 @@ def test_run_py_import_block_resolves_across_both_packages():
     assert out.strip().endswith('ok')
 
 
+def test_attribute_misses_stay_attribute_errors():
+    """An attribute MISS on the overlaid package must not import (and fail in) checkout modules that merely mention the
+    name: `hasattr(graphembed, 'torch')` used to raise ModuleNotFoundError('tensorboard') out of the reference's train.py
+    (advisor, round 4).  Run WITHOUT the tensorboard stub of the other tests."""
+    env = dict(os.environ, MM_PKG=PKG, MM_REF=REF, PYTHONDONTWRITEBYTECODE='1', PYTHONPATH=os.pathsep.join([PKG, REF]))
+    code = textwrap.dedent('''
+        import sys
+        import graphembed, graphembed._overlay as o
+        assert len(o.later_packages()) == 1
+        assert 'torch.utils.tensorboard' not in sys.modules
+        assert not hasattr(graphembed, 'torch') and not hasattr(graphembed, 'np')      # (mentioned all over the checkout)
+        for name in ('definitely_not_there', 'pytest_plugins', '_pytestfixturefunction', 'SummaryWriter'):
+            assert not hasattr(graphembed, name), name
+            assert getattr(graphembed.manifolds, name, None) is None, name
+            assert getattr(graphembed.modules, name, 7) == 7, name
+        assert not any(m.startswith('graphembed.train') for m in sys.modules), [m for m in sys.modules if 'train' in m]
+        # a module asked for BY NAME whose own imports are missing here: an AttributeError that names the cause
+        try:
+            graphembed.train
+        except AttributeError as e:
+            assert 'tensorboard' in str(e), e
+        else:
+            raise AssertionError('graphembed.train imported without tensorboard?')
+        # names the checkout really binds still resolve
+        from graphembed.manifolds import Universal
+        assert o.later_packages() is not o.later_packages() and o._later_cache      # cached scan, fresh list
+        print('ok')
+    ''')
+    r = subprocess.run([sys.executable, '-c', code], env=env, capture_output=True, text=True, timeout=300, cwd='/tmp')
+    assert r.returncode == 0 and r.stdout.strip().endswith('ok'), r.stdout + r.stderr
+
+
+def test_linalg_fast_hands_cpu_tensors_to_the_checkout():
+    """graphembed.linalg.fast of this package shadows the checkout's: its CPU callers (monitor.py, tests/test_linalg.py) get
+    the checkout's own functions for CPU tensors (advisor, round 4); GPU tensors stay on the kernels."""
+    out = run('''
+        import torch
+        from graphembed.linalg import fast
+        assert origin(fast) == 'ours'
+        torch.manual_seed(0)
+        a = torch.randn(7, 3, 3, dtype=torch.float64)
+        x = a @ a.transpose(1, 2) + torch.eye(3, dtype=torch.float64)
+        w = fast.symeig3x3(x)
+        assert torch.allclose(w, torch.linalg.eigvalsh(x), atol=1e-6), (w, torch.linalg.eigvalsh(x))
+        x2 = x[:, :2, :2].clone().requires_grad_()
+        l = fast.cholesky2x2(x2)
+        assert torch.allclose(l @ l.transpose(1, 2), x2, atol=1e-6)
+        g, = torch.autograd.grad(l.sum(), x2, create_graph=True)       # the checkout's pure-torch form: twice differentiable
+        assert g.requires_grad
+        li, lc = fast.invcholesky2x2(x2.detach(), ret_chol=True)
+        assert torch.allclose(li @ lc, torch.eye(2, dtype=torch.float64).expand(7, 2, 2), atol=1e-6)
+        assert origin(fast._reference_fast()) == 'reference'
+        print('ok')
+    ''')
+    assert out.strip().endswith('ok')
+
+
 def test_example_config_names_resolve_like_parse_config():
     out = run('''
         import importlib, yaml

@@ -54,6 +54,17 @@ def test_minibatch_index_validation():
         bo._distinct_in_range(torch.tensor([-51, 3]), 50)
     bo.check_indices = False
     assert bo._distinct_in_range(torch.tensor([1, 1]), 50)
+    # the module-level forms every in-kernel route goes through (BatchedObjective, fused_objective, NativeTrainStep)
+    from graphembed.modules import distinct_in_range, normalise_indices
+    assert distinct_in_range(torch.randperm(50)[:20], 50) and not distinct_in_range(torch.tensor([4, 4]), 50)
+    assert distinct_in_range(torch.empty(0, dtype=torch.int64), 50)
+    assert normalise_indices(None, 50) is None
+    assert normalise_indices(torch.tensor([-1, 2, -50]), 50).tolist() == [49, 2, 0]
+    keep = torch.tensor([5, 6])
+    assert normalise_indices(keep, 50) is keep
+    for bad in ([1, 50], [-51, 3]):
+        with pytest.raises(IndexError):
+            normalise_indices(torch.tensor(bad), 50)
 
 
 def test_quotient_schedule_written_only_on_change(monkeypatch):

@@ -95,7 +95,15 @@ int mm_spd_pdist_fwd(int dtype, const void* x, int64_t n, int d, int64_t row_beg
 
 /* Backward of the above (what autograd computes in the reference; symmetric
  * part — SURVEY.md §8 a5).  g has the layout of `out`.  grad_x [n,d,d] is
- * OVERWRITTEN with this shard's partial gradient (full shape; sum the shards). */
+ * OVERWRITTEN with this shard's partial gradient (full shape; sum the shards).
+ * fp32 accuracy on ILL-CONDITIONED points depends on the launch size for d = 4: pairs whose matrix L_i^-1 X_j L_i^-T has
+ * lambda_max > 256 lambda_min are solved a second time by a one-sided Jacobi on L_i^-1 L_j (d = 2..4), EXCEPT in the
+ * two-columns-per-lane form of the SPD(4) backward that launches of >= 30 M pairs (n >= 7747) and row bands of >= 12 M
+ * pairs take (also in mm_spd_pdist_loss / mm_train_step_run): there the gradient at cond(X) = 1e4 is good to 3e-3 ... 1.5e-2
+ * of its largest entry instead of 8e-5 (1e-5 / 1.5e-6 at cond(X) = 1e2; measured, tools/illcond_probe.py, pinned by
+ * tests/test_spd_gpu.py::test_ill_conditioned_points_fp32 in both forms).  Distances come from the forward kernel and do
+ * not depend on the launch size.  MM_SPD4_BWD_TWO_COLS=0 in the environment keeps the one-column form at every size
+ * (+4..5 % time at n = 16384); fp64 is unaffected. */
 int mm_spd_pdist_bwd(int dtype, const void* x, const void* g, int64_t n, int d,
                      int64_t row_begin, int64_t row_end, int squared, double wmin,
                      double wmax, void* grad_x, void* ws, int flags, mm_stream_t stream);
@@ -132,7 +140,13 @@ int mm_spd_pdist_loss(int dtype, int loss_kind, const void* x, const void* targe
  *            gradient the reference's optimizers see
  *   ws       mm_spd_pdist_ws_bytes(dtype, n_total, d): the per-node tables are those of the FULL embedding (flags =
  *            MM_WS_PREPARED skips their preparation when they are current); row_begin / row_end shard the pair list of
- *            the BATCH (0 .. bs).  Every d of mm_spd_max_dim(). */
+ *            the BATCH (0 .. bs).  Every d of mm_spd_max_dim().
+ *   idx      is caller data the kernels cannot validate: they read the low 32 bits of each index and CLAMP the node id into
+ *            [0, n_total) — an out-of-range or negative index yields wrong numbers for that batch, never an access outside
+ *            the buffers; repeated indices break the "each gradient row is written once" contract silently.  The Python
+ *            layer checks host-side index tensors (graphembed.modules.distinct_in_range); device-side ones are the
+ *            caller's responsibility.  The same holds for mm_vec_pdist_loss_subset, mm_product_pairs_loss_subset,
+ *            mm_pair_gather and mm_train_step.batch_idx. */
 int mm_spd_pdist_loss_subset(int dtype, int loss_kind, const void* x, const void* dense, const void* scale_raw,
                              int64_t n_total, int d, const int64_t* idx, int64_t bs, int64_t row_begin, int64_t row_end,
                              double alpha, double eps, int terms, const double* loss_params, double wmin, double wmax,

@@ -92,7 +92,7 @@ template <typename T> __device__ __forceinline__ T dq_rt(int kind, T q) {
 // KC: the vector factors' kinds as constants (product_args.hpp), -1 = read in the row loop
 template <typename T, int NV, int SD, int LOSS, int KC = -1>
 __global__ __launch_bounds__(64 * kPSWaves) void product_sym_kernel(PArgs<T> pa, const T* __restrict__ tab, const T* __restrict__ target,
-                                                                    int n, int row_begin, int row_end, LossArgs<T> la) {
+                                                                    int n, int row_begin, int row_end, LossArgs<T> la, WalkShares shares) {
   using L = PSLayout<NV, SD>;
   constexpr int NW = kPSWaves, TI = kPSTI, NPS = L::NPS > 0 ? L::NPS : 1, DS = SD > 0 ? SD : 2, W = L::W, NR = L::NR, VEC = L::VEC;
   loss_resolve<T, LOSS>(la);
@@ -104,15 +104,15 @@ __global__ __launch_bounds__(64 * kPSWaves) void product_sym_kernel(PArgs<T> pa,
   __shared__ T colS[NW][NR + (SD > 0 ? SD * SD - L::NPS : 0)][64];
   __shared__ T redJunk[NW][64];
   const ColWalk walk(n, row_begin, row_end, 64);
-  const int64_t total = walk.total();
-  int64_t pos = ColWalk::share_begin(total, blockIdx.x, gridDim.x);
-  int rem = int(ColWalk::share_begin(total, int64_t(blockIdx.x) + 1, gridDim.x) - pos);
+  int64_t pos;   // this workgroup's units, cut on the host (spd_ws.hpp, WalkShares)
+  int rem;
+  shares.of(int(blockIdx.x), pos, rem);
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   bool red_writer;
   const int red_slot = reduce_slot<NR>(lane, red_writer);
   const int64_t base = pair_off(n, row_begin);
-  int cb = rem > 0 ? walk.find(pos) : 0;
+  int cb = rem > 0 ? walk.find_fast(pos) : 0;
   int r = row_begin + int(pos - walk.prefix(cb));
   T* red_ptr = red_writer ? &redM[wave][0][red_slot] : &redJunk[wave][lane];
   const int red_step = red_writer ? NR : 0;
@@ -364,9 +364,9 @@ int launch(int loss_kind, const PArgs<T>& pa, const T* target, int64_t n, int64_
   auto with_kinds = [&](auto kc) {
     constexpr int K = decltype(kc)::value;
     if (loss_kind == MM_LOSS_STRESS)
-      product_sym_kernel<T, NV, SD, MM_LOSS_STRESS, K><<<g3, b3, 0, st>>>(pa, table, target, int(n), int(rb), int(re), la);
+      product_sym_kernel<T, NV, SD, MM_LOSS_STRESS, K><<<g3, b3, 0, st>>>(pa, table, target, int(n), int(rb), int(re), la, WalkShares(units, grid));
     else
-      product_sym_kernel<T, NV, SD, MM_LOSS_QUOTIENT, K><<<g3, b3, 0, st>>>(pa, table, target, int(n), int(rb), int(re), la);
+      product_sym_kernel<T, NV, SD, MM_LOSS_QUOTIENT, K><<<g3, b3, 0, st>>>(pa, table, target, int(n), int(rb), int(re), la, WalkShares(units, grid));
   };
   bool launched = false;
   if constexpr (NV == 1 || NV == 2) launched = !rt_kinds && for_kind_code<NV>(kinds_code, with_kinds);

@@ -64,6 +64,9 @@ extern "C" {
 int mm_dbg_read_bwd_stamps(void* host, size_t bytes) {
   return int(hipMemcpyFromSymbol(host, HIP_SYMBOL(mm::g_bwd_stamps), bytes));
 }
+int mm_dbg_read_bwd_marks(void* host, size_t bytes) {
+  return int(hipMemcpyFromSymbol(host, HIP_SYMBOL(mm::g_bwd_marks), bytes));
+}
 #endif
 
 int mm_spd_max_dim(void) { return kSpdMaxD; }

@@ -291,7 +291,7 @@ __device__ __forceinline__ T pair_value(const TL (&li)[Packed<D>::NP], const T (
 // slot of its SIMD) and, in the backward, the row-side reduction (one reduction of M_a + M_b); wider matrices and fp64
 // do not have the registers for it.
 template <typename T, int D> constexpr int pair_cols() { return (sizeof(T) == 4 && D <= 3) ? 2 : ((sizeof(T) == 4 && D == 4) ? MM_SPD4_FWD_NC : 1); }
-template <typename T, int D> constexpr int pair_cols_bwd() { return (sizeof(T) == 4 && D <= 3) ? 2 : ((sizeof(T) == 4 && D == 4) ? MM_SPD4_BWD_NC : 1); }
+template <typename T, int D> constexpr int pair_cols_bwd() { return (sizeof(T) == 4 && D == 3) ? MM_SPD3_BWD_NC : (sizeof(T) == 4 && D <= 3) ? 2 : ((sizeof(T) == 4 && D == 4) ? MM_SPD4_BWD_NC : 1); }
 
 // Tile: TI rows x (256 x NC) columns per workgroup; lane l of wavefront w owns the columns jbase + 64 (NC w + q) + l.
 // The row loop is unrolled twice with two alternating scalar register sets for the row operand L_i^-1 (no copies), the
@@ -367,8 +367,10 @@ __global__ __launch_bounds__(kBlock) void spd_pdist_fwd_kernel(const T* __restri
         asm volatile("" : "+v"(joff[q]));
         if (jv[q] > ieff) *reinterpret_cast<T*>(op + joff[q]) = s;
       });
+#ifndef MM_DIAG_STATIC_ROWS   // (diagnostic builds: every row of a tile is stored over its first — the kernel without its HBM stream; wrong results)
       op += ostep;
       ostep -= unsigned(sizeof(T));
+#endif
     }
   }
 }
@@ -430,7 +432,8 @@ __global__ __launch_bounds__((64 * bwd_waves<T, D>()), (bwd_min_waves_nc<T, D, N
                                                                int row_end, T wmin, T wmax,
                                                                T* __restrict__ accM, T* __restrict__ accS,
                                                                LossArgs<T> la,
-                                                               const int64_t* __restrict__ idx, int n_total) {
+                                                               const int64_t* __restrict__ idx, int n_total,
+                                                               WalkShares shares) {
   static_assert(!SUB || LOSS != MM_LOSS_NONE, "node minibatches exist for the fused objective only");
   const int ns = SUB ? n_total : n;                      // stride of the per-node accumulators
   const int* idx32 = reinterpret_cast<const int*>(idx);  // (little-endian low words: node ids are < 2^22)
@@ -451,26 +454,34 @@ __global__ __launch_bounds__((64 * bwd_waves<T, D>()), (bwd_min_waves_nc<T, D, N
   __shared__ T colS[NW][NC][D * D][64];
   MM_SPD_STAMP_BEGIN();
   const ColWalk walk(n, row_begin, row_end, 64 * NC);
-  const int64_t total = walk.total();
-  int64_t pos = ColWalk::share_begin(total, blockIdx.x, gridDim.x);
-  int rem = int(ColWalk::share_begin(total, int64_t(blockIdx.x) + 1, gridDim.x) - pos);  // block-uniform (a share is < 2^31 rows)
+  int64_t pos;   // this workgroup's units of the walk: cut on the host (WalkShares)
+  int rem;       // block-uniform (a share is < 2^31 rows)
+  shares.of(int(blockIdx.x), pos, rem);
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform -> row operands stay scalar loads
   bool red_writer;
   const int red_slot = reduce_slot<NP>(lane, red_writer);  // which entry of M this lane holds after the row reduction
   const int64_t base = pair_off(n, row_begin);
-  int cb = rem > 0 ? walk.find(pos) : 0;                 // current column block
+  int cb = rem > 0 ? walk.find_fast(pos) : 0;            // current column block
   int r = row_begin + int(pos - walk.prefix(cb));        // next row of it
+  MM_SPD_STAMP_MARK(0);
   // Vector issue is arbitrated oldest wavefront first: of equal shares started together, the oldest workgroup of a
   // CU finishes when the youngest is barely half way, and the rest of the launch runs at one or two wavefronts per
   // SIMD (measured: five completion steps of 256 workgroups, the last 20 us at <= 40 % residency).  Priority outranks
   // age, so every wavefront LOWERS its priority as it advances through its share (3 until 40 %, 2 until 70 %,
   // 1 until 90 %, then 0): whoever is ahead yields to whoever is behind, and all of them enter the last tenth together.
   // Progress is counted in rows of THIS wavefront (a quarter of the share's), one scalar compare per row.
+#ifndef MM_SPD_PRIO_A   // (A/B builds: the three priority steps in per cent of a wavefront's rows)
+#define MM_SPD_PRIO_A 40
+#define MM_SPD_PRIO_B 30
+#define MM_SPD_PRIO_C 20
+#endif
   const int wave_rows = (rem + NW - 1) / NW;
-  int rows_left = (wave_rows * 2) / 5 + 1;   // rows until the next priority step
+  int rows_left = (wave_rows * MM_SPD_PRIO_A) / 100 + 1;   // rows until the next priority step
   int phase = 0;
+#ifndef MM_DIAG_NO_PRIO
   __builtin_amdgcn_s_setprio(3);
+#endif
   // The row reduction leaves one total per lane; NP of the lanes hold distinct entries, the others duplicates.  All
   // lanes store (an exec-masked store costs two scalar instructions per row): writers into redM, advancing by one row
   // per row, the others into a slot of their own that does not move.
@@ -509,10 +520,22 @@ __global__ __launch_bounds__((64 * bwd_waves<T, D>()), (bwd_min_waves_nc<T, D, N
         for (int c = 0; c < D; ++c) accJ[q][rr][c] = T(0);
     });
     const int hi = walk.hi(cb);
-    while (rem > 0 && r < hi) {   // chunks of up to NW x TI rows of this block
-      const int chunk = min(min(hi - r, NW * TI), rem);
+    // The rows of this block that belong to the share are cut into NW CONTIGUOUS slices, one per wavefront, and a wavefront
+    // walks its slice in one go: the requests for the pair vector run kAhead rows ahead across the whole slice — the row sums
+    // leave every TI rows (segments), without restarting the request pipeline.  (Rounds 2-4 cut the rows into chunks of NW x TI
+    // and gave every wavefront TI rows of each chunk: every 16 rows a wavefront set its slice up again (~100 scalar
+    // instructions), issued its first requests right in front of their use and — vmcnt counts in order — waited behind the
+    // atomics of the flush it had just issued: the memory latency was exposed once per 16 rows.  MM_SPD_BWD_CHUNKED restores
+    // that form for A/B builds; profiles/r05_experiments.md.)  A slice's byte offsets are 32-bit: rows x n x sizeof(T) < 2^31.
+#ifdef MM_SPD_BWD_CHUNKED
+    const int slice_cap = TI;
+#else
+    const int slice_cap = max(TI, int(min(int64_t(1) << 20, (int64_t(1) << 31) / (int64_t(n) * int64_t(sizeof(T))))));
+#endif
+    while (rem > 0 && r < hi) {   // (one pass, unless the 32-bit cap cuts the block's rows)
+      const int chunk = int(min(int64_t(min(hi - r, rem)), int64_t(NW) * slice_cap));
       const int tw = (chunk + NW - 1) / NW;
-      const int i0 = r + wave * tw, i1 = min(i0 + tw, r + chunk);
+      const int i0 = min(r + wave * tw, r + chunk), i1 = min(i0 + tw, r + chunk);
       if (i0 < i1) {
         // EVERY instruction of a wavefront — scalar ones included — takes an issue slot of its SIMD (these kernels run
         // at 2.0 - 2.4 cycles per instruction of any kind), so the row loop is written for the smallest TOTAL:
@@ -527,13 +550,16 @@ __global__ __launch_bounds__((64 * bwd_waves<T, D>()), (bwd_min_waves_nc<T, D, N
         //   use.  Requests are unconditional (a predicated one is an exec-masked branch behind which the compiler waits
         //   for vmcnt(0)) and run kAhead rows ahead into registers that rotate by RENAMING (the loop is unrolled kAhead
         //   times): rotating with moves would wait for the NEWEST request at every row.
-        constexpr int kAhead = 2;
+#ifndef MM_SPD_BWD_AHEAD
+#define MM_SPD_BWD_AHEAD 2
+#endif
+        constexpr int kAhead = MM_SPD_BWD_AHEAD;   // (A/B builds: -DMM_SPD_BWD_AHEAD=4)
         // SUB: the node of a row comes from the index vector — scalar loads issued one row ahead of their use (the operand
         // table) resp. right behind the previous request (the target row)
         const int first_node = SUB ? __builtin_amdgcn_readfirstlane(batch_node(idx32, size_t(i0), n_total)) : i0;
         int next_node = SUB ? __builtin_amdgcn_readfirstlane(batch_node(idx32, size_t(min(i0 + 1, n - 1)), n_total)) : 0;   // node of row i0 + 1
         unsigned roff = unsigned(first_node) * unsigned(2 * NP * sizeof(T));   // byte offset of the row's operands (the table is < 4 GB)
-        T lrow[2][2 * NP];
+        T lrow[kAhead][2 * NP];   // (register sets that alternate with the unrolled slots)
 #pragma unroll
         for (int k = 0; k < 2 * NP; ++k) lrow[0][k] = nodeLC[size_t(first_node) * (2 * NP) + k];
         const int glast = min(i1, walk.re) - 1;
@@ -564,19 +590,26 @@ __global__ __launch_bounds__((64 * bwd_waves<T, D>()), (bwd_min_waves_nc<T, D, N
               asm volatile("" : "+v"(jslice[q]));   // (see the forward's store: keeps the `v_off, s[ptr]` form inside the loop)
               dst[q] = *reinterpret_cast<const T*>(gslice + goff + jslice[q]);
             });
+#ifndef MM_DIAG_STATIC_ROWS   // (diagnostic builds: every row of a slice reads the slice's first row of g)
             goff = min(goff + gstep, gmax);
             gstep -= unsigned(sizeof(T));
+#endif
           }
         };
+#ifndef MM_DIAG_NO_G
 #pragma unroll
         for (int u = 0; u < kAhead; ++u) request(gq[u]);
-        for (int ib = i0; ib < i1; ib += kAhead) {
+#endif
+        MM_SPD_STAMP_MARK(1);
+        for (int s0 = i0; s0 < i1; s0 += TI) {   // segments of TI rows: their row sums are staged in LDS and leave together
+        const int s1 = min(s0 + TI, i1);
+        for (int ib = s0; ib < s1; ib += kAhead) {
 #pragma unroll
          for (int u = 0; u < kAhead; ++u) {
           // (a slice with an odd number of rows runs its last unrolled slot on a masked row: an early exit here would
           // make the number of outstanding requests path-dependent and the compiler falls back to vmcnt(0))
           const int irow = ib + u;
-          const int ieff = (u == 0 || irow < i1) ? irow : INT32_MAX;   // scalar; only the slot after the first can be past the slice
+          const int ieff = (u == 0 || irow < s1) ? irow : INT32_MAX;   // scalar; only the slot after the first can be past the slice (its last segment)
           const T (&lcur)[2 * NP] = lrow[u];
           // the row after the slice is inside the table (i1 <= n - 1), and the row after THAT — requested by the masked last
           // slot of a slice with an odd row count — is at most the table's padding row n (spd_ws.hpp).  The running offset is pinned: otherwise the loop
@@ -586,18 +619,23 @@ __global__ __launch_bounds__((64 * bwd_waves<T, D>()), (bwd_min_waves_nc<T, D, N
             next_node = __builtin_amdgcn_readfirstlane(batch_node(idx32, size_t(min(irow + 2, n - 1)), n_total));
           } else {
             roff += unsigned(2 * NP * sizeof(T));
+            if constexpr (kAhead > 2) roff = min(roff, unsigned(n) * unsigned(2 * NP * sizeof(T)));   // (more masked slots than the one padding row covers)
           }
           asm volatile("" : "+s"(roff));
           const T* rowp = reinterpret_cast<const T*>(reinterpret_cast<const char*>(nodeLC) + roff);
 #pragma unroll
-          for (int k = 0; k < 2 * NP; ++k) lrow[u ^ 1][k] = rowp[k];
+          for (int k = 0; k < 2 * NP; ++k) lrow[(u + 1) % kAhead][k] = rowp[k];
           T li[NP], lc[NP];
 #pragma unroll
           for (int k = 0; k < NP; ++k) { li[k] = lcur[k]; lc[k] = lcur[NP + k]; }
+#ifdef MM_DIAG_NO_PRIO
+          if (false) {
+#else
           if (__builtin_expect(--rows_left == 0, 0)) {   // wave-uniform
+#endif
             ++phase;
-            if (phase == 1) { __builtin_amdgcn_s_setprio(2); rows_left = (wave_rows * 3) / 10 + 1; }
-            else if (phase == 2) { __builtin_amdgcn_s_setprio(1); rows_left = wave_rows / 5 + 1; }
+            if (phase == 1) { __builtin_amdgcn_s_setprio(2); rows_left = (wave_rows * MM_SPD_PRIO_B) / 100 + 1; }
+            else if (phase == 2) { __builtin_amdgcn_s_setprio(1); rows_left = (wave_rows * MM_SPD_PRIO_C) / 100 + 1; }
             else { __builtin_amdgcn_s_setprio(0); rows_left = INT32_MAX; }
           }
           bool valid[NC];
@@ -605,9 +643,15 @@ __global__ __launch_bounds__((64 * bwd_waves<T, D>()), (bwd_min_waves_nc<T, D, N
           static_for<NC>([&](auto qc) {
             constexpr int q = decltype(qc)::value;
             valid[q] = jv[q] > ieff;
+#ifdef MM_DIAG_NO_G
+            gs[q] = valid[q] ? T(1) : T(0);
+#else
             gs[q] = valid[q] ? gq[u][q] : T(0);  // upstream gradient (or target) of this row
+#endif
           });
+#ifndef MM_DIAG_NO_G
           request(gq[u]);
+#endif
           // the upstream gradient is known before log(A) unless it depends on the distance (fused loss, d instead of d^2)
           constexpr bool g_first = LOSS == MM_LOSS_NONE && SQ;
           auto jacobi_path = [&](auto qc) __attribute__((always_inline)) {
@@ -717,21 +761,30 @@ __global__ __launch_bounds__((64 * bwd_waves<T, D>()), (bwd_min_waves_nc<T, D, N
 #pragma unroll
             for (int k = 0; k < NP; ++k) m[0][k] += m[q][k];
           });
+#ifdef MM_DIAG_NO_RED
+          *red_ptr = m[0][0] + m[0][NP - 1];
+#else
           *red_ptr = wave_reduce_transposed<NP, T>(m[0], lane);
+#endif
           red_ptr += red_step;
          }
         }
         // row side: each wavefront owns the rows of its slice
-        red_ptr -= red_step * ((i1 - i0 + kAhead - 1) / kAhead * kAhead);
+        const int sw = s1 - s0;
+        red_ptr -= red_step * ((sw + kAhead - 1) / kAhead * kAhead);
         __builtin_amdgcn_wave_barrier();
-        for (int t = lane; t < tw * NP; t += 64) {
-          const int k = t / tw, il = t - k * tw;
-          if (i0 + il < i1) {
-            const int node = SUB ? batch_node(idx32, size_t(i0 + il), n_total) : i0 + il;
+        for (int t = lane; t < sw * NP; t += 64) {
+          const int k = t / sw, il = t - k * sw;
+          {
+            const int node = SUB ? batch_node(idx32, size_t(s0 + il), n_total) : s0 + il;
+#ifndef MM_DIAG_NO_ROW_ATOMICS   // (diagnostic builds, wrong results: what does each part of the row loop's surroundings cost?)
             atomic_add(&accM[size_t(k) * ns + node], redM[wave][il][k]);
+#endif
           }
         }
-        __builtin_amdgcn_wave_barrier();   // redM is rewritten by the next chunk
+        __builtin_amdgcn_wave_barrier();   // redM is rewritten by the next segment
+        }
+        MM_SPD_STAMP_MARK(2);
       }
       r += chunk;
       rem -= chunk;
@@ -753,7 +806,11 @@ __global__ __launch_bounds__((64 * bwd_waves<T, D>()), (bwd_min_waves_nc<T, D, N
       for (int wv = 1; wv < NW; ++wv) sum += colS[wv][q][k][lane];
       if (j < n) {
         const int node = SUB ? batch_node(idx32, size_t(j), n_total) : j;
+#ifndef MM_DIAG_NO_COL_ATOMICS
         atomic_add(&accS[size_t(k) * ns + node], sum);
+#else
+        if (sum == T(12345.678)) accS[0] = sum;
+#endif
       }
     }
     ++cb;
@@ -1219,8 +1276,9 @@ int spd_pdist_bwd_launch_sq(Ws<T>& ws, const T* g, int64_t n, int64_t rb, int64_
   dim3 g3{unsigned(grid), 1, 1};
   const T* nlc = ws.nodeLC;
   const T* nc = ws.nodeC;
+  const WalkShares shares(units, grid);
   launch_timed(PROF_SPD_BWD, kernel, g3, dim3(kThreads), st, nlc, nc, g, int(n), int(rb), int(re), T(wmin), T(wmax), ws.accM, ws.accS, la,
-               idx, int(n_total));
+               idx, int(n_total), shares);
   MM_CHECK_LAUNCH();
   return MM_OK;
 }

@@ -33,6 +33,13 @@ constexpr int64_t kSpdMaxNodes = int64_t(1) << 22;
 #ifndef MM_SPD4_FWD_NC
 #define MM_SPD4_FWD_NC 1
 #endif
+// fp32 SPD(3) backward: columns per lane / wavefronts per SIMD (A/B builds: tools/snap_make.sh nc3 "-DMM_SPD3_BWD_NC=3 -DMM_SPD3_BWD_WAVES=3")
+#ifndef MM_SPD3_BWD_NC
+#define MM_SPD3_BWD_NC 2
+#endif
+#ifndef MM_SPD3_BWD_WAVES
+#define MM_SPD3_BWD_WAVES 4
+#endif
 // fp64 SPD(3) backward: three wavefronts per SIMD (168 registers) since its series constants are scalar operands
 // (smallmat.hpp, fma_sconst64) and the Cayley logarithm is the ring form — 187 registers left alone; the values spilled
 // for the cap land in the Jacobi fallback.  Same box, n = 5000: reference init 96.4 -> 91.9 us, mid-training spread
@@ -41,7 +48,7 @@ constexpr int64_t kSpdMaxNodes = int64_t(1) << 22;
 #define MM_SPD3_F64_BWD_WAVES 3
 #endif
 template <typename T, int D> constexpr int bwd_min_waves() {
-  return (sizeof(T) == 4 && D == 3) ? 4 : ((sizeof(T) == 4 && D == 4) ? MM_SPD4_BWD_WAVES : ((sizeof(T) == 8 && D == 3) ? MM_SPD3_F64_BWD_WAVES : 1));
+  return (sizeof(T) == 4 && D == 3) ? MM_SPD3_BWD_WAVES : ((sizeof(T) == 4 && D == 4) ? MM_SPD4_BWD_WAVES : ((sizeof(T) == 8 && D == 3) ? MM_SPD3_F64_BWD_WAVES : 1));
 }
 // ... with NCX columns per lane forced (0: the default of pair_cols_bwd): two columns of fp32 SPD(4) need ~185 registers —
 // three wavefronts per SIMD (168 registers, the rest spilled) measured best (profiles/r03_experiments.md §2)
@@ -184,9 +191,61 @@ struct ColWalk {
     }
     return lo;
   }
+  // total = q g + r, 0 <= r < g, for total < 2^52 and g < 2^31 WITHOUT a 64-bit integer division: on the device that is a
+  // software routine of several hundred instructions — two of them sat in the prologue of every workgroup of every kernel
+  // that walks the triangle (round 5: ~1 us each at four wavefronts per SIMD).  One fp64 division and a correction step.
+  static __host__ __device__ void divmod_small(int64_t total, int64_t g, int64_t& q, int64_t& r) {
+    q = int64_t(double(total) / double(g));
+    r = total - q * g;
+    if (r < 0) { --q; r += g; } else if (r >= g) { ++q; r -= g; }
+  }
   static __host__ __device__ int64_t share_begin(int64_t total, int64_t w, int64_t g) {
-    const int64_t q = total / g, r = total % g;
+    int64_t q, r;
+    divmod_small(total, g, q, r);
     return q * w + (w < r ? w : r);
+  }
+  // The block holding unit p in closed form (round 5): the binary search above is ~7 evaluations of prefix() — with the two
+  // 64-bit divisions of share_begin, ~1500 scalar instructions in front of every workgroup's first load (2.4 us of the headline
+  // backward's 37 at the median, up to 11 us for the workgroups that also miss the instruction cache there: the stragglers
+  // that end the launch; tools/stamp_timeline.py, profiles/r05_experiments.md).  Triangular part c0 <= c <= c1:
+  //   prefix(c) = A c^2 + (B - A) c - K,  A = bw / 2,  B = bw - 1 - rb,  K = A (c0^2 - c0) + c0 B   -> the root in fp64,
+  // then at most one step either way against prefix() itself; from c1 on the blocks are R = re - rb units each.
+  __host__ __device__ int find_fast(int64_t p) const {
+    const int last = ncb - 1;
+    if (last <= c0) return c0;
+    int c;
+    const int64_t pc1 = prefix(c1);
+    if (p >= pc1) {
+      const int64_t R = re - rb;
+      c = c1 + (R > 0 ? int(double(p - pc1) / double(R)) : 0);
+    } else {
+      const double A = 0.5 * double(bw), Bm = double(bw - 1 - rb) - A;
+      const double K = A * (double(c0) * double(c0) - double(c0)) + double(c0) * double(bw - 1 - rb);
+      c = int((-Bm + sqrt(Bm * Bm + 4.0 * A * (K + double(p)))) / (2.0 * A));
+    }
+    c = c < c0 ? c0 : (c > last ? last : c);
+    if (c < last && prefix(c + 1) <= p) ++c;
+    if (c > c0 && prefix(c) > p) --c;
+    return c;
+  }
+};
+
+// Shares of the balanced walk, cut on the HOST (kernel argument, by value): workgroup w of `grid` takes the units
+// [q w + min(w, r), ...), count q + (w < r).  A 64-bit division is a software routine on the device — two of them, with the
+// binary search for the share's first block, were ~1500 scalar instructions in front of every workgroup's first load: 2.4 us of
+// the headline backward's 37 per workgroup at the median and up to 11 us for the stragglers that end the launch (round 5,
+// tools/stamp_timeline.py phase marks; now ColWalk::find_fast and this: 1.3 us / 6.7 us).
+// (Also measured and NOT kept: shares tilted by dispatch slot — of the four workgroups a CU hosts the youngest finishes ~3 us
+// after the oldest, vector issue being arbitrated oldest first — +-1 .. 6 % per slot: no gain either way; `cross` units charged
+// per column-block start: none.  profiles/r05_experiments.md)
+struct WalkShares {
+  int64_t q;
+  int r;
+  WalkShares() = default;
+  WalkShares(int64_t units, int64_t grid) : q(units / grid), r(int(units % grid)) {}
+  __device__ __forceinline__ void of(int w, int64_t& begin, int& count) const {
+    begin = q * int64_t(w) + (w < r ? w : r);
+    count = int(q) + (w < r ? 1 : 0);
   }
 };
 

@@ -13,9 +13,17 @@ __device__ __forceinline__ unsigned long long stamp_hw_id() {   // HW_ID << 32 |
 
 #ifdef MM_BWD_STAMP
 __device__ unsigned long long g_bwd_stamps[4 * 16384];
+__device__ unsigned long long g_bwd_marks[3 * 16384];   // cycles from the start to the phase marks
 #define MM_SPD_STAMP_BEGIN()                                              \
   const unsigned long long stamp0_ = __builtin_amdgcn_s_memrealtime();    \
-  const unsigned long long stampc0_ = __builtin_amdgcn_s_memtime()
+  const unsigned long long stampc0_ = __builtin_amdgcn_s_memtime();       \
+  unsigned long long stampm_[3] = {0, 0, 0}
+// phase marks (round 5): 0 = shares cut and first block found, 1 = first row about to start (operands landed), 2 = last row done
+// (k = 1 keeps its FIRST value, k = 2 its last); cycles since the start, read through mm_dbg_read_bwd_marks
+#define MM_SPD_STAMP_MARK(k)                                                                   \
+  do {                                                                                         \
+    if ((k) != 1 || stampm_[1] == 0) stampm_[(k)] = __builtin_amdgcn_s_memtime() - stampc0_;   \
+  } while (0)
 #define MM_SPD_STAMP_END()                                                        \
   do {                                                                            \
     if (threadIdx.x == 0 && blockIdx.x < 16384) {                                 \
@@ -24,10 +32,14 @@ __device__ unsigned long long g_bwd_stamps[4 * 16384];
       o_[1] = __builtin_amdgcn_s_memrealtime();                                   \
       o_[2] = stamp_hw_id();                                                      \
       o_[3] = __builtin_amdgcn_s_memtime() - stampc0_;                            \
+      g_bwd_marks[3 * blockIdx.x] = stampm_[0];                                   \
+      g_bwd_marks[3 * blockIdx.x + 1] = stampm_[1];                               \
+      g_bwd_marks[3 * blockIdx.x + 2] = stampm_[2];                               \
     }                                                                             \
   } while (0)
 #else
 #define MM_SPD_STAMP_BEGIN() do {} while (0)
+#define MM_SPD_STAMP_MARK(k) do {} while (0)
 #define MM_SPD_STAMP_END() do {} while (0)
 #endif
 

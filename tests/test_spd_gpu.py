@@ -286,7 +286,15 @@ def test_ill_conditioned_points_fp32(d, cond, vtol, gtol):
     fp64 checker on the SAME (rounded) inputs.  Forming A = B B^T, B = L_i^-1 L_j, costs eps cond(A) of relative accuracy in A's
     small eigenvalues whatever solves it: the rounds 1-3 route was 1.2 (!) of d^2 off at cond(X) = 1e4 for SPD(3) (7.6e-2 for
     SPD(4), 1.5 for SPD(2)).  A wavefront that holds such a pair now solves again by a one-sided Jacobi on B itself
-    (spd_pair.hpp pair_core, smallmat.hpp svd_onesided): measured 1.3e-4 / 8.9e-5 / 4.9e-4 (tools/illcond_probe.py)."""
+    (spd_pair.hpp pair_core, smallmat.hpp svd_onesided): measured 1.3e-4 / 8.9e-5 / 4.9e-4 (tools/illcond_probe.py).
+    The two-column SPD(4) backward (launches of >= 30 M pairs, bands of >= 12 M; forced here by MM_SPD4_BWD_TWO_COLS=1 through
+    test_spd4_two_columns_per_lane_forced) keeps the two-sided solve only — the second solve spilled its hot path — so its
+    GRADIENT at cond(X) = 1e4 is 3e-3 ... 1.5e-2 of the largest entry (seed-dependent: tools/illcond_probe.py 3.2e-3, this
+    test's points 1.5e-2) instead of 8e-5 (d^2 comes from the forward kernel and is the same): pinned here at 2.5e-2, stated in
+    include/mm_manifolds.h."""
+    import os
+    if d == 4 and os.environ.get('MM_SPD4_BWD_TWO_COLS') == '1':
+        gtol = max(gtol, 2.5e-2)
     from graphembed.manifolds import SymmetricPositiveDefinite as SPD
     from oracle import exact
     gen = torch.Generator().manual_seed(int(d * 10 + np.log10(cond)))
@@ -735,7 +743,7 @@ def test_spd4_two_columns_per_lane_forced():
     e = dict(os.environ, MM_SPD4_BWD_TWO_COLS='1')
     r = subprocess.run([sys.executable, '-m', 'pytest', os.path.abspath(__file__), '-x', '-q', '-m', 'gpu', '-p', 'no:cacheprovider',
                         '-k', '(pdist_vs or eigenfree or seamless or recentred or fused_loss or row_sharding or edge_cases '
-                              'or wide_spectra) and not two_columns'],
+                              'or wide_spectra or ill_conditioned) and not two_columns'],
                        env=e, capture_output=True, text=True, timeout=1500, cwd=root)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert ' passed' in r.stdout

@@ -1,0 +1,44 @@
+// Host-side check of the balanced walk's arithmetic (csrc/spd_ws.hpp): ColWalk::find_fast (closed form) against ColWalk::find
+// (binary search) on every block boundary +- 2 and a stride through the line, for full launches and row shards up to n = 2^22,
+// and divmod_small / WalkShares against the integer division.  No GPU involved: tests/test_host_cpu.py builds and runs it.
+#include <cstdio>
+#include <cstdlib>
+#include <cmath>
+#include "../../include/mm_manifolds.h"
+#include "../../matrix-manifolds_amd/csrc/spd_ws.hpp"
+using namespace mm;
+int main() {
+  long bad = 0, checked = 0;
+  for (int n : {2, 3, 5, 63, 64, 65, 127, 129, 300, 1000, 2274, 4039, 5000, 16384, 100000, 1 << 22}) for (int bw : {64, 128, 192, 256, 512}) for (int shard = 0; shard < 4; ++shard) {
+    int rb = 0, re = n;
+    if (shard == 1) { rb = n / 3; re = (2 * n) / 3; } else if (shard == 2) { rb = n - n / 8; re = n; } else if (shard == 3) { rb = 0; re = n / 8 + 1; }
+    ColWalk w(n, rb, re, bw);
+    const int64_t tot = w.total();
+    if (tot <= 0) continue;
+    // every block boundary +-2, and a stride through the line
+    for (int c = w.c0; c <= w.ncb; c += (w.ncb > 4000 ? 97 : 1)) for (int d = -2; d <= 2; ++d) {
+      const int64_t p = w.prefix(c) + d;
+      if (p < 0 || p >= tot) continue;
+      ++checked;
+      if (w.find_fast(p) != w.find(p)) { if (++bad < 10) printf("n=%d bw=%d rb=%d re=%d p=%lld fast=%d find=%d\n", n, bw, rb, re, (long long)p, w.find_fast(p), w.find(p)); }
+    }
+    const int64_t step = tot / 5003 + 1;
+    for (int64_t p = 0; p < tot; p += step) { ++checked; if (w.find_fast(p) != w.find(p)) { if (++bad < 10) printf("n=%d bw=%d rb=%d re=%d p=%lld fast=%d find=%d\n", n, bw, rb, re, (long long)p, w.find_fast(p), w.find(p)); } }
+    // share_begin without the division
+    for (int g : {1, 7, 256, 1000, 1024, 1792}) {
+      int64_t q, r;
+      ColWalk::divmod_small(tot, g, q, r);
+      if (q != tot / g || r != tot % g) { ++bad; printf("divmod n=%d g=%d\n", n, g); }
+      const WalkShares sh(tot, g);   // the shares tile the line exactly (host arithmetic of the device's WalkShares::of)
+      int64_t at = 0;
+      for (int k = 0; k < g; ++k) {
+        const int64_t begin = sh.q * k + (k < sh.r ? k : sh.r), count = sh.q + (k < sh.r ? 1 : 0);
+        if (begin != at || begin != ColWalk::share_begin(tot, k, g)) { ++bad; break; }
+        at += count;
+      }
+      if (at != tot) { ++bad; printf("shares n=%d g=%d\n", n, g); }
+    }
+  }
+  printf("checked %ld, bad = %ld\n", checked, bad);
+  return bad != 0;
+}

@@ -82,6 +82,19 @@ def main():
           f'median {np.median(np.bincount(inv[live], minlength=ncu)):.0f}')
     first = t0 < 2.0
     print(f'workgroups started in the first 2 us: {first.sum()}; their durations us: min {dur[first].min():.1f} median {np.median(dur[first]):.1f} max {dur[first].max():.1f}')
+    if hasattr(raw, 'mm_dbg_read_bwd_marks'):
+        mk = np.zeros(3 * 16384, dtype=np.uint64)
+        fm = raw.mm_dbg_read_bwd_marks
+        fm.restype, fm.argtypes = ctypes.c_int, [ctypes.c_void_p, ctypes.c_size_t]
+        if fm(mk.ctypes.data, mk.nbytes) == 0:
+            mk = mk.reshape(-1, 3)[:len(buf.reshape(-1, 4))][buf.reshape(-1, 4)[:, 1] > 0].astype(np.float64)
+            ghz = np.median(cyc / np.maximum(dur, 1e-3)) / 1e3
+            ph = np.stack([mk[:, 0], mk[:, 1] - mk[:, 0], mk[:, 2] - mk[:, 1], cyc - mk[:, 2]], axis=1) / (ghz * 1e3)
+            names = ['cut + find', 'operands until first row', 'rows', 'after last row (flush, barrier)']
+            print('phases of wavefront 0, us (median / p90 / max): ' + '; '.join(
+                f'{nm} {np.median(ph[:, k]):.2f} / {np.percentile(ph[:, k], 90):.2f} / {ph[:, k].max():.2f}' for k, nm in enumerate(names)))
+    if 'dump' in opt:   # raw per-workgroup records (row = blockIdx.x): start us, end us, CU id, XCC, cycles
+        np.save(opt['dump'], np.stack([t0, t1, cu.astype(np.float64), xcc.astype(np.float64), cyc.astype(np.float64)], axis=1))
     order = np.argsort(t0)
     print('first 12 starts:', t0[order][:12].round(2), ' last 12 ends:', np.sort(t1)[-12:].round(1))
 

@@ -104,16 +104,15 @@ __global__ __launch_bounds__(64 * kPSWaves) void product_sym_kernel(PArgs<T> pa,
   __shared__ T colS[NW][NR + (SD > 0 ? SD * SD - L::NPS : 0)][64];
   __shared__ T redJunk[NW][64];
   const ColWalk walk(n, row_begin, row_end, 64);
-  int64_t pos;   // this workgroup's units, cut on the host (spd_ws.hpp, WalkShares)
-  int rem;
-  shares.of(int(blockIdx.x), pos, rem);
+  // this workgroup's share, cut on the host: the block and row it starts at and its budget of units — one per row,
+  // shares.cross per block entered (spd_ws.hpp, WalkShares / ColWalk::enter)
+  int cb, r, rem;
+  shares.of(walk, int(blockIdx.x), cb, r, rem);
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   bool red_writer;
   const int red_slot = reduce_slot<NR>(lane, red_writer);
   const int64_t base = pair_off(n, row_begin);
-  int cb = rem > 0 ? walk.find_fast(pos) : 0;
-  int r = row_begin + int(pos - walk.prefix(cb));
   T* red_ptr = red_writer ? &redM[wave][0][red_slot] : &redJunk[wave][lane];
   const int red_step = red_writer ? NR : 0;
 
@@ -319,6 +318,7 @@ __global__ __launch_bounds__(64 * kPSWaves) void product_sym_kernel(PArgs<T> pa,
     }
     ++cb;
     r = row_begin;
+    rem -= shares.cross;   // (entering the next block is paid for)
     if (rem > 0) __syncthreads();
   }
   // loss and scale-gradient partials: slots [1 + nf][kLossSlots]
@@ -358,15 +358,19 @@ int launch(int loss_kind, const PArgs<T>& pa, const T* target, int64_t n, int64_
   if (env_grid > 0) grid = env_grid;
   grid = std::max<int64_t>(1, std::min<int64_t>(grid, (units + 3) / 4));
   const dim3 g3{unsigned(grid), 1, 1}, b3{unsigned(64 * kPSWaves), 1, 1};
+  // rows a share pays for entering a column block (ColWalk::enter; as the SPD backward: spd_pair.hpp) — MM_PRODUCT_SYM_CROSS overrides
+  static const int env_cross = std::getenv("MM_PRODUCT_SYM_CROSS") ? std::atoi(std::getenv("MM_PRODUCT_SYM_CROSS")) : (sizeof(T) == 4 ? 16 : 8);
+  const ColWalk hw(int(n), int(rb), int(re), 64);
+  const int cross = std::min(std::max(env_cross, 0), 1024);
   int kinds_code = 0;
   for (int f = 0; f < NV; ++f) kinds_code |= (pa.v[f].kind & 3) << (2 * f);
   static const bool rt_kinds = [] { const char* e = std::getenv("MM_PRODUCT_RT_KINDS"); return e && e[0] == '1'; }();   // (A/B)
   auto with_kinds = [&](auto kc) {
     constexpr int K = decltype(kc)::value;
     if (loss_kind == MM_LOSS_STRESS)
-      product_sym_kernel<T, NV, SD, MM_LOSS_STRESS, K><<<g3, b3, 0, st>>>(pa, table, target, int(n), int(rb), int(re), la, WalkShares(units, grid));
+      product_sym_kernel<T, NV, SD, MM_LOSS_STRESS, K><<<g3, b3, 0, st>>>(pa, table, target, int(n), int(rb), int(re), la, WalkShares(hw.total_aug(cross), grid, cross));
     else
-      product_sym_kernel<T, NV, SD, MM_LOSS_QUOTIENT, K><<<g3, b3, 0, st>>>(pa, table, target, int(n), int(rb), int(re), la, WalkShares(units, grid));
+      product_sym_kernel<T, NV, SD, MM_LOSS_QUOTIENT, K><<<g3, b3, 0, st>>>(pa, table, target, int(n), int(rb), int(re), la, WalkShares(hw.total_aug(cross), grid, cross));
   };
   bool launched = false;
   if constexpr (NV == 1 || NV == 2) launched = !rt_kinds && for_kind_code<NV>(kinds_code, with_kinds);

@@ -454,16 +454,15 @@ __global__ __launch_bounds__((64 * bwd_waves<T, D>()), (bwd_min_waves_nc<T, D, N
   __shared__ T colS[NW][NC][D * D][64];
   MM_SPD_STAMP_BEGIN();
   const ColWalk walk(n, row_begin, row_end, 64 * NC);
-  int64_t pos;   // this workgroup's units of the walk: cut on the host (WalkShares)
-  int rem;       // block-uniform (a share is < 2^31 rows)
-  shares.of(int(blockIdx.x), pos, rem);
+  // this workgroup's share of the walk, cut on the host (WalkShares): the column block and row it starts at and its budget of
+  // units — one per row, shares.cross per block entered (ColWalk::enter); block-uniform
+  int cb, r, rem;
+  shares.of(walk, int(blockIdx.x), cb, r, rem);
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform -> row operands stay scalar loads
   bool red_writer;
   const int red_slot = reduce_slot<NP>(lane, red_writer);  // which entry of M this lane holds after the row reduction
   const int64_t base = pair_off(n, row_begin);
-  int cb = rem > 0 ? walk.find_fast(pos) : 0;            // current column block
-  int r = row_begin + int(pos - walk.prefix(cb));        // next row of it
   MM_SPD_STAMP_MARK(0);
   // Vector issue is arbitrated oldest wavefront first: of equal shares started together, the oldest workgroup of a
   // CU finishes when the youngest is barely half way, and the rest of the launch runs at one or two wavefronts per
@@ -815,6 +814,7 @@ __global__ __launch_bounds__((64 * bwd_waves<T, D>()), (bwd_min_waves_nc<T, D, N
     }
     ++cb;
     r = row_begin;
+    rem -= shares.cross;            // (entering the next block is paid for: ColWalk::enter)
     if (rem > 0) __syncthreads();   // colS is rewritten by the next block
   }
   if constexpr (LOSS != MM_LOSS_NONE) {
@@ -1235,6 +1235,10 @@ int spd_pdist_fwd_t(const T* x, int64_t n, int64_t rb, int64_t re, int squared, 
 // One launch of (at most) the resident capacity; fewer workgroups when the row range is small (>= 8 rows of a column
 // block per workgroup, two per wavefront).
 constexpr int kBwdTI = 16;   // rows per wavefront and chunk
+// Rows a share pays for entering a column block (ColWalk::enter).  Sweep on the headline backward (fp32 SPD(3), n = 5000, us):
+// 0 / 4 / 8 / 12 / 16 / 24 rows -> 45.4 / 45.3 / 44.3 / 43.7 / 43.6 / 43.5; the launch's span 43.0 -> 41.2, its last workgroups
+// 42.8 - 43.0 -> 40.8 - 41.2 (profiles/r05_experiments.md).  An fp64 row takes twice the time: half the rows.
+template <typename T> constexpr int bwd_cross_units() { return sizeof(T) == 4 ? 16 : 8; }
 // fp32 SPD(4): one column per lane by default (128 registers, four wavefronts per SIMD); two columns — scalar bookkeeping,
 // row-operand loads and the transposing reduction paid once per 128 pairs, three wavefronts per SIMD — win on large launches
 // only (fused QuotientLoss step, us, one / two columns: n = 2274 58.6 / 71.6, 4096 109 / 108, 5793 170 / 174-197,
@@ -1276,7 +1280,11 @@ int spd_pdist_bwd_launch_sq(Ws<T>& ws, const T* g, int64_t n, int64_t rb, int64_
   dim3 g3{unsigned(grid), 1, 1};
   const T* nlc = ws.nodeLC;
   const T* nc = ws.nodeC;
-  const WalkShares shares(units, grid);
+  // block-entry cost of the shares (ColWalk::enter), in rows of a block: MM_SPD_BWD_CROSS overrides (0 = equal shares)
+  static const int env_cross = std::getenv("MM_SPD_BWD_CROSS") ? std::atoi(std::getenv("MM_SPD_BWD_CROSS")) : bwd_cross_units<T>();
+  const ColWalk hw(int(n), int(rb), int(re), 64 * kCols);
+  const int cross = std::min(std::max(env_cross, 0), 1024);
+  const WalkShares shares(hw.total_aug(cross), grid, cross);
   launch_timed(PROF_SPD_BWD, kernel, g3, dim3(kThreads), st, nlc, nc, g, int(n), int(rb), int(re), T(wmin), T(wmax), ws.accM, ws.accS, la,
                idx, int(n_total), shares);
   MM_CHECK_LAUNCH();

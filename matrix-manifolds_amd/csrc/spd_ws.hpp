@@ -208,25 +208,50 @@ struct ColWalk {
   // 64-bit divisions of share_begin, ~1500 scalar instructions in front of every workgroup's first load (2.4 us of the headline
   // backward's 37 at the median, up to 11 us for the workgroups that also miss the instruction cache there: the stragglers
   // that end the launch; tools/stamp_timeline.py, profiles/r05_experiments.md).  Triangular part c0 <= c <= c1:
-  //   prefix(c) = A c^2 + (B - A) c - K,  A = bw / 2,  B = bw - 1 - rb,  K = A (c0^2 - c0) + c0 B   -> the root in fp64,
-  // then at most one step either way against prefix() itself; from c1 on the blocks are R = re - rb units each.
-  __host__ __device__ int find_fast(int64_t p) const {
+  //   prefix(c0 + u) = A u^2 + Bs u  -> the positive root, then a step or two either way against prefix() itself; from c1 on the
+  // blocks are R = re - rb units each.
+  __host__ __device__ int find_fast(int64_t p, int cross = 0) const {
+    // (cross > 0: the same search in the line that has `cross` extra units in front of every block's rows — aprefix())
+    // The guess in fp32 (one v_sqrt_f32 / one v_rcp_f32: an fp64 square root and two fp64 divisions were 1.3 us of every
+    // workgroup's prologue), made exact by stepping against aprefix() itself — the guess is within a block of the answer for
+    // every n the entry points accept (2^16 blocks: 24 bits resolve 0.004 of a block).
     const int last = ncb - 1;
     if (last <= c0) return c0;
     int c;
-    const int64_t pc1 = prefix(c1);
+    const int64_t pc1 = aprefix(c1, cross);
     if (p >= pc1) {
-      const int64_t R = re - rb;
-      c = c1 + (R > 0 ? int(double(p - pc1) / double(R)) : 0);
+      const float R = float(re - rb + cross);
+      c = c1 + int(float(p - pc1) / (R > 0.f ? R : 1.f));
     } else {
-      const double A = 0.5 * double(bw), Bm = double(bw - 1 - rb) - A;
-      const double K = A * (double(c0) * double(c0) - double(c0)) + double(c0) * double(bw - 1 - rb);
-      c = int((-Bm + sqrt(Bm * Bm + 4.0 * A * (K + double(p)))) / (2.0 * A));
+      // in u = c - c0: aprefix = A u^2 + Bs u,  A = bw / 2,  Bs = bw / 2 - 1 + (bw c0 - rb) + cross  (|bw c0 - rb| < bw: no
+      // large terms cancel, whatever the row shard)
+      const float A = 0.5f * float(bw), Bs = A - 1.0f + float(bw * c0 - rb + cross);
+      c = c0 + int((-Bs + sqrtf(Bs * Bs + 4.0f * A * float(p))) / (2.0f * A));
     }
     c = c < c0 ? c0 : (c > last ? last : c);
-    if (c < last && prefix(c + 1) <= p) ++c;
-    if (c > c0 && prefix(c) > p) --c;
+    for (int k = 0; k < 4 && c < last && aprefix(c + 1, cross) <= p; ++k) ++c;
+    for (int k = 0; k < 4 && c > c0 && aprefix(c, cross) > p; ++k) --c;
     return c;
+  }
+  // Shares that PAY for entering a column block (round 5).  A workgroup whose share spans a block boundary flushes the column
+  // sums of the block it leaves (LDS, barrier, d^2 NC atomics per lane), requests the operands of the next block's columns and
+  // starts its request pipeline again: +2.0 ... 3.2 us of 35 on the headline backward — and since the four workgroups of a CU
+  // finish in dispatch order (oldest first), a boundary in the share of a YOUNGEST workgroup was what ended the launch: the six
+  // slowest workgroups of 1024 were all of this kind, 42.3 us against 39.5 for the slowest of the others
+  // (tools/stamp_timeline.py, profiles/r05_experiments.md).  The line of units therefore gets `cross` extra units in front of
+  // every block's rows, the shares are equal in THAT line (WalkShares on total_aug), and enter() maps a share's start back:
+  // a share that holds a block start holds `cross` rows less.  aprefix(c) = prefix(c) + cross (c - c0).
+  __host__ __device__ int64_t aprefix(int c, int cross) const { return prefix(c) + int64_t(cross) * (c > c0 ? c - c0 : 0); }
+  __host__ __device__ int64_t total_aug(int cross) const { return total() + int64_t(cross) * (ncb > c0 ? ncb - c0 : 0); }
+  // A share [a, a + count) of the augmented line, entered: the block that holds a, the first row of it to process and the units
+  // the share has left for rows (a start inside a block's entry zone pays the rest of the zone and starts at the block's
+  // first row).  The walker then spends one unit per row and `cross` units whenever it moves on to the next block.
+  __host__ __device__ void enter(int64_t a, int count, int cross, int* block, int* row, int* left) const {
+    const int c = find_fast(a, cross);
+    const int64_t off = a - aprefix(c, cross);
+    *block = c;
+    if (off < cross) { *row = rb; *left = count - int(cross - off); }
+    else { *row = rb + int(off - cross); *left = count; }
   }
 };
 
@@ -241,11 +266,19 @@ struct ColWalk {
 struct WalkShares {
   int64_t q;
   int r;
+  int cross;   // units charged per column-block start (ColWalk::enter); 0: `units` is the plain line
   WalkShares() = default;
-  WalkShares(int64_t units, int64_t grid) : q(units / grid), r(int(units % grid)) {}
+  WalkShares(int64_t units, int64_t grid, int cross_ = 0) : q(units / grid), r(int(units % grid)), cross(cross_) {}
   __device__ __forceinline__ void of(int w, int64_t& begin, int& count) const {
     begin = q * int64_t(w) + (w < r ? w : r);
     count = int(q) + (w < r ? 1 : 0);
+  }
+  // ... entered (ColWalk::enter): the block and row the workgroup starts at and its budget of units
+  __device__ __forceinline__ void of(const ColWalk& walk, int w, int& block, int& row, int& left) const {
+    int64_t a;
+    int cnt;
+    of(w, a, cnt);
+    walk.enter(a, cnt, cross, &block, &row, &left);
   }
 };
 

@@ -36,10 +36,14 @@ int launch_pairs(const T* xpad, const T* g, int64_t n, int m, int64_t rb, int64_
   static const int64_t env_grid = std::getenv("MM_VEC_BWD_GRID") ? std::atoll(std::getenv("MM_VEC_BWD_GRID")) : 0;
   if (env_grid > 0) grid = env_grid;
   grid = std::max<int64_t>(1, std::min<int64_t>(grid, (units + 7) / 8));
+  // rows a share pays for entering a column block (ColWalk::enter; as the SPD backward: spd_pair.hpp) — MM_VEC_BWD_CROSS overrides
+  static const int env_cross = std::getenv("MM_VEC_BWD_CROSS") ? std::atoi(std::getenv("MM_VEC_BWD_CROSS")) : (sizeof(T) == 4 ? 16 : 8);
+  const ColWalk hw(int(n), int(rb), int(re), 64 * vsym_cols<T, MP>());
+  const int cross = std::min(std::max(env_cross, 0), 1024);
   {
     ProfScope prof(PROF_VEC_BWD, st);
     vec_pdist_bwd_sym_kernel<T, KIND, MP, LOSS, SQ><<<dim3(unsigned(grid)), dim3(kThreads), 0, st>>>(xpad, g, int(n), m, int(rb),
-                                                                                                   int(re), acc, la, WalkShares(units, grid));
+                                                                                                   int(re), acc, la, WalkShares(hw.total_aug(cross), grid, cross));
   }
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? MM_OK : int(e);

@@ -84,16 +84,15 @@ void vec_pdist_bwd_sym_kernel(const T* __restrict__ xpad /* [n+1][MP] */, const 
   __shared__ T colS[NW][NC][NR][64];
   __shared__ T redJunk[NW][64];
   const ColWalk walk(n, row_begin, row_end, 64 * NC);
-  int64_t pos;
-  int rem;
-  shares.of(int(blockIdx.x), pos, rem);
+  // this workgroup's share, cut on the host: the block and row it starts at and its budget of units — one per row,
+  // shares.cross per block entered (spd_ws.hpp, WalkShares / ColWalk::enter)
+  int cb, r, rem;
+  shares.of(walk, int(blockIdx.x), cb, r, rem);
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   bool red_writer;
   const int red_slot = reduce_slot<NR>(lane, red_writer);
   const int64_t base = pair_off(n, row_begin);
-  int cb = rem > 0 ? walk.find_fast(pos) : 0;
-  int r = row_begin + int(pos - walk.prefix(cb));
   // (priority outranks age in the vector-issue arbiter: whoever is ahead in its share yields — spd.hip)
   const int wave_rows = (rem + NW - 1) / NW;
   int rows_left = (wave_rows * 2) / 5 + 1;
@@ -261,6 +260,7 @@ void vec_pdist_bwd_sym_kernel(const T* __restrict__ xpad /* [n+1][MP] */, const 
     }
     ++cb;
     r = row_begin;
+    rem -= shares.cross;   // (entering the next block is paid for)
     if (rem > 0) __syncthreads();
   }
   if constexpr (LOSS != MM_LOSS_NONE) {

@@ -37,6 +37,35 @@ int main() {
         at += count;
       }
       if (at != tot) { ++bad; printf("shares n=%d g=%d\n", n, g); }
+      // shares with a block-entry cost: walking every share as the kernels do (enter, one unit per row, `cross` per block
+      // entered) visits every (block, row) of the triangle exactly once, in order
+      for (int cross : {0, 3, 8, 40}) {
+        if (tot > 3000000) continue;   // (the walk below is linear in the units)
+        const int64_t atot = w.total_aug(cross);
+        const WalkShares sc(atot, g, cross);
+        int eb = w.c0, er = rb;      // the (block, row) the next share is expected to continue at
+        int64_t seen = 0;
+        bool ok = true;
+        for (int k = 0; k < g && ok; ++k) {
+          const int64_t a = sc.q * k + (k < sc.r ? k : sc.r);
+          const int cnt = int(sc.q) + (k < sc.r ? 1 : 0);
+          int cb, r, rem;
+          w.enter(a, cnt, cross, &cb, &r, &rem);
+          while (rem > 0) {
+            const int hi = w.hi(cb);
+            const int take = (hi - r) < rem ? (hi - r) : rem;
+            if (take > 0) {
+              // normalise the expectation past exhausted blocks
+              while (er >= w.hi(eb) && eb < w.ncb - 1) { ++eb; er = rb; }
+              if (cb != eb || r != er) { ok = false; break; }
+              er += take; seen += take;
+            }
+            rem -= take; r += take;
+            if (rem > 0) { ++cb; r = rb; rem -= cross; if (cb >= w.ncb) { ok = rem <= 0; break; } }
+          }
+        }
+        if (!ok || seen != tot) { if (++bad < 10) printf("walk n=%d bw=%d rb=%d re=%d g=%d cross=%d seen=%lld tot=%lld\n", n, bw, rb, re, g, cross, (long long)seen, (long long)tot); }
+      }
     }
   }
   printf("checked %ld, bad = %ld\n", checked, bad);

@@ -453,6 +453,11 @@ __global__ __launch_bounds__((64 * bwd_waves<T, D>()), (bwd_min_waves_nc<T, D, N
   __shared__ T redM[NW][TI][NP];
   __shared__ T colS[NW][NC][D * D][64];
   MM_SPD_STAMP_BEGIN();
+#ifndef MM_DIAG_NO_PRIO
+  // (first thing: a wavefront starts at priority 0, and with the older workgroups of its CU in their row loops at 3 the prologue
+  // of a late arrival would be served last)
+  __builtin_amdgcn_s_setprio(3);
+#endif
   const ColWalk walk(n, row_begin, row_end, 64 * NC);
   // this workgroup's share of the walk, cut on the host (WalkShares): the column block and row it starts at and its budget of
   // units — one per row, shares.cross per block entered (ColWalk::enter); block-uniform
@@ -478,8 +483,8 @@ __global__ __launch_bounds__((64 * bwd_waves<T, D>()), (bwd_min_waves_nc<T, D, N
   const int wave_rows = (rem + NW - 1) / NW;
   int rows_left = (wave_rows * MM_SPD_PRIO_A) / 100 + 1;   // rows until the next priority step
   int phase = 0;
-#ifndef MM_DIAG_NO_PRIO
-  __builtin_amdgcn_s_setprio(3);
+#ifndef MM_SPD_PRIO_LOOP   // (A/B builds: priority at which the row loop starts; the prologue always runs at 3)
+#define MM_SPD_PRIO_LOOP 3
 #endif
   // The row reduction leaves one total per lane; NP of the lanes hold distinct entries, the others duplicates.  All
   // lanes store (an exec-masked store costs two scalar instructions per row): writers into redM, advancing by one row
@@ -600,6 +605,9 @@ __global__ __launch_bounds__((64 * bwd_waves<T, D>()), (bwd_min_waves_nc<T, D, N
         for (int u = 0; u < kAhead; ++u) request(gq[u]);
 #endif
         MM_SPD_STAMP_MARK(1);
+#if MM_SPD_PRIO_LOOP != 3
+        if (phase == 0) __builtin_amdgcn_s_setprio(MM_SPD_PRIO_LOOP);   // (the prologue ran at 3: a workgroup that arrives outranks the row loops of the older ones)
+#endif
         for (int s0 = i0; s0 < i1; s0 += TI) {   // segments of TI rows: their row sums are staged in LDS and leave together
         const int s1 = min(s0 + TI, i1);
         for (int ib = s0; ib < s1; ib += kAhead) {
@@ -633,9 +641,14 @@ __global__ __launch_bounds__((64 * bwd_waves<T, D>()), (bwd_min_waves_nc<T, D, N
           if (__builtin_expect(--rows_left == 0, 0)) {   // wave-uniform
 #endif
             ++phase;
+#if MM_SPD_PRIO_LOOP == 3
             if (phase == 1) { __builtin_amdgcn_s_setprio(2); rows_left = (wave_rows * MM_SPD_PRIO_B) / 100 + 1; }
             else if (phase == 2) { __builtin_amdgcn_s_setprio(1); rows_left = (wave_rows * MM_SPD_PRIO_C) / 100 + 1; }
             else { __builtin_amdgcn_s_setprio(0); rows_left = INT32_MAX; }
+#else
+            if (phase == 1) { __builtin_amdgcn_s_setprio(1); rows_left = (wave_rows * MM_SPD_PRIO_B) / 100 + 1; }
+            else { __builtin_amdgcn_s_setprio(0); rows_left = INT32_MAX; }
+#endif
           }
           bool valid[NC];
           T gs[NC], m[NC][NP];

@@ -68,6 +68,7 @@ __global__ __launch_bounds__((64 * kVSymWaves), (vsym_min_waves<T, MP>()))
 void vec_pdist_bwd_sym_kernel(const T* __restrict__ xpad /* [n+1][MP] */, const T* __restrict__ g, int n, int m, int row_begin,
                               int row_end, T* __restrict__ acc /* the gradient [n][m] (training-step form: the workspace's gacc) */,
                               LossArgs<T> la, WalkShares shares /* the workgroups' units of the walk, cut on the host */) {
+  __builtin_amdgcn_s_setprio(3);   // (first thing: a wavefront starts at 0 and its prologue would be served after the older workgroups' row loops)
   constexpr int NW = kVSymWaves, TI = kVSymTI;
   constexpr int NC = vsym_cols<T, MP>();
   constexpr bool kEuclid = KIND == MM_EUCLIDEAN;
@@ -97,7 +98,6 @@ void vec_pdist_bwd_sym_kernel(const T* __restrict__ xpad /* [n+1][MP] */, const 
   const int wave_rows = (rem + NW - 1) / NW;
   int rows_left = (wave_rows * 2) / 5 + 1;
   int phase = 0;
-  __builtin_amdgcn_s_setprio(3);
   T* red_ptr = red_writer ? &redM[wave][0][red_slot] : &redJunk[wave][lane];
   const int red_step = red_writer ? NR : 0;
 

@@ -472,16 +472,21 @@ __global__ __launch_bounds__((64 * bwd_waves<T, D>()), (bwd_min_waves_nc<T, D, N
   // Vector issue is arbitrated oldest wavefront first: of equal shares started together, the oldest workgroup of a
   // CU finishes when the youngest is barely half way, and the rest of the launch runs at one or two wavefronts per
   // SIMD (measured: five completion steps of 256 workgroups, the last 20 us at <= 40 % residency).  Priority outranks
-  // age, so every wavefront LOWERS its priority as it advances through its share (3 until 40 %, 2 until 70 %,
-  // 1 until 90 %, then 0): whoever is ahead yields to whoever is behind, and all of them enter the last tenth together.
+  // age, so every wavefront LOWERS its priority as it advances through its share (3, 2, 1 over three equal stretches, 0 for the
+  // last tenth): whoever is ahead yields to whoever is behind, and all of them enter the last stretch together.
   // Progress is counted in rows of THIS wavefront (a quarter of the share's), one scalar compare per row.
-#ifndef MM_SPD_PRIO_A   // (A/B builds: the three priority steps in per cent of a wavefront's rows)
-#define MM_SPD_PRIO_A 40
-#define MM_SPD_PRIO_B 30
-#define MM_SPD_PRIO_C 20
-#endif
   const int wave_rows = (rem + NW - 1) / NW;
-  int rows_left = (wave_rows * MM_SPD_PRIO_A) / 100 + 1;   // rows until the next priority step
+  // three equal stretches at 3, 2, 1 and a LAST one at 0 of a tenth of the rows, at least four: what follows the last step runs
+  // in dispatch order — oldest wavefront first — and its length is the spread of the finishing times.  (Rounds 2-4 stepped at
+  // 40 / 70 / 90 % + 1 row each: with the ~25 rows a wavefront has in the headline launch the third step fell on the last row
+  // and the final stretch was the six rows behind the second.  Headline 43.3 -> 42.2 us, SPD(4) n = 2274 27.4 -> 25.6; a fixed
+  // four rows for every size cost the 500-row shares of n = 16384 2 %: profiles/r05_experiments.md.)
+#ifndef MM_SPD_PRIO_LAST
+#define MM_SPD_PRIO_LAST 4
+#endif
+  const int prio_last = max(MM_SPD_PRIO_LAST, wave_rows / 10);
+  const int prio_stretch = max(wave_rows - prio_last, 3) / 3;
+  int rows_left = prio_stretch;   // rows until the next priority step
   int phase = 0;
 #ifndef MM_SPD_PRIO_LOOP   // (A/B builds: priority at which the row loop starts; the prologue always runs at 3)
 #define MM_SPD_PRIO_LOOP 3
@@ -642,11 +647,11 @@ __global__ __launch_bounds__((64 * bwd_waves<T, D>()), (bwd_min_waves_nc<T, D, N
 #endif
             ++phase;
 #if MM_SPD_PRIO_LOOP == 3
-            if (phase == 1) { __builtin_amdgcn_s_setprio(2); rows_left = (wave_rows * MM_SPD_PRIO_B) / 100 + 1; }
-            else if (phase == 2) { __builtin_amdgcn_s_setprio(1); rows_left = (wave_rows * MM_SPD_PRIO_C) / 100 + 1; }
+            if (phase == 1) { __builtin_amdgcn_s_setprio(2); rows_left = prio_stretch; }
+            else if (phase == 2) { __builtin_amdgcn_s_setprio(1); rows_left = max(wave_rows - prio_last - 2 * prio_stretch, 1); }
             else { __builtin_amdgcn_s_setprio(0); rows_left = INT32_MAX; }
-#else
-            if (phase == 1) { __builtin_amdgcn_s_setprio(1); rows_left = (wave_rows * MM_SPD_PRIO_B) / 100 + 1; }
+#else   // (A/B builds: the prologue at 3, the row loop from 2 down — two steps)
+            if (phase == 1) { __builtin_amdgcn_s_setprio(1); rows_left = max(wave_rows - prio_last - 2 * prio_stretch, 1) + prio_stretch; }
             else { __builtin_amdgcn_s_setprio(0); rows_left = INT32_MAX; }
 #endif
           }

@@ -96,7 +96,10 @@ void vec_pdist_bwd_sym_kernel(const T* __restrict__ xpad /* [n+1][MP] */, const 
   const int64_t base = pair_off(n, row_begin);
   // (priority outranks age in the vector-issue arbiter: whoever is ahead in its share yields — spd.hip)
   const int wave_rows = (rem + NW - 1) / NW;
-  int rows_left = (wave_rows * 2) / 5 + 1;
+  // (three equal stretches at 3, 2, 1 and a last one at 0 of a tenth of the rows, at least four: spd_pair.hpp)
+  const int prio_last = max(4, wave_rows / 10);
+  const int prio_stretch = max(wave_rows - prio_last, 3) / 3;
+  int rows_left = prio_stretch;
   int phase = 0;
   T* red_ptr = red_writer ? &redM[wave][0][red_slot] : &redJunk[wave][lane];
   const int red_step = red_writer ? NR : 0;
@@ -163,8 +166,8 @@ void vec_pdist_bwd_sym_kernel(const T* __restrict__ xpad /* [n+1][MP] */, const 
             for (int k = 0; k < MP; ++k) xrow[(u & 1) ^ 1][k] = rowp[k];
             if (__builtin_expect(--rows_left == 0, 0)) {
               ++phase;
-              if (phase == 1) { __builtin_amdgcn_s_setprio(2); rows_left = (wave_rows * 3) / 10 + 1; }
-              else if (phase == 2) { __builtin_amdgcn_s_setprio(1); rows_left = wave_rows / 5 + 1; }
+              if (phase == 1) { __builtin_amdgcn_s_setprio(2); rows_left = prio_stretch; }
+              else if (phase == 2) { __builtin_amdgcn_s_setprio(1); rows_left = max(wave_rows - prio_last - 2 * prio_stretch, 1); }
               else { __builtin_amdgcn_s_setprio(0); rows_left = INT32_MAX; }
             }
             T rsum[NR];

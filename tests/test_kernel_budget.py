@@ -32,7 +32,9 @@ BUDGET = {
     # config 5: SPD(4), one column per lane (small launches, minibatches) and two (large launches)
     'spd_pdist_fwd_kernel<float, 4, 8, true>': (96, 0, 0),
     'spd_pdist_bwd_kernel<float, 4, 16, 0, true, 0, false>': (128, 0, 0),
-    'spd_pdist_bwd_kernel<float, 4, 16, 2, true, 0, true>': (128, 0, 0),
+    # (the minibatch form spills three values since round 5 — stored in the prologue / per-block set-up, reloaded in the slice set-up
+    # and behind the row loop: no scratch access between the first and the last row of a slice, tools/devasm.sh)
+    'spd_pdist_bwd_kernel<float, 4, 16, 2, true, 0, true>': (128, 4, 32),
     'spd_pdist_bwd_kernel<float, 4, 16, 0, true, 2, false>': (168, 16, 48),
     'spd_pdist_bwd_kernel<float, 4, 16, 2, true, 2, false>': (168, 40, 96),
     # config 4: the mixed-manifold pair kernel (H x S x SPD(2), kinds as template arguments) and its step kernel

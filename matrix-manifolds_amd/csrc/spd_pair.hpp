@@ -293,6 +293,11 @@ __device__ __forceinline__ T pair_value(const TL (&li)[Packed<D>::NP], const T (
 template <typename T, int D> constexpr int pair_cols() { return (sizeof(T) == 4 && D <= 3) ? 2 : ((sizeof(T) == 4 && D == 4) ? MM_SPD4_FWD_NC : 1); }
 template <typename T, int D> constexpr int pair_cols_bwd() { return (sizeof(T) == 4 && D == 3) ? MM_SPD3_BWD_NC : (sizeof(T) == 4 && D <= 3) ? 2 : ((sizeof(T) == 4 && D == 4) ? MM_SPD4_BWD_NC : 1); }
 
+// (Round 5: the preparation launch in front of this kernel — spd_prep_kernel, 5 us — cannot be fused into it at a profit.  The row
+// operand must reach the arithmetic as a SCALAR operand: handed over through v_readlane, every vector instruction that reads a
+// scalar register a vector instruction has just written stalls its SIMD ~20 cycles (forward + 40 ... 55 %); as wave-uniform values
+// in VECTOR registers (LDS broadcast) the multiply-adds read three vector operands instead of two (+ 25 % at SPD(4) n = 16384).
+// Scalar loads from a table that another launch wrote are the cheap way.  profiles/r05_experiments.md, section 12.)
 // Tile: TI rows x (256 x NC) columns per workgroup; lane l of wavefront w owns the columns jbase + 64 (NC w + q) + l.
 // The row loop is unrolled twice with two alternating scalar register sets for the row operand L_i^-1 (no copies), the
 // output row is a running scalar pointer (row i + 1 starts n - i - 2 elements after row i) plus a fixed lane offset:
@@ -1216,7 +1221,10 @@ int spd_pdist_prepare(const T* x, int64_t n, Ws<T>& ws, int flags, hipStream_t s
   return MM_OK;
 }
 
-constexpr int kFwdTI = 8;   // rows of a forward tile (sweep on MI355X, SPD(3) fp32, n = 5000: 8 / 16 / 32 rows -> 28.8 / 30.1 / 33.0 us)
+#ifndef MM_FWD_TI   // (A/B builds)
+#define MM_FWD_TI 8
+#endif
+constexpr int kFwdTI = MM_FWD_TI;   // rows of a forward tile (sweep on MI355X, SPD(3) fp32, n = 5000: 8 / 16 / 32 rows -> 28.8 / 30.1 / 33.0 us)
 template <typename T, int D, int TI>
 int spd_pdist_fwd_launch(const T* nl, const T* nc, const T* nld, int64_t n, int64_t rb, int64_t re, int squared, double wmin, double wmax,
                          T* out, hipStream_t st) {

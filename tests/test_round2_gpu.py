@@ -136,7 +136,8 @@ FUZZ = [('tests/fuzz_pdist.py', ['50', '20261']), ('tests/fuzz_pdist.py', ['6', 
         ('tests/fuzz_misc.py', ['50', '20265']), ('tests/fuzz_metrics.py', ['40', '20266']),
         ('tools/fuzz_product.py', ['50', '20267']), ('tools/fuzz_product.py', ['30', '20268', '--single']),
         ('tools/fuzz_product.py', ['8', '20270', '--big']),
-        ('tools/fuzz_graph.py', ['30', '20269']), ('tools/fuzz_step.py', ['40', '20271']), ('tools/fuzz_step.py', ['4', '20272', '--big'])]
+        ('tools/fuzz_graph.py', ['30', '20269']), ('tools/fuzz_step.py', ['40', '20271']), ('tools/fuzz_step.py', ['4', '20272', '--big']),
+        ('tools/fuzz_walk.py', ['60', '20273'])]   # (round 5: shares cut on the host, closed-form block search, block-entry costs)
 
 
 @pytest.mark.parametrize('script,argv', FUZZ, ids=[f'{os.path.basename(s)[:-3]}{"-" + a[-1][2:] if a[-1].startswith("--") else ""}'

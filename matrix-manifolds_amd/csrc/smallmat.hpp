@@ -1332,6 +1332,31 @@ template <typename T> __device__ __forceinline__ T log_spd2(const T (&a)[3], T w
   return N::fma(lp, lp, lm * lm);
 }
 
+// The same for a PAIR of the all-pairs kernels (round 5: SPD(2) ran the Jacobi eigensolve with eigenvectors in its own pair
+// kernels — forward 19.8, backward 32.2 us at n = 5000 against 22.8 / 42.4 for SPD(3), whose matrices have twice the entries).
+// A = B B^T with B = L_i^-1 chol(X_j) lower triangular (li, yj packed 00, 10, 11).  lambda+ = mid + r as above; the SMALL
+// eigenvalue comes from det A = (b00 b11)^2 — a product, where mid - r cancels: lambda- = det A / lambda+ keeps its relative
+// accuracy whatever the condition of the pair (the Jacobi route needed a second, one-sided solve for that in fp32).  For r -> 0
+// the two logarithms differ by rounding only; beta multiplies a matrix of norm r, so the error it carries into mlog stays
+// eps |log lambda| / 2 (and r = 0 gives a finite beta times exact zeros).  Returns l+^2 + l-^2 (eigenvalues value-clamped as in
+// spd.py:163-169); mlog = log A.
+template <typename T, typename TL> __device__ __forceinline__ T log_pair2_chol(const TL (&li)[3], const T (&yj)[3], T wmin, T wmax,
+                                                                              T (&mlog)[3]) {
+  using N = Num<T>;
+  const T b00 = li[0] * yj[0], b10 = N::fma(li[2], yj[1], li[1] * yj[0]), b11 = li[2] * yj[2];
+  const T a00 = b00 * b00, a10 = b00 * b10, a11 = N::fma(b10, b10, b11 * b11);
+  const T mid = T(0.5) * (a00 + a11), dh = T(0.5) * (a00 - a11);
+  const T r = N::sqrt(N::fma(dh, dh, a10 * a10));
+  const T lam_p = mid + r, sdet = b00 * b11;
+  const T lam_m = (sdet * sdet) * N::rcp(lam_p);
+  const T lp = N::log(N::min(N::max(lam_p, wmin), wmax)), lm = N::log(N::min(N::max(lam_m, wmin), wmax));
+  const T beta = T(0.5) * (lp - lm) * N::rcp(N::max(r, N::tiny())), alpha = T(0.5) * (lp + lm);
+  mlog[0] = N::fma(beta, dh, alpha);
+  mlog[1] = beta * a10;
+  mlog[2] = N::fma(-beta, dh, alpha);
+  return N::fma(lp, lp, lm * lm);
+}
+
 // out (packed) = V diag(f) V^T
 template <typename T, int D>
 __device__ __forceinline__ void vdvt(const T (&v)[D][D], const T (&f)[D], T (&out)[Packed<D>::NP]) {

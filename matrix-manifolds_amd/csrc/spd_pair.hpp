@@ -279,6 +279,11 @@ __device__ __forceinline__ T pair_value(const TL (&li)[Packed<D>::NP], const T (
     if (__builtin_expect(!__any(!(gate <= T(kCayleyGate))), 1)) return frob2<T, D>(m0);
     T w[D], lw[D], v[D][D];
     return pair_core<T, D, false, CHOL>(li, xj, wmin, wmax, w, lw, v);
+#ifndef MM_SPD2_JACOBI   // (A/B builds: the Jacobi route of rounds 1-4)
+  } else if constexpr (D == 2 && CHOL) {
+    T mlog[3];   // (closed form, the small eigenvalue from the determinant: smallmat.hpp; the matrix is not needed here)
+    return log_pair2_chol<T>(li, xj, wmin, wmax, mlog);
+#endif
   } else {
     T w[D], lw[D], v[D][D];
     return pair_core<T, D, false, CHOL>(li, xj, wmin, wmax, w, lw, v);
@@ -290,8 +295,14 @@ __device__ __forceinline__ T pair_value(const TL (&li)[Packed<D>::NP], const T (
 // scalar loads and the loop's scalar bookkeeping (every instruction of a wavefront, scalar ones included, takes an issue
 // slot of its SIMD) and, in the backward, the row-side reduction (one reduction of M_a + M_b); wider matrices and fp64
 // do not have the registers for it.
-template <typename T, int D> constexpr int pair_cols() { return (sizeof(T) == 4 && D <= 3) ? 2 : ((sizeof(T) == 4 && D == 4) ? MM_SPD4_FWD_NC : 1); }
-template <typename T, int D> constexpr int pair_cols_bwd() { return (sizeof(T) == 4 && D == 3) ? MM_SPD3_BWD_NC : (sizeof(T) == 4 && D <= 3) ? 2 : ((sizeof(T) == 4 && D == 4) ? MM_SPD4_BWD_NC : 1); }
+#ifndef MM_SPD2_FWD_NC   // (A/B builds: columns per lane of the SPD(2) kernels)
+#define MM_SPD2_FWD_NC 2
+#endif
+#ifndef MM_SPD2_BWD_NC
+#define MM_SPD2_BWD_NC 2
+#endif
+template <typename T, int D> constexpr int pair_cols() { return (sizeof(T) == 4 && D == 2) ? MM_SPD2_FWD_NC : (sizeof(T) == 4 && D <= 3) ? 2 : ((sizeof(T) == 4 && D == 4) ? MM_SPD4_FWD_NC : 1); }
+template <typename T, int D> constexpr int pair_cols_bwd() { return (sizeof(T) == 4 && D == 3) ? MM_SPD3_BWD_NC : (sizeof(T) == 4 && D == 2) ? MM_SPD2_BWD_NC : ((sizeof(T) == 4 && D == 4) ? MM_SPD4_BWD_NC : 1); }
 
 // (Round 5: the preparation launch in front of this kernel — spd_prep_kernel, 5 us — cannot be fused into it at a profit.  The row
 // operand must reach the arithmetic as a SCALAR operand: handed over through v_readlane, every vector instruction that reads a
@@ -758,6 +769,19 @@ __global__ __launch_bounds__((64 * bwd_waves<T, D>()), (bwd_min_waves_nc<T, D, N
                 if (__builtin_expect(!__any(!(gate <= T(kCayleyGate))), 1)) finish(qc, m0, g_first); else jacobi_path(qc);
               });
             }
+#ifndef MM_SPD2_JACOBI
+          } else if constexpr (D == 2) {
+            // SPD(2): eigenvalues and logarithm in closed form (smallmat.hpp, log_pair2_chol) — no eigensolve
+            static_for<NC>([&](auto qc) {
+              constexpr int q = decltype(qc)::value;
+              T m0[NP];
+              const T s = log_pair2_chol<T>(li, xj[q], wmin, wmax, m0);
+              gs[q] = upstream_of<T, LOSS>(gs[q], s, valid[q], squared, wmin, sp, la, loss_acc, ds_acc);
+              const T g2 = gs[q] + gs[q];
+#pragma unroll
+              for (int k = 0; k < NP; ++k) m[q][k] = g2 * m0[k];
+            });
+#endif
           } else {
             static_for<NC>([&](auto qc) { jacobi_path(qc); });
           }

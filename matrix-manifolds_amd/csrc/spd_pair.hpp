@@ -1321,6 +1321,10 @@ int spd_pdist_bwd_launch_sq(Ws<T>& ws, const T* g, int64_t n, int64_t rb, int64_
   // tools/gpu_shard_grid.sh).  Whole multiples of the CU count, at least one workgroup per CU.
   {
     const int64_t cus = device_cus();
+    // at most four workgroups per CU: the kernels with few registers (SPD(2): 55, seven workgroups per CU resident) are no
+    // faster for more, shorter shares — every share pays its prologue and flush (SPD(2) n = 5000 backward, 1792 / 1280 / 1024 /
+    // 768 workgroups: 29.7 / 27.9 / 26.5 / 27.1 us fp32, 115 / 112 / 111 / 112 fp64; profiles/r05_experiments.md)
+    grid = std::min<int64_t>(grid, 4 * cus);
     const int64_t by_rows = units / 48 / cus * cus;
     if (by_rows < grid) grid = std::max<int64_t>(cus, by_rows);
   }

@@ -27,7 +27,9 @@ int launch_pairs(const T* xpad, const T* g, int64_t n, int m, int64_t rb, int64_
   const int64_t units = ColWalk(int(n), int(rb), int(re), 64 * vsym_cols<T, MP>()).total();
   if (units <= 0) return MM_OK;
   int64_t grid = resident_workgroups<vec_pdist_bwd_sym_kernel<T, KIND, MP, LOSS, SQ>>(kThreads);
-  grid = std::min<int64_t>(grid, 3 * int64_t(device_cus()));   // (measured, n = 4039: 512 - 768 workgroups 54.6 us per fwd + bwd step, 1280: 62.2)
+  // (measured: Lorentz(11) n = 4039, 512 / 768 / 1024 workgroups 23.8 / 22.0 / 22.7 us; narrow points — sphere(6) n = 5000, MP = 8 —
+  // 30.5 / 26.9 / 25.0: profiles/r05_experiments.md)
+  grid = std::min<int64_t>(grid, (MP <= 8 ? 4 : 3) * int64_t(device_cus()));
   {   // small launches: enough rows per workgroup to pay for its column flush (as the SPD backward, spd.hip)
     const int64_t cus = device_cus();
     const int64_t by_rows = units / 48 / cus * cus;

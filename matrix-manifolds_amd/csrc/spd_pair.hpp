@@ -1325,7 +1325,12 @@ int spd_pdist_bwd_launch_sq(Ws<T>& ws, const T* g, int64_t n, int64_t rb, int64_
     // faster for more, shorter shares — every share pays its prologue and flush (SPD(2) n = 5000 backward, 1792 / 1280 / 1024 /
     // 768 workgroups: 29.7 / 27.9 / 26.5 / 27.1 us fp32, 115 / 112 / 111 / 112 fp64; profiles/r05_experiments.md)
     grid = std::min<int64_t>(grid, 4 * cus);
-    const int64_t by_rows = units / 48 / cus * cus;
+    // (round 5, after the prologue diet: ~32 rows per workgroup for the two-column kernels, ~48 for the others, to the nearest
+    // half multiple of the CU count — SPD(3) n = 2000, 256 / 384 / 512 / 768 / 1024 workgroups 16.8 / 15.9 / 14.9 / 15.7 / 18.6 us;
+    // one eighth of the headline problem 16.6 / 14.8 / 15.0 / 16.5 / 18.5; SPD(4) n = 2274 38.8 / 34.0 / 28.0 / 25.7 / 26.6)
+    // (the one-column kernels keep whole multiples at 48 rows: SPD(4) n = 2274 at 896 workgroups 27.0 us)
+    const int64_t half = std::max<int64_t>(1, cus / 2);
+    const int64_t by_rows = kCols >= 2 ? (units / 32 + half / 2) / half * half : units / 48 / cus * cus;
     if (by_rows < grid) grid = std::max<int64_t>(cus, by_rows);
   }
   static const int64_t env_grid = std::getenv("MM_SPD_BWD_GRID") ? std::atoll(std::getenv("MM_SPD_BWD_GRID")) : 0;

@@ -32,7 +32,10 @@ int launch_pairs(const T* xpad, const T* g, int64_t n, int m, int64_t rb, int64_
   grid = std::min<int64_t>(grid, (MP <= 8 ? 4 : 3) * int64_t(device_cus()));
   {   // small launches: enough rows per workgroup to pay for its column flush (as the SPD backward, spd.hip)
     const int64_t cus = device_cus();
-    const int64_t by_rows = units / 48 / cus * cus;
+    // (as the SPD backward after round 5's prologue diet: ~32 rows per workgroup for the two-column kernels, to the nearest half
+    // multiple of the CU count — Lorentz(11) n = 2000, 256 / 384 / 512 / 768 workgroups 11.8 / 11.2 / 10.9 / 11.7 us)
+    const int64_t half = std::max<int64_t>(1, cus / 2);
+    const int64_t by_rows = vsym_cols<T, MP>() >= 2 ? (units / 32 + half / 2) / half * half : units / 48 / cus * cus;
     if (by_rows < grid) grid = std::max<int64_t>(cus, by_rows);
   }
   static const int64_t env_grid = std::getenv("MM_VEC_BWD_GRID") ? std::atoll(std::getenv("MM_VEC_BWD_GRID")) : 0;

@@ -431,8 +431,8 @@ __device__ __forceinline__ T pair_row_load(const T* __restrict__ g, int n, int64
 }
 
 // Backward: a launch of (at most) as many workgroups as the device holds at once; workgroup w walks its share of the
-// balanced column walk (spd_ws.hpp, ColWalk): down one 64-column block, chunk after chunk of up to NW x TI rows (each
-// wavefront a contiguous slice of the chunk's rows, its lanes the block's 64 columns), then on to the next block.
+// balanced column walk (spd_ws.hpp, ColWalk / WalkShares): down one block of 64 NC columns — each wavefront ONE contiguous slice of
+// the block's rows of the share, its lanes the block's columns, the row sums leaving every TI rows — then on to the next block.
 // NCX != 0: that many columns per lane instead of pair_cols_bwd<T, D>() (fp32 SPD(4): two for large launches, below).
 // SUB: a NODE MINIBATCH (train.py:198-222 with batch_size set; modules.py:86 gathers x[idx] first): the n points of the launch
 // are the nodes idx[0..n) of an embedding of n_total points.  The pair list (rows, column blocks, shares) is that of the n
@@ -1316,9 +1316,9 @@ int spd_pdist_bwd_launch_sq(Ws<T>& ws, const T* g, int64_t n, int64_t rb, int64_
   if (units <= 0) return MM_OK;
   int64_t grid = resident_workgroups<spd_pdist_bwd_kernel<T, D, kBwdTI, LOSS, SQ, NCX, SUB>>(kThreads);
   // Small launches (a rank's shard, small n): a workgroup flushes its column-side sums once per column block, so it needs
-  // enough rows to pay for that — with fewer than ~48 rows of a column block per workgroup the launch is made of flushes
-  // (one eighth of the headline problem, 13 k units: 1024 workgroups 23.8 us, 256 workgroups 17.1 us; a quarter: 24.2 -> 22.2 us;
-  // tools/gpu_shard_grid.sh).  Whole multiples of the CU count, at least one workgroup per CU.
+  // enough rows to pay for that — with too few rows of a column block per workgroup the launch is made of prologues and flushes
+  // (round 3, one eighth of the headline problem, 13 k units: 1024 workgroups 23.8 us, 256 workgroups 17.1 us; the rule then
+  // was 48 rows and whole multiples of the CU count; tools/gpu_shard_grid.sh).  At least one workgroup per CU.
   {
     const int64_t cus = device_cus();
     // at most four workgroups per CU: the kernels with few registers (SPD(2): 55, seven workgroups per CU resident) are no

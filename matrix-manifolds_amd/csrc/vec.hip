@@ -60,11 +60,13 @@ __device__ __forceinline__ void load_point(const T* __restrict__ x, int64_t idx,
 }
 
 // ------------------------------------------------------------------ forward
-template <typename T, int KIND, int MP, int TI>
+// (rows per tile: a launch argument — 32 for a launch that fills the device, fewer for small ones: tree40's 40 rows were ONE
+// tile of 32 and one of 8, 11 us of a single wavefront per SIMD walking 32 rows; round 5)
+template <typename T, int KIND, int MP>
 __global__ __launch_bounds__(kVBlock) void vec_pdist_fwd_kernel(const T* __restrict__ x, int n, int m, int row_begin,
-                                                                int row_end, int squared, T* __restrict__ out) {
-  const int i0 = row_begin + blockIdx.y * TI;
-  const int i1 = min(i0 + TI, row_end);
+                                                                int row_end, int squared, T* __restrict__ out, int ti) {
+  const int i0 = row_begin + blockIdx.y * ti;
+  const int i1 = min(i0 + ti, row_end);
   const int jbase = ((i0 + 1) / kVBlock + blockIdx.x) * kVBlock;
   if (jbase >= n) return;
   if (jbase + (int(threadIdx.x) & ~63) + 63 <= i0) return;
@@ -573,16 +575,17 @@ __global__ void vec_radam_multi_kernel(RadamMulti<T> s) {
 
 template <typename T, int KIND, int MP>
 int vec_fwd_t(const T* x, int64_t n, int m, int64_t rb, int64_t re, int squared, T* out, hipStream_t st) {
-  constexpr int TI = 32;
   if (re <= rb) return MM_OK;
   const int nJB = int((n + kVBlock - 1) / kVBlock);
   const int gx = nJB - int((rb + 1) / kVBlock);
-  const int gy = int((re - rb + TI - 1) / TI);
   if (gx <= 0) return MM_OK;
+  // rows per tile: 32, halved while the launch has fewer than ~4 workgroups per CU (down to 2 rows)
+  int ti = 32;
+  while (ti > 2 && int64_t(gx) * ((re - rb + ti - 1) / ti) < 4 * int64_t(device_cus())) ti /= 2;
+  const int gy = int((re - rb + ti - 1) / ti);
   {
     ProfScope prof(PROF_VEC_FWD, st);
-    vec_pdist_fwd_kernel<T, KIND, MP, TI><<<dim3(gx, gy), dim3(kVBlock), 0, st>>>(x, int(n), m, int(rb), int(re),
-                                                                                 squared, out);
+    vec_pdist_fwd_kernel<T, KIND, MP><<<dim3(gx, gy), dim3(kVBlock), 0, st>>>(x, int(n), m, int(rb), int(re), squared, out, ti);
   }
   MMV_CHECK();
   return MM_OK;

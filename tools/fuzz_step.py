@@ -74,6 +74,7 @@ def main():
     cases = int(args[0]) if args else 100
     rng = random.Random(int(args[1]) if len(args) > 1 else 0)
     worst = {torch.float32: 0.0, torch.float64: 0.0}
+    only = int(os.environ['FUZZ_ONLY']) if os.environ.get('FUZZ_ONLY') else None
     for c in range(cases):
         dt = rng.choice([torch.float32, torch.float64])
         if os.environ.get('FUZZ_FORCE_F64') == '1':    # (same case stream in double precision: tells a rounding effect from a bug)
@@ -82,26 +83,29 @@ def main():
         if '--big' in sys.argv:
             n = rng.choice([600, 1025, 1500, 2100])
         mans = layout(rng)
+        amount = rng.choice([0.05, 0.3])
+        minibatch = len(mans) == 1 and n >= 4 and rng.random() < 0.4
+        fn = rng.choice([StressLoss, QuotientLoss])()
+        seed = rng.random()
+        epochs, edit_at = rng.randint(2, 5), rng.choice([None, 1, 2])
+        if only is not None and c != only:     # (FUZZ_ONLY=<case>: the same case stream, one case run)
+            continue
         torch.manual_seed(c)
         torch.set_default_dtype(dt)
         try:
             with torch.device('cuda'):
                 emb_a = ManifoldEmbedding(n, mans)
                 with torch.no_grad():
-                    emb_a.perturb(rng.choice([0.05, 0.3]))
+                    emb_a.perturb(amount)
                 target = torch.rand(n * (n - 1) // 2) * 0.9 + 0.05
         finally:
             torch.set_default_dtype(torch.float32)
         emb_b = copy.deepcopy(emb_a)
         # node minibatches (train.py:198-222 with batch_size set; single factors: mm_train_step.batch_idx — the index vector inside
         # the factor's own pair kernel, every point stepped): a fresh slice of a randperm every epoch, full batches in between
-        minibatch = len(mans) == 1 and n >= 4 and rng.random() < 0.4
         dense = squareform(target, n) if minibatch else None
-        fn = rng.choice([StressLoss, QuotientLoss])()
-        seed = rng.random()
         oa, what = optimizers(emb_a, seed)
         ob, _ = optimizers(emb_b, seed)
-        epochs, edit_at = rng.randint(2, 5), rng.choice([None, 1, 2])
         what = (f'case {c}: n={n} {[str(m) for m in mans]} {str(dt)[6:]} {type(fn).__name__} {what} epochs={epochs} edit={edit_at}'
                 + (' minibatch' if minibatch else ''))
         step = NativeTrainStep(emb_b, fn, target, ob, dense=dense)
@@ -135,6 +139,16 @@ def main():
             # a run that blows up amplifies the rounding of either implementation without bound: nothing to compare
             print('skipped (the eager run diverges)', what, flush=True)
             continue
+        far = max([x.detach().abs().max().item() for x, m in zip(emb_a.xs, emb_a.manifolds) if isinstance(m, M.Lorentz)] + [0.0])
+        if far > 1e3:
+            # Hyperboloid points at radius > asinh(1e3) = 7.6 (a sum loss stepped at lr 1e-3 without clipping throws them there:
+            # case 95 of seed 907, coordinates up to 7e4): -<x, x> = 1 is then a difference of squares >= 1e6 and the last
+            # exp map multiplies its rounding by cosh |v| — the five losses of that case agree to 3e-4 (fp32) / 1e-8 (fp64) while
+            # the final points differ by 4.6 (fp32) / 1e-6 (fp64) of their magnitude.  Nothing to compare point by point.
+            for a, b in zip(la, lb):
+                assert abs(a - b) <= (3e-4 if dt == torch.float32 else 1e-8) * max(abs(a), 1e-30), f'{what}: losses {la} vs {lb}'
+            print(f'skipped (hyperboloid points out to {far:.1e}; losses agree)', what, flush=True)
+            continue
         tol = 3e-4 if dt == torch.float32 else 1e-8
         for a, b in zip(la, lb):
             assert abs(a - b) <= tol * max(abs(a), 1e-30), f'{what}: losses {la} vs {lb}'
@@ -144,6 +158,12 @@ def main():
             # the two implementations and moves its two points by lr / (alpha g) — case 271 of seed 101: 7.9e-3 in fp32, 7e-15 with
             # FUZZ_FORCE_F64=1.  The losses above still have to agree.)
             ptol = 3e-2 if (dt == torch.float32 and isinstance(fn, QuotientLoss)) else tol * 3
+            if err > ptol and os.environ.get('FUZZ_ONLY'):     # which rows, by how much
+                rows = (a.detach() - b.detach()).abs().reshape(a.shape[0], -1).amax(1)
+                bad = (rows > ptol * a.detach().abs().max()).nonzero().flatten()
+                print('shape', tuple(a.shape), 'rows off:', bad.tolist()[:20], 'of', a.shape[0], flush=True)
+                for r in bad.tolist()[:3]:
+                    print(' eager', a.detach()[r].flatten().tolist(), '\n native', b.detach()[r].flatten().tolist(), flush=True)
             assert err <= ptol, f'{what}: parameters differ by {err:.3e}'
             worst[dt] = max(worst[dt], err)
         assert all(torch.isfinite(p.grad).all() for p in emb_b.xs), what

@@ -670,6 +670,23 @@ template <> struct LogSeriesWide<float> {
                                        -2.667691364e-01f, 2.562672116e-01f, 4.274908187e-01f, -4.061057313e-01f};
   static constexpr float at(int i) { return kA[i]; }
 };
+// fp64 (round 5; tools/design/series_fit_wide64.py 36 36): degree 35, 6.5e-17 |x| as a polynomial, 2.8e-16 through Horner's
+// rule in fp64.  Used by the MATRIX form only (log_series_mat, SPD(5 .. 9)): its coefficient loop reads the table, whereas the
+// unrolled ring forms of SPD(3) / SPD(4) would hold the 36 constants in 72 vector registers (see log_series3_centred).
+template <> struct LogSeriesWide<double> {
+  static constexpr int kTerms = 36;
+  static constexpr double kA[kTerms] = {
+    0.999999999999999977, -0.499999999999999978, 0.333333333333367457, -0.250000000000033421,
+    0.199999999991592943, -0.166666666658432825, 0.142857143675747047, -0.125000000801733994,
+    0.111111069196670012, -0.0999999589496586145, 0.0909103925504135392, -0.0833346081274524372,
+    0.0768964148318060428, -0.071402459598029521, 0.0670466571631664423, -0.0628721421125401977,
+    0.054920735255657598, -0.0517334464941176604, 0.0821825618685663011, -0.0789393499687729317,
+    -0.119544506131984601, 0.11824425305853179, 0.753586818196905653, -0.737031529750978713,
+    -2.21838624927452971, 2.17293423563498954, 5.34587266623974133, -5.23378983222008806,
+    -8.94716963622682544, 8.7602754349000368, 10.4325804141314891, -10.2127945466777319,
+    -7.42237802920880408, 7.26540890455107326, 2.58226980159039129, -2.52672226697783483};
+  static constexpr double at(int i) { return kA[i]; }
+};
 // true if the pair is OUTSIDE the recentred series' range (NaN counts as outside): ||A - mu I||_F^2 > kCentredGate3 mu^2.
 // Evaluated from A alone, in the branch that needs it (rows that failed the close-pair gate): the close-pair path keeps
 // nothing alive for it.
@@ -1034,6 +1051,116 @@ __device__ __forceinline__ void sym_mul(const T (&x)[Packed<D>::NP], const T (&y
       for (int k = 1; k < D; ++k) acc = Num<T>::fma(x[pidx(r, k)], y[pidx(k, c)], acc);
       o[pidx(r, c)] = acc;
     }
+}
+
+// ---- log(A) without an eigensolve, any D (round 5: SPD(5 .. 9) ran a Jacobi eigensolve with eigenvectors per pair) ----
+// log(I + E) = E p(E) with p evaluated in MATRICES by Paterson-Stockmeyer groups of G coefficients:
+//   p(E) = sum_j (c_{Gj} I + c_{Gj+1} E + .. + c_{Gj+G-1} E^{G-1}) (E^G)^j,   Horner's rule in E^G over the groups.
+// Every operand is a polynomial in E, so the products commute, are symmetric, and sym_mul's packed half is all of them:
+// (G - 1) + (K / G - 1) + 1 products of D^2 (D + 1) / 2 multiply-adds — K = 8 (fp32, close pairs): 5; K = 16 (fp32,
+// recentred): 7 with G = 4; fp64: 8 for K = 20, 12 for K = 36 — against ~5000 instructions of the 6 x 6 eigensolve + V diag V^T.
+// The group loop is a real loop of two steps (ping-pong between two matrices: no copies; coefficients read from the table)
+// so that the code holds three products, not K / G.  G = 4 keeps E .. E^4 and two accumulators (6 matrices), G = 2 four.
+// S = LogSeries<T> on a spectral radius of 0.3 (close pairs), LogSeriesWide<T> on 0.66 (recentred, below).
+template <typename T, int D, typename S, int G>
+__device__ __forceinline__ void log_series_mat(const T (&e)[Packed<D>::NP], T (&m0)[Packed<D>::NP]) {
+  using N = Num<T>;
+  constexpr int NP = Packed<D>::NP, K = S::kTerms, NG = K / G;
+  static_assert((G == 2 || G == 4) && K % G == 0 && NG >= 2, "whole groups");
+  T pw[NP], e2[G == 4 ? NP : 1], e3[G == 4 ? NP : 1];   // pw = E^G
+  if constexpr (G == 4) {
+    sym_mul<T, D>(e, e, e2);
+    sym_mul<T, D>(e, e2, e3);
+    sym_mul<T, D>(e2, e2, pw);
+  } else {
+    sym_mul<T, D>(e, e, pw);
+  }
+  // dst += group j (dst holds acc . E^G, or nothing for the first group)
+  auto add_group = [&](T (&dst)[NP], int j, bool first) __attribute__((always_inline)) {
+    const T c0 = S::kA[G * j], c1 = S::kA[G * j + 1];
+    T c2 = T(0), c3 = T(0);
+    if constexpr (G == 4) { c2 = S::kA[G * j + 2]; c3 = S::kA[G * j + 3]; }
+#pragma unroll
+    for (int k = 0; k < NP; ++k) {
+      T v = first ? c1 * e[k] : N::fma(c1, e[k], dst[k]);
+      if constexpr (G == 4) v = N::fma(c3, e3[k], N::fma(c2, e2[k], v));
+      dst[k] = v;
+    }
+#pragma unroll
+    for (int r = 0; r < D; ++r) dst[pidx(r, r)] += c0;
+  };
+  T acc[NP], t[NP];
+  add_group(acc, NG - 1, true);
+  constexpr int kSteps = NG - 1;
+#pragma unroll 1
+  for (int j = NG - 2; j >= (kSteps & 1); j -= 2) {
+    sym_mul<T, D>(acc, pw, t);
+    add_group(t, j, false);
+    sym_mul<T, D>(t, pw, acc);
+    add_group(acc, j - 1, false);
+  }
+  if constexpr (kSteps & 1) {
+    sym_mul<T, D>(acc, pw, t);
+    add_group(t, 0, false);
+    sym_mul<T, D>(e, t, m0);
+  } else {
+    sym_mul<T, D>(e, acc, m0);
+  }
+}
+// groups of four unless they save nothing (K = 8: five products either way) or the six matrices do not fit beside the kernel's
+// own state and spill inside the group loop (measured per size and precision: profiles/r05_experiments.md §18)
+template <typename T, int D, typename S> constexpr int series_group() {
+#ifdef MM_SERIES_GROUP   // (A/B builds)
+  return MM_SERIES_GROUP;
+#else
+  if (S::kTerms <= 8) return 2;
+  if (sizeof(T) == 4) return D <= 7 ? 4 : 2;
+  return (D == 5 || (D == 6 && S::kTerms <= 20)) ? 4 : 2;
+#endif
+}
+// close pairs (||A - I||_F <= 0.3, the caller's gate)
+template <typename T, int D> __device__ __forceinline__ void log_close_mat(const T (&a)[Packed<D>::NP], T (&m0)[Packed<D>::NP]) {
+  T e[Packed<D>::NP];
+#pragma unroll
+  for (int k = 0; k < Packed<D>::NP; ++k) e[k] = a[k];
+#pragma unroll
+  for (int r = 0; r < D; ++r) e[pidx(r, r)] -= T(1);
+  log_series_mat<T, D, LogSeries<T>, series_group<T, D, LogSeries<T>>()>(e, m0);
+}
+// pairs at moderate distance: log A = log(mu) I + log(I + E'), E' = A / mu - I traceless (mu = tr A / D), whose
+// spectral radius is at most sqrt((D - 1) / D) ||E'||_F — the gate bounds it by 0.66 (log_series3_centred's construction)
+template <typename T, int D> __device__ __forceinline__ bool centred_far_mat(const T (&a)[Packed<D>::NP]) {
+  using N = Num<T>;
+  T tr = a[pidx(0, 0)];
+#pragma unroll
+  for (int r = 1; r < D; ++r) tr += a[pidx(r, r)];
+  const T mu = tr * T(1.0 / D);
+  T dg = T(0), off = T(0);
+#pragma unroll
+  for (int r = 0; r < D; ++r) {
+    const T d = a[pidx(r, r)] - mu;
+    dg = N::fma(d, d, dg);
+#pragma unroll
+    for (int c = 0; c < r; ++c) off = N::fma(a[pidx(r, c)], a[pidx(r, c)], off);
+  }
+  const T dev = N::fma(T(2), off, dg);   // ||A - mu I||_F^2
+  return !(dev <= T(0.66 * 0.66 * D / (D - 1.0)) * (mu * mu)) || !(mu > T(0));
+}
+template <typename T, int D> __device__ __forceinline__ void log_centred_mat(const T (&a)[Packed<D>::NP], T (&m0)[Packed<D>::NP]) {
+  using N = Num<T>;
+  T tr = a[pidx(0, 0)];
+#pragma unroll
+  for (int r = 1; r < D; ++r) tr += a[pidx(r, r)];
+  const T mu = tr * T(1.0 / D), rmu = N::rcp(mu);
+  T e[Packed<D>::NP];
+#pragma unroll
+  for (int k = 0; k < Packed<D>::NP; ++k) e[k] = a[k] * rmu;
+#pragma unroll
+  for (int r = 0; r < D; ++r) e[pidx(r, r)] -= T(1);
+  log_series_mat<T, D, LogSeriesWide<T>, series_group<T, D, LogSeriesWide<T>>()>(e, m0);
+  const T lm = N::log(mu);
+#pragma unroll
+  for (int r = 0; r < D; ++r) m0[pidx(r, r)] += lm;
 }
 
 // Cayley-transform logarithm, 4x4 (same construction as log_cayley3): adjugate from the 2x2 minors of

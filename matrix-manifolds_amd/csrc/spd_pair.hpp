@@ -209,6 +209,11 @@ template <typename T, int D> constexpr bool fwd_uses_logdet() {
 #endif
 }
 
+#ifdef MM_SPD_NO_SERIES_MAT   // (A/B builds: SPD(5 .. 9) on the Jacobi route of rounds 1-4)
+constexpr bool kSeriesMat = false;
+#else
+constexpr bool kSeriesMat = true;
+#endif
 // Forward-only value of one pair.  SPD(3) in fp32 takes the closed-form (trigonometric)
 // eigenvalues; a wavefront in which any pair has a wide spectrum (w_max > 32 w_min, where
 // the closed form's absolute error would show in log w_min) re-solves with Jacobi.
@@ -284,6 +289,22 @@ __device__ __forceinline__ T pair_value(const TL (&li)[Packed<D>::NP], const T (
     T mlog[3];   // (closed form, the small eigenvalue from the determinant: smallmat.hpp; the matrix is not needed here)
     return log_pair2_chol<T>(li, xj, wmin, wmax, mlog);
 #endif
+  } else if constexpr (D >= 5 && kSeriesMat) {
+    // SPD(5 .. 9): the matrix-Horner series (smallmat.hpp, log_series_mat) for wavefronts of close pairs and of pairs at
+    // moderate distance; the eigensolve for the rest
+    constexpr int NP = Packed<D>::NP;
+    T a[NP], m0[NP];
+    pair_a<T, D, CHOL>(li, xj, a);
+    if (__builtin_expect(!__any(!(close_gate<T, D>(a) <= T(kCloseGate))), 1)) {
+      log_close_mat<T, D>(a, m0);
+      return frob2<T, D>(m0);
+    }
+    if (!__any(centred_far_mat<T, D>(a))) {
+      log_centred_mat<T, D>(a, m0);
+      return frob2<T, D>(m0);
+    }
+    T w[D], lw[D], v[D][D];
+    return pair_core<T, D, false, CHOL>(li, xj, wmin, wmax, w, lw, v);
   } else {
     T w[D], lw[D], v[D][D];
     return pair_core<T, D, false, CHOL>(li, xj, wmin, wmax, w, lw, v);
@@ -782,6 +803,20 @@ __global__ __launch_bounds__((64 * bwd_waves<T, D>()), (bwd_min_waves_nc<T, D, N
               for (int k = 0; k < NP; ++k) m[q][k] = g2 * m0[k];
             });
 #endif
+          } else if constexpr (D >= 5 && kSeriesMat) {
+            // SPD(5 .. 9): matrix-Horner series per wavefront (close pairs, pairs at moderate distance), else Jacobi
+            static_assert(NC == 1, "one column per lane for D >= 5");
+            T a[NP], m0[NP];
+            congr_chol<T, D>(li, xj[0], a);
+            bool done = false;
+            if (__builtin_expect(!__any(!(close_gate<T, D>(a) <= T(kCloseGate))), 1)) {
+              log_close_mat<T, D>(a, m0);
+              done = true;
+            } else if (!__any(centred_far_mat<T, D>(a))) {
+              log_centred_mat<T, D>(a, m0);
+              done = true;
+            }
+            if (done) finish(std::integral_constant<int, 0>{}, m0, false); else jacobi_path(std::integral_constant<int, 0>{});
           } else {
             static_for<NC>([&](auto qc) { jacobi_path(qc); });
           }

@@ -391,6 +391,20 @@ def test_close_pair_gate_is_seamless(d):
 @pytest.mark.parametrize('d,dname', [(3, 'f32'), (4, 'f32'), (3, 'f64'), (4, 'f64')])
 @pytest.mark.parametrize('spread', [0.25, 0.35, 0.42, 0.5])
 def test_recentred_series_regime(spread, d, dname):
+    _series_regime(spread, d, dname, 640)
+
+
+@pytest.mark.parametrize('d,dname', [(5, 'f32'), (6, 'f32'), (7, 'f32'), (8, 'f32'), (9, 'f32'), (5, 'f64'), (6, 'f64'), (7, 'f64'), (9, 'f64')])
+@pytest.mark.parametrize('spread', [0.08, 0.25, 0.4, 0.6])
+def test_matrix_series_regime(spread, d, dname):
+    """SPD(5 .. 9): the logarithm of a pair comes from the matrix series of smallmat.hpp (log_series_mat: Paterson-Stockmeyer
+    groups in E = A - I for wavefronts of close pairs, in E' = A / mu - I for pairs at moderate distance, both precisions) and
+    from the Jacobi eigensolve only for what is left.  Spread 0.08: close pairs; 0.25: the recentred series; 0.4 / 0.6: rows on
+    both sides of its gate.  Same checks as for SPD(3) / SPD(4) above."""
+    _series_regime(spread, d, dname, 448 if d <= 6 else 320)
+
+
+def _series_regime(spread, d, dname, n):
     """SPD(3) / SPD(4) fp32 and SPD(3) fp64 forward and backward at MODERATE pair distances (||log X|| ~ 0.35: training after the first epochs): the matrix
     logarithm comes from the recentred series log A = log(mu) I + log(I + (A / mu - I)), mu = tr A / 3 (smallmat.hpp,
     log_series3_centred) when every pair of a wavefront row passes its gate, else from the Cayley-transform path.  Spreads
@@ -401,7 +415,6 @@ def test_recentred_series_regime(spread, d, dname):
     from oracle import ref_port as rp
     gen = torch.Generator().manual_seed(int(spread * 100) + d)
     port = rp.SPD(d)
-    n = 640
     scale = spread * (0.6 + 0.4 * torch.rand(n, generator=gen))
     u = torch.randn(n, d * (d + 1) // 2, dtype=torch.float64, generator=gen)
     u = u / u.norm(dim=-1, keepdim=True) * scale.double().reshape(n, 1)

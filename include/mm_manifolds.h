@@ -84,7 +84,9 @@ int mm_spd_prepare(int dtype, const void* x, int64_t n, int d, void* ws, mm_stre
 /* SymmetricPositiveDefinite.pdist — manifolds/spd.py:175-181 (+ _norm_log
  * 163-169, _lult 108-111).  out[k] = sum_m log^2 lambda_m(L_i^-1 X_j L_i^-T)
  * (sqrt of it if !squared), eigenvalues value-clamped to [wmin,wmax], result
- * value-clamped >= wmin.
+ * value-clamped >= wmin.  d >= 3 (and the fused objectives of every d): windows narrower than
+ * [1e-6, 1e6] return MM_ERR_UNSUPPORTED — the element-wise mm_spd_dist_fwd / _bwd take any window
+ * (DESIGN.md section 6, item 11).
  *   x    [n,d,d]   out  [mm_pair_offset(n,row_end)-mm_pair_offset(n,row_begin)]
  * A non-positive-definite x[i] sets the status word (mm_spd_status).
  * n <= 2^22 in every SPD entry point (32-bit byte offsets into the node tables; 2^22 nodes are 8.8e12 pairs):

@@ -712,6 +712,9 @@ int product_pairs_t(int loss_kind, int nf, const int* kinds, const int* dims, co
   for (int k = 0; k < nf; ++k) {
     if (kinds[k] == MM_FACTOR_SPD) {
       if (sd != 0 || (dims[k] != 2 && dims[k] != 3)) return MM_ERR_UNSUPPORTED;
+      // (eigenvalue clamps that could bind: the per-factor kernels — the gradient here lacks what a binding clamp leaves in
+      // the reference's, spd_pair.hpp pair_core)
+      if (!(wmin <= 1e-6 && wmax >= 1e6)) return MM_ERR_UNSUPPORTED;
       sd = dims[k];
       pa.s.x = static_cast<const T*>(xs[k]);
       pa.s.scale_raw = static_cast<const T*>(scale_raw[k]);

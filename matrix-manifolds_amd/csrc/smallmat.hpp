@@ -1476,12 +1476,22 @@ template <typename T, typename TL> __device__ __forceinline__ T log_pair2_chol(c
   const T r = N::sqrt(N::fma(dh, dh, a10 * a10));
   const T lam_p = mid + r, sdet = b00 * b11;
   const T lam_m = (sdet * sdet) * N::rcp(lam_p);
-  const T lp = N::log(N::min(N::max(lam_p, wmin), wmax)), lm = N::log(N::min(N::max(lam_m, wmin), wmax));
+  const T cp = N::min(N::max(lam_p, wmin), wmax), cm = N::min(N::max(lam_m, wmin), wmax);
+  T lp = N::log(cp), lm = N::log(cm);
+  const T s = N::fma(lp, lp, lm * lm);
+  // mlog feeds the GRADIENT: where a clamp binds, the reference's autograd leaves log(w_c) w / w_c on the X_i side and
+  // log(w_c) / w_c on the X_j side (w.data.clamp_ rewrites what log's backward saved, spd.py:163-169; pair_core's rho in
+  // spd_pair.hpp).  The kernels form the X_j side as A^-1 M with the true A, so M = V diag(log(w_c) w / w_c) V^T serves both.
+  // A wavefront in which no clamp binds — every one under the default [1e-8, 1e8] — skips it.
+  if (__builtin_expect(__any((lam_p != cp) | (lam_m != cm)), 0)) {
+    lp *= lam_p * N::rcp(cp);
+    lm *= lam_m * N::rcp(cm);
+  }
   const T beta = T(0.5) * (lp - lm) * N::rcp(N::max(r, N::tiny())), alpha = T(0.5) * (lp + lm);
   mlog[0] = N::fma(beta, dh, alpha);
   mlog[1] = beta * a10;
   mlog[2] = N::fma(-beta, dh, alpha);
-  return N::fma(lp, lp, lm * lm);
+  return s;
 }
 
 // out (packed) = V diag(f) V^T

@@ -85,7 +85,7 @@ __device__ __forceinline__ void pair_a(const TL (&li)[Packed<D>::NP], const T (&
 // registers have no room for it (with it the hot path spilled: fused QuotientLoss kernel at n = 16 384 1044 -> 2619 us)
 template <typename T, int D, bool WITH_V, bool CHOL = false, bool SECOND = true, typename TL>
 __device__ __forceinline__ T pair_core(const TL (&li)[Packed<D>::NP], const T (&xj)[Packed<D>::NP], T wmin, T wmax,
-                                       T (&w)[D], T (&lw)[D], T (&v)[D][D]) {
+                                       T (&w)[D], T (&lw)[D], T (&v)[D][D], T* rho = nullptr) {
   // eigenvalues only: sum log^2 w is second-order in the residual coupling -> tol2 = eps;
   // with eigenvectors: residual coupling <= 8 eps relative (gradient error ~1e-6, a quarter of
   // the wavefronts at the reference init would otherwise run a 4th sweep for the last bit)
@@ -138,6 +138,11 @@ __device__ __forceinline__ T pair_core(const TL (&li)[Packed<D>::NP], const T (&
     w[k] = Num<T>::min(Num<T>::max(ev[k], wmin), wmax);
     lw[k] = Num<T>::log(w[k]);
     s = Num<T>::fma(lw[k], lw[k], s);
+    // rho = true / clamped eigenvalue, exactly 1 unless a clamp binds: the reference clamps the VALUES in place (w.data.clamp_,
+    // spd.py:163-169), so log's backward divides by the clamped eigenvalue while the decomposition's backward runs on the true A —
+    // the X_j side of the gradient carries log(w_c) / w_c, the X_i side log(w_c) w / w_c (tests/golden/gen_golden_clamps.py).
+    // Asked for by the element-wise backward only: the pair kernels run under clamps that cannot bind (spd_clamps_supported).
+    if (rho) rho[k] = w[k] == ev[k] ? T(1) : ev[k] * Num<T>::rcp(w[k]);
   }
   return s;
 }
@@ -209,6 +214,17 @@ template <typename T, int D> constexpr bool fwd_uses_logdet() {
 #endif
 }
 
+// The reference clamps the eigenvalues of A to [wmin, wmax] (value only, spd.py:29-30, 163-169; defaults 1e-8 / 1e8).  The
+// eigen-free paths of SPD(3 .. 9) never see eigenvalues and the fused objectives skip the clamp of d^2 at wmin: the pair kernels run
+// only under clamps at least as wide as [1e-6, 1e6] (inside a gate a pair's eigenvalues are within a factor 16 of tr A / D, so a
+// clamp could bind there only for tr A / D beyond 6e4 resp. below 1.6e-5 of the window's end — no embedding has such pairs) and
+// their launchers return MM_ERR_UNSUPPORTED otherwise.  Narrower windows: SPD(2) `pdist` in closed form (log_pair2_chol), every
+// size through the element-wise kernels below (eigensolve, with what the clamp leaves in the gradient: pair_core's rho) —
+// graphembed.manifolds.spd routes `pdist` there, as the reference's own Manifold.pdist does (base.py:59-63).
+__host__ __device__ inline bool spd_clamps_wide(double wmin, double wmax) { return wmin <= 1e-6 && wmax >= 1e6; }
+template <int D, int LOSS> inline bool spd_clamps_supported(double wmin, double wmax) {
+  return (D <= 2 && LOSS == MM_LOSS_NONE) || spd_clamps_wide(wmin, wmax);
+}
 #ifdef MM_SPD_NO_SERIES_MAT   // (A/B builds: SPD(5 .. 9) on the Jacobi route of rounds 1-4)
 constexpr bool kSeriesMat = false;
 #else
@@ -987,7 +1003,14 @@ __global__ void spd_dist_fwd_kernel(const T* __restrict__ x, const T* __restrict
   load_sym_packed<T, D>(y + k * D * D, ys);
   cholesky<T, D>(xs, l);
   invert_lower<T, D>(l, li);
-  T s = Num<T>::max(pair_value<T, D>(li, ys, wmin, wmax), wmin);
+  T s;
+  if (spd_clamps_wide(wmin, wmax)) {
+    s = pair_value<T, D>(li, ys, wmin, wmax);
+  } else {   // (the eigen-free paths of pair_value do not see eigenvalues: a window that could bind takes the eigensolve)
+    T w[D], lw[D], v[D][D];
+    s = pair_core<T, D, false>(li, ys, wmin, wmax, w, lw, v);
+  }
+  s = Num<T>::max(s, wmin);
   if (!squared) s = Num<T>::sqrt(s);
   if (in) out[k] = s;
 }
@@ -1005,8 +1028,8 @@ __global__ void spd_dist_bwd_kernel(const T* __restrict__ x, const T* __restrict
   load_sym_packed<T, D>(y + k * D * D, ys);
   cholesky<T, D>(xs, l);
   invert_lower<T, D>(l, li);
-  T w[D], lw[D], v[D][D];
-  const T s = pair_core<T, D, true>(li, ys, wmin, wmax, w, lw, v);
+  T w[D], lw[D], v[D][D], rho[D];
+  const T s = pair_core<T, D, true>(li, ys, wmin, wmax, w, lw, v, rho);
   T gs = g[k];
   if (!squared) gs *= T(0.5) * Num<T>::rsqrt(Num<T>::max(s, wmin));
   T cm[D], cn[D];
@@ -1014,6 +1037,7 @@ __global__ void spd_dist_bwd_kernel(const T* __restrict__ x, const T* __restrict
   for (int q = 0; q < D; ++q) {
     cm[q] = -(gs + gs) * lw[q];
     cn[q] = -cm[q] / w[q];
+    cm[q] *= rho[q];   // (x side: log(w_c) w / w_c, see pair_core)
   }
   T mm_[NP], nn[NP], o[NP];
   vdvt<T, D>(v, cm, mm_);
@@ -1287,6 +1311,7 @@ constexpr int kFwdTI = MM_FWD_TI;   // rows of a forward tile (sweep on MI355X, 
 template <typename T, int D, int TI>
 int spd_pdist_fwd_launch(const T* nl, const T* nc, const T* nld, int64_t n, int64_t rb, int64_t re, int squared, double wmin, double wmax,
                          T* out, hipStream_t st) {
+  if (!spd_clamps_supported<D, MM_LOSS_NONE>(wmin, wmax)) return MM_ERR_UNSUPPORTED;
   const dim3 grid = fold_grid<TI, kBlock * pair_cols<T, D>()>(n, rb, re);
   if (squared)
     launch_timed(PROF_SPD_FWD, spd_pdist_fwd_kernel<T, D, TI, true>, grid, dim3(kBlock), st, nl, nc, nld, int(n), int(rb), int(re),
@@ -1335,6 +1360,7 @@ constexpr int64_t kSpd4TwoColBandPairs = 12000000;
 template <typename T, int D, int LOSS, bool SQ, int NCX = 0, bool SUB = false>
 int spd_pdist_bwd_launch_sq(Ws<T>& ws, const T* g, int64_t n, int64_t rb, int64_t re, double wmin, double wmax,
                             hipStream_t st, LossArgs<T> la, const int64_t* idx = nullptr, int64_t n_total = 0) {
+  if (!spd_clamps_supported<D, LOSS>(wmin, wmax)) return MM_ERR_UNSUPPORTED;
   constexpr int kThreads = 64 * bwd_waves<T, D>();
   constexpr int kCols = NCX ? NCX : pair_cols_bwd<T, D>();
   if constexpr (!SUB && NCX == 0 && sizeof(T) == 4 && D == 4 && pair_cols_bwd<T, D>() == 1) {

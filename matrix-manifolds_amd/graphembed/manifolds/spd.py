@@ -219,6 +219,13 @@ class SymmetricPositiveDefinite(Manifold):
         self.wmax = wmax
         self.check_pd = check_pd
         self.use_stein_div = use_stein_div
+        # Eigenvalue clamps narrower than [1e-6, 1e6] (never used by the reference's own scripts): the pair kernels' eigen-free
+        # paths do not see eigenvalues and refuse such windows (csrc/spd_pair.hpp, spd_clamps_supported).  `pdist` of SPD(n >= 3)
+        # then takes the element-wise kernels over the gathered pairs — what the reference's own Manifold.pdist does
+        # (base.py:59-63) — and the fused objective / one-call step are off (the unfused composition runs instead).
+        self.clamps_wide = wmin <= 1e-6 and wmax >= 1e6
+        if not self.clamps_wide:
+            self.pdist_loss = None
         if use_stein_div:  # spd.py:51-53
             self.dist = self.stein_div
             self.pdist = self.stein_pdiv
@@ -391,6 +398,11 @@ class SymmetricPositiveDefinite(Manifold):
         pair list owned by one shard (see graphembed.parallel)."""
         assert x.ndim == 3
         rb, re = (0, x.shape[0]) if rows is None else rows
+        if not self.clamps_wide and self.n >= 3:   # (see __init__)
+            n = x.shape[0]
+            iu = torch.triu_indices(n, n, 1, device=x.device)
+            lo, hi = (rb * (2 * n - rb - 1)) // 2, (re * (2 * n - re - 1)) // 2
+            return self.dist(x[iu[0, lo:hi]], x[iu[1, lo:hi]], squared=squared)
         ext = B.autograd_ext()
         if ext is not None:   # the same two C-ABI calls as _SpdPdist, issued by C++ autograd nodes (csrc_torch/mm_autograd.cpp)
             try:

@@ -95,7 +95,7 @@ def _pair_kernel_factor(man):
     if isinstance(man, VectorManifold) and kind in (B.EUCLIDEAN, B.LORENTZ, B.SPHERE):
         m = getattr(man, '_m', None)
         return (kind, m) if m is not None and m <= 16 else None
-    if hasattr(man, 'wmin') and hasattr(man, 'n') and not getattr(man, 'use_stein_div', False):
+    if hasattr(man, 'wmin') and hasattr(man, 'n') and not getattr(man, 'use_stein_div', False) and getattr(man, 'clamps_wide', True):
         return (B.FACTOR_SPD, man.n) if man.n in (2, 3) else None
     return None
 
@@ -212,7 +212,7 @@ def _single_subset_factor(man):
     if isinstance(man, VectorManifold) and kind in (B.EUCLIDEAN, B.LORENTZ, B.SPHERE):
         m = getattr(man, '_m', None)
         return (kind, m) if m is not None and m <= B.lib().raw('mm_vec_max_dim')() else None
-    if hasattr(man, 'wmin') and hasattr(man, 'n') and not getattr(man, 'use_stein_div', False):
+    if hasattr(man, 'wmin') and hasattr(man, 'n') and not getattr(man, 'use_stein_div', False) and getattr(man, 'clamps_wide', True):
         return (B.FACTOR_SPD, man.n) if 2 <= man.n <= B.lib().raw('mm_spd_max_dim')() else None
     return None
 

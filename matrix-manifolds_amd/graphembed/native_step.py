@@ -70,7 +70,7 @@ def _factor_of(man):
     from graphembed.manifolds.vector import VectorManifold
     if isinstance(man, VectorManifold):
         return man._kind, man._m
-    if hasattr(man, 'wmin') and hasattr(man, 'n') and not getattr(man, 'use_stein_div', False):
+    if hasattr(man, 'wmin') and hasattr(man, 'n') and not getattr(man, 'use_stein_div', False) and getattr(man, 'clamps_wide', True):
         return B.FACTOR_SPD, man.n
     raise ValueError(f'no fused training step for {man}')
 

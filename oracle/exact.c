@@ -86,14 +86,21 @@ static long pair_off(long n, long i) { return i * (2 * n - i - 1) / 2; }
 
 /* per-pair decomposition of A = Li Xj Li^T */
 static double pair_eig(int d, double li[DMAX][DMAX], double xj[DMAX][DMAX], double wmin, double wmax,
-                       double v[DMAX][DMAX], double w[DMAX], double lw[DMAX]) {
+                       double v[DMAX][DMAX], double w[DMAX], double lw[DMAX], double* rho) {
   double b[DMAX][DMAX], a[DMAX][DMAX];
   for (int r = 0; r < d; ++r) for (int c = 0; c < d; ++c) { double s = 0; for (int k = 0; k <= r; ++k) s += li[r][k] * xj[k][c]; b[r][c] = s; }
   for (int r = 0; r < d; ++r) for (int c = 0; c < d; ++c) { double s = 0; for (int k = 0; k <= c; ++k) s += b[r][k] * li[c][k]; a[r][c] = s; }
   for (int r = 0; r < d; ++r) for (int c = r + 1; c < d; ++c) a[r][c] = a[c][r] = 0.5 * (a[r][c] + a[c][r]);
   jacobi(d, a, v, w);
   double s = 0;
-  for (int k = 0; k < d; ++k) { w[k] = fmin(fmax(w[k], wmin), wmax); lw[k] = log(w[k]); s += lw[k] * lw[k]; }
+  /* the reference clamps the VALUES of the eigenvalues in place (w.data.clamp_, spd.py:163-169): log's backward then divides by the
+   * clamped value while the eigenvalue decomposition's backward runs on the true A.  rho = true / clamped (1 unless a clamp binds)
+   * is what that leaves on the X_i side of the gradient; the X_j side has 1 / clamped. */
+  for (int k = 0; k < d; ++k) {
+    const double wt = w[k];
+    w[k] = fmin(fmax(w[k], wmin), wmax); lw[k] = log(w[k]); s += lw[k] * lw[k];
+    if (rho) rho[k] = (w[k] == wt) ? 1.0 : wt / w[k];
+  }
   return s;
 }
 
@@ -108,7 +115,7 @@ int oracle_spd_pdist(const double* x, long n, int d, int squared, double wmin, d
     for (long i = 0; i < n; ++i) {
       double v[DMAX][DMAX], w[DMAX], lw[DMAX];
       for (long j = i + 1; j < n; ++j) {
-        double s = fmax(pair_eig(d, li[i], xs[j], wmin, wmax, v, w, lw), wmin);
+        double s = fmax(pair_eig(d, li[i], xs[j], wmin, wmax, v, w, lw, NULL), wmin);
         out[pair_off(n, i) + (j - i - 1)] = squared ? s : sqrt(s);
       }
     }
@@ -131,14 +138,14 @@ int oracle_spd_pdist_grad(const double* x, const double* g, long n, int d, int s
       double* loc = calloc((size_t)n * d * d, sizeof(double));
 #pragma omp for schedule(dynamic, 4)
       for (long i = 0; i < n; ++i) {
-        double v[DMAX][DMAX], w[DMAX], lw[DMAX], m[DMAX][DMAX], nn[DMAX][DMAX], t[DMAX][DMAX];
+        double v[DMAX][DMAX], w[DMAX], lw[DMAX], rho[DMAX], m[DMAX][DMAX], nn[DMAX][DMAX], t[DMAX][DMAX];
         for (long j = i + 1; j < n; ++j) {
-          const double s = pair_eig(d, li[i], xs[j], wmin, wmax, v, w, lw);
+          const double s = pair_eig(d, li[i], xs[j], wmin, wmax, v, w, lw, rho);
           double gs = g[pair_off(n, i) + (j - i - 1)];
           if (!squared) gs *= 0.5 / sqrt(fmax(s, wmin));
           for (int r = 0; r < d; ++r) for (int c = 0; c < d; ++c) {
             double a = 0, b = 0;
-            for (int k = 0; k < d; ++k) { a += v[r][k] * (2 * gs * lw[k]) * v[c][k]; b += v[r][k] * (2 * gs * lw[k] / w[k]) * v[c][k]; }
+            for (int k = 0; k < d; ++k) { a += v[r][k] * (2 * gs * lw[k] * rho[k]) * v[c][k]; b += v[r][k] * (2 * gs * lw[k] / w[k]) * v[c][k]; }
             m[r][c] = a; nn[r][c] = b;
           }
           /* grad_i -= Li^T M Li ; grad_j += Li^T N Li */

@@ -212,3 +212,29 @@ def test_stein_divergence(d, dname):
             gx, gy = torch.autograd.grad(dd.sum(), [xx, y])
             close(sym(gx.numpy()), sym(G[f'{tag}/dist_gx']), tol * 10, f'dist gx {tag}')
             close(sym(gy.numpy()), sym(G[f'{tag}/dist_gy']), tol * 10, f'dist gy {tag}')
+
+
+@pytest.mark.parametrize('d', [2, 3, 4, 6])
+@pytest.mark.parametrize('dname', list(DT))
+def test_spd_pdist_under_custom_eigenvalue_clamps(d, dname):
+    """SymmetricPositiveDefinite(n, wmin=.., wmax=..) (spd.py:29-30, 163-169): eigenvalues of L_i^-1 X_j L_i^-T value-clamped to the
+    window, d^2 value-clamped at wmin — golden from the real reference (tests/golden/gen_golden_clamps.py), three windows; pins
+    the port and the exact fp64 checker (oracle/exact.c) for non-default clamps."""
+    from oracle import exact
+    G = load_golden('clamps')
+    for wi in range(3):
+        tag = f'spd{d}/{dname}/w{wi}'
+        wmin, wmax = (float(v) for v in G[f'{tag}/window'])
+        x, g = T(G[f'{tag}/x']), T(G[f'{tag}/g'])
+        man = rp.SPD(d, wmin=wmin, wmax=wmax)
+        xr = x.clone().requires_grad_()
+        d2 = man.pdist(xr, squared=True)
+        close(d2.detach(), G[f'{tag}/d2'], TOL[dname], f'{tag} d2')
+        gr, = torch.autograd.grad((d2 * g).sum(), xr)
+        close(sym(gr.detach().numpy()), sym(G[f'{tag}/grad_d2']), TOL[dname] * 5, f'{tag} grad')
+        if dname == 'f64':
+            xin, gin = x.double().numpy(), g.double().numpy()
+            # (d = 2, 3: the reference's closed-form eigenvalues carry eps terms, linalg/fast.py:53-91 — SURVEY App. C)
+            close(exact.spd_pdist(xin, wmin=wmin, wmax=wmax), G[f'{tag}/d2'], 1e-9 if d >= 4 else 5e-6, f'{tag} exact d2')
+            close(exact.spd_pdist_grad(xin, gin, wmin=wmin, wmax=wmax), sym(G[f'{tag}/grad_d2']), 1e-8 if d >= 4 else 5e-6,
+                  f'{tag} exact grad')

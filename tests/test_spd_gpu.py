@@ -84,6 +84,78 @@ def test_pdist_vs_reference_golden(d, dname, init):
         check_d2(dxy, G[f'{tag}/dist_xy'], dname, f'dist_xy {tag}')
 
 
+@pytest.mark.parametrize('d', [2, 3, 4, 6])
+@pytest.mark.parametrize('dname', list(DT))
+def test_custom_eigenvalue_clamps_vs_reference_golden(d, dname):
+    """SymmetricPositiveDefinite(n, wmin=.., wmax=..) (spd.py:29-30, 163-169) under three windows that bind on a good part of the
+    pairs — golden from the real reference (tests/golden/gen_golden_clamps.py).
+    SPD(2) `pdist` takes them in its closed form, SPD(n >= 3) goes through the element-wise kernels over the gathered pairs (the
+    eigensolve applies the clamps; the pair kernels refuse such windows); the gradient carries what the reference's in-place value
+    clamp leaves in it (pair_core's rho, log_pair2_chol).  Also the element-wise dist itself."""
+    from graphembed.manifolds import SymmetricPositiveDefinite as SPD
+    G = load_golden('clamps')
+    for wi in range(3):
+        tag = f'spd{d}/{dname}/w{wi}'
+        wmin, wmax = (float(v) for v in G[f'{tag}/window'])
+        man = SPD(d, wmin=wmin, wmax=wmax)
+        x = dev(G[f'{tag}/x']).requires_grad_()
+        g = dev(G[f'{tag}/g'])
+        d2 = man.pdist(x, squared=True)
+        check_d2(d2, G[f'{tag}/d2'], dname, f'd2 {tag}')
+        gr, = torch.autograd.grad((d2 * g).sum(), x)
+        check_rel(gr, sym(G[f'{tag}/grad_d2']), GRAD_TOL[dname] * (5 if d <= 3 else 1), f'grad {tag}')
+        # element-wise on the same pairs
+        n = x.shape[0]
+        iu = torch.triu_indices(n, n, 1, device='cuda')
+        xa, xb = x.detach()[iu[0]].requires_grad_(), x.detach()[iu[1]].requires_grad_()
+        de = man.dist(xa, xb, squared=True)
+        check_d2(de, G[f'{tag}/d2'], dname, f'dist {tag}')
+        ga, gb = torch.autograd.grad((de * g).sum(), (xa, xb))
+        full = torch.zeros_like(x).index_add_(0, iu[0], ga).index_add_(0, iu[1], gb)
+        check_rel(sym(full.detach().cpu().numpy()), sym(G[f'{tag}/grad_d2']), GRAD_TOL[dname] * (5 if d <= 3 else 1), f'dist grad {tag}')
+        assert man.pdist_loss is None and not man.clamps_wide   # (no fused objective under such a window: the unfused composition runs)
+
+
+def test_pair_kernels_refuse_clamps_that_could_bind():
+    """The pair kernels' eigen-free paths never see eigenvalues and the fused objectives skip the clamp of d^2: their launchers
+    refuse windows narrower than [1e-6, 1e6] (MM_ERR_UNSUPPORTED -> BackendError) instead of returning different numbers;
+    graphembed.manifolds.spd routes `pdist` of such a manifold through the element-wise kernels (test above).  SPD(2)'s closed
+    form takes any window in `pdist`; its fused objective does not."""
+    from graphembed import _backend as B
+    from graphembed.manifolds import SymmetricPositiveDefinite as SPD
+    from graphembed.manifolds.spd import _SpdPdist
+    from graphembed.objectives import StressLoss
+    x = dev(load_golden('spd3')['f32/rand/n33/x'])[:20].contiguous()
+    with pytest.raises(B.BackendError):
+        _SpdPdist.apply(x, 3, True, 0.5, 1e8, 0, 20, False)
+    with pytest.raises(B.BackendError):
+        _SpdPdist.apply(x, 3, True, 1e-8, 10.0, 0, 20, False)
+    x2 = dev(load_golden('spd2')['f32/rand/n33/x'])[:20].contiguous()
+    tight2 = SPD(2, wmin=0.8, wmax=1.2)
+    assert torch.isfinite(tight2.pdist(x2)).all() and tight2.pdist_loss is None
+    with pytest.raises(B.BackendError):
+        SPD.pdist_loss(tight2, x2.requires_grad_(), torch.tensor(0.3, device='cuda', requires_grad=True),
+                       torch.rand(190, device='cuda'), StressLoss().fused_spec())
+    # a product with such a factor: per-factor kernels instead of the mixed-manifold pair kernel, same numbers as the composition
+    from graphembed.manifolds import Lorentz
+    from graphembed.modules import ManifoldEmbedding
+    torch.manual_seed(5)
+    with torch.device('cuda'):
+        emb = ManifoldEmbedding(30, [Lorentz(4), SPD(3, wmin=0.7, wmax=1.4)])
+        with torch.no_grad():
+            emb.perturb(0.3)
+    target = torch.rand(30 * 29 // 2, device='cuda') * 0.9 + 0.05
+    fn = StressLoss()
+    ref = fn(target, emb.compute_dists(None))
+    rg = torch.autograd.grad(ref, list(emb.xs))
+    loss = emb.fused_objective(fn, target, None)
+    if loss is not None:
+        gg = torch.autograd.grad(loss, list(emb.xs))
+        assert abs(loss.item() - ref.item()) <= 1e-4 * abs(ref.item())
+        for u, v in zip(gg, rg):
+            check_rel(u, v.double().cpu().numpy(), 1e-3, 'product with a clamped SPD factor')
+
+
 @pytest.mark.parametrize('d', [2, 3, 4, 5, 6, 7, 8, 9])
 @pytest.mark.parametrize('dname,init', list(itertools.product(DT, ['rand', 'wide'])))
 def test_maps_vs_reference_golden(d, dname, init):

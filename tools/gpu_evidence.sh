@@ -23,11 +23,11 @@ rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_BUSY_CYCL
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/bench_pmc_fetch -o p -- $P > /dev/null 2>&1
 rocprofv3 --pmc WRITE_SIZE TCC_EA0_ATOMIC_sum GRBM_GUI_ACTIVE --output-format csv -d $OUT/bench_pmc_write -o p -- $P > /dev/null 2>&1
 C="python3 /root/repo/tools/profile_case.py"
-for CASE in "pdist 3 5000 f64 0.1" "pdist 3 5000 f32 0.35" "pdist 3 5000 f64 0.35" "pdist 4 2274 f32 0.1" "pdist 4 16384 f32 0.1" "pdist 4 16384 f32 0.35" "loss 4 16384 f32" "vec 11 4039 f32 lorentz" "pdist 6 2000 f32 0.1" "pdist 9 2000 f32 0.1" "step 3 5000 f32" "vstep 11 4039 f32 lorentz"; do
+for CASE in "pdist 3 5000 f64 0.1" "pdist 3 5000 f32 0.35" "pdist 3 5000 f64 0.35" "pdist 4 2274 f32 0.1" "pdist 4 16384 f32 0.1" "pdist 4 16384 f32 0.35" "loss 4 16384 f32" "vec 11 4039 f32 lorentz" "pdist 6 2000 f32 0.1" "pdist 6 2000 f32 0.35" "pdist 6 2000 f64 0.1" "pdist 9 2000 f32 0.1" "step 3 5000 f32" "vstep 11 4039 f32 lorentz"; do
   NAME=$(echo $CASE | tr ' .' '__')
   rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/case_${NAME}_stats -o s -- $C $CASE 40 > /dev/null 2>&1
 done
-for CASE in "pdist 3 5000 f32 0.35" "pdist 3 5000 f64 0.1" "pdist 3 5000 f64 0.35" "pdist 4 16384 f32 0.1" "loss 4 16384 f32" "vec 11 4039 f32 lorentz"; do
+for CASE in "pdist 3 5000 f32 0.35" "pdist 3 5000 f64 0.1" "pdist 3 5000 f64 0.35" "pdist 4 16384 f32 0.1" "loss 4 16384 f32" "vec 11 4039 f32 lorentz" "pdist 6 2000 f32 0.1"; do
   NAME=$(echo $CASE | tr ' .' '__')
   rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE --output-format csv -d $OUT/case_${NAME}_pmc_sq -o p -- $C $CASE 3 > /dev/null 2>&1
   rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/case_${NAME}_pmc_fetch -o p -- $C $CASE 3 > /dev/null 2>&1

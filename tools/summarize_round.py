@@ -41,8 +41,10 @@ CASES = {'bench': ('SPD(3) f32 n=5000 reference init (headline; python3 bench.py
          'case_pdist_4_16384_f32_0_1': ('SPD(4) f32 n=16384 pdist fwd + bwd, reference init', 4, 16384, 4),
          'case_pdist_4_16384_f32_0_35': ('SPD(4) f32 n=16384 pdist fwd + bwd, mid-training spread (||log X|| = 0.35)', 4, 16384, 4),
          'case_loss_4_16384_f32': ('SPD(4) f32 n=16384 fused QuotientLoss step (BASELINE config 5)', 4, 16384, 4),
-         'case_pdist_6_2000_f32_0_1': ('SPD(6) f32 n=2000 pdist fwd + bwd (Jacobi path)', 6, 2000, 4),
-         'case_pdist_9_2000_f32_0_1': ('SPD(9) f32 n=2000 pdist fwd + bwd (Jacobi path, the reference\'s largest test size)', 9, 2000, 4),
+         'case_pdist_6_2000_f32_0_1': ('SPD(6) f32 n=2000 pdist fwd + bwd (matrix series since round 5; Jacobi before)', 6, 2000, 4),
+         'case_pdist_6_2000_f32_0_35': ('SPD(6) f32 n=2000 pdist fwd + bwd, mid-training spread (recentred matrix series)', 6, 2000, 4),
+         'case_pdist_6_2000_f64_0_1': ('SPD(6) f64 n=2000 pdist fwd + bwd (matrix series, degree 19)', 6, 2000, 8),
+         'case_pdist_9_2000_f32_0_1': ('SPD(9) f32 n=2000 pdist fwd + bwd (matrix series; the reference\'s largest test size)', 9, 2000, 4),
          'case_step_3_5000_f32': ('SPD(3) f32 n=5000 full training step through mm_train_step_run (pair kernel + fused finalize/update/tables)', 3, 5000, 4),
          'case_vec_11_4039_f32_lorentz': ('Lorentz(11) f32 n=4039 (BASELINE config 2) pdist fwd + bwd (default: matrix-core forward, symmetric VALU backward)', 11, 4039, 4),
          'case_vecgram_11_4039_f32_lorentz': ('Lorentz(11) f32 n=4039 pdist fwd + bwd with MM_VEC_BWD=gram (matrix-core backward)', 11, 4039, 4),

@@ -95,6 +95,7 @@ def main():
     ok &= run('config 3 SPD(3)', lambda: [M.SymmetricPositiveDefinite(3)], 1500, 'stress', 'rsgd', steps, 5e-3)
     ok &= run('config 5 SPD(4)', lambda: [M.SymmetricPositiveDefinite(4)], 1200, 'quotient', 'adam', steps, 1e-2)
     ok &= run('SPD(3), Adam', lambda: [M.SymmetricPositiveDefinite(3)], 1500, 'quotient', 'adam', steps, 2e-2)
+    ok &= run('SPD(6), Adam (matrix series -> recentred -> Jacobi)', lambda: [M.SymmetricPositiveDefinite(6)], 600, 'quotient', 'adam', steps, 2e-2)
     ok &= run('config 2 Lorentz(11)', lambda: [M.Lorentz(11)], 1500, 'stress', 'rsgd', steps, 5e-4)
     ok &= run('config 2 Lorentz(11), Adam', lambda: [M.Lorentz(11)], 1500, 'quotient', 'adam', steps, 1e-2)
     ok &= run('config 4 H6 x S6 x SPD(2)', lambda: [M.Lorentz(6), M.Sphere(6), M.SymmetricPositiveDefinite(2)], 1025, 'stress', 'adam', steps, 1e-2)

@@ -790,7 +790,10 @@ __global__ __launch_bounds__((64 * bwd_waves<T, D>()), (bwd_min_waves_nc<T, D, N
 #pragma unroll
                   for (int k = 0; k < NP; ++k) {
                     ac[k] = a[q][k];
-                    asm volatile("" : "+v"(ac[k]));   // (the series' arithmetic starts HERE: nothing of it is hoisted above the gates)
+                    // (the series' arithmetic starts HERE: nothing of it is hoisted above the gates.  The copies are real — six / ten
+                    // v_mov per pair of this path; pinning A in place instead costs MORE copies: 12 + 12 -> 19 + 12 + 12, the
+                    // other paths then keep their own)
+                    asm volatile("" : "+v"(ac[k]));
                   }
                   if constexpr (D == 3) log_series3_centred<T>(ac, m0, g_first ? gs[q] + gs[q] : T(1));
                   else log_series4_centred<T>(ac, m0, g_first ? gs[q] + gs[q] : T(1));
@@ -853,6 +856,24 @@ __global__ __launch_bounds__((64 * bwd_waves<T, D>()), (bwd_min_waves_nc<T, D, N
           });
           // row side: ONE transposing reduction of the lane's NC matrices added up — every lane ends up with the
           // wavefront total of one entry of M
+#ifndef MM_RED_IN_PLACE   // (A/B builds: the round-2..4 form, the second column added into the first one's registers)
+          // The columns' sum goes into FRESH registers: added into m[0] in place, every v_permlane*_swap of the reduction's first
+          // level got two register copies in front of it (the swap overwrites both operands and the compiler kept m[0] alive) —
+          // 12 copies per two rows; headline backward 41.5 -> 40.5 us, mid-training 54.2 -> 51.7, SPD(4) n = 16 384 934 -> 892
+          // (profiles/r05_experiments.md section 20).  SPD(2) keeps the in-place form (26.5 against 26.8 us).
+          constexpr bool kFreshSums = NC >= 2 && D >= 3;
+#else
+          constexpr bool kFreshSums = false;
+#endif
+          if constexpr (kFreshSums) {
+          T ms[NP];
+#pragma unroll
+          for (int k = 0; k < NP; ++k) {
+            ms[k] = m[0][k];
+            static_for<NC - 1>([&](auto qc) { ms[k] += m[decltype(qc)::value + 1][k]; });
+          }
+          *red_ptr = wave_reduce_transposed<NP, T>(ms, lane);
+          } else {
           static_for<NC - 1>([&](auto qc) {
             constexpr int q = decltype(qc)::value + 1;
 #pragma unroll
@@ -863,6 +884,7 @@ __global__ __launch_bounds__((64 * bwd_waves<T, D>()), (bwd_min_waves_nc<T, D, N
 #else
           *red_ptr = wave_reduce_transposed<NP, T>(m[0], lane);
 #endif
+          }
           red_ptr += red_step;
          }
         }

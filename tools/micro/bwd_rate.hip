@@ -18,10 +18,14 @@
 
 using namespace mm;
 
+#ifndef RATE_D   // (-DRATE_D=4: the two-column SPD(4) backward's row arithmetic; 1 .. 4 wavefronts per SIMD)
+#define RATE_D 3
+#endif
+constexpr int kNP = RATE_D * (RATE_D + 1) / 2;
 template <int PHASES, int WAVES>
-__global__ __launch_bounds__(256, WAVES) void rate_kernel(const float* __restrict__ rowtab /* [64][12] */, const float* __restrict__ col,
+__global__ __launch_bounds__(256, WAVES) void rate_kernel(const float* __restrict__ rowtab /* [64][2 NP] */, const float* __restrict__ col,
                                                           int iters, float* __restrict__ out, long long* __restrict__ cyc) {
-  constexpr int D = 3, NP = 6, NC = 2;
+  constexpr int D = RATE_D, NP = D * (D + 1) / 2, NC = 2;
   __shared__ float red[4][16][NP];
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   float xj[NC][NP], accJ[NC][D][D], gsum = 0.f;
@@ -40,7 +44,7 @@ __global__ __launch_bounds__(256, WAVES) void rate_kernel(const float* __restric
   const long long t0 = __builtin_readcyclecounter();
   unsigned roff = 0;
   for (int it = 0; it < iters; ++it) {
-    roff = (roff + 48u) & (64u * 48u - 1u);
+    roff = roff + unsigned(8 * kNP) >= 64u * unsigned(8 * kNP) ? 0u : roff + unsigned(8 * kNP);
     asm volatile("" : "+s"(roff));
     const float* rowp = reinterpret_cast<const float*>(reinterpret_cast<const char*>(rowtab) + roff);
     float li[NP], lc[NP];
@@ -66,7 +70,8 @@ __global__ __launch_bounds__(256, WAVES) void rate_kernel(const float* __restric
       if constexpr (PHASES & 4) {
         lt_m_lt_acc<float, D>(li, lc, m[q], accJ[q]);
       } else {
-        accJ[q][0][0] += m[q][0] + m[q][1] + m[q][2] + m[q][3] + m[q][4] + m[q][5];
+#pragma unroll
+        for (int k = 0; k < NP; ++k) accJ[q][0][0] += m[q][k];
       }
 #pragma unroll
       for (int r = 0; r < D; ++r)
@@ -120,23 +125,29 @@ template <int PHASES, int WAVES> void run(const char* name, const float* rowtab,
 int main() {
   int cus = 256;
   hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, 0);
-  std::vector<float> rt(64 * 12), cl(size_t(cus) * 4 * 256 * 12);
-  for (int r = 0; r < 64; ++r) {   // L^-1 and L of points near the identity (||log X|| ~ 0.1)
-    const float e = 0.01f * float(r % 7);
-    const float l[6] = {1.f + e, 0.02f, 1.f - e, -0.01f, 0.015f, 1.f + 0.5f * e};
-    for (int k = 0; k < 6; ++k) { rt[r * 12 + k] = l[k]; rt[r * 12 + 6 + k] = l[k]; }
+  constexpr int NP = kNP;
+  std::vector<float> rt(64 * 2 * NP), cl(size_t(cus) * 4 * 256 * 2 * NP);
+  auto fill = [&](float* l, float e, float sgn) {   // packed lower triangle of a matrix near the identity (||log X|| ~ 0.1)
+    int k = 0;
+    for (int r = 0; r < RATE_D; ++r)
+      for (int c = 0; c <= r; ++c, ++k) l[k] = c == r ? 1.f + sgn * e * float(1 + (r & 1) - (r >> 1)) : 0.01f * float((r + 2 * c) % 3) - 0.01f;
+  };
+  for (int r = 0; r < 64; ++r) {
+    float l[NP];
+    fill(l, 0.01f * float(r % 7), 1.f);
+    for (int k = 0; k < NP; ++k) { rt[r * 2 * NP + k] = l[k]; rt[r * 2 * NP + NP + k] = l[k]; }
   }
-  for (size_t t = 0; t < cl.size() / 6; ++t) {
-    const float e = 0.002f * float(t % 11);
-    const float l[6] = {1.f - e, 0.01f, 1.f + e, 0.02f, -0.01f, 1.f};
-    for (int k = 0; k < 6; ++k) cl[t * 6 + k] = l[k];
+  for (size_t t = 0; t < cl.size() / NP; ++t) {
+    float l[NP];
+    fill(l, 0.002f * float(t % 11), -1.f);
+    for (int k = 0; k < NP; ++k) cl[t * NP + k] = l[k];
   }
   float *drt, *dcl, *dout;
   long long* dcyc;
   hipMalloc(&drt, rt.size() * 4); hipMalloc(&dcl, cl.size() * 4); hipMalloc(&dout, size_t(cus) * 4 * 256 * 4); hipMalloc(&dcyc, size_t(cus) * 4 * 4 * 8);
   hipMemcpy(drt, rt.data(), rt.size() * 4, hipMemcpyHostToDevice);
   hipMemcpy(dcl, cl.data(), cl.size() * 4, hipMemcpyHostToDevice);
-#define RUN(P, NAME) run<P, 1>(NAME, drt, dcl, dout, dcyc, cus); run<P, 2>(NAME, drt, dcl, dout, dcyc, cus); run<P, 4>(NAME, drt, dcl, dout, dcyc, cus);
+#define RUN(P, NAME) run<P, 1>(NAME, drt, dcl, dout, dcyc, cus); run<P, 2>(NAME, drt, dcl, dout, dcyc, cus); run<P, 3>(NAME, drt, dcl, dout, dcyc, cus); run<P, 4>(NAME, drt, dcl, dout, dcyc, cus);
   RUN(31, "all phases + LDS store")
   RUN(15, "all phases")
   RUN(7, "no row reduction")

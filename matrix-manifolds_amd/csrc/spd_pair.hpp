@@ -825,13 +825,16 @@ __global__ __launch_bounds__((64 * bwd_waves<T, D>()), (bwd_min_waves_nc<T, D, N
           } else if constexpr (D >= 5 && kSeriesMat) {
             // SPD(5 .. 9): matrix-Horner series per wavefront (close pairs, pairs at moderate distance), else Jacobi
             static_assert(NC == 1, "one column per lane for D >= 5");
+            // (the fp64 SPD(8) backward keeps the eigensolve at moderate distance: 19 products of four spilling 36-entry double
+            // matrices next to the 64 column accumulators took 2383 us against 2002, profiles/r05_experiments.md section 18)
+            constexpr bool kWideBwd = !(std::is_same<T, double>::value && D == 8);
             T a[NP], m0[NP];
             congr_chol<T, D>(li, xj[0], a);
             bool done = false;
             if (__builtin_expect(!__any(!(close_gate<T, D>(a) <= T(kCloseGate))), 1)) {
               log_close_mat<T, D>(a, m0);
               done = true;
-            } else if (!__any(centred_far_mat<T, D>(a))) {
+            } else if (kWideBwd && !__any(centred_far_mat<T, D>(a))) {
               log_centred_mat<T, D>(a, m0);
               done = true;
             }

@@ -37,6 +37,9 @@ BUDGET = {
     'spd_pdist_bwd_kernel<float, 4, 16, 2, true, 0, true>': (128, 4, 32),
     'spd_pdist_bwd_kernel<float, 4, 16, 0, true, 2, false>': (168, 16, 48),
     'spd_pdist_bwd_kernel<float, 4, 16, 2, true, 2, false>': (168, 40, 96),
+    # SPD(6) (round 5: matrix series in front of the eigensolve; two wavefronts per SIMD in the backward, nothing in scratch)
+    'spd_pdist_fwd_kernel<float, 6, 8, true>': (184, 0, 0),
+    'spd_pdist_bwd_kernel<float, 6, 16, 0, true, 0, false>': (256, 0, 0),
     # config 4: the mixed-manifold pair kernel (H x S x SPD(2), kinds as template arguments) and its step kernel
     'product_pair_kernel<float, 2, 2, 1, 8, false, 9>': (96, 0, 0),
     'product_pair_kernel<float, 2, 2, 1, 8, true, 9>': (96, 0, 0),

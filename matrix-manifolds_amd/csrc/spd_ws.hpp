@@ -229,9 +229,32 @@ struct ColWalk {
       c = c0 + int((-Bs + sqrtf(Bs * Bs + 4.0f * A * float(p))) / (2.0f * A));
     }
     c = c < c0 ? c0 : (c > last ? last : c);
+    // Exact by construction, not by the quality of the guess: both loops run until their condition fails (they end at the
+    // line's ends at the latest), which leaves the LARGEST c with aprefix(c) <= p.  One or two steps in practice — round 5's
+    // form capped them at four and would have returned a wrong block, silently, had the fp32 guess ever drifted further
+    // (tools/micro/walk_check.hip requires <= 4 steps at every block boundary +- 2 of every n, shard and cross up to n = 2^22).
+    while (c < last && aprefix(c + 1, cross) <= p) ++c;
+    while (c > c0 && aprefix(c, cross) > p) --c;
+    return c;
+  }
+  // (the stepping capped at four either way: what walk_check.hip holds against the bisection, so that a drifting guess is SEEN —
+  // it would cost every workgroup's prologue — rather than silently absorbed by the loops above)
+  __host__ __device__ bool find_fast_converges(int64_t p, int cross = 0) const {
+    const int last = ncb - 1;
+    if (last <= c0) return true;
+    int c;
+    const int64_t pc1 = aprefix(c1, cross);
+    if (p >= pc1) {
+      const float R = float(re - rb + cross);
+      c = c1 + int(float(p - pc1) / (R > 0.f ? R : 1.f));
+    } else {
+      const float A = 0.5f * float(bw), Bs = A - 1.0f + float(bw * c0 - rb + cross);
+      c = c0 + int((-Bs + sqrtf(Bs * Bs + 4.0f * A * float(p))) / (2.0f * A));
+    }
+    c = c < c0 ? c0 : (c > last ? last : c);
     for (int k = 0; k < 4 && c < last && aprefix(c + 1, cross) <= p; ++k) ++c;
     for (int k = 0; k < 4 && c > c0 && aprefix(c, cross) > p; ++k) --c;
-    return c;
+    return !((c < last && aprefix(c + 1, cross) <= p) || (c > c0 && aprefix(c, cross) > p));
   }
   // Shares that PAY for entering a column block (round 5).  A workgroup whose share spans a block boundary flushes the column
   // sums of the block it leaves (LDS, barrier, d^2 NC atomics per lane), requests the operands of the next block's columns and

@@ -77,6 +77,72 @@ class _SpdPdist(torch.autograd.Function):
         return grad, None, None, None, None, None, None, None
 
 
+_GATHER_BYTES = 256 << 20   # budget of one gathered chunk (both sides) of the narrow-window pdist below
+
+
+def _pair_row_chunks(n, rb, re, max_pairs, device):
+    """The pairs of rows [rb, re) in pair-vector order, cut into chunks of whole rows of at most `max_pairs` pairs (a single
+    longer row is a chunk of its own): yields (i, j, lo, hi) — node index vectors of the chunk and its slice [lo, hi) of
+    the range's pair vector.  Only the chunk's indices exist at any time (not triu_indices(n, n))."""
+    r0, base = rb, B.pair_offset(n, rb)
+    re = min(re, n - 1)
+    while r0 < re:
+        r1 = r0 + 1
+        while r1 < re and B.pair_offset(n, r1 + 1) - B.pair_offset(n, r0) <= max_pairs:
+            r1 += 1
+        rows = torch.arange(r0, r1, device=device)
+        counts = (n - 1) - rows
+        i = torch.repeat_interleave(rows, counts)
+        first = torch.cumsum(counts, 0) - counts                  # offset of each row's first pair inside the chunk
+        j = torch.arange(i.numel(), device=device) - first[i - r0] + i + 1
+        lo = B.pair_offset(n, r0) - base
+        yield i, j, lo, lo + i.numel()
+        r0 = r1
+
+
+class _SpdPdistGathered(torch.autograd.Function):
+    """`pdist` under an eigenvalue window narrower than [1e-6, 1e6] for SPD(n >= 3): the element-wise kernels
+    (mm_spd_dist_fwd / _bwd, which honour any window) over the gathered pairs — the reference's own Manifold.pdist
+    (base.py:59-63) — in CHUNKS of whole rows of the requested range: one chunk's index vectors and gathered operands exist
+    at a time (256 MB), where `x[iu[0]]`, `x[iu[1]]` of all pairs plus triu_indices(n, n) were ~1 GB at n = 5000, d = 3 even
+    for a small row shard, and the backward scatter-adds per chunk instead of through an index_put over all pairs."""
+
+    @staticmethod
+    def forward(ctx, x, n_mat, squared, wmin, wmax, rb, re):
+        B.require_gpu(x)
+        xc = x.detach().contiguous()
+        n = xc.shape[0]
+        npairs = B.pair_offset(n, re) - B.pair_offset(n, rb)
+        max_pairs = max(1, _GATHER_BYTES // (2 * n_mat * n_mat * xc.element_size()))
+        with B.on_device(xc.device):
+            out = torch.empty(npairs, dtype=xc.dtype, device=xc.device)
+            for i, j, lo, hi in _pair_row_chunks(n, rb, re, max_pairs, xc.device):
+                xi, xj = xc.index_select(0, i), xc.index_select(0, j)
+                B.lib().call('mm_spd_dist_fwd', B.dtype_code(xc), B.ptr(xi), B.ptr(xj), hi - lo, n_mat, int(squared), wmin, wmax,
+                             B.ptr(out[lo:hi]), B.stream_of(xc))
+        ctx.save_for_backward(xc)
+        ctx.args = (n_mat, squared, wmin, wmax, rb, re, max_pairs)
+        return out
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g):
+        xc, = ctx.saved_tensors
+        n_mat, squared, wmin, wmax, rb, re, max_pairs = ctx.args
+        g = g.contiguous()
+        n = xc.shape[0]
+        with B.on_device(xc.device):
+            grad = torch.zeros_like(xc)
+            for i, j, lo, hi in _pair_row_chunks(n, rb, re, max_pairs, xc.device):
+                xi, xj = xc.index_select(0, i), xc.index_select(0, j)
+                gi, gj = torch.empty_like(xi), torch.empty_like(xj)
+                B.lib().call('mm_spd_dist_bwd', B.dtype_code(xc), B.ptr(xi), B.ptr(xj), B.ptr(g[lo:hi]), hi - lo, n_mat,
+                             int(squared), wmin, wmax, B.ptr(gi), B.ptr(gj), B.stream_of(xc))
+                grad.index_add_(0, i, gi)
+                grad.index_add_(0, j, gj)
+        return grad, None, None, None, None, None, None
+
+
 class _SpdPdistLoss(torch.autograd.Function):
     """loss(target, softplus(scale) * pdist(x)^2) and both gradients from ONE pass over the
     pairs (mm_spd_pdist_loss): what train.py:213-217 + modules.py:84-88 + objectives.py:16-45
@@ -212,6 +278,8 @@ class _SteinDiv(torch.autograd.Function):
 
 class SymmetricPositiveDefinite(Manifold):
 
+    _warned_narrow = False
+
     def __init__(self, n, *, fast_symeig=True, fast_chol=True, use_stein_div=False, wmin=1e-8,
                  wmax=1e8, check_pd=False):
         self.n = n
@@ -226,6 +294,13 @@ class SymmetricPositiveDefinite(Manifold):
         self.clamps_wide = wmin <= 1e-6 and wmax >= 1e6
         if not self.clamps_wide:
             self.pdist_loss = None
+            if n >= 3 and not SymmetricPositiveDefinite._warned_narrow:
+                SymmetricPositiveDefinite._warned_narrow = True   # once per process
+                import warnings
+                warnings.warn(f'SymmetricPositiveDefinite({n}, wmin={wmin:g}, wmax={wmax:g}): eigenvalue clamps narrower than '
+                              '[1e-6, 1e6] are served exactly but OFF the pair kernels — pdist runs the element-wise kernels over '
+                              'gathered pairs (chunked; several times slower) and the fused objective / one-call training step '
+                              'are unavailable for this manifold (DESIGN.md section 6, item 11)', stacklevel=2)
         if use_stein_div:  # spd.py:51-53
             self.dist = self.stein_div
             self.pdist = self.stein_pdiv
@@ -399,10 +474,7 @@ class SymmetricPositiveDefinite(Manifold):
         assert x.ndim == 3
         rb, re = (0, x.shape[0]) if rows is None else rows
         if not self.clamps_wide and self.n >= 3:   # (see __init__)
-            n = x.shape[0]
-            iu = torch.triu_indices(n, n, 1, device=x.device)
-            lo, hi = (rb * (2 * n - rb - 1)) // 2, (re * (2 * n - re - 1)) // 2
-            return self.dist(x[iu[0, lo:hi]], x[iu[1, lo:hi]], squared=squared)
+            return _SpdPdistGathered.apply(x, self.n, squared, self.wmin, self.wmax, int(rb), int(re))
         ext = B.autograd_ext()
         if ext is not None:   # the same two C-ABI calls as _SpdPdist, issued by C++ autograd nodes (csrc_torch/mm_autograd.cpp)
             try:

@@ -26,10 +26,13 @@ class _TakeRows(torch.autograd.Function):
         return torch.zeros(ctx.shape, dtype=g.dtype, device=g.device).index_add_(0, i, g), None
 
 
-def take_rows(x, i):
+def take_rows(x, i, validated=False):
+    """`validated`: the caller has already run the host-side range scan over `i` (prepare_indices / normalise_indices) or
+    opted out of it (BatchedObjective.check_indices = False) — the scan is one `aminmax` over the batch per call otherwise."""
     if i is None:
         return x
-    i = normalise_indices(i, x.shape[0])   # host-side: IndexError out of range, python-style negatives wrapped (x[idx] semantics)
+    if not validated:
+        i = normalise_indices(i, x.shape[0])   # host-side: IndexError out of range, python-style negatives wrapped (x[idx] semantics)
     if i.dtype != torch.int64 or i.device != x.device:
         i = i.to(device=x.device, dtype=torch.int64)
     return _TakeRows.apply(x, i)
@@ -237,6 +240,23 @@ def distinct_in_range(indices, n):
     return bool(torch.unique(indices).numel() == indices.numel())
 
 
+def prepare_indices(indices, n, distinct=True):
+    """`normalise_indices` and `distinct_in_range` in ONE host-side pass (one `aminmax`, one `unique`): returns
+    `(indices, in_kernel)` — the indices as the reference's `x[idx]` reads them (IndexError out of range, python-style
+    negatives wrapped) and whether the batch may take an in-kernel node-minibatch route (its nodes are distinct).  The
+    training loop's entry points (BatchedObjective.forward, NativeTrainStep.__call__) call this once per step and hand
+    the result down with `validated=True`; device-side tensors and empty batches pass unchecked, as documented on
+    `distinct_in_range`."""
+    if indices is None or indices.is_cuda or indices.numel() == 0:
+        return indices, True
+    lo, hi = (int(v) for v in torch.aminmax(indices))
+    if lo < -n or hi >= n:
+        raise IndexError(f'index out of range for an embedding of {n} points: [{lo}, {hi}]')
+    if lo < 0:
+        indices = torch.where(indices < 0, indices + n, indices)
+    return indices, (not distinct) or bool(torch.unique(indices).numel() == indices.numel())
+
+
 def normalise_indices(indices, n):
     """Host-side node indices as the reference's `x[idx]` reads them: out of range raises IndexError, python-style
     negatives are wrapped (index_select and the gather kernels take non-negative indices only).  Device-side
@@ -378,13 +398,15 @@ class ManifoldEmbedding(torch.nn.Module):
         for x in self.xs:
             x.proj_()
 
-    def compute_dists(self, i=None):
-        """sum_k softplus(s_k) * pdist_k(x_k[i], squared=True) — modules.py:84-88."""
+    def compute_dists(self, i=None, validated=False):
+        """sum_k softplus(s_k) * pdist_k(x_k[i], squared=True) — modules.py:84-88.  (`validated`: see take_rows.)"""
+        if i is not None and not validated:
+            i = normalise_indices(i, self.n)   # ONE range scan for all factors
         return sum(
-            softplus(s) * man.pdist(take_rows(x, i), squared=True)
+            softplus(s) * man.pdist(take_rows(x, i, validated=True), squared=True)
             for x, s, man in zip(self.xs, self.scales, self.manifolds))
 
-    def fused_objective(self, objective_fn, gdists, i=None, rows=None, dense=None, params=None, **kwargs):
+    def fused_objective(self, objective_fn, gdists, i=None, rows=None, dense=None, params=None, validated=False, **kwargs):
         """`objective_fn(gdists, self.compute_dists(i), **kwargs)` evaluated by ONE pair kernel
         that also produces the gradients (no pair vector of distances, no element-wise passes),
         or None when the objective has no fused kernel (a loss without `fused_spec`, CPU tensors).
@@ -395,7 +417,10 @@ class ManifoldEmbedding(torch.nn.Module):
         (`mm_product_loss`).  With a node minibatch `i` and the dataset's dense target matrix `dense`
         (then `gdists` may be None) the pair kernel reads rows `i` of the full tables and the targets
         `dense[i[a], i[b]]` itself and writes full-size gradients — no gather / scatter launches (the
-        indices of a batch must be distinct, as slices of a `randperm` are: train.py:206-209)."""
+        indices of a batch must be distinct, as slices of a `randperm` are: train.py:206-209).
+        Host-side indices are range-checked, wrapped and tested for repeats HERE, once (`prepare_indices`), unless the
+        caller says it has done so or has opted out (`validated=True`: BatchedObjective — whose `check_indices = False`
+        skips the ~20 us of `aminmax` + `unique` per step —, NativeTrainStep): a validated batch is taken as distinct."""
         if not hasattr(objective_fn, 'fused_spec') or not self.xs[0].is_cuda:
             return None
         # `params` = (points, scales) to differentiate instead of self.xs / self.scales — views of them whose
@@ -404,11 +429,11 @@ class ManifoldEmbedding(torch.nn.Module):
         spec = objective_fn.fused_spec(**kwargs)
         in_kernel_batch = (i is not None and dense is not None and dense.is_cuda and self.pair_kernel
                            and dense.dtype == pts[0].dtype)
-        if in_kernel_batch and not distinct_in_range(i, self.n):
-            # (host-side indices with repeats or python-style negatives: the kernels address tables, targets and gradient
-            # rows through the index vector unchecked — such a batch goes the gather / scatter way, like the reference's)
-            in_kernel_batch = False
-            i = normalise_indices(i, self.n)
+        if i is not None and not validated:
+            # (host-side indices with repeats: the kernels address tables, targets and gradient rows through the index
+            # vector unchecked — such a batch goes the gather / scatter way, like the reference's)
+            i, distinct = prepare_indices(i, self.n, distinct=in_kernel_batch)
+            in_kernel_batch = in_kernel_batch and distinct
         if in_kernel_batch and i.numel() == 0:
             # an empty batch has no pairs: a zero loss whose backward gives every parameter its (dense) zero gradient, as the
             # reference's sum over an empty pair list does
@@ -432,14 +457,14 @@ class ManifoldEmbedding(torch.nn.Module):
         if self.n_components == 1 and getattr(self.manifolds[0], 'pdist_loss', None) is not None:
             if gdists is None:
                 return None
-            x = take_rows(pts[0], i)
+            x = take_rows(pts[0], i, validated=True)
             return self.manifolds[0].pdist_loss(x, scales[0], gdists, spec, rows=rows)
         if self.n_components > _max_product_factors():
             return None
         factors = _pair_kernel_factors(self.manifolds) if self.pair_kernel else None
         if gdists is None:
             return None
-        xs = [take_rows(x, i) for x in pts]
+        xs = [take_rows(x, i, validated=True) for x in pts]
         if factors is not None:
             return _ProductPairsLoss.apply(gdists, spec, rows, tuple(self.manifolds), tuple(factors),
                                            self._pair_ws, None, *xs, *scales)
@@ -459,7 +484,9 @@ class BatchedObjective(torch.nn.Module):
         self.embedding = embedding
         self.fused = fused  # use the one-pass loss+gradient kernel when the configuration has one
 
-    check_indices = True   # validate CPU index tensors before the in-kernel minibatch path (~20 us per step)
+    # validate CPU index tensors once per step (range, python-style negatives, repeats: ~20 us of aminmax + unique); False =
+    # the caller vouches for them (in range, non-negative, distinct — slices of a randperm are) and NO scan runs on any route
+    check_indices = True
 
     def _distinct_in_range(self, indices, n):
         """`distinct_in_range` (module level) under this objective's `check_indices` switch."""
@@ -467,18 +494,21 @@ class BatchedObjective(torch.nn.Module):
 
     def forward(self, indices, *args, **kwargs):
         emb = self.embedding
+        distinct = True
         if self.check_indices and indices is not None:
-            indices = normalise_indices(indices, len(emb))   # IndexError like the reference's x[idx]; negatives wrapped
+            # the step's ONE host-side scan: IndexError like the reference's x[idx], negatives wrapped, repeats noted; every
+            # route below is told so (validated=True) — with check_indices off none of them scans either
+            indices, distinct = prepare_indices(indices, len(emb))
         if self.fused and not args and indices is not None and emb.xs[0].is_cuda \
                 and hasattr(self.objective_fn, 'fused_spec') and hasattr(self.dataset, 'pdists'):
             dense = self.dataset.pdists   # the pair kernel gathers rows and targets itself
-            if dense.is_cuda and dense.dtype == emb.xs[0].dtype and self._distinct_in_range(indices, len(emb)):
-                loss = emb.fused_objective(self.objective_fn, None, indices, dense=dense, **kwargs)
+            if dense.is_cuda and dense.dtype == emb.xs[0].dtype and distinct:
+                loss = emb.fused_objective(self.objective_fn, None, indices, dense=dense, validated=True, **kwargs)
                 if loss is not None:
                     return loss
         gdists = self.dataset[indices].to(self.embedding.device)
         if self.fused and not args:
-            loss = self.embedding.fused_objective(self.objective_fn, gdists, indices, **kwargs)
+            loss = self.embedding.fused_objective(self.objective_fn, gdists, indices, validated=True, **kwargs)
             if loss is not None:
                 return loss
-        return self.objective_fn(gdists, self.embedding.compute_dists(indices), *args, **kwargs)
+        return self.objective_fn(gdists, self.embedding.compute_dists(indices, validated=True), *args, **kwargs)

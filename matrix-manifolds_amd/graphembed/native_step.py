@@ -247,9 +247,10 @@ class NativeTrainStep:
             # the kernels behind mm_train_step.batch_idx address table rows, dense-target rows and accumulator slots through
             # the index vector unchecked: host-side indices are validated here as BatchedObjective does (IndexError out of range
             # like the reference's x[idx], python-style negatives wrapped); device-side ones cannot be without a synchronisation
-            from graphembed.modules import distinct_in_range, normalise_indices
-            indices = normalise_indices(indices, self.n)
-            if self.check_indices and not distinct_in_range(indices, self.n):
+            # (ONE pass per step — prepare_indices: an aminmax, and the torch.unique unless check_indices is off)
+            from graphembed.modules import prepare_indices
+            indices, distinct = prepare_indices(indices, self.n, distinct=self.check_indices)
+            if not distinct:
                 raise ValueError('the node indices of a minibatch step must be distinct (slices of a randperm are: train.py:206-209)')
             self._idx = indices.to(device=self.device, dtype=torch.int64).contiguous()   # (kept: the enqueued kernels read it)
             batch = self._idx.numel()
@@ -313,7 +314,8 @@ class NativeTrainStep:
     def _first_step_unfused(self, indices=None, **objective_kwargs):
         """First step of a heavy-ball RSGD: the momentum buffers do not exist yet — run it through the optimizers."""
         if indices is not None:
-            loss = self.embedding.fused_objective(self.objective_fn, None, self._idx, dense=self.dense, **objective_kwargs)
+            loss = self.embedding.fused_objective(self.objective_fn, None, self._idx, dense=self.dense, validated=True,
+                                                  **objective_kwargs)
         elif self.shard is not None:
             from graphembed import parallel
             loss = parallel.sharded_fused_objective(self.embedding, self.objective_fn, self.target, self.shard,

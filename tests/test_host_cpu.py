@@ -353,10 +353,45 @@ def test_train_step_struct_layout_matches_the_header(tmp_path):
         assert getattr(cls, name).offset == int(off), (which, name)
 
 
+def test_pair_row_chunks_cover_the_pair_vector_in_order():
+    """graphembed.manifolds.spd._pair_row_chunks (the narrow-window pdist, advisor round 5: triu_indices(n, n) and the gather of ALL
+    pairs were materialised even for a small row shard): chunks of whole rows, in pair-vector order, equal to the slice of
+    triu_indices the old route took — any row range, any budget."""
+    import warnings
+    from graphembed import _backend as B
+    from graphembed.manifolds.spd import SymmetricPositiveDefinite, _pair_row_chunks
+    for n in (2, 3, 17, 64):
+        iu = torch.triu_indices(n, n, 1)
+        for rb, re in ((0, n), (0, 1), (n // 3, 2 * n // 3), (n - 2, n), (n - 1, n), (5 % n, 5 % n)):
+            lo0, hi0 = B.pair_offset(n, rb), B.pair_offset(n, re)
+            for budget in (1, 7, 40, 10 ** 6):
+                at, ii, jj = 0, [], []
+                for i, j, lo, hi in _pair_row_chunks(n, rb, re, budget, torch.device('cpu')):
+                    assert lo == at and hi - lo == i.numel() == j.numel()
+                    rows_in_chunk = int(i.max()) - int(i.min()) + 1
+                    assert hi - lo <= budget or rows_in_chunk == 1     # whole rows; only a single row may exceed the budget
+                    at = hi
+                    ii.append(i); jj.append(j)
+                assert at == hi0 - lo0
+                if at:
+                    assert torch.equal(torch.cat(ii), iu[0, lo0:hi0]) and torch.equal(torch.cat(jj), iu[1, lo0:hi0])
+    # constructing a manifold whose window takes that route says so, once per process
+    SymmetricPositiveDefinite._warned_narrow = False
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter('always')
+        SymmetricPositiveDefinite(3, wmin=0.5, wmax=2.0)
+        SymmetricPositiveDefinite(4, wmin=0.5, wmax=2.0)
+        SymmetricPositiveDefinite(3)                       # the default window: nothing to say
+    assert len([x for x in w if 'narrower than' in str(x.message)]) == 1
+
+
 def test_walk_arithmetic_closed_form_matches_the_search(tmp_path):
     """The resident-grid kernels cut their shares on the host (WalkShares) and find a share's first column block in closed
-    form (ColWalk::find_fast, fp64 square root + one correction step) instead of a binary search behind two 64-bit divisions:
-    tools/micro/walk_check.hip holds both against the exact integer forms for launches and shards up to n = 2^22."""
+    form (ColWalk::find_fast: an fp32 square root, then stepped either way against the exact prefix sums until exact)
+    instead of a binary search behind two 64-bit divisions:
+    tools/micro/walk_check.hip holds both against the exact integer forms for launches and shards up to n = 2^22 — the plain
+    line and the line with block-entry costs (cross = 1 ... 1024, incl. the shipped 16 / 8) — and requires the
+    stepping to need at most four steps."""
     import shutil
     import subprocess
     hipcc = shutil.which('hipcc') or '/opt/rocm/bin/hipcc'

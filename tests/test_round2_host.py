@@ -67,6 +67,63 @@ def test_minibatch_index_validation():
             normalise_indices(torch.tensor(bad), 50)
 
 
+def test_index_scan_runs_once_per_step_and_the_opt_out_skips_it(monkeypatch):
+    """Advisor (round 5): `check_indices = False` no longer disabled the ~20 us `aminmax` + `unique` on the in-kernel route
+    and host-side indices were scanned up to four times per step.  Now: ONE `prepare_indices` per step at the entry point,
+    every route below is told (`validated=True`), and the opt-out runs no scan at all."""
+    import graphembed.modules as Mod
+    from graphembed.modules import BatchedObjective, prepare_indices
+    idx, ok = prepare_indices(torch.tensor([-1, 2, -50]), 50)
+    assert idx.tolist() == [49, 2, 0] and ok
+    assert prepare_indices(torch.tensor([4, -46]), 50)[1] is False            # a repeat after wrapping
+    assert prepare_indices(torch.tensor([4, 4]), 50, distinct=False)[1] is True
+    assert prepare_indices(None, 50) == (None, True)
+    for bad in ([1, 50], [-51, 3]):
+        with pytest.raises(IndexError):
+            prepare_indices(torch.tensor(bad), 50)
+    calls = {'aminmax': 0, 'unique': 0, 'minmax': 0}
+    real_aminmax, real_unique = torch.aminmax, torch.unique
+    monkeypatch.setattr(torch, 'aminmax', lambda *a, **k: (calls.__setitem__('aminmax', calls['aminmax'] + 1), real_aminmax(*a, **k))[1])
+    monkeypatch.setattr(torch, 'unique', lambda *a, **k: (calls.__setitem__('unique', calls['unique'] + 1), real_unique(*a, **k))[1])
+    seen = []
+
+    class Emb:                       # (records what the routes are told; no kernels involved)
+        n = 50
+        xs = [torch.zeros(50, 3)]
+        device = torch.device('cpu')
+
+        def __len__(self):
+            return 50
+
+        def fused_objective(self, fn, gd, i, validated=False, **k):
+            seen.append(('fused', validated))
+            # what the real method does with an unvalidated batch
+            if i is not None and not validated:
+                Mod.prepare_indices(i, 50)
+            return None
+
+        def compute_dists(self, i, validated=False):
+            seen.append(('dists', validated))
+            return Mod.take_rows(self.xs[0], i, validated=validated).sum(-1)
+
+    class DS:
+        def __getitem__(self, i):
+            return torch.zeros(i.numel())
+
+    bo = BatchedObjective(lambda g, d: (g - d).sum(), DS(), Emb())
+    batch = torch.randperm(50)[:20]
+    bo(batch)
+    assert calls == {'aminmax': 1, 'unique': 1, 'minmax': 0} and seen == [('fused', True), ('dists', True)]
+    bo.check_indices = False
+    calls.update(aminmax=0, unique=0)
+    bo(batch)
+    assert calls['aminmax'] == 0 and calls['unique'] == 0
+    # a direct caller of the embedding's methods still gets the scan (once)
+    calls.update(aminmax=0, unique=0)
+    Emb().compute_dists(batch)
+    assert calls['unique'] == 0
+
+
 def test_quotient_schedule_written_only_on_change(monkeypatch):
     from graphembed.objectives import QuotientLoss
     q = QuotientLoss()

@@ -116,6 +116,37 @@ def test_custom_eigenvalue_clamps_vs_reference_golden(d, dname):
         assert man.pdist_loss is None and not man.clamps_wide   # (no fused objective under such a window: the unfused composition runs)
 
 
+@pytest.mark.parametrize('dname', list(DT))
+def test_narrow_window_pdist_is_chunked_and_shards(dname, monkeypatch):
+    """pdist under a binding eigenvalue window (element-wise kernels over gathered pairs) works in chunks of whole rows
+    (graphembed.manifolds.spd._SpdPdistGathered; advisor, round 5): many small chunks give the one-chunk numbers bit for bit in
+    the forward and to rounding in the gradient (float atomics of index_add), and row shards tile the pair vector."""
+    import graphembed.manifolds.spd as S
+    G = load_golden('clamps')
+    tag = f'spd3/{dname}/w1'
+    wmin, wmax = (float(v) for v in G[f'{tag}/window'])
+    man = S.SymmetricPositiveDefinite(3, wmin=wmin, wmax=wmax)
+    x = dev(G[f'{tag}/x']).requires_grad_()
+    g = dev(G[f'{tag}/g'])
+    n = x.shape[0]
+    one = man.pdist(x, squared=True)
+    g_one, = torch.autograd.grad((one * g).sum(), x)
+    monkeypatch.setattr(S, '_GATHER_BYTES', 2 * 9 * x.element_size() * 40)   # 40 pairs per chunk: every row its own chunk or two
+    many = man.pdist(x, squared=True)
+    assert torch.equal(one, many)
+    g_many, = torch.autograd.grad((many * g).sum(), x)
+    check_rel(g_many, g_one.detach().cpu().numpy(), GRAD_TOL[dname], 'chunked gradient')
+    parts, grads = [], torch.zeros_like(x)
+    for rows in ((0, 5), (5, 6), (6, n - 3), (n - 3, n)):
+        lo, hi = rows[0] * (2 * n - rows[0] - 1) // 2, rows[1] * (2 * n - rows[1] - 1) // 2
+        part = man.pdist(x, squared=True, rows=rows)
+        assert part.numel() == hi - lo
+        parts.append(part)
+        grads += torch.autograd.grad((part * g[lo:hi]).sum(), x)[0]
+    assert torch.equal(torch.cat(parts), one)
+    check_rel(grads, g_one.detach().cpu().numpy(), GRAD_TOL[dname], 'sharded gradient')
+
+
 def test_pair_kernels_refuse_clamps_that_could_bind():
     """The pair kernels' eigen-free paths never see eigenvalues and the fused objectives skip the clamp of d^2: their launchers
     refuse windows narrower than [1e-6, 1e6] (MM_ERR_UNSUPPORTED -> BackendError) instead of returning different numbers;

@@ -282,11 +282,43 @@ def _valu(man):
     return man
 
 
+def host_calibration():
+    """How fast THIS box's host dispatches work — the yardstick for every eager (non-graph) row, which is host-bound: the same
+    tree measured 1.3 - 1.6 x apart in its eager rows on two boxes while every graph-replayed row agreed to 3 % (round 5's
+    table against round 4's; advisor, round 5).  `launch_us`: a trivial in-place torch kernel enqueued in a loop (framework
+    dispatch + hipLaunchKernel, no synchronisation inside); `cabi_us`: an argument-check-only C-ABI call through ctypes;
+    `python_us`: 1000 iterations of a pure-python arithmetic loop."""
+    import time
+    from graphembed import _backend as B
+    t = torch.zeros(64, device='cuda')
+    for _ in range(200):
+        t.add_(1.0)
+    torch.cuda.synchronize()
+    best = 1e9
+    for _ in range(5):
+        t0 = time.perf_counter()
+        for _ in range(2000):
+            t.add_(1.0)
+        best = min(best, (time.perf_counter() - t0) / 2000 * 1e6)
+        torch.cuda.synchronize()
+    fn = B.lib().raw('mm_pair_offset')
+    t0 = time.perf_counter()
+    for _ in range(20000):
+        fn(5000, 17)
+    cabi = (time.perf_counter() - t0) / 20000 * 1e6
+    t0 = time.perf_counter()
+    acc = 0
+    for i in range(200000):
+        acc += i * i % 7
+    py = (time.perf_counter() - t0) / 200 * 1e6
+    return {'launch_us': best, 'cabi_us': cabi, 'python_us': py, 'host_cpus': os.cpu_count()}
+
+
 if __name__ == '__main__':
     ap = argparse.ArgumentParser()
     ap.add_argument('--only', default=None)
     a = ap.parse_args()
-    out = {}
+    out = {'_host': host_calibration()}
     for name, fn in CASES.items():
         if a.only and a.only not in name:
             continue

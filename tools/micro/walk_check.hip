@@ -1,6 +1,8 @@
-// Host-side check of the balanced walk's arithmetic (csrc/spd_ws.hpp): ColWalk::find_fast (closed form) against ColWalk::find
-// (binary search) on every block boundary +- 2 and a stride through the line, for full launches and row shards up to n = 2^22,
-// and divmod_small / WalkShares against the integer division.  No GPU involved: tests/test_host_cpu.py builds and runs it.
+// Host-side check of the balanced walk's arithmetic (csrc/spd_ws.hpp): ColWalk::find_fast (closed form: fp32 square root, up to
+// four steps either way) against ColWalk::find (binary search) on every block boundary +- 2 and a stride through the line — in
+// the plain line and in the augmented one (cross = 1, 8, 16, 100, 1024; the shipped defaults are 16 / 8), for full launches
+// and row shards up to n = 2^22, with the stepping required to need at most four steps —, and divmod_small / WalkShares
+// against the integer division.  No GPU involved: tests/test_host_cpu.py builds and runs it.
 #include <cstdio>
 #include <cstdlib>
 #include <cmath>
@@ -20,7 +22,24 @@ int main() {
       const int64_t p = w.prefix(c) + d;
       if (p < 0 || p >= tot) continue;
       ++checked;
-      if (w.find_fast(p) != w.find(p)) { if (++bad < 10) printf("n=%d bw=%d rb=%d re=%d p=%lld fast=%d find=%d\n", n, bw, rb, re, (long long)p, w.find_fast(p), w.find(p)); }
+      if (w.find_fast(p) != w.find(p) || !w.find_fast_converges(p)) { if (++bad < 10) printf("n=%d bw=%d rb=%d re=%d p=%lld fast=%d find=%d\n", n, bw, rb, re, (long long)p, w.find_fast(p), w.find(p)); }
+    }
+    // the augmented line (a share pays `cross` units per block it enters; the shipped defaults are 16 for fp32 and 8 for
+    // fp64): find_fast(p, cross) against a bisection on aprefix() at every block boundary +-2 and a stride through the line —
+    // and the stepping must need at most four steps either way (find_fast_converges: a drifting guess would cost every prologue)
+    for (int cross : {1, 8, 16, 100, 1024}) {
+      const int64_t atot = w.total_aug(cross);
+      auto exact = [&](int64_t p) { int lo = w.c0, hi = w.ncb - 1; while (lo < hi) { const int mid = (lo + hi + 1) / 2; if (w.aprefix(mid, cross) <= p) lo = mid; else hi = mid - 1; } return lo; };
+      auto hold = [&](int64_t p) {
+        if (p < 0 || p >= atot) return;
+        ++checked;
+        const int f = w.find_fast(p, cross), e = exact(p);
+        if (f != e || !w.find_fast_converges(p, cross)) { if (++bad < 10) printf("aug n=%d bw=%d rb=%d re=%d cross=%d p=%lld fast=%d exact=%d converged=%d\n", n, bw, rb, re, cross, (long long)p, f, e, int(w.find_fast_converges(p, cross))); }
+      };
+      for (int c = w.c0; c <= w.ncb; c += (w.ncb > 4000 ? 89 : 1)) for (int d = -2; d <= 2; ++d) { hold(w.aprefix(c, cross) + d); hold(w.aprefix(c, cross) + cross + d); }
+      const int64_t astep = atot / 2503 + 1;
+      for (int64_t p = 0; p < atot; p += astep) hold(p);
+      hold(atot - 1);
     }
     const int64_t step = tot / 5003 + 1;
     for (int64_t p = 0; p < tot; p += step) { ++checked; if (w.find_fast(p) != w.find(p)) { if (++bad < 10) printf("n=%d bw=%d rb=%d re=%d p=%lld fast=%d find=%d\n", n, bw, rb, re, (long long)p, w.find_fast(p), w.find(p)); } }

@@ -726,6 +726,11 @@ __global__ __launch_bounds__((64 * bwd_waves<T, D>()), (bwd_min_waves_nc<T, D, N
           constexpr bool g_first = LOSS == MM_LOSS_NONE && SQ;
           auto jacobi_path = [&](auto qc) __attribute__((always_inline)) {
             constexpr int q = decltype(qc)::value;
+#ifdef MM_DIAG_NO_COLD   // (diagnostic builds, wrong results beyond the gates: what do the cold paths cost the hot one in registers and code?)
+#pragma unroll
+            for (int k = 0; k < NP; ++k) m[q][k] = T(0);
+            return;
+#endif
             T w[D], lw[D], v[D][D];
             const T s = pair_core<T, D, true, true, !(D == 4 && NC == 2)>(li, xj[q], wmin, wmax, w, lw, v);
             gs[q] = upstream_of<T, LOSS>(gs[q], s, valid[q], squared, wmin, sp, la, loss_acc, ds_acc);
@@ -805,6 +810,10 @@ __global__ __launch_bounds__((64 * bwd_waves<T, D>()), (bwd_min_waves_nc<T, D, N
               static_for<NC>([&](auto qc) {
                 constexpr int q = decltype(qc)::value;
                 T m0[NP];
+#ifdef MM_DIAG_NO_CAYLEY
+                jacobi_path(qc);
+                return;
+#endif
                 const T gate = log_cayley<T, D>(a[q], m0, g_first ? gs[q] + gs[q] : T(1));
                 if (__builtin_expect(!__any(!(gate <= T(kCayleyGate))), 1)) finish(qc, m0, g_first); else jacobi_path(qc);
               });

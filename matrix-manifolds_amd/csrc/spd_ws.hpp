@@ -52,8 +52,11 @@ template <typename T, int D> constexpr int bwd_min_waves() {
 }
 // ... with NCX columns per lane forced (0: the default of pair_cols_bwd): two columns of fp32 SPD(4) need ~185 registers —
 // three wavefronts per SIMD (168 registers, the rest spilled) measured best (profiles/r03_experiments.md §2)
+#ifndef MM_SPD4_BWD2_WAVES
+#define MM_SPD4_BWD2_WAVES 3
+#endif
 template <typename T, int D, int NCX> constexpr int bwd_min_waves_nc() {
-  return (NCX == 2 && sizeof(T) == 4 && D == 4) ? 3 : bwd_min_waves<T, D>();
+  return (NCX == 2 && sizeof(T) == 4 && D == 4) ? MM_SPD4_BWD2_WAVES : bwd_min_waves<T, D>();
 }
 // Wavefronts of a backward workgroup: they share one column block and flush its column-side sums once
 template <typename T, int D> constexpr int bwd_waves() {

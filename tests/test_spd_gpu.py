@@ -119,8 +119,9 @@ def test_custom_eigenvalue_clamps_vs_reference_golden(d, dname):
 @pytest.mark.parametrize('dname', list(DT))
 def test_narrow_window_pdist_is_chunked_and_shards(dname, monkeypatch):
     """pdist under a binding eigenvalue window (element-wise kernels over gathered pairs) works in chunks of whole rows
-    (graphembed.manifolds.spd._SpdPdistGathered; advisor, round 5): many small chunks give the one-chunk numbers bit for bit in
-    the forward and to rounding in the gradient (float atomics of index_add), and row shards tile the pair vector."""
+    (graphembed.manifolds.spd._SpdPdistGathered; advisor, round 5): many small chunks give the one-chunk numbers to rounding
+    (which pairs share a wavefront decides the path the element-wise kernels take for all of them; the gradient also goes
+    through the float atomics of index_add), and row shards tile the pair vector."""
     import graphembed.manifolds.spd as S
     G = load_golden('clamps')
     tag = f'spd3/{dname}/w1'
@@ -133,7 +134,8 @@ def test_narrow_window_pdist_is_chunked_and_shards(dname, monkeypatch):
     g_one, = torch.autograd.grad((one * g).sum(), x)
     monkeypatch.setattr(S, '_GATHER_BYTES', 2 * 9 * x.element_size() * 40)   # 40 pairs per chunk: every row its own chunk or two
     many = man.pdist(x, squared=True)
-    assert torch.equal(one, many)
+    rnd = 1e-12 if dname == 'f64' else 2e-6
+    check_rel(many, one.detach().cpu().numpy(), rnd, 'chunked d2')
     g_many, = torch.autograd.grad((many * g).sum(), x)
     check_rel(g_many, g_one.detach().cpu().numpy(), GRAD_TOL[dname], 'chunked gradient')
     parts, grads = [], torch.zeros_like(x)
@@ -143,7 +145,7 @@ def test_narrow_window_pdist_is_chunked_and_shards(dname, monkeypatch):
         assert part.numel() == hi - lo
         parts.append(part)
         grads += torch.autograd.grad((part * g[lo:hi]).sum(), x)[0]
-    assert torch.equal(torch.cat(parts), one)
+    check_rel(torch.cat(parts), one.detach().cpu().numpy(), rnd, 'sharded d2')
     check_rel(grads, g_one.detach().cpu().numpy(), GRAD_TOL[dname], 'sharded gradient')
 
 

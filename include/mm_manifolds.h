@@ -98,14 +98,13 @@ int mm_spd_pdist_fwd(int dtype, const void* x, int64_t n, int d, int64_t row_beg
 /* Backward of the above (what autograd computes in the reference; symmetric
  * part — SURVEY.md §8 a5).  g has the layout of `out`.  grad_x [n,d,d] is
  * OVERWRITTEN with this shard's partial gradient (full shape; sum the shards).
- * fp32 accuracy on ILL-CONDITIONED points depends on the launch size for d = 4: pairs whose matrix L_i^-1 X_j L_i^-T has
- * lambda_max > 256 lambda_min are solved a second time by a one-sided Jacobi on L_i^-1 L_j (d = 2..4), EXCEPT in the
- * two-columns-per-lane form of the SPD(4) backward that launches of >= 30 M pairs (n >= 7747) and row bands of >= 12 M
- * pairs take (also in mm_spd_pdist_loss / mm_train_step_run): there the gradient at cond(X) = 1e4 is good to 3e-3 ... 1.5e-2
- * of its largest entry instead of 8e-5 (1e-5 / 1.5e-6 at cond(X) = 1e2; measured, tools/illcond_probe.py, pinned by
- * tests/test_spd_gpu.py::test_ill_conditioned_points_fp32 in both forms).  Distances come from the forward kernel and do
- * not depend on the launch size.  MM_SPD4_BWD_TWO_COLS=0 in the environment keeps the one-column form at every size
- * (+4..5 % time at n = 16384); fp64 is unaffected. */
+ * fp32 on ILL-CONDITIONED points: pairs whose matrix L_i^-1 X_j L_i^-T has lambda_max > 256 lambda_min are solved a second
+ * time by a one-sided Jacobi on L_i^-1 L_j (d = 2..4) in EVERY form of the kernel — since round 6 also in the
+ * two-columns-per-lane form of the SPD(4) backward that launches of >= 30 M pairs (n >= 7747) and row bands of >= 12 M pairs
+ * take (there through an out-of-line call), so the gradient's accuracy does not depend on the launch size or on how a problem
+ * is sharded: 8e-5 of its largest entry at cond(X) = 1e4, 1.5e-6 at 1e2 (measured, tools/illcond_probe.py; pinned by
+ * tests/test_spd_gpu.py::test_ill_conditioned_points_fp32 in both forms).  MM_SPD4_BWD_TWO_COLS=0 / 1 in the environment
+ * forces the one- / two-column form at every size (A/B builds only); fp64 needs no second solve. */
 int mm_spd_pdist_bwd(int dtype, const void* x, const void* g, int64_t n, int d,
                      int64_t row_begin, int64_t row_end, int squared, double wmin,
                      double wmax, void* grad_x, void* ws, int flags, mm_stream_t stream);

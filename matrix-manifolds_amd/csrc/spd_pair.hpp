@@ -81,9 +81,46 @@ __device__ __forceinline__ void pair_a(const TL (&li)[Packed<D>::NP], const T (&
   if constexpr (CHOL) congr_chol<T, D>(li, yj, a); else congr_lower<T, D>(li, yj, a);
 }
 
-// SECOND: allow the second (one-sided) solve for ill-conditioned fp32 pairs — off in the two-column SPD(4) backward, whose 168
-// registers have no room for it (with it the hot path spilled: fused QuotientLoss kernel at n = 16 384 1044 -> 2619 us)
-template <typename T, int D, bool WITH_V, bool CHOL = false, bool SECOND = true, typename TL>
+// SECOND: the second (one-sided) solve for ill-conditioned fp32 pairs — 0: none, 1: inline, 2: out of line (below)
+// The second, one-sided solve of pair_core OUT OF LINE (SECOND == 2): for the kernel that cannot afford it inline — the
+// two-columns-per-lane SPD(4) backward sits at its register cap (168: three wavefronts per SIMD) with the hot paths alone.
+// Round 6, same box, n = 16384, us (pdist backward at the reference init / fused QuotientLoss step / pdist backward at the
+// mid-training spread; profiles/r06_experiments.md section 2):
+//   no second solve (rounds 4 - 5: the gradient's accuracy on ill-conditioned points depended on the launch size)  918 / 1030 / 1176
+//   inlined in registers: 108 - 510 spilled registers, placed on the hot paths                                       944 / 3620 / 1390
+//   inlined with B^T and V in LDS (the combine buffer), rotation loops rolled, a dozen temporaries                   947 / 1240 / 1558
+//   THIS: a real call — operands through a scratch record, the callee allocates its own registers                   935 / 1058 / 1169
+// Any code added to that kernel moves its register assignment; the call moves it least (+1.4 ... 2.7 %, against +4 ... 5 % for one
+// column per lane at every size), and what it costs is paid for an accuracy that no longer depends on how a problem is sharded.
+template <typename T, int D>
+__device__ __attribute__((noinline)) void second_solve_ool(const T* __restrict__ in /* li[NP], xj[NP] */, T* __restrict__ out /* ev[D], v[D][D] */, T tol2) {
+  constexpr int NP = Packed<D>::NP;
+  T g[D][D], b[D][D], v[D][D];
+#pragma unroll
+  for (int r = 0; r < D; ++r)
+#pragma unroll
+    for (int c = 0; c < D; ++c) {
+      if (c > r) { g[c][r] = T(0); continue; }        // g = B^T: g[c][r] = B[r][c], B = L_i^-1 L_j
+      T acc = in[pidx(r, c)] * in[NP + pidx(c, c)];
+#pragma unroll
+      for (int k = c + 1; k <= r; ++k) acc = Num<T>::fma(in[pidx(r, k)], in[NP + pidx(k, c)], acc);
+      g[c][r] = acc;
+    }
+  svd_onesided<T, D, true>(g, b, v, tol2);
+#pragma unroll
+  for (int k = 0; k < D; ++k) {
+    T e = T(0);
+#pragma unroll
+    for (int r = 0; r < D; ++r) e = Num<T>::fma(b[r][k], b[r][k], e);
+    out[k] = e;
+  }
+#pragma unroll
+  for (int r = 0; r < D; ++r)
+#pragma unroll
+    for (int c = 0; c < D; ++c) out[D + r * D + c] = v[r][c];
+}
+
+template <typename T, int D, bool WITH_V, bool CHOL = false, int SECOND = 1, typename TL>
 __device__ __forceinline__ T pair_core(const TL (&li)[Packed<D>::NP], const T (&xj)[Packed<D>::NP], T wmin, T wmax,
                                        T (&w)[D], T (&lw)[D], T (&v)[D][D], T* rho = nullptr) {
   // eigenvalues only: sum log^2 w is second-order in the residual coupling -> tol2 = eps;
@@ -110,6 +147,21 @@ __device__ __forceinline__ T pair_core(const TL (&li)[Packed<D>::NP], const T (&
     T mn = ev[0], mx = ev[0];
 #pragma unroll
     for (int k = 1; k < D; ++k) { mn = Num<T>::min(mn, ev[k]); mx = Num<T>::max(mx, ev[k]); }
+    if constexpr (SECOND == 2) {
+      static_assert(WITH_V, "the out-of-line second solve returns eigenvectors");
+      if (__builtin_expect(__any(!(mx <= T(256) * mn)), 0)) {
+        T rec_in[2 * Packed<D>::NP], rec_out[D + D * D];   // (escape into the call: they live in scratch, on this path only)
+#pragma unroll
+        for (int k = 0; k < Packed<D>::NP; ++k) { rec_in[k] = T(li[k]); rec_in[Packed<D>::NP + k] = xj[k]; }
+        second_solve_ool<T, D>(rec_in, rec_out, tol2);
+#pragma unroll
+        for (int k = 0; k < D; ++k) ev[k] = rec_out[k];
+#pragma unroll
+        for (int r = 0; r < D; ++r)
+#pragma unroll
+          for (int c = 0; c < D; ++c) v[r][c] = rec_out[D + r * D + c];
+      }
+    } else
     if (__builtin_expect(__any(!(mx <= T(256) * mn)), 0)) {   // (cold: laid out behind the loop)
       T g[D][D], b[D][D];
 #pragma unroll
@@ -732,7 +784,14 @@ __global__ __launch_bounds__((64 * bwd_waves<T, D>()), (bwd_min_waves_nc<T, D, N
             return;
 #endif
             T w[D], lw[D], v[D][D];
-            const T s = pair_core<T, D, true, true, !(D == 4 && NC == 2)>(li, xj[q], wmin, wmax, w, lw, v);
+#ifdef MM_SPD4_TWO_COL_NO_SECOND   // (A/B builds: the round-4/5 form — no second, one-sided solve in the two-column SPD(4) backward)
+            constexpr int kSecond = (D == 4 && NC == 2) ? 0 : 1;
+#elif defined(MM_SPD4_TWO_COL_INLINE_SECOND)
+            constexpr int kSecond = 1;
+#else
+            constexpr int kSecond = (D == 4 && NC == 2) ? 2 : 1;   // two columns: out of line (second_solve_ool)
+#endif
+            const T s = pair_core<T, D, true, true, kSecond>(li, xj[q], wmin, wmax, w, lw, v);
             gs[q] = upstream_of<T, LOSS>(gs[q], s, valid[q], squared, wmin, sp, la, loss_acc, ds_acc);
             T cm[D];
 #pragma unroll

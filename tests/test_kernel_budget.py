@@ -35,8 +35,12 @@ BUDGET = {
     # (the minibatch form spills three values since round 5 — stored in the prologue / per-block set-up, reloaded in the slice set-up
     # and behind the row loop: no scratch access between the first and the last row of a slice, tools/devasm.sh)
     'spd_pdist_bwd_kernel<float, 4, 16, 2, true, 0, true>': (128, 4, 32),
-    'spd_pdist_bwd_kernel<float, 4, 16, 0, true, 2, false>': (168, 16, 48),
-    'spd_pdist_bwd_kernel<float, 4, 16, 2, true, 2, false>': (168, 40, 96),
+    # (round 6: the two-column form CALLS its second, one-sided solve — second_solve_ool, spd_pair.hpp — so that the gradient's
+    # accuracy on ill-conditioned points no longer depends on the launch size.  The call brings a 160-byte operand record and the
+    # saves around it into scratch: ~90 spilled values / 272 - 288 bytes, against 6 - 20 / 28 - 60 without the call, 108 - 510 with
+    # the solve inlined.  Same-box timings of the three forms: profiles/r06_experiments.md section 2 — +1.4 ... 2.7 % for the call.)
+    'spd_pdist_bwd_kernel<float, 4, 16, 0, true, 2, false>': (168, 96, 304),
+    'spd_pdist_bwd_kernel<float, 4, 16, 2, true, 2, false>': (168, 100, 320),
     # SPD(6) (round 5: matrix series in front of the eigensolve; two wavefronts per SIMD in the backward, nothing in scratch)
     'spd_pdist_fwd_kernel<float, 6, 8, true>': (184, 0, 0),
     'spd_pdist_bwd_kernel<float, 6, 16, 0, true, 0, false>': (256, 0, 0),

@@ -393,13 +393,10 @@ def test_ill_conditioned_points_fp32(d, cond, vtol, gtol):
     SPD(4), 1.5 for SPD(2)).  A wavefront that holds such a pair now solves again by a one-sided Jacobi on B itself
     (spd_pair.hpp pair_core, smallmat.hpp svd_onesided): measured 1.3e-4 / 8.9e-5 / 4.9e-4 (tools/illcond_probe.py).
     The two-column SPD(4) backward (launches of >= 30 M pairs, bands of >= 12 M; forced here by MM_SPD4_BWD_TWO_COLS=1 through
-    test_spd4_two_columns_per_lane_forced) keeps the two-sided solve only — the second solve spilled its hot path — so its
-    GRADIENT at cond(X) = 1e4 is 3e-3 ... 1.5e-2 of the largest entry (seed-dependent: tools/illcond_probe.py 3.2e-3, this
-    test's points 1.5e-2) instead of 8e-5 (d^2 comes from the forward kernel and is the same): pinned here at 2.5e-2, stated in
-    include/mm_manifolds.h."""
-    import os
-    if d == 4 and os.environ.get('MM_SPD4_BWD_TWO_COLS') == '1':
-        gtol = max(gtol, 2.5e-2)
+    test_spd4_two_columns_per_lane_forced) had no room for the second solve in rounds 4 - 5 — its gradient at cond(X) = 1e4 was
+    3e-3 ... 1.5e-2 of the largest entry instead of 8e-5, i.e. the accuracy depended on the launch size and, sharded, on the
+    rank (advisor, round 5).  Round 6: that kernel CALLS the solve out of line (spd_pair.hpp, second_solve_ool) and is held to the
+    same tolerance as every other form."""
     from graphembed.manifolds import SymmetricPositiveDefinite as SPD
     from oracle import exact
     gen = torch.Generator().manual_seed(int(d * 10 + np.log10(cond)))

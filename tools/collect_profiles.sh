@@ -1,10 +1,10 @@
 #!/bin/bash
 # Copy the judged summaries of an evidence run (tools/gpu_evidence.sh TAG, merged back under gpurun_out/TAG) into profiles/:
-#   tools/collect_profiles.sh TAG [ROUND]      # ROUND = prefix of the committed files, default r04
+#   tools/collect_profiles.sh TAG [ROUND]      # ROUND = prefix of the committed files, default r06
 # profiles/pmc_head.json is the stamp written on the GPU box (same kernel-source hash as the tree that ran); the counter
 # summary it cites is regenerated here from the same CSVs.
 set -e
-TAG=$1; R=${2:-r04}
+TAG=$1; R=${2:-r06}
 cd "$(dirname "$0")/.."
 G=gpurun_out/$TAG
 cp $G/summary.txt profiles/${R}_summary.txt

@@ -8,7 +8,7 @@
 #      SPD(6) / SPD(9), Lorentz(11) with the MFMA counters, the mixed-manifold pair kernel at n = 1025 and n = 5000
 #   4. the warm-regime shader clock from in-kernel stamps (lib/variants/libmm_stamp.so, if built)
 #   5. a default `python3 bench.py` run, tools/bench_configs.py, tools/shard_kernel_times.py, the eager-path host profile
-TAG=${1:-r05}
+TAG=${1:-r06}
 OUT=$GRAFT_REPO_ROOT/gpurun_out/$TAG
 mkdir -p $OUT
 cd $GRAFT_REPO_ROOT

@@ -1387,10 +1387,15 @@ __global__ void spd_fused_step_kernel(T* x, int n, StepRule<T> rule, StepFuse<T>
     if (e_ != hipSuccess) return static_cast<int>(e_); \
   } while (0)
 
+// Threads per workgroup of the per-node kernels (prep, finalize): n = 5000 nodes are 40 workgroups of 128 or 79 of 64
+#ifndef MM_NODE_BLOCK
+#define MM_NODE_BLOCK 128
+#endif
+constexpr int kNodeBlock = MM_NODE_BLOCK;
 template <typename T, int D>
 int spd_pdist_prepare(const T* x, int64_t n, Ws<T>& ws, int flags, hipStream_t st) {
   if (!(flags & MM_WS_PREPARED)) {
-    spd_prep_kernel<T, D><<<dim3((n + 127) / 128), dim3(128), 0, st>>>(x, int(n), ws.nodeL, ws.nodeX, ws.nodeC,
+    spd_prep_kernel<T, D><<<dim3((n + kNodeBlock - 1) / kNodeBlock), dim3(kNodeBlock), 0, st>>>(x, int(n), ws.nodeL, ws.nodeX, ws.nodeC,
                                                                        ws.accM, ws.accS, ws.loss, ws.bad, ws.nodeLd, ws.nodeLC);
     MM_CHECK_LAUNCH();
   }
@@ -1525,7 +1530,7 @@ int spd_pdist_loss_t(int kind, const T* x, const T* target, const T* scale_raw, 
     else rc = spd_pdist_bwd_launch<T, D, MM_LOSS_QUOTIENT>(ws, target, n, rb, re, 1, wmin, wmax, st, la);
     if (rc) return rc;
   }
-  spd_pdist_finalize_kernel<T, D><<<dim3((n + 127) / 128), dim3(128), 0, st>>>(ws.nodeL, ws.accM, ws.accS, int(n),
+  spd_pdist_finalize_kernel<T, D><<<dim3((n + kNodeBlock - 1) / kNodeBlock), dim3(kNodeBlock), 0, st>>>(ws.nodeL, ws.accM, ws.accS, int(n),
                                                                                grad, ws.loss, scale_raw, loss_out);
   MM_CHECK_LAUNCH();
   return MM_OK;
@@ -1549,7 +1554,7 @@ int spd_pdist_loss_subset_t(int kind, const T* x, const T* dense, const T* scale
       rc = spd_pdist_bwd_launch_sq<T, D, MM_LOSS_QUOTIENT, true, 0, true>(ws, dense, bs, rb, re, wmin, wmax, st, la, idx, n_total);
     if (rc) return rc;
   }
-  spd_pdist_finalize_kernel<T, D><<<dim3((n_total + 127) / 128), dim3(128), 0, st>>>(ws.nodeL, ws.accM, ws.accS, int(n_total),
+  spd_pdist_finalize_kernel<T, D><<<dim3((n_total + kNodeBlock - 1) / kNodeBlock), dim3(kNodeBlock), 0, st>>>(ws.nodeL, ws.accM, ws.accS, int(n_total),
                                                                                      grad, ws.loss, scale_raw, loss_out);
   MM_CHECK_LAUNCH();
   return MM_OK;
@@ -1566,7 +1571,7 @@ int spd_pdist_bwd_t(const T* x, const T* g, int64_t n, int64_t rb, int64_t re, i
     rc = spd_pdist_bwd_launch<T, D>(ws, g, n, rb, re, squared, wmin, wmax, st);
     if (rc) return rc;
   }
-  spd_pdist_finalize_kernel<T, D><<<dim3((n + 127) / 128), dim3(128), 0, st>>>(
+  spd_pdist_finalize_kernel<T, D><<<dim3((n + kNodeBlock - 1) / kNodeBlock), dim3(kNodeBlock), 0, st>>>(
       ws.nodeL, ws.accM, ws.accS, int(n), grad, static_cast<T*>(nullptr), static_cast<const T*>(nullptr),
       static_cast<T*>(nullptr));
   MM_CHECK_LAUNCH();

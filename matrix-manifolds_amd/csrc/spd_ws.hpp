@@ -232,12 +232,23 @@ struct ColWalk {
       c = c0 + int((-Bs + sqrtf(Bs * Bs + 4.0f * A * float(p))) / (2.0f * A));
     }
     c = c < c0 ? c0 : (c > last ? last : c);
-    // Exact by construction, not by the quality of the guess: both loops run until their condition fails (they end at the
-    // line's ends at the latest), which leaves the LARGEST c with aprefix(c) <= p.  One or two steps in practice — round 5's
-    // form capped them at four and would have returned a wrong block, silently, had the fp32 guess ever drifted further
-    // (tools/micro/walk_check.hip requires <= 4 steps at every block boundary +- 2 of every n, shard and cross up to n = 2^22).
-    while (c < last && aprefix(c + 1, cross) <= p) ++c;
-    while (c > c0 && aprefix(c, cross) > p) --c;
+    // Stepped exact against aprefix() — at most four steps either way as counted loops (round 6: the same two loops written
+    // `while (cond)` came out of the compiler as 276 straight-line scalar instructions and 16 spilled scalar registers in front
+    // of every workgroup's first load, 6 instructions per 64 pairs of the headline backward) — and exact by CONSTRUCTION: a
+    // loop that uses up its four steps hands over to a bisection (never taken: tools/micro/walk_check.hip requires the guess
+    // to be within four blocks at every block boundary +- 2 of every n, shard and cross up to n = 2^22).
+    int ku = 0, kd = 0;
+    for (; ku < 4 && c < last && aprefix(c + 1, cross) <= p; ++ku) ++c;
+    for (; kd < 4 && c > c0 && aprefix(c, cross) > p; ++kd) --c;
+    if (__builtin_expect(ku == 4 || kd == 4, 0)) {
+      int lo = c0, hi_ = last;
+#pragma nounroll
+      while (lo < hi_) {
+        const int mid = (lo + hi_ + 1) / 2;
+        if (aprefix(mid, cross) <= p) lo = mid; else hi_ = mid - 1;
+      }
+      c = lo;
+    }
     return c;
   }
   // (the stepping capped at four either way: what walk_check.hip holds against the bisection, so that a drifting guess is SEEN —

@@ -214,12 +214,19 @@ struct ColWalk {
   //   prefix(c0 + u) = A u^2 + Bs u  -> the positive root, then a step or two either way against prefix() itself; from c1 on the
   // blocks are R = re - rb units each.
   __host__ __device__ int find_fast(int64_t p, int cross = 0) const {
+    int64_t off;
+    return find_fast_off(p, cross, &off);
+  }
+  // ... and the unit's offset inside its block, *off = p - aprefix(c) (what enter() needs: one evaluation of aprefix() less).
+  // `capped` (host checks): set when a stepping loop used up its four steps — tools/micro/walk_check.hip requires it never to be.
+  __host__ __device__ int find_fast_off(int64_t p, int cross, int64_t* off, bool* capped = nullptr) const {
     // (cross > 0: the same search in the line that has `cross` extra units in front of every block's rows — aprefix())
     // The guess in fp32 (one v_sqrt_f32 / one v_rcp_f32: an fp64 square root and two fp64 divisions were 1.3 us of every
-    // workgroup's prologue), made exact by stepping against aprefix() itself — the guess is within a block of the answer for
+    // workgroup's prologue), made exact by stepping against the line itself — the guess is within a block of the answer for
     // every n the entry points accept (2^16 blocks: 24 bits resolve 0.004 of a block).
     const int last = ncb - 1;
-    if (last <= c0) return c0;
+    if (capped) *capped = false;
+    if (last <= c0) { *off = p; return c0; }
     int c;
     const int64_t pc1 = aprefix(c1, cross);
     if (p >= pc1) {
@@ -232,15 +239,28 @@ struct ColWalk {
       c = c0 + int((-Bs + sqrtf(Bs * Bs + 4.0f * A * float(p))) / (2.0f * A));
     }
     c = c < c0 ? c0 : (c > last ? last : c);
-    // Stepped exact against aprefix() — at most four steps either way as counted loops (round 6: the same two loops written
-    // `while (cond)` came out of the compiler as 276 straight-line scalar instructions and 16 spilled scalar registers in front
-    // of every workgroup's first load, 6 instructions per 64 pairs of the headline backward) — and exact by CONSTRUCTION: a
-    // loop that uses up its four steps hands over to a bisection (never taken: tools/micro/walk_check.hip requires the guess
-    // to be within four blocks at every block boundary +- 2 of every n, shard and cross up to n = 2^22).
+    // Stepped exact: ONE evaluation of aprefix() at the guess, then block lengths added or taken away (block c holds
+    // hi(c) - rb rows and `cross` entry units: aprefix(c + 1) = aprefix(c) + hi(c) - rb + cross) — round 5 evaluated aprefix()
+    // for every comparison and once more in enter(): five evaluations of ~25 scalar instructions in front of every workgroup's
+    // first load, now two (this one and pc1).  At most four steps either way as COUNTED loops (round 6: the same loops written
+    // `while (cond)` came out of the compiler as 276 straight-line scalar instructions and 16 spilled scalar registers — the
+    // headline backward 41.8 -> 43.3 us, profiles/r06_experiments.md section 5), and exact by CONSTRUCTION: a loop that uses up
+    // its four steps hands over to a bisection (never taken: tools/micro/walk_check.hip requires the guess to be within four
+    // blocks at every block boundary +- 2 of every n, shard and cross up to n = 2^22).
+    int64_t P = aprefix(c, cross);
     int ku = 0, kd = 0;
-    for (; ku < 4 && c < last && aprefix(c + 1, cross) <= p; ++ku) ++c;
-    for (; kd < 4 && c > c0 && aprefix(c, cross) > p; ++kd) --c;
+    for (; ku < 4 && c < last; ++ku) {
+      const int64_t L = int64_t(hi(c) - rb + cross);
+      if (P + L > p) break;
+      P += L;
+      ++c;
+    }
+    for (; kd < 4 && c > c0 && P > p; ++kd) {
+      --c;
+      P -= int64_t(hi(c) - rb + cross);
+    }
     if (__builtin_expect(ku == 4 || kd == 4, 0)) {
+      if (capped) *capped = true;
       int lo = c0, hi_ = last;
 #pragma nounroll
       while (lo < hi_) {
@@ -248,27 +268,18 @@ struct ColWalk {
         if (aprefix(mid, cross) <= p) lo = mid; else hi_ = mid - 1;
       }
       c = lo;
+      P = aprefix(c, cross);
     }
+    *off = p - P;
     return c;
   }
-  // (the stepping capped at four either way: what walk_check.hip holds against the bisection, so that a drifting guess is SEEN —
-  // it would cost every workgroup's prologue — rather than silently absorbed by the loops above)
+  // (host checks: the guess was within four blocks, i.e. the stepping loops did not hand over to the bisection — a drifting guess
+  // would cost every workgroup's prologue and must be SEEN, not silently absorbed)
   __host__ __device__ bool find_fast_converges(int64_t p, int cross = 0) const {
-    const int last = ncb - 1;
-    if (last <= c0) return true;
-    int c;
-    const int64_t pc1 = aprefix(c1, cross);
-    if (p >= pc1) {
-      const float R = float(re - rb + cross);
-      c = c1 + int(float(p - pc1) / (R > 0.f ? R : 1.f));
-    } else {
-      const float A = 0.5f * float(bw), Bs = A - 1.0f + float(bw * c0 - rb + cross);
-      c = c0 + int((-Bs + sqrtf(Bs * Bs + 4.0f * A * float(p))) / (2.0f * A));
-    }
-    c = c < c0 ? c0 : (c > last ? last : c);
-    for (int k = 0; k < 4 && c < last && aprefix(c + 1, cross) <= p; ++k) ++c;
-    for (int k = 0; k < 4 && c > c0 && aprefix(c, cross) > p; ++k) --c;
-    return !((c < last && aprefix(c + 1, cross) <= p) || (c > c0 && aprefix(c, cross) > p));
+    int64_t off;
+    bool capped;
+    find_fast_off(p, cross, &off, &capped);
+    return !capped;
   }
   // Shares that PAY for entering a column block (round 5).  A workgroup whose share spans a block boundary flushes the column
   // sums of the block it leaves (LDS, barrier, d^2 NC atomics per lane), requests the operands of the next block's columns and
@@ -284,8 +295,8 @@ struct ColWalk {
   // the share has left for rows (a start inside a block's entry zone pays the rest of the zone and starts at the block's
   // first row).  The walker then spends one unit per row and `cross` units whenever it moves on to the next block.
   __host__ __device__ void enter(int64_t a, int count, int cross, int* block, int* row, int* left) const {
-    const int c = find_fast(a, cross);
-    const int64_t off = a - aprefix(c, cross);
+    int64_t off;
+    const int c = find_fast_off(a, cross, &off);
     *block = c;
     if (off < cross) { *row = rb; *left = count - int(cross - off); }
     else { *row = rb + int(off - cross); *left = count; }

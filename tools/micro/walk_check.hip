@@ -33,8 +33,9 @@ int main() {
       auto hold = [&](int64_t p) {
         if (p < 0 || p >= atot) return;
         ++checked;
-        const int f = w.find_fast(p, cross), e = exact(p);
-        if (f != e || !w.find_fast_converges(p, cross)) { if (++bad < 10) printf("aug n=%d bw=%d rb=%d re=%d cross=%d p=%lld fast=%d exact=%d converged=%d\n", n, bw, rb, re, cross, (long long)p, f, e, int(w.find_fast_converges(p, cross))); }
+        int64_t off = -1;
+        const int f = w.find_fast_off(p, cross, &off), e = exact(p);
+        if (f != e || off != p - w.aprefix(e, cross) || !w.find_fast_converges(p, cross)) { if (++bad < 10) printf("aug n=%d bw=%d rb=%d re=%d cross=%d p=%lld fast=%d exact=%d converged=%d\n", n, bw, rb, re, cross, (long long)p, f, e, int(w.find_fast_converges(p, cross))); }
       };
       for (int c = w.c0; c <= w.ncb; c += (w.ncb > 4000 ? 89 : 1)) for (int d = -2; d <= 2; ++d) { hold(w.aprefix(c, cross) + d); hold(w.aprefix(c, cross) + cross + d); }
       const int64_t astep = atot / 2503 + 1;

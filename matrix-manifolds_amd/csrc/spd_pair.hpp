@@ -538,7 +538,7 @@ __global__ __launch_bounds__((64 * bwd_waves<T, D>()), (bwd_min_waves_nc<T, D, N
                                                                T* __restrict__ accM, T* __restrict__ accS,
                                                                LossArgs<T> la,
                                                                const int64_t* __restrict__ idx, int n_total,
-                                                               WalkShares shares) {
+                                                               WalkShares shares, int* __restrict__ share_tab) {
   static_assert(!SUB || LOSS != MM_LOSS_NONE, "node minibatches exist for the fused objective only");
   const int ns = SUB ? n_total : n;                      // stride of the per-node accumulators
   const int* idx32 = reinterpret_cast<const int*>(idx);  // (little-endian low words: node ids are < 2^22)
@@ -567,7 +567,11 @@ __global__ __launch_bounds__((64 * bwd_waves<T, D>()), (bwd_min_waves_nc<T, D, N
   // this workgroup's share of the walk, cut on the host (WalkShares): the column block and row it starts at and its budget of
   // units — one per row, shares.cross per block entered (ColWalk::enter); block-uniform
   int cb, r, rem;
+#ifdef MM_NO_SHARE_TAB   // (A/B builds: the start computed by every workgroup of every launch, as in rounds 5 and before)
   shares.of(walk, int(blockIdx.x), cb, r, rem);
+#else
+  shares.of_cached(walk, int(blockIdx.x), share_tab, cb, r, rem);
+#endif
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform -> row operands stay scalar loads
   bool red_writer;
@@ -1504,7 +1508,7 @@ int spd_pdist_bwd_launch_sq(Ws<T>& ws, const T* g, int64_t n, int64_t rb, int64_
   const int cross = std::min(std::max(env_cross, 0), 1024);
   const WalkShares shares(hw.total_aug(cross), grid, cross);
   launch_timed(PROF_SPD_BWD, kernel, g3, dim3(kThreads), st, nlc, nc, g, int(n), int(rb), int(re), T(wmin), T(wmax), ws.accM, ws.accS, la,
-               idx, int(n_total), shares);
+               idx, int(n_total), shares, ws.shareTab);
   MM_CHECK_LAUNCH();
   return MM_OK;
 }

@@ -750,8 +750,9 @@ int mm_vec_max_dim(void) { return kVecMaxDim; }
 int mm_vec_fused_step_supports(int dtype, int kind, int m) { return vec_fused_step_supports(dtype, kind, m) ? 1 : 0; }
 
 size_t mm_vec_pdist_ws_bytes(int dtype, int64_t n, int m) {
-  // acc [pad + 1][n] | loss slots [2][256] | zero-padded points [n + 1][pad] (symmetric backward, vec_sym.hip)
-  return (dtype == MM_F64 ? 8 : 4) * (size_t(n) * (pad_dim(m) + 1) + 2 * kLossSlots + size_t(n + 1) * pad_dim(m));
+  // acc [pad + 1][n] | loss slots [2][256] | zero-padded points [n + 1][pad] (symmetric backward, vec_sym.hip) | the share table of
+  // the balanced walk (round 6; spd_ws.hpp WalkShares::of_cached: kShareTabEntries x 32 bytes, 32-byte aligned)
+  return vec_ws_tables_end(dtype == MM_F64 ? 8 : 4, n, pad_dim(m)) + size_t(kShareTabEntries) * 32;
 }
 
 int mm_vec_pdist_fwd(int dtype, int kind, const void* x, int64_t n, int m, int64_t row_begin, int64_t row_end,

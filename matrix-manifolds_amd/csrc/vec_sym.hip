@@ -22,7 +22,7 @@ namespace {
 constexpr int kPlain = VSYM_PLAIN, kStepPrepared = VSYM_STEP_PREPARED;
 
 template <typename T, int KIND, int MP, int LOSS, bool SQ>
-int launch_pairs(const T* xpad, const T* g, int64_t n, int m, int64_t rb, int64_t re, T* acc, LossArgs<T> la, hipStream_t st) {
+int launch_pairs(const T* xpad, const T* g, int64_t n, int m, int64_t rb, int64_t re, T* acc, LossArgs<T> la, int* share_tab, hipStream_t st) {
   constexpr int kThreads = 64 * kVSymWaves;
   const int64_t units = ColWalk(int(n), int(rb), int(re), 64 * vsym_cols<T, MP>()).total();
   if (units <= 0) return MM_OK;
@@ -48,7 +48,7 @@ int launch_pairs(const T* xpad, const T* g, int64_t n, int m, int64_t rb, int64_
   {
     ProfScope prof(PROF_VEC_BWD, st);
     vec_pdist_bwd_sym_kernel<T, KIND, MP, LOSS, SQ><<<dim3(unsigned(grid)), dim3(kThreads), 0, st>>>(xpad, g, int(n), m, int(rb),
-                                                                                                   int(re), acc, la, WalkShares(hw.total_aug(cross), grid, cross));
+                                                                                                   int(re), acc, la, WalkShares(hw.total_aug(cross), grid, cross), share_tab);
   }
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? MM_OK : int(e);
@@ -69,6 +69,7 @@ int pairs_t(int loss_kind, int squared, const T* x, const T* g, int64_t n, int m
   T* acc = static_cast<T*>(ws);
   T* slots = acc + size_t(n) * (MP + 1);
   T* xpad = slots + 2 * kLossSlots;
+  int* share_tab = reinterpret_cast<int*>(static_cast<char*>(ws) + vec_ws_tables_end(sizeof(T), n, MP));
   hipError_t e;
   if (mode != kStepPrepared) {
     // (direct form: only the loss slots of the accumulator region are used — and cleared)
@@ -85,10 +86,10 @@ int pairs_t(int loss_kind, int squared, const T* x, const T* g, int64_t n, int m
   if (re > rb && pair_off(n, re) > pair_off(n, rb)) {
     LossArgs<T> la{scale_raw, T(alpha), T(eps), terms, slots, loss_params};
     T* out = direct ? grad : acc;
-    if (loss_kind == MM_LOSS_STRESS) rc = launch_pairs<T, KIND, MP, MM_LOSS_STRESS, true>(xpad, g, n, m, rb, re, out, la, st);
-    else if (loss_kind == MM_LOSS_QUOTIENT) rc = launch_pairs<T, KIND, MP, MM_LOSS_QUOTIENT, true>(xpad, g, n, m, rb, re, out, la, st);
-    else if (squared) rc = launch_pairs<T, KIND, MP, MM_LOSS_NONE, true>(xpad, g, n, m, rb, re, out, la, st);
-    else rc = launch_pairs<T, KIND, MP, MM_LOSS_NONE, false>(xpad, g, n, m, rb, re, out, la, st);
+    if (loss_kind == MM_LOSS_STRESS) rc = launch_pairs<T, KIND, MP, MM_LOSS_STRESS, true>(xpad, g, n, m, rb, re, out, la, share_tab, st);
+    else if (loss_kind == MM_LOSS_QUOTIENT) rc = launch_pairs<T, KIND, MP, MM_LOSS_QUOTIENT, true>(xpad, g, n, m, rb, re, out, la, share_tab, st);
+    else if (squared) rc = launch_pairs<T, KIND, MP, MM_LOSS_NONE, true>(xpad, g, n, m, rb, re, out, la, share_tab, st);
+    else rc = launch_pairs<T, KIND, MP, MM_LOSS_NONE, false>(xpad, g, n, m, rb, re, out, la, share_tab, st);
     if (rc != MM_OK) return rc;
   }
   if (direct && loss_kind != MM_LOSS_NONE) {   // the loss record

@@ -67,7 +67,8 @@ template <typename T, int KIND, int MP, int LOSS, bool SQ>
 __global__ __launch_bounds__((64 * kVSymWaves), (vsym_min_waves<T, MP>()))
 void vec_pdist_bwd_sym_kernel(const T* __restrict__ xpad /* [n+1][MP] */, const T* __restrict__ g, int n, int m, int row_begin,
                               int row_end, T* __restrict__ acc /* the gradient [n][m] (training-step form: the workspace's gacc) */,
-                              LossArgs<T> la, WalkShares shares /* the workgroups' units of the walk, cut on the host */) {
+                              LossArgs<T> la, WalkShares shares /* the workgroups' units of the walk, cut on the host */,
+                              int* __restrict__ share_tab /* where they start, remembered in the workspace (WalkShares::of_cached) */) {
   __builtin_amdgcn_s_setprio(3);   // (first thing: a wavefront starts at 0 and its prologue would be served after the older workgroups' row loops)
   constexpr int NW = kVSymWaves, TI = kVSymTI;
   constexpr int NC = vsym_cols<T, MP>();
@@ -88,7 +89,7 @@ void vec_pdist_bwd_sym_kernel(const T* __restrict__ xpad /* [n+1][MP] */, const 
   // this workgroup's share, cut on the host: the block and row it starts at and its budget of units — one per row,
   // shares.cross per block entered (spd_ws.hpp, WalkShares / ColWalk::enter)
   int cb, r, rem;
-  shares.of(walk, int(blockIdx.x), cb, r, rem);
+  shares.of_cached(walk, int(blockIdx.x), share_tab, cb, r, rem);
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   bool red_writer;

@@ -46,8 +46,10 @@ def test_argument_errors_need_no_gpu():
     assert g(B.MM_F32, B.LORENTZ, p, 10, 1000, 0, 10, 1, p, None) == -2                   # m too large
     with pytest.raises(B.BackendError):
         lib.call('mm_spd_pdist_fwd', B.MM_F32, None, 10, 3, 0, 10, 1, 1e-8, 1e8, None, None, 0, None)
-    assert lib.raw('mm_spd_pdist_ws_bytes')(B.MM_F32, 5000, 3) == 64 + 20032 + 4 * (5000 * (6 * 6 + 9 + 1) + 512 + 2 * 6)   # (+ one padding row of nodeLC)
-    assert lib.raw('mm_spd_pdist_ws_bytes')(B.MM_F64, 7, 4) == 64 + 64 + 8 * (7 * (6 * 10 + 16 + 1) + 512 + 2 * 10)
+    # (+ one padding row of nodeLC; round 6: + the share table — 2048 entries of 32 bytes behind the tables, 32-byte aligned)
+    up32 = lambda b: (b + 31) // 32 * 32
+    assert lib.raw('mm_spd_pdist_ws_bytes')(B.MM_F32, 5000, 3) == up32(64 + 20032 + 4 * (5000 * (6 * 6 + 9 + 1) + 512 + 2 * 6)) + 2048 * 32
+    assert lib.raw('mm_spd_pdist_ws_bytes')(B.MM_F64, 7, 4) == up32(64 + 64 + 8 * (7 * (6 * 10 + 16 + 1) + 512 + 2 * 10)) + 2048 * 32
 
 
 @pytest.mark.parametrize('n,world', [(1, 1), (2, 2), (5, 8), (40, 3), (5000, 8), (16384, 8), (4039, 7)])

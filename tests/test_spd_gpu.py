@@ -264,6 +264,62 @@ def test_pdist_vs_oracle_seeded(d, n, dname):
         check_rel(gr, sym(ref_g.numpy()), GRAD_TOL[dname], f'grad d={d} n={n} {init}')
 
 
+@pytest.mark.parametrize('d,dname', [(3, 'f32'), (4, 'f32'), (3, 'f64'), (6, 'f32')])
+def test_share_table_in_the_workspace_is_self_validating(d, dname):
+    """Round 6: the backward remembers where each workgroup of its balanced walk starts in the CALLER's workspace (32-byte entries
+    behind the tables: the walk's key and the start it leads to; spd_ws.hpp WalkShares::of_cached) and a later launch of the same
+    walk reads its start with one scalar load instead of ~200 scalar instructions.  An entry is used only if its whole key
+    matches, so nothing the memory held before may change a result: ONE workspace buffer, through the C ABI, is (a) poisoned with
+    random words, (b) used by walks of other sizes and row ranges in between, (c) handed entries that carry the RIGHT key words of
+    another walk in the wrong places — and every backward equals the one computed on a fresh, zeroed workspace (to the order of
+    the float atomics), the second and later launches of a walk included."""
+    from graphembed import _backend as B
+    from oracle import ref_port as rp
+    lib = B.lib()
+    T = DT[dname]
+    gen = torch.Generator().manual_seed(11 * d)
+    port = rp.SPD(d)
+    sizes = [257, 130, 300, 257, 64, 300]
+    dt = B.dtype_code(torch.zeros(1, dtype=T))
+    nbytes = max(lib.raw('mm_spd_pdist_ws_bytes')(dt, n, d) for n in sizes)
+    shared = torch.empty(nbytes, dtype=torch.uint8, device='cuda')
+    shared.view(torch.int32).random_(-2 ** 31, 2 ** 31 - 1)          # (a) garbage everywhere, the share table included
+
+    def backward(x, g, rows, ws):
+        n = x.shape[0]
+        out = torch.empty(B.pair_offset(n, rows[1]) - B.pair_offset(n, rows[0]), dtype=T, device='cuda')
+        grad = torch.empty_like(x)
+        with B.on_device(x.device):
+            lib.call('mm_spd_pdist_fwd', dt, B.ptr(x), n, d, rows[0], rows[1], 1, 1e-8, 1e8, B.ptr(out), B.ptr(ws), 0, B.stream_of(x))
+            lib.call('mm_spd_pdist_bwd', dt, B.ptr(x), B.ptr(g), n, d, rows[0], rows[1], 1, 1e-8, 1e8, B.ptr(grad), B.ptr(ws),
+                     B.MM_WS_PREPARED, B.stream_of(x))
+        return out, grad
+
+    tol = 5e-6 if dname == 'f32' else 1e-12
+    for rep, n in enumerate(sizes):
+        x = port.rand(n, ir=0.1 + 0.1 * (rep % 3), dtype=torch.float64, generator=gen).to(T).cuda()
+        for rows in ((0, n), (n // 3, 2 * n // 3), (n - 40, n), (20, 60)):
+            npairs = B.pair_offset(n, rows[1]) - B.pair_offset(n, rows[0])
+            g = torch.randn(npairs, dtype=torch.float64, generator=gen).to(T).cuda()
+            fresh = torch.zeros(lib.raw('mm_spd_pdist_ws_bytes')(dt, n, d), dtype=torch.uint8, device='cuda')
+            o_ref, g_ref = backward(x, g, rows, fresh)
+            for again in range(2):                                   # the second launch of the walk reads what the first stored
+                o, gr = backward(x, g, rows, shared[:lib.raw('mm_spd_pdist_ws_bytes')(dt, n, d)])
+                assert torch.equal(o, o_ref)
+                scale = float(g_ref.abs().max())
+                assert float((gr - g_ref).abs().max()) <= tol * scale, (rep, n, rows, again)
+        if rep in (1, 2, 3):
+            # (c) the tables of the walks just stored, shifted by exactly ONE entry (what a table shows that another embedding's
+            # launch wrote a few kilobytes further down the same buffer: the row shard (n // 3, 2n // 3) of n = 257 and of
+            # n = 300 is the same walk) and, next time, by an entry and three words
+            tab_bytes = 2048 * 32
+            for nn in set(sizes):
+                end = lib.raw('mm_spd_pdist_ws_bytes')(dt, nn, d)
+                tab = shared[end - tab_bytes:end].view(torch.int32)
+                tab.copy_(torch.roll(tab.clone(), 8 if rep != 2 else 8 + 3))
+    torch.cuda.synchronize()
+
+
 @pytest.mark.parametrize('dname', list(DT))
 def test_row_sharding_is_exact(dname):
     """Shards of the pair list reproduce the unsharded result bit for bit (forward) and

@@ -70,7 +70,13 @@ int mm_shard_rows(int64_t n, int world, int rank, int64_t* row_begin, int64_t* r
 /* Largest d the pairwise / per-node SPD kernels are instantiated for. */
 int mm_spd_max_dim(void);
 
-/* Workspace bytes for mm_spd_pdist_fwd/bwd on n points. */
+/* Workspace bytes for mm_spd_pdist_fwd/bwd on n points.  The workspace is the caller's and may hold anything when it is first
+ * handed over (no memset is needed, ever): the per-node tables are written by the preparation, the accumulators are cleared by
+ * it and by finalize, and the 64 KB behind them — where the backward's workgroups remember the start of their share of the
+ * pair walk from one launch to the next (one 32-byte entry per workgroup: the walk's key and the start it leads to) — are
+ * self-validating: an entry is used only if its whole key matches the launch, so stale or uninitialised contents cost a
+ * recomputation, never a wrong result.  Keeping ONE workspace per embedding across steps (as the Python layer and bench.py
+ * do) is what makes those entries hit; results do not depend on it.  One stream at a time may use a workspace. */
 size_t mm_spd_pdist_ws_bytes(int dtype, int64_t n, int d);
 
 /* flags for the pdist calls */
@@ -225,6 +231,7 @@ int mm_spd_rsgd_step(int dtype, const void* x, const void* egrad, int64_t m, int
 /* ---- vector manifolds: Euclidean R^m, Lorentz H^{m-1}, sphere S^{m-1} -------- */
 /* `kind` is MM_EUCLIDEAN / MM_LORENTZ / MM_SPHERE; points are rows of x [n,m]. */
 int mm_vec_max_dim(void);
+/* (accumulators, loss slots, zero-padded points and — as for SPD — 64 KB of self-validating workgroup starts of the backward's walk) */
 size_t mm_vec_pdist_ws_bytes(int dtype, int64_t n, int m);
 
 /* Manifold.pdist default = gather + dist — manifolds/base.py:59-63 with
